@@ -1,0 +1,25 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """One libsosvo context on cuda:0 for the whole GPU session (single process)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from vo_single_camera_sos_amd.device import Context
+    c = Context(0)
+    yield c
+    c.synchronize()
+    c.close()

@@ -1,0 +1,31 @@
+"""CPU: the C-ABI library loads and exports every symbol include/sosvo.h declares; the Python
+signature table covers exactly that set.  No compute call is made here."""
+import ctypes
+import os
+
+import pytest
+
+from vo_single_camera_sos_amd import _lib
+
+
+def test_library_is_built():
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    declared = _lib.declared_functions()
+    assert declared, "header parse found nothing"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), "libsosvo.so lacks %s" % name
+    assert sorted(_lib.SIGNATURES) == declared
+
+
+def test_abi_version_and_loud_failure_without_gpu():
+    lib = _lib.load()
+    assert lib.sosvo_abi_version() >= 1
+    import torch
+    if not torch.cuda.is_available():
+        from vo_single_camera_sos_amd.device import Context
+        with pytest.raises(_lib.SosvoError):
+            Context(0)

@@ -1,0 +1,108 @@
+"""GPU parity: sosvo_match_hamming / sosvo_sort_matches (through the C ABI) against the CPU
+oracle, bit-exact (integer work).  Edge cases follow the reference call site semantics
+(camera_models.py:404-446): empty sides, ties -> first train index, stable sort."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(ctx, q, t, nq, nt, k):
+    dev = ctx.device
+    keys = ctx.match_hamming(torch.from_numpy(q).to(dev), torch.from_numpy(t).to(dev),
+                             torch.from_numpy(nq).to(dev), torch.from_numpy(nt).to(dev), k=k)
+    ctx.synchronize()
+    return keys.cpu().numpy()
+
+
+def _check(ctx, P, Sq, St, nq, nt, k, seed, planted=True):
+    rng = np.random.default_rng(seed)
+    q = rng.integers(0, 256, (P, Sq, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (P, St, 32), dtype=np.uint8)
+    nq = np.asarray(nq, dtype=np.int32)
+    nt = np.asarray(nt, dtype=np.int32)
+    if planted:  # plant noisy copies and exact duplicates so that ties really occur
+        for p in range(P):
+            m = min(nq[p], nt[p]) // 2
+            if m > 1:
+                src = rng.integers(0, nq[p], m)
+                dst = rng.integers(0, nt[p], m)
+                noise = (rng.random((m, 32, 8)) < 0.05)
+                t[p, dst] = q[p, src] ^ np.packbits(noise, axis=-1)[..., 0]
+                t[p, dst[: m // 4]] = q[p, src[: m // 4]]
+                if nt[p] > 3:
+                    t[p, nt[p] - 1] = t[p, 0]  # duplicate train rows: lowest index must win
+    got = _run(ctx, q, t, nq, nt, k)
+    for p in range(P):
+        want = oracle.match_hamming(q[p, : nq[p]], t[p, : nt[p]], k=k)
+        assert np.array_equal(got[p, : nq[p]], want), "problem %d" % p
+    return q, t, nq, nt, got
+
+
+def test_single_small(ctx):
+    _check(ctx, 1, 64, 64, [64], [64], 1, seed=1)
+
+
+def test_ragged_batch_and_edge_counts(ctx):
+    nq = [0, 1, 5, 64, 65, 255, 256, 257, 300, 300]
+    nt = [7, 1, 0, 300, 1, 256, 257, 255, 300, 2]
+    _check(ctx, 10, 300, 300, nq, nt, 1, seed=2)
+    _check(ctx, 10, 300, 300, nq, nt, 2, seed=3)
+
+
+def test_bucket_sized_batch(ctx):
+    # 48 stereo-bucket sized problems (12 masks x 2 frames x 2), ~170 keypoints each
+    rng = np.random.default_rng(5)
+    nq = rng.integers(100, 200, 48)
+    nt = rng.integers(100, 200, 48)
+    _check(ctx, 48, 200, 200, nq, nt, 1, seed=6)
+
+
+def test_c2_size_split_path(ctx):
+    # BASELINE config 2: 2000 x 2000, 1-NN; few problems -> the train range is split over
+    # grid.z and merged with atomicMin on the packed key.
+    _check(ctx, 2, 2048, 2048, [2000, 1777], [2000, 2048], 1, seed=7)
+
+
+def test_c2_size_batched_no_split(ctx):
+    P = 40
+    rng = np.random.default_rng(8)
+    _check(ctx, P, 2048, 2048, rng.integers(1500, 2049, P), rng.integers(1500, 2049, P), 1, seed=9)
+
+
+def test_c3_size_knn2(ctx):
+    # BASELINE config 3: 8000 x 8000 with the two nearest neighbours (ratio-test input)
+    _check(ctx, 1, 8000, 8000, [8000], [8000], 2, seed=10)
+
+
+def test_sort_matches_stable(ctx):
+    P, S = 6, 2048
+    nq = np.array([0, 1, 2, 500, 2000, 2048], dtype=np.int32)
+    q, t, nq, nt, keys = _check(ctx, P, S, S, nq, [5, 0, 700, 1000, 2000, 64], 1, seed=11)
+    dev = ctx.device
+    order = ctx.sort_matches(torch.from_numpy(keys).to(dev), torch.from_numpy(nq).to(dev))
+    ctx.synchronize()
+    order = order.cpu().numpy()
+    for p in range(P):
+        want = oracle.sort_matches(keys[p, : nq[p], 0])
+        assert np.array_equal(order[p, : nq[p]], want), "problem %d" % p
+        d = keys[p, order[p, : nq[p]], 0] >> 20
+        assert np.all(np.diff(d.astype(np.int64)) >= 0)
+
+
+def test_properties_at_full_size(ctx):
+    # size-independent properties: a query planted verbatim in the train set matches it with
+    # distance 0; permuting the train rows permutes the matched indices' descriptors only.
+    rng = np.random.default_rng(12)
+    P, S = 3, 4096
+    q = rng.integers(0, 256, (P, S, 32), dtype=np.uint8)
+    perm = np.stack([rng.permutation(S) for _ in range(P)])
+    t = np.stack([q[p][perm[p]] for p in range(P)])
+    n = np.full(P, S, dtype=np.int32)
+    keys = _run(ctx, q, t, n, n, 1)[..., 0]
+    assert np.all(keys >> 20 == 0)
+    inv = np.stack([np.argsort(perm[p]) for p in range(P)])
+    assert np.array_equal((keys & 0xFFFFF).astype(np.int64), inv)

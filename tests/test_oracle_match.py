@@ -1,0 +1,59 @@
+"""CPU: pin the matching oracle with hand-computable known answers (the reference holds no
+golden vectors for this path)."""
+import numpy as np
+
+import oracle
+
+
+def _desc(bits_set):
+    d = np.zeros(32, dtype=np.uint8)
+    for b in bits_set:
+        d[b // 8] |= 1 << (b % 8)
+    return d
+
+
+def test_known_distances_and_first_minimum_wins():
+    q = np.stack([_desc([]), _desc(range(256)), _desc([0, 9, 200])])
+    t = np.stack([_desc([1]), _desc([]), _desc([2]), _desc(range(255)), _desc([])])
+    keys = oracle.match_hamming(q, t, k=1)[:, 0]
+    dist, idx = keys >> 20, keys & 0xFFFFF
+    # q0 = zeros: distances 1,0,1,255,0 -> min 0 first at train 1 (not 4)
+    assert (dist[0], idx[0]) == (0, 1)
+    # q1 = ones: distances 255,256,255,1,256 -> train 3
+    assert (dist[1], idx[1]) == (1, 3)
+    # q2 has 3 bits: distances 4,3,4,252(=255-3+0)...,3 -> 3 at train 1
+    assert (dist[2], idx[2]) == (3, 1)
+
+
+def test_knn2_order_and_missing():
+    q = np.stack([_desc([])])
+    t = np.stack([_desc([0, 1]), _desc([0]), _desc([5]), _desc([])])
+    k2 = oracle.match_hamming(q, t, k=2)
+    assert [(int(x) >> 20, int(x) & 0xFFFFF) for x in k2[0]] == [(0, 3), (1, 1)]
+    one = oracle.match_hamming(q, t[:1], k=2)
+    assert (int(one[0, 0]) >> 20, int(one[0, 0]) & 0xFFFFF) == (2, 0)
+    assert int(one[0, 1]) == oracle.KEY_NONE
+    none = oracle.match_hamming(q, t[:0], k=1)
+    assert int(none[0, 0]) == oracle.KEY_NONE
+
+
+def test_against_numpy_bruteforce():
+    rng = np.random.default_rng(3)
+    q = rng.integers(0, 256, (57, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (91, 32), dtype=np.uint8)
+    t[17] = q[5]
+    t[40] = q[5]  # duplicate: first wins
+    d = np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=-1).sum(-1)
+    keys = oracle.match_hamming(q, t, k=1)[:, 0]
+    assert np.array_equal(keys & 0xFFFFF, d.argmin(1))  # argmin returns the first minimum
+    assert np.array_equal(keys >> 20, d.min(1))
+    assert keys[5] == 17
+
+
+def test_sort_is_stable_by_distance():
+    dist = np.array([5, 3, 5, 0, 3, 3, 256, 0], dtype=np.uint32)
+    keys = (dist << 20) | np.arange(8, dtype=np.uint32)[::-1]  # train idx must not affect order
+    order = oracle.sort_matches(keys)
+    assert order.tolist() == [3, 7, 1, 4, 5, 0, 2, 6]
+    assert order.tolist() == sorted(range(8), key=lambda i: dist[i])
+    assert oracle.sort_matches(np.zeros(0, np.uint32)).shape == (0,)

@@ -1,0 +1,80 @@
+"""ctypes binding of libsosvo.so (the C ABI declared in include/sosvo.h).
+
+The product path has no CPU fallback: if the HIP library is missing or a symbol is
+absent this module raises, it never routes anywhere else.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsosvo.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sosvo.h")
+
+c_i32 = ctypes.c_int32
+c_f64 = ctypes.c_double
+c_f32 = ctypes.c_float
+c_u64 = ctypes.c_uint64
+c_p = ctypes.c_void_p
+
+SOSVO_OK = 0
+STATUS_NAMES = {0: "SOSVO_OK", -1: "SOSVO_ERR_ARG", -2: "SOSVO_ERR_HIP", -3: "SOSVO_ERR_NODEVICE",
+                -4: "SOSVO_ERR_CAPACITY"}
+
+KEY_SHIFT = 20
+KEY_IDX_MASK = 0xFFFFF
+KEY_NONE = 0xFFFFFFFF
+DESC_BYTES = 32
+
+
+class SosvoError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes); must list every function of include/sosvo.h (tested).
+SIGNATURES = {
+    "sosvo_abi_version": (c_i32, []),
+    "sosvo_create": (c_i32, [ctypes.POINTER(c_p), c_i32, c_p]),
+    "sosvo_destroy": (c_i32, [c_p]),
+    "sosvo_set_stream": (c_i32, [c_p, c_p]),
+    "sosvo_synchronize": (c_i32, [c_p]),
+    "sosvo_last_error": (ctypes.c_char_p, [c_p]),
+    "sosvo_timer_start": (c_i32, [c_p]),
+    "sosvo_timer_stop": (c_i32, [c_p]),
+    "sosvo_timer_elapsed_ms": (c_i32, [c_p, ctypes.POINTER(c_f32)]),
+    "sosvo_match_hamming": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p]),
+    "sosvo_sort_matches": (c_i32, [c_p, c_p, c_p, c_i32, c_i32, c_p]),
+}
+
+_lib = None
+
+
+def declared_functions(header_path=HEADER_PATH):
+    """Names of all functions declared in include/sosvo.h."""
+    text = open(header_path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sosvo_[a-z0-9_]+)\s*\(", text)))
+
+
+def load():
+    """Load libsosvo.so (once).  Raises SosvoError loudly when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SosvoError(
+            "libsosvo.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C vo_single_camera_sos_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    # torch must be imported first so that its bundled libamdhip64.so.7 is the HIP runtime
+    # this library binds to (one runtime per process).
+    import torch  # noqa: F401
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise SosvoError("libsosvo.so does not export %s; rebuild it" % name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib

@@ -1,0 +1,78 @@
+// Context, error reporting and the HIP-event timer of libsosvo.so.
+#include "common.h"
+
+#include <stdlib.h>
+
+extern "C" {
+
+int32_t sosvo_abi_version(void) { return 1; }
+
+int32_t sosvo_create(sosvo_ctx** out, int32_t device, void* stream) {
+  if (!out) return SOSVO_ERR_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return SOSVO_ERR_NODEVICE;
+  if (device < 0 || device >= n) return SOSVO_ERR_NODEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return SOSVO_ERR_HIP;
+  // The code object only holds gfx950 ISA; refuse anything else up front instead of
+  // failing at the first launch.
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return SOSVO_ERR_NODEVICE;
+  sosvo_ctx* ctx = (sosvo_ctx*)calloc(1, sizeof(sosvo_ctx));
+  if (!ctx) return SOSVO_ERR_HIP;
+  ctx->device = device;
+  ctx->stream = (hipStream_t)stream;
+  if (hipSetDevice(device) != hipSuccess || hipEventCreate(&ctx->ev_start) != hipSuccess ||
+      hipEventCreate(&ctx->ev_stop) != hipSuccess) {
+    free(ctx);
+    return SOSVO_ERR_HIP;
+  }
+  *out = ctx;
+  return SOSVO_OK;
+}
+
+int32_t sosvo_destroy(sosvo_ctx* ctx) {
+  if (!ctx) return SOSVO_OK;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->ws) (void)hipFree(ctx->ws);
+  (void)hipEventDestroy(ctx->ev_start);
+  (void)hipEventDestroy(ctx->ev_stop);
+  free(ctx);
+  return SOSVO_OK;
+}
+
+int32_t sosvo_set_stream(sosvo_ctx* ctx, void* stream) {
+  SOSVO_ENTER(ctx);
+  ctx->stream = (hipStream_t)stream;
+  return SOSVO_OK;
+}
+
+int32_t sosvo_synchronize(sosvo_ctx* ctx) {
+  SOSVO_ENTER(ctx);
+  SOSVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SOSVO_OK;
+}
+
+const char* sosvo_last_error(const sosvo_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+int32_t sosvo_timer_start(sosvo_ctx* ctx) {
+  SOSVO_ENTER(ctx);
+  SOSVO_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+  return SOSVO_OK;
+}
+
+int32_t sosvo_timer_stop(sosvo_ctx* ctx) {
+  SOSVO_ENTER(ctx);
+  SOSVO_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+  return SOSVO_OK;
+}
+
+int32_t sosvo_timer_elapsed_ms(sosvo_ctx* ctx, float* ms) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, ms != nullptr, "ms is null");
+  SOSVO_HIP(ctx, hipEventSynchronize(ctx->ev_stop));
+  SOSVO_HIP(ctx, hipEventElapsedTime(ms, ctx->ev_start, ctx->ev_stop));
+  return SOSVO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,197 @@
+// K7 -- brute-force Hamming matching and the stable sort of matches by distance.
+//
+// Reference call sites: cv2.BFMatcher(NORM_HAMMING).match / knnMatch at
+// omnistereo/camera_models.py:442 / :420 and sorted(matches, key=distance) at :444.
+//
+// Mapping to CDNA4: one query descriptor lives in 8 VGPRs of one lane (QPT queries per
+// lane to reuse every LDS read), the train set streams through an 8 KB LDS tile and is
+// read back as wave-wide broadcasts (all lanes read the same 32 bytes), distance is
+// 8 x (v_xor_b32 + accumulating v_bcnt_u32_b32).  The result is carried as the packed key
+// (distance << 20 | train index): an unsigned min over keys is exactly "smallest
+// distance, first train index wins", so partial results of train-range splits merge with
+// one atomicMin and stay bit-identical to a sequential scan.  No MFMA: there is no
+// contraction here, only popcounts.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kTrainTile = 256;  // descriptors per LDS tile (8 KB)
+
+__device__ __forceinline__ uint32_t hamming256(const uint4& a0, const uint4& a1, const uint4& b0,
+                                               const uint4& b1) {
+  uint32_t d = __popc(a0.x ^ b0.x);
+  d += __popc(a0.y ^ b0.y);
+  d += __popc(a0.z ^ b0.z);
+  d += __popc(a0.w ^ b0.w);
+  d += __popc(a1.x ^ b1.x);
+  d += __popc(a1.y ^ b1.y);
+  d += __popc(a1.z ^ b1.z);
+  d += __popc(a1.w ^ b1.w);
+  return d;
+}
+
+template <int QPT, int K>
+__global__ __launch_bounds__(kThreads) void match_hamming_kernel(
+    const uint4* __restrict__ q_desc, const uint4* __restrict__ t_desc, const int32_t* __restrict__ nq,
+    const int32_t* __restrict__ nt, int q_stride, int t_stride, int nsplit, uint32_t* __restrict__ keys) {
+  __shared__ uint4 tile[kTrainTile * 2];
+  const int tid = threadIdx.x;
+  const int p = blockIdx.y;
+  const int nqp = min(nq[p], q_stride);
+  const int ntp = min(nt[p], t_stride);
+  const int q0 = blockIdx.x * (kThreads * QPT);
+  if (q0 >= nqp) return;  // uniform over the workgroup
+
+  // train range of this split, whole tiles
+  const int tiles = (ntp + kTrainTile - 1) / kTrainTile;
+  const int tiles_per = (tiles + nsplit - 1) / nsplit;
+  const int tb = blockIdx.z * tiles_per * kTrainTile;
+  const int te = min(ntp, tb + tiles_per * kTrainTile);
+  if (nsplit > 1 && tb >= te) return;  // keys were pre-set to NONE
+
+  uint4 qa[QPT], qb[QPT];
+  uint32_t best[QPT], second[QPT];
+#pragma unroll
+  for (int r = 0; r < QPT; ++r) {
+    const int qi = q0 + r * kThreads + tid;
+    const bool valid = qi < nqp;
+    const size_t row = (size_t)p * q_stride + (valid ? qi : q0);
+    qa[r] = q_desc[row * 2 + 0];
+    qb[r] = q_desc[row * 2 + 1];
+    best[r] = SOSVO_KEY_NONE;
+    second[r] = SOSVO_KEY_NONE;
+  }
+
+  const uint4* tsrc = t_desc + (size_t)p * t_stride * 2;
+  for (int t0 = tb; t0 < te; t0 += kTrainTile) {
+    const int lim = min(kTrainTile, te - t0);
+    __syncthreads();
+    for (int i = tid; i < lim * 2; i += kThreads) tile[i] = tsrc[(size_t)t0 * 2 + i];
+    __syncthreads();
+#pragma unroll 4
+    for (int j = 0; j < lim; ++j) {
+      const uint4 ta = tile[2 * j + 0];
+      const uint4 tb4 = tile[2 * j + 1];
+      const uint32_t tj = (uint32_t)(t0 + j);
+#pragma unroll
+      for (int r = 0; r < QPT; ++r) {
+        const uint32_t key = (hamming256(qa[r], qb[r], ta, tb4) << SOSVO_KEY_SHIFT) | tj;
+        if (K == 2) second[r] = min(second[r], max(best[r], key));
+        best[r] = min(best[r], key);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int r = 0; r < QPT; ++r) {
+    const int qi = q0 + r * kThreads + tid;
+    if (qi < nqp) {
+      uint32_t* out = keys + ((size_t)p * q_stride + qi) * K;
+      if (K == 1 && nsplit > 1) {
+        atomicMin(out, best[r]);
+      } else {
+        out[0] = best[r];
+        if (K == 2) out[1] = second[r];
+      }
+    }
+  }
+}
+
+// Rank sort: the sort key of query i is (distance << 20 | i); its rank is the number of
+// smaller sort keys.  Keys are unique, so ranks are a permutation and ties on distance
+// keep query order (stable), as Python's sorted() does at camera_models.py:444.
+__global__ __launch_bounds__(kThreads) void sort_matches_kernel(const uint32_t* __restrict__ keys,
+                                                                const int32_t* __restrict__ nq,
+                                                                int q_stride, int32_t* __restrict__ order) {
+  extern __shared__ uint32_t sk[];
+  const int tid = threadIdx.x;
+  const int p = blockIdx.y;
+  const int n = min(nq[p], q_stride);
+  const int i0 = blockIdx.x * kThreads;
+  if (i0 >= n) return;
+  const int n4 = (n + 3) & ~3;
+  const uint32_t* src = keys + (size_t)p * q_stride;
+  for (int i = tid; i < n4; i += kThreads)
+    sk[i] = i < n ? ((src[i] & ~SOSVO_KEY_IDX_MASK) | (uint32_t)i) : 0xFFFFFFFFu;
+  __syncthreads();
+  const int i = i0 + tid;
+  const uint32_t mine = i < n ? sk[i] : 0u;
+  int rank = 0;
+  const uint4* sk4 = reinterpret_cast<const uint4*>(sk);
+  for (int j = 0; j < n4 / 4; ++j) {
+    const uint4 v = sk4[j];
+    rank += (v.x < mine) + (v.y < mine) + (v.z < mine) + (v.w < mine);
+  }
+  if (i < n) order[(size_t)p * q_stride + rank] = i;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t sosvo_match_hamming(sosvo_ctx* ctx, const uint8_t* q_desc, const uint8_t* t_desc,
+                            const int32_t* nq, const int32_t* nt, int32_t nprob, int32_t q_stride,
+                            int32_t t_stride, int32_t k, uint32_t* keys) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, q_desc && t_desc && nq && nt && keys, "null pointer");
+  SOSVO_REQUIRE(ctx, k == 1 || k == 2, "k must be 1 or 2");
+  SOSVO_REQUIRE(ctx, nprob >= 0 && nprob <= 65535, "nprob out of range");
+  SOSVO_REQUIRE(ctx, q_stride > 0 && q_stride <= (1 << SOSVO_KEY_SHIFT), "q_stride out of range");
+  SOSVO_REQUIRE(ctx, t_stride > 0 && t_stride <= (1 << SOSVO_KEY_SHIFT), "t_stride out of range");
+  SOSVO_REQUIRE(ctx, ((uintptr_t)q_desc & 15) == 0 && ((uintptr_t)t_desc & 15) == 0,
+                "descriptor arrays must be 16-byte aligned");
+  if (nprob == 0) return SOSVO_OK;
+  const uint4* q4 = reinterpret_cast<const uint4*>(q_desc);
+  const uint4* t4 = reinterpret_cast<const uint4*>(t_desc);
+
+  // Queries per lane: 4 when there is enough work to still fill the chip, else 1.
+  const int qpt = (q_stride >= 1024) ? 4 : 1;
+  const int gx = cdiv(q_stride, kThreads * qpt);
+  // Split the train range over grid.z until ~2k workgroups exist (1-NN only: the split
+  // results merge with atomicMin on the packed key).
+  int nsplit = 1;
+  if (k == 1) {
+    const int tiles = cdiv(t_stride, kTrainTile);
+    nsplit = cdiv(2048, gx * nprob);
+    if (nsplit > tiles) nsplit = tiles;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > 64) nsplit = 64;
+  }
+  if (nsplit > 1)
+    SOSVO_HIP(ctx, hipMemsetAsync(keys, 0xFF, (size_t)nprob * q_stride * sizeof(uint32_t), ctx->stream));
+  dim3 grid(gx, nprob, nsplit), block(kThreads);
+  if (k == 1) {
+    if (qpt == 4)
+      hipLaunchKernelGGL((match_hamming_kernel<4, 1>), grid, block, 0, ctx->stream, q4, t4, nq, nt,
+                         q_stride, t_stride, nsplit, keys);
+    else
+      hipLaunchKernelGGL((match_hamming_kernel<1, 1>), grid, block, 0, ctx->stream, q4, t4, nq, nt,
+                         q_stride, t_stride, nsplit, keys);
+  } else {
+    if (qpt == 4)
+      hipLaunchKernelGGL((match_hamming_kernel<4, 2>), grid, block, 0, ctx->stream, q4, t4, nq, nt,
+                         q_stride, t_stride, nsplit, keys);
+    else
+      hipLaunchKernelGGL((match_hamming_kernel<1, 2>), grid, block, 0, ctx->stream, q4, t4, nq, nt,
+                         q_stride, t_stride, nsplit, keys);
+  }
+  SOSVO_LAUNCH_CHECK(ctx);
+  return SOSVO_OK;
+}
+
+int32_t sosvo_sort_matches(sosvo_ctx* ctx, const uint32_t* keys, const int32_t* nq, int32_t nprob,
+                           int32_t q_stride, int32_t* order) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, keys && nq && order, "null pointer");
+  SOSVO_REQUIRE(ctx, nprob >= 0 && nprob <= 65535, "nprob out of range");
+  SOSVO_REQUIRE(ctx, q_stride > 0 && q_stride <= 16384, "q_stride out of range (max 16384)");
+  if (nprob == 0) return SOSVO_OK;
+  const size_t lds = (size_t)((q_stride + 3) & ~3) * sizeof(uint32_t);
+  dim3 grid(cdiv(q_stride, kThreads), nprob), block(kThreads);
+  hipLaunchKernelGGL(sort_matches_kernel, grid, block, lds, ctx->stream, keys, nq, q_stride, order);
+  SOSVO_LAUNCH_CHECK(ctx);
+  return SOSVO_OK;
+}
+
+}  // extern "C"
