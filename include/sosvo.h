@@ -89,6 +89,48 @@ int32_t sosvo_match_hamming(sosvo_ctx* ctx, const uint8_t* q_desc, const uint8_t
 int32_t sosvo_sort_matches(sosvo_ctx* ctx, const uint32_t* keys, const int32_t* nq,
                            int32_t nprob, int32_t q_stride, int32_t* order);
 
+/* ---- K8 / K10: 3D-2D absolute-pose RANSAC ------------------------------------------------
+ * Replaces pyopengv.absolute_pose_noncentral_ransac (omnistereo/pose_est_tools.py:785) and
+ * pyopengv.absolute_pose_ransac (:915).  Batched: problem b owns rows [b*stride, b*stride+n[b]).
+ *   f   [nprob*stride, 3] f64  unit bearings of the CURRENT frame, in their camera's frame
+ *   p   [nprob*stride, 3] f64  3-D points of the REFERENCE frame (frame [C], model units)
+ *   cam [nprob*stride]    i32  camera index per correspondence, or NULL for the central case
+ *   cam_off [ncam,3], cam_rot [ncam,3,3] f64 row-major: camera position / rotation wrt the
+ *       viewpoint (TrackerStereoSE3.bootstrap_tracker, pose_est_tools.py:852-859); shared by the batch
+ *   flags: SOSVO_FLAG_CAM_ROT_IDENTITY promises cam_rot are identities (skips a mat-vec; results
+ *       are bit-identical for finite data)
+ *   thr: inlier iff 1 - f . f_hat < thr (pose_est_tools.py:675-676: 1 - cos 5 deg)
+ *   max_iter hypotheses are drawn by a counter-based sampler from (seed + b, iteration); with
+ *   adaptive != 0 the sequential early stop of OpenGV's sac::Ransac (probability 0.99, sample
+ *   size 4) is replayed over them, so the result equals a sequential run on the same samples.
+ * Outputs per problem: T_out [nprob,3,4] = [R|t] (pose of the current viewpoint in the reference
+ * frame: X_ref = R x + t), inlier_mask [nprob*stride] u8, inlier_idx [nprob*stride] i32 ascending
+ * (first n_inliers[b] entries), n_inliers [nprob], info [nprob,4] = {best iteration (-1: none),
+ * iterations drawn, status (0 ok / 1 no model -> T = identity), number of valid hypotheses}.
+ * hyp_counts: optional [nprob,max_iter] i32, receives each hypothesis' inlier count (-1: the
+ * minimal solve failed); NULL to keep them in the context workspace.                         */
+#define SOSVO_FLAG_CAM_ROT_IDENTITY 1
+int32_t sosvo_ransac_abs_pose(sosvo_ctx* ctx, const double* f, const double* p, const int32_t* cam,
+                              const double* cam_off, const double* cam_rot, int32_t ncam, int32_t flags,
+                              const int32_t* n, int32_t nprob, int32_t stride, double thr,
+                              int32_t max_iter, int32_t adaptive, uint64_t seed, double* T_out,
+                              uint8_t* inlier_mask, int32_t* inlier_idx, int32_t* n_inliers,
+                              int32_t* info, int32_t* hyp_counts);
+
+/* ---- K9: non-linear refinement --------------------------------------------------------------
+ * Replaces pyopengv.absolute_pose_noncentral_optimize_nonlinear (pose_est_tools.py:830) and
+ * absolute_pose_optimize_nonlinear (:937): Levenberg-Marquardt on (t, Cayley(R)), residual
+ * 1 - f . f_hat per correspondence, forward-difference Jacobian.  Same layout as the RANSAC call;
+ * idx/m (both or neither): the first m[b] entries of idx[b*stride ...] select the correspondences
+ * (e.g. inlier_idx / n_inliers of sosvo_ransac_abs_pose); NULL = all n[b].
+ * T_io [nprob,3,4] in: start pose, out: refined pose.  cost_out [nprob] f64 and iters_out
+ * [nprob] i32 are optional.                                                                      */
+int32_t sosvo_refine_abs_pose(sosvo_ctx* ctx, const double* f, const double* p, const int32_t* cam,
+                              const double* cam_off, const double* cam_rot, int32_t ncam,
+                              const int32_t* n, int32_t nprob, int32_t stride, const int32_t* idx,
+                              const int32_t* m, int32_t max_lm_iter, double* T_io, double* cost_out,
+                              int32_t* iters_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,3 +61,102 @@ def sort_matches(keys):
     order = np.empty(keys.shape[0], dtype=np.int32)
     lib().orc_sort_matches(_p(keys), ctypes.c_int32(keys.shape[0]), _p(order))
     return order
+
+
+# ---- K8/K9/K10: absolute-pose RANSAC and refinement ----------------------------------------
+def _opt_cam(cam, cam_off, cam_rot):
+    if cam is None:
+        return None, None, None, 1
+    cam = _c(cam, np.int32).reshape(-1)
+    cam_off = _c(cam_off, np.float64).reshape(-1, 3)
+    cam_rot = _c(cam_rot, np.float64).reshape(-1, 3, 3)
+    return cam, cam_off, cam_rot, cam_off.shape[0]
+
+
+def _pn(a):
+    return _p(a) if a is not None else ctypes.c_void_p(0)
+
+
+def score_points(f, p, T, cam=None, cam_off=None, cam_rot=None):
+    f = _c(f, np.float64).reshape(-1, 3)
+    p = _c(p, np.float64).reshape(-1, 3)
+    T = _c(T, np.float64).reshape(3, 4)
+    cam, cam_off, cam_rot, _ = _opt_cam(cam, cam_off, cam_rot)
+    out = np.empty(f.shape[0], dtype=np.float64)
+    lib().orc_score_points(_p(f), _p(p), _pn(cam), _pn(cam_off), _pn(cam_rot), ctypes.c_int32(f.shape[0]),
+                           _p(T), _p(out))
+    return out
+
+
+def ransac_abs_pose(f, p, thr, max_iter, seed=0, adaptive=False, cam=None, cam_off=None, cam_rot=None,
+                    want_counts=False):
+    """-> dict(T [3,4], mask [n] bool, n_inliers, best_iter, iters_used, status[, counts])."""
+    f = _c(f, np.float64).reshape(-1, 3)
+    p = _c(p, np.float64).reshape(-1, 3)
+    n = f.shape[0]
+    cam, cam_off, cam_rot, ncam = _opt_cam(cam, cam_off, cam_rot)
+    T = np.zeros((3, 4), dtype=np.float64)
+    mask = np.zeros(max(n, 1), dtype=np.uint8)
+    n_inl = ctypes.c_int32(0)
+    best_it = ctypes.c_int32(0)
+    used = ctypes.c_int32(0)
+    counts = np.zeros(max(max_iter, 1), dtype=np.int32) if want_counts else None
+    L = lib()
+    L.orc_ransac_abs_pose.restype = ctypes.c_int32
+    st = L.orc_ransac_abs_pose(_p(f), _p(p), _pn(cam), _pn(cam_off), _pn(cam_rot), ctypes.c_int32(n),
+                               ctypes.c_int32(ncam), ctypes.c_double(thr), ctypes.c_int32(max_iter),
+                               ctypes.c_int32(1 if adaptive else 0), ctypes.c_uint64(seed), _p(T), _p(mask),
+                               ctypes.byref(n_inl), ctypes.byref(best_it), ctypes.byref(used), _pn(counts))
+    out = dict(T=T, mask=mask[:n].astype(bool), n_inliers=n_inl.value, best_iter=best_it.value,
+               iters_used=used.value, status=st)
+    if want_counts:
+        out["counts"] = counts[:max_iter]
+    return out
+
+
+def hypothesis_once(f, p, seed, it, cam=None, cam_off=None, cam_rot=None):
+    f = _c(f, np.float64).reshape(-1, 3)
+    p = _c(p, np.float64).reshape(-1, 3)
+    cam, cam_off, cam_rot, ncam = _opt_cam(cam, cam_off, cam_rot)
+    T = np.zeros((3, 4), dtype=np.float64)
+    s4 = np.zeros(4, dtype=np.int32)
+    L = lib()
+    L.orc_hypothesis_once.restype = ctypes.c_int32
+    ok = L.orc_hypothesis_once(_p(f), _p(p), _pn(cam), _pn(cam_off), _pn(cam_rot), ctypes.c_int32(f.shape[0]),
+                               ctypes.c_int32(ncam), ctypes.c_uint64(seed), ctypes.c_int32(it), _p(T), _p(s4))
+    return bool(ok), T, s4
+
+
+def p3p_kneip(f3, p3):
+    f3 = _c(f3, np.float64).reshape(3, 3)
+    p3 = _c(p3, np.float64).reshape(3, 3)
+    R = np.zeros((4, 3, 3))
+    C = np.zeros((4, 3))
+    L = lib()
+    L.orc_p3p_kneip.restype = ctypes.c_int32
+    n = L.orc_p3p_kneip(_p(f3), _p(p3), _p(R), _p(C))
+    return R[:n], C[:n]
+
+
+def quartic_real_roots(a5):
+    a5 = _c(a5, np.float64).reshape(5)
+    r = np.zeros(4)
+    L = lib()
+    L.orc_quartic_real_roots.restype = ctypes.c_int32
+    n = L.orc_quartic_real_roots(_p(a5), _p(r))
+    return r[:n]
+
+
+def refine_abs_pose(f, p, T0, idx=None, cam=None, cam_off=None, cam_rot=None, max_lm_iter=30):
+    f = _c(f, np.float64).reshape(-1, 3)
+    p = _c(p, np.float64).reshape(-1, 3)
+    cam, cam_off, cam_rot, _ = _opt_cam(cam, cam_off, cam_rot)
+    T = _c(T0, np.float64).reshape(3, 4).copy()
+    if idx is not None:
+        idx = _c(idx, np.int32).reshape(-1)
+    cost = ctypes.c_double(0)
+    iters = ctypes.c_int32(0)
+    lib().orc_refine_abs_pose(_p(f), _p(p), _pn(cam), _pn(cam_off), _pn(cam_rot), ctypes.c_int32(f.shape[0]),
+                              _pn(idx), ctypes.c_int32(0 if idx is None else idx.shape[0]), _p(T),
+                              ctypes.c_int32(max_lm_iter), ctypes.byref(cost), ctypes.byref(iters))
+    return T, cost.value, iters.value

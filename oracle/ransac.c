@@ -1,0 +1,263 @@
+/*
+ * ORACLE -- TEST INFRASTRUCTURE ONLY.  Never imported, linked or executed by the product
+ * path; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
+ *
+ * CPU restatement of the 3D-2D absolute-pose RANSAC + non-linear refinement stage.
+ *
+ * The arithmetic lives in OpenGV (pyopengv, fork ubuntuslave/opengv branch
+ * non_central-python, commit unpinned: reference README.md:253-258), a third-party dependency
+ * that is NOT under the reference tree.  The restatement follows the published algorithms and
+ * is anchored on the reference's own call sites and on its in-repo restatement of the score:
+ *   omnistereo/pose_est_tools.py:785   absolute_pose_noncentral_ransac(b, cam, p, offsets, rots, thr, iters)
+ *   omnistereo/pose_est_tools.py:915   absolute_pose_ransac(b, p, "EPNP"|"KNEIP"|..., thr, iters)
+ *   omnistereo/pose_est_tools.py:830/:937  *_optimize_nonlinear(...)
+ *   omnistereo/pose_est_tools.py:150-203   get_selected_distances_to_model: score = 1 - f . normalize(R^T (p - t))
+ *   omnistereo/pose_est_tools.py:181-185   non-central form: R_c^T (R^T (p - t) - o_c)
+ *   omnistereo/pose_est_tools.py:672-720   threshold 1 - cos(5 deg), iteration budget
+ * Published algorithms restated: Kneip, Scaramuzza, Siegwart, "A novel parametrization of the
+ * P3P problem", CVPR 2011 (minimal solver); Fischler & Bolles RANSAC with the adaptive stop
+ * k = log(1 - 0.99) / log(1 - w^s) as in OpenGV's sac::Ransac; Levenberg-Marquardt on
+ * (t, Cayley(R)) with residual 1 - f . f_hat and forward-difference Jacobian as in OpenGV's
+ * optimize_nonlinear.
+ * Deliberate, documented deviations (DESIGN.md "RANSAC"): (1) OpenGV seeds its sampler from the
+ * clock, so the reference does not reproduce its own inlier sets; the sampler here is a
+ * counter-based hash of (seed, iteration, draw) shared with the HIP path.  (2) The non-central
+ * minimal solver draws its three solve points from ONE camera of the rig (central P3P in that
+ * camera, moved to the body frame) and disambiguates/scores non-centrally, instead of OpenGV's
+ * gP3P Groebner template, which cannot be restated from the reference tree.  (3) Real quartic
+ * roots only (OpenGV takes real parts of complex roots; those candidates never survive the
+ * 4th-point check).
+ * Parity status: UNPINNED against OpenGV binaries (no golden vectors exist in the reference);
+ * pinned by noise-free known-pose tests (tests/test_oracle_ransac.py) and, for the score, by a
+ * fixture generated from the reference's own get_selected_distances_to_model
+ * (tests/golden/make_fixtures.py).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "ransac_core.h"
+
+/* ---- scoring of all points under one pose --------------------------------------------- */
+void orc_score_points(const double* f, const double* p, const int32_t* cam, const double* cam_off,
+                      const double* cam_rot, int32_t n, const double* T, double* scores) {
+  double R[9], t[3];
+  orc_T_to_Rt(T, R, t);
+  const double zero3[3] = {0, 0, 0};
+  const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int i = 0; i < n; ++i) {
+    int c = cam ? cam[i] : 0;
+    const double* o = cam ? cam_off + 3 * c : zero3;
+    const double* Rc = cam ? cam_rot + 9 * c : eye;
+    scores[i] = orc_score(R, t, f + 3 * i, p + 3 * i, o, Rc);
+  }
+}
+
+/* ---- RANSAC ------------------------------------------------------------------------------ */
+/* cam == NULL -> central problem (one camera at the body origin).
+ * T_out: 3x4 row-major [R|t].  Returns 0 on success, 1 if no valid hypothesis was found. */
+int32_t orc_ransac_abs_pose(const double* f, const double* p, const int32_t* cam, const double* cam_off,
+                            const double* cam_rot, int32_t n, int32_t ncam, double thr, int32_t max_iter,
+                            int32_t adaptive, uint64_t seed, double* T_out, uint8_t* inlier_mask,
+                            int32_t* n_inliers, int32_t* best_iter, int32_t* iters_used,
+                            int32_t* counts_out /* [max_iter] or NULL */) {
+  const double zero3[3] = {0, 0, 0};
+  const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (!cam) {
+    ncam = 1;
+    cam_off = zero3;
+    cam_rot = eye;
+  }
+  /* stable partition of point indices by camera */
+  int32_t* perm = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+  int32_t* cstart = (int32_t*)calloc((size_t)ncam + 1, sizeof(int32_t));
+  int32_t* ccount = (int32_t*)calloc((size_t)ncam, sizeof(int32_t));
+  for (int i = 0; i < n; ++i) ccount[cam ? cam[i] : 0]++;
+  for (int c = 0; c < ncam; ++c) cstart[c + 1] = cstart[c] + ccount[c];
+  {
+    int32_t* fill = (int32_t*)calloc((size_t)ncam, sizeof(int32_t));
+    for (int i = 0; i < n; ++i) {
+      int c = cam ? cam[i] : 0;
+      perm[cstart[c] + fill[c]++] = i;
+    }
+    free(fill);
+  }
+
+  int best_count = -1, best_it = -1;
+  double best_R[9], best_t[3];
+  double base = 1.0; /* (1 - w^4) of the best model so far, see orc_ransac_continue */
+  int iterations = 0, used = 0;
+  for (int it = 0; it < max_iter; ++it) {
+    if (adaptive && iterations > 0 && !orc_ransac_continue(base, iterations)) break;
+    used = it + 1;
+    double R[9], t[3];
+    int ok = orc_hypothesis(f, p, cam, cam_off, cam_rot, n, perm, cstart, ccount, seed, (uint64_t)it, R, t);
+    if (counts_out) counts_out[it] = -1;
+    if (!ok) continue; /* failed solve: skipped, does not count as an iteration */
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) {
+      int c = cam ? cam[i] : 0;
+      if (orc_score(R, t, f + 3 * i, p + 3 * i, cam_off + 3 * c, cam_rot + 9 * c) < thr) cnt++;
+    }
+    if (counts_out) counts_out[it] = cnt;
+    if (cnt > best_count) {
+      best_count = cnt;
+      best_it = it;
+      memcpy(best_R, R, sizeof(R));
+      memcpy(best_t, t, sizeof(t));
+      base = orc_adaptive_base(cnt, n);
+    }
+    iterations++;
+  }
+  for (int it = used; counts_out && it < max_iter; ++it) counts_out[it] = -2; /* never drawn */
+
+  int status = 0;
+  if (best_it < 0) {
+    status = 1;
+    memcpy(best_R, eye, sizeof(eye));
+    memcpy(best_t, zero3, sizeof(zero3));
+    best_count = 0;
+  }
+  int cnt = 0;
+  for (int i = 0; i < n; ++i) {
+    int c = cam ? cam[i] : 0;
+    uint8_t in = (status == 0) && (orc_score(best_R, best_t, f + 3 * i, p + 3 * i, cam_off + 3 * c, cam_rot + 9 * c) < thr);
+    inlier_mask[i] = in;
+    cnt += in;
+  }
+  orc_Rt_to_T(best_R, best_t, T_out);
+  *n_inliers = cnt;
+  *best_iter = best_it;
+  *iters_used = used;
+  free(perm);
+  free(cstart);
+  free(ccount);
+  return status;
+}
+
+/* One hypothesis (for unit tests of the minimal solver and the sampler). */
+int32_t orc_hypothesis_once(const double* f, const double* p, const int32_t* cam, const double* cam_off,
+                            const double* cam_rot, int32_t n, int32_t ncam, uint64_t seed, int32_t it,
+                            double* T_out, int32_t* sample4) {
+  const double zero3[3] = {0, 0, 0};
+  const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (!cam) {
+    ncam = 1;
+    cam_off = zero3;
+    cam_rot = eye;
+  }
+  int32_t* perm = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+  int32_t* cstart = (int32_t*)calloc((size_t)ncam + 1, sizeof(int32_t));
+  int32_t* ccount = (int32_t*)calloc((size_t)ncam, sizeof(int32_t));
+  for (int i = 0; i < n; ++i) ccount[cam ? cam[i] : 0]++;
+  for (int c = 0; c < ncam; ++c) cstart[c + 1] = cstart[c] + ccount[c];
+  int32_t* fill = (int32_t*)calloc((size_t)ncam, sizeof(int32_t));
+  for (int i = 0; i < n; ++i) {
+    int c = cam ? cam[i] : 0;
+    perm[cstart[c] + fill[c]++] = i;
+  }
+  free(fill);
+  double R[9], t[3];
+  int32_t s[4] = {-1, -1, -1, -1};
+  int ok = orc_sample4(cam, n, perm, cstart, ccount, seed, (uint64_t)it, s);
+  if (sample4) memcpy(sample4, s, sizeof(s));
+  if (ok) ok = orc_hypothesis(f, p, cam, cam_off, cam_rot, n, perm, cstart, ccount, seed, (uint64_t)it, R, t);
+  if (ok) orc_Rt_to_T(R, t, T_out);
+  free(perm);
+  free(cstart);
+  free(ccount);
+  return ok;
+}
+
+/* All solutions of the central P3P for three correspondences (unit tests). */
+int32_t orc_p3p_kneip(const double* f3x3, const double* p3x3, double* R_out /*[4][9]*/, double* C_out /*[4][3]*/) {
+  return orc_p3p(f3x3, f3x3 + 3, f3x3 + 6, p3x3, p3x3 + 3, p3x3 + 6, R_out, C_out);
+}
+
+int32_t orc_quartic_real_roots(const double* a5, double* roots4) { return orc_quartic(a5, roots4); }
+
+/* ---- non-linear refinement ------------------------------------------------------------------ */
+/* Levenberg-Marquardt on x = (t, cayley(R)), residual_i = 1 - f_i . f_hat_i(x), forward
+ * differences.  idx == NULL -> all n points, else the m listed points.  T_io: 3x4 in/out. */
+int32_t orc_refine_abs_pose(const double* f, const double* p, const int32_t* cam, const double* cam_off,
+                            const double* cam_rot, int32_t n, const int32_t* idx, int32_t m, double* T_io,
+                            int32_t max_lm_iter, double* final_cost, int32_t* lm_iters) {
+  const double zero3[3] = {0, 0, 0};
+  const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (!cam) {
+    cam_off = zero3;
+    cam_rot = eye;
+  }
+  int cnt = idx ? m : n;
+  double R[9], t[3], x[6];
+  orc_T_to_Rt(T_io, R, t);
+  x[0] = t[0];
+  x[1] = t[1];
+  x[2] = t[2];
+  orc_rot2cayley(R, x + 3);
+  double lambda = ORC_LM_LAMBDA0;
+  double cost = 0.0;
+  int it_done = 0;
+  for (int it = 0; it < max_lm_iter; ++it) {
+    double A[21], g[6];
+    cost = 0.0;
+    for (int a = 0; a < 21; ++a) A[a] = 0.0;
+    for (int a = 0; a < 6; ++a) g[a] = 0.0;
+    for (int q = 0; q < cnt; ++q) {
+      int i = idx ? idx[q] : q;
+      int c = cam ? cam[i] : 0;
+      double r, J[6];
+      orc_residual_jac(x, f + 3 * i, p + 3 * i, cam_off + 3 * c, cam_rot + 9 * c, &r, J);
+      cost += r * r;
+      int a = 0;
+      for (int u = 0; u < 6; ++u) {
+        g[u] += J[u] * r;
+        for (int v = u; v < 6; ++v) A[a++] += J[u] * J[v];
+      }
+    }
+    it_done = it;
+    /* inner loop: raise lambda until the step reduces the cost */
+    int accepted = 0, converged = 0;
+    for (int tries = 0; tries < ORC_LM_MAX_TRIES; ++tries) {
+      double dx[6], xn[6];
+      if (!orc_solve_damped(A, g, lambda, dx)) {
+        lambda *= 10.0;
+        continue;
+      }
+      for (int u = 0; u < 6; ++u) xn[u] = x[u] + dx[u];
+      double cn = 0.0;
+      for (int q = 0; q < cnt; ++q) {
+        int i = idx ? idx[q] : q;
+        int c = cam ? cam[i] : 0;
+        double r = orc_residual(xn, f + 3 * i, p + 3 * i, cam_off + 3 * c, cam_rot + 9 * c);
+        cn += r * r;
+      }
+      if (cn < cost) {
+        double dxn = 0.0, xnn = 0.0;
+        for (int u = 0; u < 6; ++u) {
+          dxn += dx[u] * dx[u];
+          xnn += xn[u] * xn[u];
+        }
+        converged = ((cost - cn) <= ORC_LM_FTOL * cost) || (sqrt(dxn) <= ORC_LM_XTOL * (sqrt(xnn) + ORC_LM_XTOL));
+        for (int u = 0; u < 6; ++u) x[u] = xn[u];
+        cost = cn;
+        lambda *= 0.1;
+        if (lambda < 1e-15) lambda = 1e-15;
+        accepted = 1;
+        break;
+      }
+      lambda *= 10.0;
+    }
+    it_done = it + 1;
+    if (!accepted || converged) break;
+  }
+  orc_cayley2rot(x + 3, R);
+  t[0] = x[0];
+  t[1] = x[1];
+  t[2] = x[2];
+  orc_Rt_to_T(R, t, T_io);
+  if (final_cost) *final_cost = cost;
+  if (lm_iters) *lm_iters = it_done;
+  return 0;
+}

@@ -1,0 +1,167 @@
+"""GPU parity: sosvo_ransac_abs_pose / sosvo_refine_abs_pose (through the C ABI) against the
+CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): inlier masks, inlier index lists, per-hypothesis inlier counts
+and the winning iteration are integer work -> bit-exact.  The RANSAC pose is produced by the same
+IEEE operations in the same order on both sides -> compared bit-exact too.  The LM-refined pose
+uses a different (fixed) summation order on the GPU -> rel-tol 1e-6 as north_star states."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _pack(problems, S, noncentral):
+    P = len(problems)
+    f = np.zeros((P, S, 3))
+    p = np.zeros((P, S, 3))
+    cam = np.zeros((P, S), dtype=np.int32)
+    n = np.zeros(P, dtype=np.int32)
+    for b, pr in enumerate(problems):
+        k = pr["f"].shape[0]
+        n[b] = k
+        f[b, :k] = pr["f"]
+        p[b, :k] = pr["p"]
+        if noncentral:
+            cam[b, :k] = pr["cam"]
+    return f, p, cam, n
+
+
+def _to(dev, *arrs):
+    return [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in arrs]
+
+
+def _run_batch(ctx, problems, S, noncentral, max_iter, seed, adaptive=False, ident=True, thr=synth.THR_5DEG):
+    f, p, cam, n = _pack(problems, S, noncentral)
+    dev = ctx.device
+    tf, tp, tcam, tn = _to(dev, f, p, cam, n)
+    kw = {}
+    if noncentral:
+        off, rot = _to(dev, problems[0]["cam_off"], problems[0]["cam_rot"])
+        kw = dict(cam=tcam, cam_off=off, cam_rot=rot, cam_rot_identity=ident)
+    out = ctx.ransac_abs_pose(tf, tp, tn, thr, max_iter, seed=seed, adaptive=adaptive, want_counts=True, **kw)
+    ctx.synchronize()
+    got = {k: v.cpu().numpy() for k, v in out.items()}
+    for b, pr in enumerate(problems):
+        okw = dict(cam=pr["cam"], cam_off=pr["cam_off"], cam_rot=pr["cam_rot"]) if noncentral else {}
+        want = oracle.ransac_abs_pose(pr["f"], pr["p"], thr, max_iter, seed=seed + b, adaptive=adaptive,
+                                      want_counts=True, **okw)
+        k = n[b]
+        used = want["iters_used"]
+        assert got["info"][b, 1] == used, "iterations drawn, problem %d" % b
+        assert np.array_equal(got["counts"][b, :used], want["counts"][:used]), "hypothesis counts, problem %d" % b
+        assert got["info"][b, 0] == want["best_iter"], "winning iteration, problem %d" % b
+        assert got["info"][b, 2] == want["status"]
+        assert np.array_equal(got["mask"][b, :k].astype(bool), want["mask"]), "inlier mask, problem %d" % b
+        assert got["n_inliers"][b] == want["n_inliers"]
+        assert np.array_equal(got["idx"][b, : want["n_inliers"]], np.nonzero(want["mask"])[0])
+        assert np.array_equal(got["T"][b], want["T"]), "RANSAC pose bits, problem %d" % b
+    return (tf, tp, tcam, tn, kw), out, got
+
+
+def test_sqrt_div_are_ieee(ctx):
+    # the bit-exactness argument rests on correctly rounded FP64 sqrt and divide on the device:
+    # torch's sqrt/div kernels use the same device instructions sequences; check against numpy.
+    rng = np.random.default_rng(0)
+    a = np.abs(rng.normal(size=200000)) * 10.0 ** rng.integers(-30, 30, 200000)
+    b = rng.normal(size=200000) * 10.0 ** rng.integers(-30, 30, 200000)
+    ta, tb = _to(ctx.device, a, b)
+    assert np.array_equal(torch.sqrt(ta).cpu().numpy(), np.sqrt(a))
+    assert np.array_equal((ta / tb).cpu().numpy(), a / b)
+
+
+def test_central_small_batch(ctx):
+    rng = np.random.default_rng(1)
+    probs = [synth.make_abs_pose_problem(rng, n, inlier_frac=fr, noise_deg=nz, noncentral=False)
+             for n, fr, nz in [(64, 1.0, 0.0), (100, 0.5, 0.1), (257, 0.35, 0.2), (512, 0.8, 0.5), (5, 1.0, 0.0)]]
+    _run_batch(ctx, probs, 512, False, 100, seed=1234)
+
+
+def test_noncentral_ragged_batch_identity_and_general_path(ctx):
+    rng = np.random.default_rng(2)
+    probs = [synth.make_abs_pose_problem(rng, n, inlier_frac=0.4, noise_deg=0.2, noncentral=True, n_top=nt)
+             for n, nt in [(300, 150), (1000, 100), (33, 30), (700, 699), (64, 0), (1024, 512)]]
+    _run_batch(ctx, probs, 1024, True, 200, seed=77, ident=True)
+    _run_batch(ctx, probs, 1024, True, 200, seed=77, ident=False)
+
+
+def test_rotated_cameras_general_path(ctx):
+    rng = np.random.default_rng(3)
+    # rig whose cameras are rotated wrt the body: bearings are expressed in the rotated frames
+    Rc = np.stack([synth.rot_from_axis_angle([0, 0, 1], 0.3), synth.rot_from_axis_angle([1, 1, 0], -0.2)])
+    probs = []
+    for n in (400, 800):
+        pr = synth.make_abs_pose_problem(rng, n, inlier_frac=0.5, noise_deg=0.1, noncentral=True)
+        pr["f"] = np.einsum("nji,nj->ni", Rc[pr["cam"]], pr["f"])  # f_cam = Rc^T f_body
+        pr["cam_rot"] = Rc
+        probs.append(pr)
+    _, _, got = _run_batch(ctx, probs, 800, True, 150, seed=5, ident=False)
+    for b, pr in enumerate(probs):
+        assert got["n_inliers"][b] >= 0.9 * pr["is_inlier"].sum()
+
+
+def test_degenerate_inputs(ctx):
+    rng = np.random.default_rng(4)
+    few = synth.make_abs_pose_problem(rng, 3, inlier_frac=1.0, noise_deg=0.0, noncentral=False)
+    empty = dict(f=np.zeros((0, 3)), p=np.zeros((0, 3)), cam=None, cam_off=None, cam_rot=None)
+    coll = synth.make_abs_pose_problem(rng, 50, inlier_frac=1.0, noise_deg=0.0, noncentral=False)
+    coll["p"][:] = np.outer(np.linspace(1, 2, 50), [100.0, 200.0, 300.0])  # collinear world points
+    _, _, got = _run_batch(ctx, [few, empty, coll], 64, False, 20, seed=9)
+    assert got["info"][0, 2] == 1 and got["info"][1, 2] == 1 and got["info"][2, 2] == 1
+    assert np.array_equal(got["T"][1][:, :3], np.eye(3))
+
+
+def test_adaptive_stop_matches_sequential_semantics(ctx):
+    rng = np.random.default_rng(5)
+    probs = [synth.make_abs_pose_problem(rng, 900, inlier_frac=fr, noise_deg=0.2, noncentral=True)
+             for fr in (0.3, 0.6, 0.95)]
+    _, _, got = _run_batch(ctx, probs, 900, True, 500, seed=21, adaptive=True)
+    assert got["info"][2, 1] < got["info"][0, 1] <= 500  # more inliers -> earlier stop
+
+
+def test_c2_full_size(ctx):
+    # BASELINE config 2: N = 4000 stacked top+bottom correspondences, 2000 iterations, 35 % inliers
+    rng = np.random.default_rng(6)
+    probs = [synth.make_abs_pose_problem(rng, 4000, inlier_frac=0.35, noise_deg=0.2, noncentral=True)
+             for _ in range(3)]
+    (tf, tp, tcam, tn, kw), out, got = _run_batch(ctx, probs, 4000, True, 2000, seed=2024)
+    for b, pr in enumerate(probs):
+        assert got["n_inliers"][b] >= 0.9 * pr["is_inlier"].sum()
+    # K9 on the RANSAC inliers, compared with the oracle's LM started from the same pose
+    T = out["T"].clone()
+    kw2 = {k: v for k, v in kw.items() if k != "cam_rot_identity"}
+    T, cost, iters = ctx.refine_abs_pose(tf, tp, tn, T, idx=out["idx"], m=out["n_inliers"], **kw2)
+    ctx.synchronize()
+    T = T.cpu().numpy()
+    for b, pr in enumerate(probs):
+        idx = got["idx"][b, : got["n_inliers"][b]]
+        want, wcost, wit = oracle.refine_abs_pose(pr["f"], pr["p"], got["T"][b], idx=idx, cam=pr["cam"],
+                                                  cam_off=pr["cam_off"], cam_rot=pr["cam_rot"])
+        assert np.allclose(T[b], want, rtol=1e-6, atol=1e-9), "refined pose, problem %d" % b
+        assert wcost <= oracle.score_points(pr["f"][idx], pr["p"][idx], got["T"][b], cam=pr["cam"][idx],
+                                            cam_off=pr["cam_off"], cam_rot=pr["cam_rot"]).__pow__(2).sum()
+
+
+def test_refine_noise_free_reaches_ground_truth(ctx):
+    rng = np.random.default_rng(7)
+    probs = [synth.make_abs_pose_problem(rng, 500, inlier_frac=1.0, noise_deg=0.0, noncentral=nc)
+             for nc in (True, True)]
+    f, p, cam, n = _pack(probs, 512, True)
+    T0 = np.stack([np.hstack([pr["R"] @ synth.rot_from_axis_angle([1, 2, 3], 0.02),
+                              (pr["t"] + [5., -3, 4])[:, None]]) for pr in probs])
+    dev = ctx.device
+    tf, tp, tcam, tn, tT, off, rot = _to(dev, f, p, cam, n, T0, probs[0]["cam_off"], probs[0]["cam_rot"])
+    T, cost, iters = ctx.refine_abs_pose(tf, tp, tn, tT, cam=tcam, cam_off=off, cam_rot=rot, max_lm_iter=200)
+    ctx.synchronize()
+    T = T.cpu().numpy()
+    for b, pr in enumerate(probs):
+        want, _, _ = oracle.refine_abs_pose(pr["f"], pr["p"], T0[b], cam=pr["cam"], cam_off=pr["cam_off"],
+                                            cam_rot=pr["cam_rot"], max_lm_iter=200)
+        a1, t1 = synth.pose_error(T[b], pr["R"], pr["t"])
+        a0, t0 = synth.pose_error(T0[b], pr["R"], pr["t"])
+        assert a1 < 1e-2 * a0 and t1 < 1e-2 * t0
+        assert np.allclose(T[b], want, rtol=1e-6, atol=1e-6)

@@ -1,0 +1,106 @@
+"""CPU: pin the RANSAC / P3P / LM oracle with noise-free known-pose problems (the reference has
+no golden vectors for OpenGV's output) and check the sampler's invariants."""
+import numpy as np
+
+import oracle
+import synth
+
+
+def test_quartic_real_roots():
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        r = np.sort(rng.uniform(-2, 2, 4))
+        if np.min(np.diff(r)) < 1e-2:
+            continue
+        got = np.sort(oracle.quartic_real_roots(np.poly(r) * rng.uniform(0.1, 10)))
+        assert got.shape == (4,) and np.allclose(got, r, atol=1e-8)
+    # two real + one complex pair
+    a = np.convolve(np.poly([0.3, -1.2]), [1, -2 * 0.5, 0.25 + 0.7 ** 2])
+    assert np.allclose(np.sort(oracle.quartic_real_roots(a)), [-1.2, 0.3], atol=1e-10)
+    # no real root
+    assert oracle.quartic_real_roots([1, 0, 2, 0, 5]).size == 0
+    # biquadratic
+    assert np.allclose(np.sort(oracle.quartic_real_roots([1, 0, -5, 0, 4])), [-2, -1, 1, 2], atol=1e-12)
+
+
+def test_p3p_recovers_known_pose():
+    rng = np.random.default_rng(1)
+    errs = []
+    for _ in range(300):
+        pr = synth.make_abs_pose_problem(rng, 3, inlier_frac=1.0, noise_deg=0.0, noncentral=False)
+        Rs, Cs = oracle.p3p_kneip(pr["f"], pr["p"])
+        assert 1 <= len(Rs) <= 4
+        for R in Rs:
+            assert np.allclose(R @ R.T, np.eye(3), atol=1e-8) and np.linalg.det(R) > 0
+        errs.append(min(max(np.abs(R - pr["R"]).max(), np.abs(C - pr["t"]).max() / np.linalg.norm(pr["t"]))
+                        for R, C in zip(Rs, Cs)))
+    errs = np.array(errs)
+    assert np.median(errs) < 1e-11 and np.percentile(errs, 95) < 1e-8
+
+
+def test_sampler_distinct_and_same_camera():
+    rng = np.random.default_rng(2)
+    pr = synth.make_abs_pose_problem(rng, 50, inlier_frac=1.0, noise_deg=0.0, noncentral=True, n_top=20)
+    seen = set()
+    errs = []
+    for it in range(400):
+        ok, T, s = oracle.hypothesis_once(pr["f"], pr["p"], 99, it, pr["cam"], pr["cam_off"], pr["cam_rot"])
+        assert len(set(s.tolist())) == 4 and s.min() >= 0 and s.max() < 50
+        assert len({int(pr["cam"][i]) for i in s[:3]}) == 1
+        seen.add(tuple(s.tolist()))
+        if ok:
+            errs.append(max(synth.pose_error(T, pr["R"], pr["t"])))
+    assert len(seen) > 390
+    errs = np.array(errs)  # minimal samples can be ill-conditioned: bound the bulk, not the tail
+    assert len(errs) > 390 and np.median(errs) < 1e-9 and np.percentile(errs, 95) < 1e-5
+
+
+def test_ransac_noise_free_is_exact_and_deterministic():
+    rng = np.random.default_rng(3)
+    for nc in (False, True):
+        pr = synth.make_abs_pose_problem(rng, 200, inlier_frac=1.0, noise_deg=0.0, noncentral=nc)
+        kw = dict(cam=pr["cam"], cam_off=pr["cam_off"], cam_rot=pr["cam_rot"])
+        r1 = oracle.ransac_abs_pose(pr["f"], pr["p"], synth.THR_5DEG, 20, seed=5, **kw)
+        r2 = oracle.ransac_abs_pose(pr["f"], pr["p"], synth.THR_5DEG, 20, seed=5, **kw)
+        assert r1["status"] == 0 and r1["n_inliers"] == 200 and r1["mask"].all()
+        assert np.array_equal(r1["T"], r2["T"])
+        ang, terr = synth.pose_error(r1["T"], pr["R"], pr["t"])
+        assert ang < 1e-6 and terr < 1e-6  # reference bar: pose within 1e-6 rel
+
+
+def test_ransac_with_outliers_and_adaptive_stop():
+    rng = np.random.default_rng(4)
+    pr = synth.make_abs_pose_problem(rng, 1500, inlier_frac=0.35, noise_deg=0.2, noncentral=True)
+    kw = dict(cam=pr["cam"], cam_off=pr["cam_off"], cam_rot=pr["cam_rot"])
+    full = oracle.ransac_abs_pose(pr["f"], pr["p"], synth.THR_5DEG, 600, seed=11, want_counts=True, **kw)
+    assert full["iters_used"] == 600
+    assert full["n_inliers"] >= 0.9 * pr["is_inlier"].sum()
+    assert full["counts"].max() == full["n_inliers"] and full["counts"][full["best_iter"]] == full["n_inliers"]
+    assert np.argmax(full["counts"]) == full["best_iter"]  # first maximum wins
+    scores = oracle.score_points(pr["f"], pr["p"], full["T"], **kw)
+    assert np.array_equal(scores < synth.THR_5DEG, full["mask"])
+    ad = oracle.ransac_abs_pose(pr["f"], pr["p"], synth.THR_5DEG, 600, seed=11, adaptive=True, **kw)
+    assert ad["iters_used"] < 600
+    first = full["counts"][: ad["iters_used"]]
+    assert ad["best_iter"] == int(np.argmax(first)) and ad["n_inliers"] == first.max()
+    # too few points -> no model
+    none = oracle.ransac_abs_pose(pr["f"][:3], pr["p"][:3], synth.THR_5DEG, 10, seed=1)
+    assert none["status"] == 1 and none["n_inliers"] == 0 and np.array_equal(none["T"][:, :3], np.eye(3))
+
+
+def test_refine_converges_to_known_pose():
+    rng = np.random.default_rng(5)
+    for nc in (False, True):
+        pr = synth.make_abs_pose_problem(rng, 300, inlier_frac=1.0, noise_deg=0.0, noncentral=nc)
+        kw = dict(cam=pr["cam"], cam_off=pr["cam_off"], cam_rot=pr["cam_rot"])
+        T0 = np.hstack([pr["R"] @ synth.rot_from_axis_angle([1, 2, 3], 0.02), (pr["t"] + [5., -3, 4])[:, None]])
+        T1, cost, its = oracle.refine_abs_pose(pr["f"], pr["p"], T0, max_lm_iter=200, **kw)
+        a0, t0 = synth.pose_error(T0, pr["R"], pr["t"])
+        a1, t1 = synth.pose_error(T1, pr["R"], pr["t"])
+        assert a1 < 1e-2 * a0 and t1 < 1e-2 * t0 and cost < 1e-18
+        idx = np.arange(0, 300, 2, dtype=np.int32)
+        T2, _, _ = oracle.refine_abs_pose(pr["f"], pr["p"], T0, idx=idx, max_lm_iter=50, **kw)
+        T3, _, _ = oracle.refine_abs_pose(pr["f"][idx], pr["p"][idx], T0, max_lm_iter=50,
+                                          cam=None if pr["cam"] is None else pr["cam"][idx],
+                                          cam_off=pr["cam_off"], cam_rot=pr["cam_rot"])
+        assert np.array_equal(T2, T3)

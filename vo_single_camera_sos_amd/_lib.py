@@ -44,7 +44,13 @@ SIGNATURES = {
     "sosvo_timer_elapsed_ms": (c_i32, [c_p, ctypes.POINTER(c_f32)]),
     "sosvo_match_hamming": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p]),
     "sosvo_sort_matches": (c_i32, [c_p, c_p, c_p, c_i32, c_i32, c_p]),
+    "sosvo_ransac_abs_pose": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_p, c_i32, c_i32, c_f64,
+                                      c_i32, c_i32, c_u64, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "sosvo_refine_abs_pose": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_p, c_i32, c_i32, c_p, c_p, c_i32,
+                                      c_p, c_p, c_p]),
 }
+
+FLAG_CAM_ROT_IDENTITY = 1
 
 _lib = None
 

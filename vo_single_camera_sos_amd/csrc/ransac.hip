@@ -1,0 +1,617 @@
+// K8/K10 -- 3D-2D absolute-pose RANSAC (central and non-central rig) and K9 -- LM refinement.
+//
+// Reference call sites replaced (the arithmetic itself lives in OpenGV, outside the tree):
+//   omnistereo/pose_est_tools.py:785  absolute_pose_noncentral_ransac(b, cam, p, offsets, rots, thr, iters)
+//   omnistereo/pose_est_tools.py:915  absolute_pose_ransac(b, p, algo, thr, iters)
+//   omnistereo/pose_est_tools.py:830 / :937  *_optimize_nonlinear
+//
+// Mapping to CDNA4 (no MFMA: there is no contraction, only per-point FP64 geometry):
+//   1. prepare     one workgroup per problem: stable partition of point indices by camera.
+//   2. hypotheses  one lane per (problem, iteration): counter-based sample, Kneip P3P in the
+//                  sampled camera, 4th-point disambiguation -> (R, t, -R^T t) in HBM (128 B each).
+//   3. score       the iters x N hot loop.  A lane keeps its point(s) in VGPRs; the hypothesis is
+//                  wave-uniform, fetched with scalar loads (SGPR operands); the inlier decision is
+//                  a 64-bit __ballot + popcount per wave, summed in LDS, one integer atomic per
+//                  (workgroup, hypothesis).  A squared-cosine test with a 1e-9 guard band decides
+//                  all but near-threshold points without FP64 sqrt/div; the guard band falls back
+//                  to the exact reference formula, so counts are bit-identical to it.
+//   4. select      sequential semantics of sac::Ransac (strictly-better update, adaptive stop)
+//                  replayed over the counts; exact inlier mask + ascending index list of the winner.
+//   5. refine      one workgroup per problem, Levenberg-Marquardt on (t, Cayley) with fixed-order
+//                  reductions (deterministic run to run).
+#include "common.h"
+#include "ransac_core.h"
+
+namespace {
+
+constexpr int kMaxCam = 8;
+constexpr int kHypDoubles = 16;  // R[9], t[3], -R^T t [3], pad
+constexpr int kThreads = 256;
+constexpr int kScoreHypChunkMax = 512;
+
+__device__ const double kEye9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+__device__ const double kZero3[3] = {0, 0, 0};
+
+__device__ __forceinline__ uint64_t problem_seed(uint64_t seed, int b) { return seed + (uint64_t)b; }
+
+// ---- 1. prepare -----------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void ransac_prepare_kernel(const int32_t* __restrict__ cam,
+                                                                  const int32_t* __restrict__ n_arr, int stride,
+                                                                  int ncam, int32_t* __restrict__ perm,
+                                                                  int32_t* __restrict__ cinfo) {
+  __shared__ int cnt[kThreads][kMaxCam];
+  __shared__ int cstart[kMaxCam + 1];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int n = min(n_arr[b], stride);
+  const int chunk = (n + kThreads - 1) / kThreads;
+  const int begin = min(n, tid * chunk), end = min(n, begin + chunk);
+  const int32_t* camb = cam ? cam + (size_t)b * stride : nullptr;
+  int local[kMaxCam];
+#pragma unroll
+  for (int c = 0; c < kMaxCam; ++c) local[c] = 0;
+  for (int i = begin; i < end; ++i) {
+    int c = camb ? camb[i] : 0;
+    c = max(0, min(ncam - 1, c));
+#pragma unroll
+    for (int k = 0; k < kMaxCam; ++k) local[k] += (k == c);
+  }
+#pragma unroll
+  for (int c = 0; c < kMaxCam; ++c) cnt[tid][c] = local[c];
+  __syncthreads();
+  if (tid < kMaxCam) {
+    int running = 0;
+    for (int t = 0; t < kThreads; ++t) {
+      const int v = cnt[t][tid];
+      cnt[t][tid] = running;
+      running += v;
+    }
+    cinfo[(size_t)b * (2 * kMaxCam + 1) + kMaxCam + 1 + tid] = running;  // ccount
+    cstart[tid + 1] = running;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    cstart[0] = 0;
+    for (int c = 0; c < kMaxCam; ++c) cstart[c + 1] += cstart[c];
+    for (int c = 0; c <= kMaxCam; ++c) cinfo[(size_t)b * (2 * kMaxCam + 1) + c] = cstart[c];
+  }
+  __syncthreads();
+  int pos[kMaxCam];
+#pragma unroll
+  for (int c = 0; c < kMaxCam; ++c) pos[c] = cstart[c] + cnt[tid][c];
+  for (int i = begin; i < end; ++i) {
+    int c = camb ? camb[i] : 0;
+    c = max(0, min(ncam - 1, c));
+    int dst = 0;
+#pragma unroll
+    for (int k = 0; k < kMaxCam; ++k) {
+      if (k == c) {
+        dst = pos[k];
+        pos[k] += 1;
+      }
+    }
+    perm[(size_t)b * stride + dst] = i;
+  }
+}
+
+// ---- 2. hypotheses --------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void ransac_hyp_kernel(const double* __restrict__ f, const double* __restrict__ p,
+                                                        const int32_t* __restrict__ cam,
+                                                        const double* __restrict__ cam_off,
+                                                        const double* __restrict__ cam_rot,
+                                                        const int32_t* __restrict__ n_arr, int stride, int H,
+                                                        uint64_t seed, const int32_t* __restrict__ perm,
+                                                        const int32_t* __restrict__ cinfo, double* __restrict__ hyp,
+                                                        int32_t* __restrict__ counts) {
+  const int b = blockIdx.y;
+  const int it = blockIdx.x * blockDim.x + threadIdx.x;
+  if (it >= H) return;
+  const int n = min(n_arr[b], stride);
+  const size_t base = (size_t)b * stride;
+  const int32_t* ci = cinfo + (size_t)b * (2 * kMaxCam + 1);
+  const double* off = cam ? cam_off : kZero3;
+  const double* rot = cam ? cam_rot : kEye9;
+  double R[9], t[3];
+  const int ok = sv_hypothesis(f + 3 * base, p + 3 * base, cam ? cam + base : nullptr, off, rot, n, perm + base, ci,
+                               ci + kMaxCam + 1, problem_seed(seed, b), (uint64_t)it, R, t);
+  double* h = hyp + ((size_t)b * H + it) * kHypDoubles;
+  if (ok) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) h[k] = R[k];
+    h[9] = t[0];
+    h[10] = t[1];
+    h[11] = t[2];
+    h[12] = -(((R[0] * t[0]) + (R[3] * t[1])) + (R[6] * t[2]));
+    h[13] = -(((R[1] * t[0]) + (R[4] * t[1])) + (R[7] * t[2]));
+    h[14] = -(((R[2] * t[0]) + (R[5] * t[1])) + (R[8] * t[2]));
+  } else {
+    h[0] = __longlong_as_double(0x7FF8000000000000LL);
+  }
+  counts[(size_t)b * H + it] = ok ? 0 : -1;
+}
+
+// ---- 3. score -------------------------------------------------------------------------------
+// Exact reference decision for one point given (R, it = -R^T t): sv_score(...) < thr, with the
+// translation term already folded (bitwise the same value sv_score computes internally).
+template <bool IDENT>
+__device__ __forceinline__ bool inlier_exact(const double* __restrict__ h, const double fx, const double fy,
+                                             const double fz, const double px, const double py, const double pz,
+                                             const double ox, const double oy, const double oz, const double* Rc,
+                                             const double thr) {
+  const double vx = (((h[0] * px) + (h[3] * py)) + (h[6] * pz)) + h[12];
+  const double vy = (((h[1] * px) + (h[4] * py)) + (h[7] * pz)) + h[13];
+  const double vz = (((h[2] * px) + (h[5] * py)) + (h[8] * pz)) + h[14];
+  const double wx = vx - ox, wy = vy - oy, wz = vz - oz;
+  double ux = wx, uy = wy, uz = wz;
+  if (!IDENT) {
+    ux = ((Rc[0] * wx) + (Rc[3] * wy)) + (Rc[6] * wz);
+    uy = ((Rc[1] * wx) + (Rc[4] * wy)) + (Rc[7] * wz);
+    uz = ((Rc[2] * wx) + (Rc[5] * wy)) + (Rc[8] * wz);
+  }
+  const double nrm = sqrt(((ux * ux) + (uy * uy)) + (uz * uz));
+  const double gx = ux / nrm, gy = uy / nrm, gz = uz / nrm;
+  return (1.0 - (((fx * gx) + (fy * gy)) + (fz * gz))) < thr;
+}
+
+template <bool IDENT, int PPT>
+__global__ __launch_bounds__(kThreads) void ransac_score_kernel(
+    const double* __restrict__ f, const double* __restrict__ p, const int32_t* __restrict__ cam,
+    const double* __restrict__ cam_off, const double* __restrict__ cam_rot, const int32_t* __restrict__ n_arr,
+    int stride, int H, int hchunk, double thr, int fast_ok, const double* __restrict__ hyp,
+    int32_t* __restrict__ counts) {
+  __shared__ int lcnt[kScoreHypChunkMax];
+  const int tid = threadIdx.x, b = blockIdx.z;
+  const int n = min(n_arr[b], stride);
+  const int p0 = blockIdx.x * (kThreads * PPT);
+  if (p0 >= n) return;
+  const int h0 = blockIdx.y * hchunk;
+  const int h1 = min(H, h0 + hchunk);
+  for (int k = tid; k < hchunk; k += kThreads) lcnt[k] = 0;
+
+  double fx[PPT], fy[PPT], fz[PPT], px[PPT], py[PPT], pz[PPT], ox[PPT], oy[PPT], oz[PPT];
+  double Rc[IDENT ? 1 : 9];
+  bool valid[PPT];
+  const size_t base = (size_t)b * stride;
+#pragma unroll
+  for (int r = 0; r < PPT; ++r) {
+    const int i = p0 + r * kThreads + tid;
+    valid[r] = i < n;
+    const size_t row = base + (valid[r] ? i : p0);
+    fx[r] = f[3 * row + 0];
+    fy[r] = f[3 * row + 1];
+    fz[r] = f[3 * row + 2];
+    px[r] = p[3 * row + 0];
+    py[r] = p[3 * row + 1];
+    pz[r] = p[3 * row + 2];
+    const int c = cam ? cam[row] : 0;
+    const double* o = cam ? cam_off + 3 * c : kZero3;
+    ox[r] = o[0];
+    oy[r] = o[1];
+    oz[r] = o[2];
+    if (!IDENT) {
+      const double* rc = cam ? cam_rot + 9 * c : kEye9;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Rc[k] = rc[k];
+    }
+  }
+  const double c1 = 1.0 - thr;
+  const double c2 = c1 * c1;
+  const double c2hi = c2 * (1.0 + 1e-9), c2lo = c2 * (1.0 - 1e-9);
+  __syncthreads();
+
+  const double* hb = hyp + (size_t)b * H * kHypDoubles;
+  for (int h = h0; h < h1; ++h) {
+    const double* hp = hb + (size_t)h * kHypDoubles;  // wave-uniform address -> scalar loads
+    const double r0 = hp[0];
+    if (r0 != r0) continue;  // failed minimal solve
+    const double r1 = hp[1], r2 = hp[2], r3 = hp[3], r4 = hp[4], r5 = hp[5], r6 = hp[6], r7 = hp[7], r8 = hp[8];
+    const double ix = hp[12], iy = hp[13], iz = hp[14];
+    int wave_total = 0;
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) {
+      const double vx = (((r0 * px[r]) + (r3 * py[r])) + (r6 * pz[r])) + ix;
+      const double vy = (((r1 * px[r]) + (r4 * py[r])) + (r7 * pz[r])) + iy;
+      const double vz = (((r2 * px[r]) + (r5 * py[r])) + (r8 * pz[r])) + iz;
+      const double wx = vx - ox[r], wy = vy - oy[r], wz = vz - oz[r];
+      double ux = wx, uy = wy, uz = wz;
+      if (!IDENT) {
+        ux = ((Rc[0] * wx) + (Rc[3] * wy)) + (Rc[6] * wz);
+        uy = ((Rc[1] * wx) + (Rc[4] * wy)) + (Rc[7] * wz);
+        uz = ((Rc[2] * wx) + (Rc[5] * wy)) + (Rc[8] * wz);
+      }
+      const double s = ((fx[r] * ux) + (fy[r] * uy)) + (fz[r] * uz);
+      const double q = ((ux * ux) + (uy * uy)) + (uz * uz);
+      const double lhs = s * s;
+      bool inl;
+      if (fast_ok && !(s > 0.0)) {
+        inl = false;
+      } else if (fast_ok && lhs > c2hi * q) {
+        inl = true;
+      } else if (fast_ok && lhs < c2lo * q) {
+        inl = false;
+      } else {
+        const double nrm = sqrt(q);
+        const double gx = ux / nrm, gy = uy / nrm, gz = uz / nrm;
+        inl = (1.0 - (((fx[r] * gx) + (fy[r] * gy)) + (fz[r] * gz))) < thr;
+      }
+      wave_total += __popcll(__ballot(inl && valid[r]));
+    }
+    if ((tid & 63) == 0 && wave_total) atomicAdd(&lcnt[h - h0], wave_total);
+  }
+  __syncthreads();
+  for (int k = tid; k < h1 - h0; k += kThreads) {
+    const int v = lcnt[k];
+    if (v) atomicAdd(&counts[(size_t)b * H + h0 + k], v);
+  }
+}
+
+// ---- 4. select ------------------------------------------------------------------------------
+template <bool IDENT>
+__global__ __launch_bounds__(kThreads) void ransac_select_kernel(
+    const double* __restrict__ f, const double* __restrict__ p, const int32_t* __restrict__ cam,
+    const double* __restrict__ cam_off, const double* __restrict__ cam_rot, const int32_t* __restrict__ n_arr,
+    int stride, int H, double thr, int adaptive, const double* __restrict__ hyp, const int32_t* __restrict__ counts,
+    double* __restrict__ T_out, uint8_t* __restrict__ mask, int32_t* __restrict__ inl_idx,
+    int32_t* __restrict__ n_inl, int32_t* __restrict__ info) {
+  __shared__ long long red[kThreads / 64];
+  __shared__ int redv[kThreads / 64];
+  __shared__ int s_best_it, s_used, s_nvalid;
+  __shared__ int wave_off[kThreads / 64 + 1];
+  __shared__ int s_running;
+  const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int n = min(n_arr[b], stride);
+  const int32_t* cb = counts + (size_t)b * H;
+
+  // number of valid hypotheses (diagnostic) and, when not adaptive, the arg-max
+  long long best_key = -1;
+  int nvalid = 0;
+  for (int it = tid; it < H; it += kThreads) {
+    const int c = cb[it];
+    if (c >= 0) {
+      nvalid++;
+      const long long key = ((long long)c << 32) | (long long)(0x7FFFFFFF - it);  // max count, then min it
+      best_key = key > best_key ? key : best_key;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const long long other = __shfl_down(best_key, o);
+    best_key = other > best_key ? other : best_key;
+    nvalid += __shfl_down(nvalid, o);
+  }
+  if (lane == 0) {
+    red[wid] = best_key;
+    redv[wid] = nvalid;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    long long k = red[0];
+    int nv = redv[0];
+    for (int w = 1; w < kThreads / 64; ++w) {
+      k = red[w] > k ? red[w] : k;
+      nv += redv[w];
+    }
+    s_nvalid = nv;
+    if (!adaptive) {
+      s_best_it = k < 0 ? -1 : (0x7FFFFFFF - (int)(k & 0xFFFFFFFFLL));
+      s_used = H;
+    } else {
+      // replay of the sequential loop: strictly-better update, stop when iterations >= k
+      int best_count = -1, best_it = -1, iterations = 0, used = 0;
+      double base = 1.0;
+      for (int it = 0; it < H; ++it) {
+        if (iterations > 0 && !sv_ransac_continue(base, iterations)) break;
+        used = it + 1;
+        const int c = cb[it];
+        if (c < 0) continue;
+        if (c > best_count) {
+          best_count = c;
+          best_it = it;
+          base = sv_adaptive_base(c, n);
+        }
+        iterations++;
+      }
+      s_best_it = best_it;
+      s_used = used;
+    }
+    s_running = 0;
+  }
+  __syncthreads();
+  const int best_it = s_best_it;
+  const size_t base = (size_t)b * stride;
+  if (best_it < 0) {
+    for (int i = tid; i < n; i += kThreads) mask[base + i] = 0;
+    if (tid < 12) T_out[(size_t)b * 12 + tid] = (tid == 0 || tid == 5 || tid == 10) ? 1.0 : 0.0;
+    if (tid == 0) {
+      n_inl[b] = 0;
+      info[4 * b + 0] = -1;
+      info[4 * b + 1] = s_used;
+      info[4 * b + 2] = 1;
+      info[4 * b + 3] = s_nvalid;
+    }
+    return;
+  }
+  const double* hp = hyp + ((size_t)b * H + best_it) * kHypDoubles;
+  // exact inlier mask of the winner + ascending index list (stable compaction)
+  for (int i0 = 0; i0 < n; i0 += kThreads) {
+    const int i = i0 + tid;
+    bool inl = false;
+    if (i < n) {
+      const size_t row = base + i;
+      const int c = cam ? cam[row] : 0;
+      const double* o = cam ? cam_off + 3 * c : kZero3;
+      const double* rc = cam ? cam_rot + 9 * c : kEye9;
+      inl = inlier_exact<IDENT>(hp, f[3 * row], f[3 * row + 1], f[3 * row + 2], p[3 * row], p[3 * row + 1],
+                                p[3 * row + 2], o[0], o[1], o[2], rc, thr);
+      mask[row] = inl ? 1 : 0;
+    }
+    const unsigned long long bal = __ballot(inl);
+    if (lane == 0) wave_off[wid + 1] = __popcll(bal);
+    __syncthreads();
+    if (tid == 0) {
+      wave_off[0] = s_running;
+      for (int w = 0; w < kThreads / 64; ++w) wave_off[w + 1] += wave_off[w];
+      s_running = wave_off[kThreads / 64];
+    }
+    __syncthreads();
+    if (inl) {
+      const int pos = wave_off[wid] + __popcll(bal & ((1ULL << lane) - 1ULL));
+      inl_idx[base + pos] = i;
+    }
+    __syncthreads();
+  }
+  if (tid < 12) {
+    const int r = tid >> 2, c = tid & 3;
+    T_out[(size_t)b * 12 + tid] = (c < 3) ? hp[3 * r + c] : hp[9 + r];
+  }
+  if (tid == 0) {
+    n_inl[b] = s_running;
+    info[4 * b + 0] = best_it;
+    info[4 * b + 1] = s_used;
+    info[4 * b + 2] = 0;
+    info[4 * b + 3] = s_nvalid;
+  }
+}
+
+// ---- 5. refine ------------------------------------------------------------------------------
+// Fixed-order workgroup sum: wave shuffles, then the four wave partials in order.
+__device__ __forceinline__ double block_sum(double v, double* scratch /*[4]*/, int tid) {
+  for (int o = 32; o > 0; o >>= 1) v = v + __shfl_down(v, o);
+  __syncthreads();
+  if ((tid & 63) == 0) scratch[tid >> 6] = v;
+  __syncthreads();
+  return ((scratch[0] + scratch[1]) + scratch[2]) + scratch[3];
+}
+
+__global__ __launch_bounds__(kThreads) void refine_kernel(
+    const double* __restrict__ f, const double* __restrict__ p, const int32_t* __restrict__ cam,
+    const double* __restrict__ cam_off, const double* __restrict__ cam_rot, const int32_t* __restrict__ n_arr,
+    int stride, const int32_t* __restrict__ idx, const int32_t* __restrict__ m_arr, int max_lm_iter,
+    double* __restrict__ T_io, double* __restrict__ cost_out, int32_t* __restrict__ iters_out) {
+  __shared__ double scratch[4];
+  __shared__ double sx[6], sxn[6], sdx[6];
+  __shared__ double sA[21], sg[6];
+  __shared__ int s_flag;  // 0 continue tries, 1 accepted, 2 accepted+converged, 3 give up
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int n = min(n_arr[b], stride);
+  const int cnt = idx ? min(m_arr[b], n) : n;
+  const size_t base = (size_t)b * stride;
+  double* T = T_io + (size_t)b * 12;
+  if (tid == 0) {
+    double R[9], t[3];
+    sv_T_to_Rt(T, R, t);
+    sx[0] = t[0];
+    sx[1] = t[1];
+    sx[2] = t[2];
+    sv_rot2cayley(R, sx + 3);
+  }
+  __syncthreads();
+  double lambda = SV_LM_LAMBDA0;
+  double cost = 0.0;
+  int it_done = 0;
+  for (int it = 0; it < max_lm_iter; ++it) {
+    double x[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) x[u] = sx[u];
+    double A[21], g[6], c = 0.0;
+#pragma unroll
+    for (int a = 0; a < 21; ++a) A[a] = 0.0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) g[a] = 0.0;
+    for (int q = tid; q < cnt; q += kThreads) {
+      const int i = idx ? idx[base + q] : q;
+      const size_t row = base + i;
+      const int cc = cam ? cam[row] : 0;
+      const double* o = cam ? cam_off + 3 * cc : kZero3;
+      const double* rc = cam ? cam_rot + 9 * cc : kEye9;
+      double r, J[6];
+      sv_residual_jac(x, f + 3 * row, p + 3 * row, o, rc, &r, J);
+      c += r * r;
+      int a = 0;
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        g[u] += J[u] * r;
+#pragma unroll
+        for (int v = u; v < 6; ++v) A[a++] += J[u] * J[v];
+      }
+    }
+    cost = block_sum(c, scratch, tid);
+#pragma unroll
+    for (int a = 0; a < 21; ++a) {
+      const double s = block_sum(A[a], scratch, tid);
+      if (tid == 0) sA[a] = s;
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const double s = block_sum(g[a], scratch, tid);
+      if (tid == 0) sg[a] = s;
+    }
+    __syncthreads();
+    int accepted = 0, converged = 0;
+    for (int tries = 0; tries < SV_LM_MAX_TRIES; ++tries) {
+      if (tid == 0) {
+        double dx[6];
+        if (sv_solve_damped(sA, sg, lambda, dx)) {
+#pragma unroll
+          for (int u = 0; u < 6; ++u) {
+            sdx[u] = dx[u];
+            sxn[u] = sx[u] + dx[u];
+          }
+          s_flag = 0;
+        } else {
+          s_flag = 3;
+        }
+      }
+      __syncthreads();
+      if (s_flag == 3) {  // singular: raise lambda and retry (uniform)
+        lambda *= 10.0;
+        __syncthreads();
+        continue;
+      }
+      double xn[6];
+#pragma unroll
+      for (int u = 0; u < 6; ++u) xn[u] = sxn[u];
+      double cn = 0.0;
+      for (int q = tid; q < cnt; q += kThreads) {
+        const int i = idx ? idx[base + q] : q;
+        const size_t row = base + i;
+        const int cc = cam ? cam[row] : 0;
+        const double* o = cam ? cam_off + 3 * cc : kZero3;
+        const double* rc = cam ? cam_rot + 9 * cc : kEye9;
+        const double r = sv_residual(xn, f + 3 * row, p + 3 * row, o, rc);
+        cn += r * r;
+      }
+      cn = block_sum(cn, scratch, tid);
+      if (cn < cost) {
+        double dxn = 0.0, xnn = 0.0;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+          dxn += sdx[u] * sdx[u];
+          xnn += xn[u] * xn[u];
+        }
+        converged = ((cost - cn) <= SV_LM_FTOL * cost) || (sqrt(dxn) <= SV_LM_XTOL * (sqrt(xnn) + SV_LM_XTOL));
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+          for (int u = 0; u < 6; ++u) sx[u] = xn[u];
+        }
+        cost = cn;
+        lambda *= 0.1;
+        if (lambda < 1e-15) lambda = 1e-15;
+        accepted = 1;
+        __syncthreads();
+        break;
+      }
+      lambda *= 10.0;
+      __syncthreads();
+    }
+    it_done = it + 1;
+    if (!accepted || converged) break;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double R[9], t[3];
+    sv_cayley2rot(sx + 3, R);
+    t[0] = sx[0];
+    t[1] = sx[1];
+    t[2] = sx[2];
+    sv_Rt_to_T(R, t, T);
+    if (cost_out) cost_out[b] = cost;
+    if (iters_out) iters_out[b] = it_done;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t sosvo_ransac_abs_pose(sosvo_ctx* ctx, const double* f, const double* p, const int32_t* cam,
+                              const double* cam_off, const double* cam_rot, int32_t ncam, int32_t flags,
+                              const int32_t* n, int32_t nprob, int32_t stride, double thr, int32_t max_iter,
+                              int32_t adaptive, uint64_t seed, double* T_out, uint8_t* inlier_mask,
+                              int32_t* inlier_idx, int32_t* n_inliers, int32_t* info, int32_t* hyp_counts) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, f && p && n && T_out && inlier_mask && inlier_idx && n_inliers && info, "null pointer");
+  SOSVO_REQUIRE(ctx, cam == nullptr || (cam_off && cam_rot), "cam given without cam_off / cam_rot");
+  SOSVO_REQUIRE(ctx, ncam >= 1 && ncam <= kMaxCam, "ncam out of range (1..8)");
+  SOSVO_REQUIRE(ctx, nprob >= 0 && nprob <= 65535, "nprob out of range");
+  SOSVO_REQUIRE(ctx, stride > 0 && stride <= (1 << 20), "stride out of range");
+  SOSVO_REQUIRE(ctx, max_iter > 0 && max_iter <= (1 << 20), "max_iter out of range");
+  SOSVO_REQUIRE(ctx, thr > 0.0, "threshold must be positive");
+  if (nprob == 0) return SOSVO_OK;
+  const int H = max_iter;
+  // workspace carve-up
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    size_t o = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return o;
+  };
+  const size_t o_perm = carve(sizeof(int32_t) * (size_t)nprob * stride);
+  const size_t o_cinfo = carve(sizeof(int32_t) * (size_t)nprob * (2 * kMaxCam + 1));
+  const size_t o_hyp = carve(sizeof(double) * (size_t)nprob * H * kHypDoubles);
+  const size_t o_counts = carve(sizeof(int32_t) * (size_t)nprob * H);
+  int32_t rc = sosvo_ws_reserve(ctx, off);
+  if (rc != SOSVO_OK) return rc;
+  char* ws = (char*)ctx->ws;
+  int32_t* perm = (int32_t*)(ws + o_perm);
+  int32_t* cinfo = (int32_t*)(ws + o_cinfo);
+  double* hyp = (double*)(ws + o_hyp);
+  int32_t* counts = hyp_counts ? hyp_counts : (int32_t*)(ws + o_counts);
+
+  hipLaunchKernelGGL(ransac_prepare_kernel, dim3(nprob), dim3(kThreads), 0, ctx->stream, cam, n, stride,
+                     cam ? ncam : 1, perm, cinfo);
+  SOSVO_LAUNCH_CHECK(ctx);
+  hipLaunchKernelGGL(ransac_hyp_kernel, dim3(cdiv(H, 64), nprob), dim3(64), 0, ctx->stream, f, p, cam, cam_off,
+                     cam_rot, n, stride, H, seed, perm, cinfo, hyp, counts);
+  SOSVO_LAUNCH_CHECK(ctx);
+
+  const bool ident = (flags & SOSVO_FLAG_CAM_ROT_IDENTITY) != 0 || cam == nullptr;
+  const int fast_ok = thr < 0.5 ? 1 : 0;
+  // hypothesis chunks: enough workgroups to fill 256 CUs a few times over
+  const int ppt = ident ? 2 : 1;
+  const int gx = cdiv(stride, kThreads * ppt);
+  int hchunks = cdiv(2048, gx * nprob);
+  if (hchunks < 1) hchunks = 1;
+  int hchunk = cdiv(H, hchunks);
+  if (hchunk > kScoreHypChunkMax) hchunk = kScoreHypChunkMax;
+  if (hchunk < 16) hchunk = H < 16 ? H : 16;
+  hchunks = cdiv(H, hchunk);
+  dim3 grid(gx, hchunks, nprob);
+  if (ident)
+    hipLaunchKernelGGL((ransac_score_kernel<true, 2>), grid, dim3(kThreads), 0, ctx->stream, f, p, cam, cam_off,
+                       cam_rot, n, stride, H, hchunk, thr, fast_ok, hyp, counts);
+  else
+    hipLaunchKernelGGL((ransac_score_kernel<false, 1>), grid, dim3(kThreads), 0, ctx->stream, f, p, cam, cam_off,
+                       cam_rot, n, stride, H, hchunk, thr, fast_ok, hyp, counts);
+  SOSVO_LAUNCH_CHECK(ctx);
+  if (ident)
+    hipLaunchKernelGGL((ransac_select_kernel<true>), dim3(nprob), dim3(kThreads), 0, ctx->stream, f, p, cam,
+                       cam_off, cam_rot, n, stride, H, thr, adaptive, hyp, counts, T_out, inlier_mask, inlier_idx,
+                       n_inliers, info);
+  else
+    hipLaunchKernelGGL((ransac_select_kernel<false>), dim3(nprob), dim3(kThreads), 0, ctx->stream, f, p, cam,
+                       cam_off, cam_rot, n, stride, H, thr, adaptive, hyp, counts, T_out, inlier_mask, inlier_idx,
+                       n_inliers, info);
+  SOSVO_LAUNCH_CHECK(ctx);
+  return SOSVO_OK;
+}
+
+int32_t sosvo_refine_abs_pose(sosvo_ctx* ctx, const double* f, const double* p, const int32_t* cam,
+                              const double* cam_off, const double* cam_rot, int32_t ncam, const int32_t* n,
+                              int32_t nprob, int32_t stride, const int32_t* idx, const int32_t* m,
+                              int32_t max_lm_iter, double* T_io, double* cost_out, int32_t* iters_out) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, f && p && n && T_io, "null pointer");
+  SOSVO_REQUIRE(ctx, cam == nullptr || (cam_off && cam_rot), "cam given without cam_off / cam_rot");
+  SOSVO_REQUIRE(ctx, (idx == nullptr) == (m == nullptr), "idx and m go together");
+  SOSVO_REQUIRE(ctx, ncam >= 1 && ncam <= kMaxCam, "ncam out of range (1..8)");
+  SOSVO_REQUIRE(ctx, nprob >= 0 && nprob <= 65535, "nprob out of range");
+  SOSVO_REQUIRE(ctx, stride > 0 && stride <= (1 << 20), "stride out of range");
+  SOSVO_REQUIRE(ctx, max_lm_iter > 0 && max_lm_iter <= 10000, "max_lm_iter out of range");
+  if (nprob == 0) return SOSVO_OK;
+  hipLaunchKernelGGL(refine_kernel, dim3(nprob), dim3(kThreads), 0, ctx->stream, f, p, cam, cam_off, cam_rot, n,
+                     stride, idx, m, max_lm_iter, T_io, cost_out, iters_out);
+  SOSVO_LAUNCH_CHECK(ctx);
+  return SOSVO_OK;
+}
+
+}  // extern "C"

@@ -108,3 +108,63 @@ class Context(object):
         _check(order, torch.int32, "order", (P, Sq))
         self._call(self._lib.sosvo_sort_matches, _ptr(keys), _ptr(nq), P, Sq, _ptr(order))
         return order
+
+    # ---- K8 / K10 / K9 -----------------------------------------------------------------
+    def _rig(self, cam, cam_off, cam_rot, P, S):
+        """Validate the optional non-central rig description; returns (cam_ptr, off_ptr, rot_ptr, ncam)."""
+        if cam is None:
+            return c_p(0), c_p(0), c_p(0), 1
+        _check(cam, torch.int32, "cam", (P, S))
+        _check(cam_off, torch.float64, "cam_off", (None, 3))
+        ncam = cam_off.shape[0]
+        _check(cam_rot, torch.float64, "cam_rot", (ncam, 3, 3))
+        if not 1 <= ncam <= 8:
+            raise SosvoError("ncam %d out of range 1..8" % ncam)
+        return _ptr(cam), _ptr(cam_off), _ptr(cam_rot), ncam
+
+    def ransac_abs_pose(self, f, p, n, thr, max_iter, seed=0, adaptive=False, cam=None, cam_off=None,
+                        cam_rot=None, cam_rot_identity=False, want_counts=False):
+        """f, p [P, S, 3] f64, n [P] i32 (+ cam [P, S] i32, cam_off [C,3], cam_rot [C,3,3]) ->
+        dict(T [P,3,4], mask [P,S] u8, idx [P,S] i32, n_inliers [P] i32, info [P,4] i32[, counts [P,max_iter]])."""
+        _check(f, torch.float64, "f", (None, None, 3))
+        P, S = f.shape[0], f.shape[1]
+        _check(p, torch.float64, "p", (P, S, 3))
+        _check(n, torch.int32, "n", (P,))
+        cam_p, off_p, rot_p, ncam = self._rig(cam, cam_off, cam_rot, P, S)
+        dev = f.device
+        T = torch.empty((P, 3, 4), dtype=torch.float64, device=dev)
+        mask = torch.zeros((P, S), dtype=torch.uint8, device=dev)
+        idx = torch.full((P, S), -1, dtype=torch.int32, device=dev)
+        n_inl = torch.empty((P,), dtype=torch.int32, device=dev)
+        info = torch.empty((P, 4), dtype=torch.int32, device=dev)
+        counts = torch.empty((P, int(max_iter)), dtype=torch.int32, device=dev) if want_counts else None
+        flags = _lib.FLAG_CAM_ROT_IDENTITY if cam_rot_identity else 0
+        self._call(self._lib.sosvo_ransac_abs_pose, _ptr(f), _ptr(p), cam_p, off_p, rot_p, ncam, flags,
+                   _ptr(n), P, S, float(thr), int(max_iter), 1 if adaptive else 0, int(seed) & (2 ** 64 - 1),
+                   _ptr(T), _ptr(mask), _ptr(idx), _ptr(n_inl), _ptr(info),
+                   _ptr(counts) if counts is not None else c_p(0))
+        out = dict(T=T, mask=mask, idx=idx, n_inliers=n_inl, info=info)
+        if want_counts:
+            out["counts"] = counts
+        return out
+
+    def refine_abs_pose(self, f, p, n, T, idx=None, m=None, cam=None, cam_off=None, cam_rot=None,
+                        max_lm_iter=30):
+        """In-place LM refinement of T [P,3,4]; returns (T, cost [P] f64, iters [P] i32)."""
+        _check(f, torch.float64, "f", (None, None, 3))
+        P, S = f.shape[0], f.shape[1]
+        _check(p, torch.float64, "p", (P, S, 3))
+        _check(n, torch.int32, "n", (P,))
+        _check(T, torch.float64, "T", (P, 3, 4))
+        cam_p, off_p, rot_p, ncam = self._rig(cam, cam_off, cam_rot, P, S)
+        if (idx is None) != (m is None):
+            raise SosvoError("idx and m go together")
+        if idx is not None:
+            _check(idx, torch.int32, "idx", (P, S))
+            _check(m, torch.int32, "m", (P,))
+        cost = torch.empty((P,), dtype=torch.float64, device=f.device)
+        iters = torch.empty((P,), dtype=torch.int32, device=f.device)
+        self._call(self._lib.sosvo_refine_abs_pose, _ptr(f), _ptr(p), cam_p, off_p, rot_p, ncam, _ptr(n), P, S,
+                   _ptr(idx) if idx is not None else c_p(0), _ptr(m) if m is not None else c_p(0),
+                   int(max_lm_iter), _ptr(T), _ptr(cost), _ptr(iters))
+        return T, cost, iters
