@@ -199,23 +199,31 @@ int32_t orc_refine_abs_pose(const double* f, const double* p, const int32_t* cam
   double lambda = ORC_LM_LAMBDA0;
   double cost = 0.0;
   int it_done = 0;
+  /* Sums over correspondences are DEFINED as 256-way interleaved partial sums (term q goes to
+   * partial q mod 256, in increasing q) combined by orc_tree_sum256; the HIP path evaluates the
+   * same order (one partial per lane, wave shuffle tree, four wave partials), which makes the
+   * LM trajectory reproducible bit for bit. */
+  double(*part)[256] = (double(*)[256])malloc(sizeof(double) * 28 * 256);
   for (int it = 0; it < max_lm_iter; ++it) {
     double A[21], g[6];
-    cost = 0.0;
-    for (int a = 0; a < 21; ++a) A[a] = 0.0;
-    for (int a = 0; a < 6; ++a) g[a] = 0.0;
+    for (int a = 0; a < 28; ++a)
+      for (int l = 0; l < 256; ++l) part[a][l] = 0.0;
     for (int q = 0; q < cnt; ++q) {
       int i = idx ? idx[q] : q;
       int c = cam ? cam[i] : 0;
+      int l = q & 255;
       double r, J[6];
       orc_residual_jac(x, f + 3 * i, p + 3 * i, cam_off + 3 * c, cam_rot + 9 * c, &r, J);
-      cost += r * r;
+      part[27][l] += r * r;
       int a = 0;
       for (int u = 0; u < 6; ++u) {
-        g[u] += J[u] * r;
-        for (int v = u; v < 6; ++v) A[a++] += J[u] * J[v];
+        part[21 + u][l] += J[u] * r;
+        for (int v = u; v < 6; ++v) part[a++][l] += J[u] * J[v];
       }
     }
+    cost = orc_tree_sum256(part[27]);
+    for (int a = 0; a < 21; ++a) A[a] = orc_tree_sum256(part[a]);
+    for (int a = 0; a < 6; ++a) g[a] = orc_tree_sum256(part[21 + a]);
     it_done = it;
     /* inner loop: raise lambda until the step reduces the cost */
     int accepted = 0, converged = 0;
@@ -226,13 +234,14 @@ int32_t orc_refine_abs_pose(const double* f, const double* p, const int32_t* cam
         continue;
       }
       for (int u = 0; u < 6; ++u) xn[u] = x[u] + dx[u];
-      double cn = 0.0;
+      for (int l = 0; l < 256; ++l) part[0][l] = 0.0;
       for (int q = 0; q < cnt; ++q) {
         int i = idx ? idx[q] : q;
         int c = cam ? cam[i] : 0;
         double r = orc_residual(xn, f + 3 * i, p + 3 * i, cam_off + 3 * c, cam_rot + 9 * c);
-        cn += r * r;
+        part[0][q & 255] += r * r;
       }
+      const double cn = orc_tree_sum256(part[0]);
       if (cn < cost) {
         double dxn = 0.0, xnn = 0.0;
         for (int u = 0; u < 6; ++u) {
@@ -257,6 +266,7 @@ int32_t orc_refine_abs_pose(const double* f, const double* p, const int32_t* cam
   t[1] = x[1];
   t[2] = x[2];
   orc_Rt_to_T(R, t, T_io);
+  free(part);
   if (final_cost) *final_cost = cost;
   if (lm_iters) *lm_iters = it_done;
   return 0;

@@ -450,6 +450,20 @@ static inline int orc_hypothesis(const double* f, const double* p, const int32_t
   return found;
 }
 
+/* Sum of 256 partials: four groups of 64, each by the binary tree v[l] += v[l + o], o = 32..1,
+ * then ((w0 + w1) + w2) + w3. */
+static inline double orc_tree_sum256(const double* part) {
+  double w[4];
+  for (int k = 0; k < 4; ++k) {
+    double v[64];
+    for (int l = 0; l < 64; ++l) v[l] = part[64 * k + l];
+    for (int o = 32; o > 0; o >>= 1)
+      for (int l = 0; l < o; ++l) v[l] = v[l] + v[l + o];
+    w[k] = v[0];
+  }
+  return ((w[0] + w[1]) + w[2]) + w[3];
+}
+
 /* ---- Cayley parametrisation -------------------------------------------------------------- */
 static inline void orc_rot2cayley(const double* R, double* c) {
   const double s = 1.0 + ((R[0] + R[4]) + R[8]);

@@ -3,8 +3,9 @@ CPU oracle on the same seeded inputs.
 
 Bars (BASELINE.json north_star): inlier masks, inlier index lists, per-hypothesis inlier counts
 and the winning iteration are integer work -> bit-exact.  The RANSAC pose is produced by the same
-IEEE operations in the same order on both sides -> compared bit-exact too.  The LM-refined pose
-uses a different (fixed) summation order on the GPU -> rel-tol 1e-6 as north_star states."""
+IEEE operations in the same order on both sides -> compared bit-exact too.  The LM refinement
+defines its sums as 256-way interleaved partials combined by a tree on both sides, so the refined
+pose is compared bit-exact as well (north_star only asks for rel-tol 1e-6)."""
 import numpy as np
 import pytest
 import torch
@@ -141,9 +142,13 @@ def test_c2_full_size(ctx):
         idx = got["idx"][b, : got["n_inliers"][b]]
         want, wcost, wit = oracle.refine_abs_pose(pr["f"], pr["p"], got["T"][b], idx=idx, cam=pr["cam"],
                                                   cam_off=pr["cam_off"], cam_rot=pr["cam_rot"])
-        assert np.allclose(T[b], want, rtol=1e-6, atol=1e-9), "refined pose, problem %d" % b
-        assert wcost <= oracle.score_points(pr["f"][idx], pr["p"][idx], got["T"][b], cam=pr["cam"][idx],
-                                            cam_off=pr["cam_off"], cam_rot=pr["cam_rot"]).__pow__(2).sum()
+        # north_star bar is rel-tol 1e-6; the summation order is part of the spec on both sides
+        # (256-way interleaved partials + tree), so the LM trajectory is reproduced bit for bit
+        assert np.array_equal(T[b], want), "refined pose, problem %d" % b
+        assert wit == int(iters[b]) and wcost == float(cost[b])
+        start = (oracle.score_points(pr["f"][idx], pr["p"][idx], got["T"][b], cam=pr["cam"][idx],
+                                     cam_off=pr["cam_off"], cam_rot=pr["cam_rot"]) ** 2).sum()
+        assert wcost <= start
 
 
 def test_refine_noise_free_reaches_ground_truth(ctx):
@@ -164,4 +169,4 @@ def test_refine_noise_free_reaches_ground_truth(ctx):
         a1, t1 = synth.pose_error(T[b], pr["R"], pr["t"])
         a0, t0 = synth.pose_error(T0[b], pr["R"], pr["t"])
         assert a1 < 1e-2 * a0 and t1 < 1e-2 * t0
-        assert np.allclose(T[b], want, rtol=1e-6, atol=1e-6)
+        assert np.array_equal(T[b], want)
