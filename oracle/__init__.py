@@ -160,3 +160,72 @@ def refine_abs_pose(f, p, T0, idx=None, cam=None, cam_off=None, cam_rot=None, ma
                               _pn(idx), ctypes.c_int32(0 if idx is None else idx.shape[0]), _p(T),
                               ctypes.c_int32(max_lm_iter), ctypes.byref(cost), ctypes.byref(iters))
     return T, cost.value, iters.value
+
+
+# ---- geometry (the reference's own numpy code, pinned by tests/golden) ------------------------
+def pano_to_angles(u, v, cols, rows, pixel_size, h_max):
+    u = _c(u, np.float64).reshape(-1)
+    v = _c(v, np.float64).reshape(-1)
+    pano = np.array([cols, rows, pixel_size, h_max], dtype=np.float64)
+    az = np.empty_like(u)
+    el = np.empty_like(u)
+    lib().orc_pano_to_angles(_p(u), _p(v), ctypes.c_int32(u.shape[0]), _p(pano), _p(az), _p(el))
+    return az, el
+
+
+def angles_to_bearing(az, el):
+    az = _c(az, np.float64).reshape(-1)
+    el = _c(el, np.float64).reshape(-1)
+    b = np.empty((az.shape[0], 3), dtype=np.float64)
+    lib().orc_angles_to_bearing(_p(az), _p(el), ctypes.c_int32(az.shape[0]), _p(b))
+    return b
+
+
+def triangulate_midpoint(az1, el1, az2, el2, F1, F2):
+    az1, el1, az2, el2 = [_c(a, np.float64).reshape(-1) for a in (az1, el1, az2, el2)]
+    F1 = _c(F1, np.float64).reshape(3)
+    F2 = _c(F2, np.float64).reshape(3)
+    X = np.empty((az1.shape[0], 3), dtype=np.float64)
+    lib().orc_triangulate_midpoint(_p(az1), _p(el1), _p(az2), _p(el2), ctypes.c_int32(az1.shape[0]), _p(F1), _p(F2),
+                                   _p(X))
+    return X
+
+
+def range_filter_homo(X, min_range, max_range):
+    X = _c(X, np.float64).reshape(-1, 3)
+    ok = np.empty(X.shape[0], dtype=np.uint8)
+    lib().orc_range_filter_homo(_p(X), ctypes.c_int32(X.shape[0]), ctypes.c_double(min_range),
+                                ctypes.c_double(max_range), _p(ok))
+    return ok.astype(bool)
+
+
+def pixel_gates(top_uv, bot_uv, min_disp, max_hdiff):
+    top_uv = _c(top_uv, np.float64).reshape(-1, 2)
+    bot_uv = _c(bot_uv, np.float64).reshape(-1, 2)
+    ok = np.empty(top_uv.shape[0], dtype=np.uint8)
+    lib().orc_pixel_gates(_p(top_uv), _p(bot_uv), ctypes.c_int32(top_uv.shape[0]), ctypes.c_double(min_disp),
+                          ctypes.c_double(max_hdiff), _p(ok))
+    return ok.astype(bool)
+
+
+def rgbd_backproject(depth, u, v, intr, depth_is_Z):
+    depth = _c(depth, np.float32)
+    u = _c(u, np.int32).reshape(-1)
+    v = _c(v, np.int32).reshape(-1)
+    intr = _c(intr, np.float64).reshape(5)
+    xyz = np.empty((u.shape[0], 3), dtype=np.float64)
+    b = np.empty((u.shape[0], 3), dtype=np.float64)
+    lib().orc_rgbd_backproject(_p(depth), ctypes.c_int32(depth.shape[0]), ctypes.c_int32(depth.shape[1]), _p(u), _p(v),
+                               ctypes.c_int32(u.shape[0]), _p(intr), ctypes.c_int32(1 if depth_is_Z else 0), _p(xyz),
+                               _p(b))
+    return xyz, b
+
+
+def unwrap_lut(gum13, cols, rows, pixel_size, h_max, h_min, elev_low, elev_high):
+    gum13 = _c(gum13, np.float64).reshape(13)
+    pano = np.array([cols, rows, pixel_size, h_max, h_min], dtype=np.float64)
+    elev = np.array([elev_low, elev_high], dtype=np.float64)
+    mx = np.empty((int(rows), int(cols)), dtype=np.float64)
+    my = np.empty((int(rows), int(cols)), dtype=np.float64)
+    lib().orc_unwrap_lut(_p(gum13), _p(pano), _p(elev), _p(mx), _p(my))
+    return mx, my
