@@ -71,23 +71,26 @@ int32_t sosvo_timer_elapsed_ms(sosvo_ctx* ctx, float* ms);
  * Replaces cv2.BFMatcher(NORM_HAMMING).match / .knnMatch as called from
  * omnistereo/camera_models.py:442 and :420 (FeatureMatcher.match, :404-446).
  *
- * For each problem p < nprob and each query row i < nq[p]:
- *   keys[(p*q_stride + i)*k + 0] = min over j < nt[p] of (hamming(q_i, t_j) << 20 | j)
+ * Problem p < nprob matches the query rows of block qs = q_slot ? q_slot[p] : p against the
+ * train rows of block ts = t_slot ? t_slot[p] : p (the slots let many problems share one
+ * descriptor store, e.g. frame-to-frame problems index frames).  For each query row i < nq[qs]:
+ *   keys[(p*q_stride + i)*k + 0] = min over j < nt[ts] of (hamming(q_i, t_j) << 20 | j)
  *   keys[(p*q_stride + i)*k + 1] = second smallest such key            (only if k == 2)
- * Missing neighbours (nt[p] < k) are SOSVO_KEY_NONE.  Rows i >= nq[p] are not written.
- * q_desc: [nprob*q_stride, 32] u8, t_desc: [nprob*t_stride, 32] u8; nq, nt: [nprob] i32.
- * k is 1 or 2.  q_stride, t_stride <= 2^20.                                             */
+ * Missing neighbours (nt[ts] < k) are SOSVO_KEY_NONE.  Rows i >= nq[qs] are unspecified.
+ * q_desc: [*, q_stride, 32] u8, t_desc: [*, t_stride, 32] u8 (16-byte aligned); nq, nt: i32
+ * counts per block; q_slot, t_slot: [nprob] i32 or NULL.  k is 1 or 2.  strides <= 2^20.   */
 int32_t sosvo_match_hamming(sosvo_ctx* ctx, const uint8_t* q_desc, const uint8_t* t_desc,
-                            const int32_t* nq, const int32_t* nt, int32_t nprob,
-                            int32_t q_stride, int32_t t_stride, int32_t k, uint32_t* keys);
+                            const int32_t* nq, const int32_t* nt, const int32_t* q_slot,
+                            const int32_t* t_slot, int32_t nprob, int32_t q_stride,
+                            int32_t t_stride, int32_t k, uint32_t* keys);
 
 /* Stable sort of each problem's 1-NN matches by distance, the `sorted(matches,
  * key=distance)` of omnistereo/camera_models.py:444.  Input keys as written by
- * sosvo_match_hamming with k = 1.  Output, for rank r < nq[p]:
+ * sosvo_match_hamming with k = 1.  Output, for rank r < nq[qs]:
  *   order[p*q_stride + r] = query index of the r-th match (ties keep query order).
- * Queries whose key is SOSVO_KEY_NONE (empty train set) sort last.                       */
+ * Queries whose key is SOSVO_KEY_NONE (empty train set) sort last.  q_stride <= 16384.    */
 int32_t sosvo_sort_matches(sosvo_ctx* ctx, const uint32_t* keys, const int32_t* nq,
-                           int32_t nprob, int32_t q_stride, int32_t* order);
+                           const int32_t* q_slot, int32_t nprob, int32_t q_stride, int32_t* order);
 
 /* ---- K8 / K10: 3D-2D absolute-pose RANSAC ------------------------------------------------
  * Replaces pyopengv.absolute_pose_noncentral_ransac (omnistereo/pose_est_tools.py:785) and
@@ -130,6 +133,90 @@ int32_t sosvo_refine_abs_pose(sosvo_ctx* ctx, const double* f, const double* p, 
                               const int32_t* n, int32_t nprob, int32_t stride, const int32_t* idx,
                               const int32_t* m, int32_t max_lm_iter, double* T_io, double* cost_out,
                               int32_t* iters_out);
+
+/* ---- geometry: a7-a10, a12 -------------------------------------------------------------------
+ * Elementwise restatements of the reference's numpy geometry (FP64; values agree with the
+ * reference to rel-tol 1e-12, the transcendental functions come from the device math library).
+ *
+ * sosvo_pano_to_bearing: uv [n,2] pano pixel -> az, el, bearing [n,3] (any output may be NULL).
+ *   Panorama.get_direction_angles_from_pixel_pano (omnistereo/panorama.py:650, closed form :635,:616),
+ *   GUM.get_3D_point_from_angles_wrt_focus (gum.py:2564) -> map_angles_to_unit_sphere
+ *   (camera_models.py:1031).  NaN outside [0,cols) x [0,rows).
+ * sosvo_triangulate_midpoint: OmniStereoModel.get_triangulated_point_from_direction_angles
+ *   (camera_models.py:3323, use_midpoint_triangulation=True) -> get_triangulated_midpoint (:2420)
+ *   -> triangulate_for_skew_rays (:2481).  F_top_host / F_bot_host: HOST pointers to 3 doubles.
+ * sosvo_range_filter: filter_panoramic_points_due_to_range (camera_models.py:3299) as called with
+ *   homogeneous rows at pose_est_tools.py:372 (norm includes the trailing 1); limit <= 0 disables.
+ * sosvo_rgbd_backproject: RGBDCamModel.get_XYZ (camera_models.py:835) + get_depth_Z (:781) at
+ *   integer pixels + get_normalized_points (:203).  depth [rows,cols] f32; zeros -> NaN.        */
+int32_t sosvo_pano_to_bearing(sosvo_ctx* ctx, const double* uv, int32_t n, double cols, double rows,
+                              double pixel_size, double cyl_height_max, double* az, double* el,
+                              double* bearing);
+int32_t sosvo_triangulate_midpoint(sosvo_ctx* ctx, const double* az_top, const double* el_top,
+                                   const double* az_bot, const double* el_bot, int32_t n,
+                                   const double* F_top_host, const double* F_bot_host, double* X);
+int32_t sosvo_range_filter(sosvo_ctx* ctx, const double* X, int32_t n, double min_range,
+                           double max_range, uint8_t* ok);
+int32_t sosvo_rgbd_backproject(sosvo_ctx* ctx, const float* depth, int32_t rows, int32_t cols,
+                               const int32_t* u, const int32_t* v, int32_t n, double fx, double fy,
+                               double cx, double cy, double focal_length_m, int32_t depth_is_Z,
+                               double* xyz, double* bearing);
+
+/* Constants of one calibrated omnistereo rig as the hot path needs them (HOST struct, passed by
+ * pointer and copied into kernel arguments).  pano_* = {cols, rows, pixel_size, cyl_height_max}
+ * of Panorama (panorama.py:142-172); F_* = mirror foci wrt [C]; ranges in model units
+ * (pose_est_tools.py:306-308); gates of pose_est_tools.py:298-304 and :866; pct_good_matches of
+ * FeatureMatcher (camera_models.py:379).                                                         */
+typedef struct sosvo_rig {
+  double pano_top[4];
+  double pano_bot[4];
+  double F_top[3];
+  double F_bot[3];
+  double min_range;        /* <= 0 disables */
+  double max_range;        /* <= 0 disables */
+  double stereo_min_disp;  /* v_top - v_bot >= this, < 0 disables (common_cv.py:182) */
+  double stereo_max_hdiff; /* |u_top - u_bot| <= this, <= 0 disables (common_cv.py:177) */
+  double f2f_max_hdiff;    /* frame-to-frame |du| gate, < 0 disables (pose_est_tools.py:245) */
+  double pct_good_matches; /* 1.0 */
+} sosvo_rig;
+
+/* ---- stereo assemble: a6 + a7..a11 fused ------------------------------------------------------
+ * Replaces OmniStereoModel.match_features_panoramic_top_bottom (camera_models.py:3027-3101) after
+ * the per-bucket matcher call, and StereoPanoramicFrame.establish_stereo_correspondences
+ * (pose_est_tools.py:339-397).  Problem p = frame*nmask + mask owns rows [p*cap, p*cap + n_*[p]) of
+ * kp_* [.,2] f32 / desc_* [.,32] u8; keys/order [nframes*nmask, cap] come from sosvo_match_hamming
+ * (query = bottom, train = top, k = 1) and sosvo_sort_matches.  Per frame, candidates are visited
+ * in bucket order then rank order (empty buckets skipped), gated (|du|, dv), lifted to angles and
+ * bearings, triangulated, range-filtered, and the survivors are written in that order:
+ * m_top/m_bot [nframes,out_cap,2] f32, d_top/d_bot [nframes,out_cap,32] u8, X (frame [C]),
+ * b_top/b_bot [nframes,out_cap,3] f64, M [nframes] i32 (count), n_cand [nframes] (optional:
+ * candidates before the gates).  This is the PanoramicCorrespondences contract
+ * (camera_models.py:291-362) in structure-of-arrays form.                                        */
+int32_t sosvo_stereo_assemble(sosvo_ctx* ctx, const sosvo_rig* rig_host, const float* kp_top,
+                              const float* kp_bot, const uint8_t* desc_top, const uint8_t* desc_bot,
+                              const int32_t* n_top, const int32_t* n_bot, const uint32_t* keys,
+                              const int32_t* order, int32_t nframes, int32_t nmask, int32_t cap,
+                              int32_t out_cap, float* m_top, float* m_bot, uint8_t* d_top,
+                              uint8_t* d_bot, double* X, double* b_top, double* b_bot, int32_t* M,
+                              int32_t* n_cand);
+
+/* ---- frame-to-frame assemble: a13 + the stacking of a14 ---------------------------------------
+ * Replaces match_features_frame_to_frame (pose_est_tools.py:211-269) after the matcher call and
+ * the correspondence stacking of TrackerStereoSE3.track_frame (:752-778).  Pair pr tracks frame
+ * cur_frame[pr] against (key)frame ref_frame[pr]; keys_top, order_top, keys_bot, order_bot
+ * [npairs, frame_cap] come from
+ * matching query = current, train = reference per view (use q_slot = cur_frame, t_slot =
+ * ref_frame).  Output rows [pr*corr_cap ...): top-view correspondences first, then bottom view,
+ * each in rank order after the |du| gate: f = bearing of the current frame, p = 3-D point of the
+ * reference frame, cam = 0/1, corr_q / corr_t = indices into the two frames, n [npairs] = count,
+ * n_topview [npairs] (optional) = how many of them are top-view.                                 */
+int32_t sosvo_f2f_assemble(sosvo_ctx* ctx, const sosvo_rig* rig_host, const float* m_top,
+                           const float* m_bot, const double* X, const double* b_top,
+                           const double* b_bot, const int32_t* M, int32_t frame_cap,
+                           const int32_t* ref_frame, const int32_t* cur_frame, const uint32_t* keys_top,
+                           const int32_t* order_top, const uint32_t* keys_bot, const int32_t* order_bot,
+                           int32_t npairs, int32_t corr_cap, double* f, double* p, int32_t* cam,
+                           int32_t* corr_q, int32_t* corr_t, int32_t* n, int32_t* n_topview);
 
 #ifdef __cplusplus
 }

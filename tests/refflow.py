@@ -1,0 +1,107 @@
+"""The reference's per-frame / per-pair control flow restated on top of the CPU oracle (test
+infrastructure; also the `cpu_baseline` leg of bench.py).  Each function cites the reference lines
+it follows; the arithmetic is the oracle's (oracle/*.c)."""
+import numpy as np
+
+import oracle
+
+IDX = 0xFFFFF
+
+
+class RigParams(object):
+    """Constants of one calibrated rig (host floats), mirrors struct sosvo_rig."""
+
+    def __init__(self, pano_top, pano_bot, F_top, F_bot, min_range, max_range, stereo_min_disp=1.0,
+                 stereo_max_hdiff=2.5, f2f_max_hdiff=-1.0, pct_good_matches=1.0):
+        self.pano_top, self.pano_bot = tuple(pano_top), tuple(pano_bot)  # (cols, rows, pixel_size, h_max)
+        self.F_top, self.F_bot = np.asarray(F_top, np.float64), np.asarray(F_bot, np.float64)
+        self.min_range, self.max_range = min_range, max_range
+        self.stereo_min_disp, self.stereo_max_hdiff = stereo_min_disp, stereo_max_hdiff
+        self.f2f_max_hdiff, self.pct_good_matches = f2f_max_hdiff, pct_good_matches
+
+
+def match_sorted(query_desc, train_desc):
+    """FeatureMatcher.match (camera_models.py:404-446): 1-NN then stable sort by distance.
+    -> (query_idx, train_idx, dist) in sorted order."""
+    if len(query_desc) == 0 or len(train_desc) == 0:
+        z = np.zeros(0, dtype=np.int64)
+        return z, z, z
+    keys = oracle.match_hamming(query_desc, train_desc, k=1)[:, 0]
+    order = oracle.sort_matches(keys)
+    return order.astype(np.int64), (keys[order] & IDX).astype(np.int64), (keys[order] >> 20).astype(np.int64)
+
+
+def stereo_frame(rig, kp_top, kp_bot, desc_top, desc_bot):
+    """match_features_panoramic_top_bottom (camera_models.py:3027-3101) followed by
+    establish_stereo_correspondences (pose_est_tools.py:339-397).  kp_* / desc_*: lists over buckets of
+    [n,2] float32 / [n,32] uint8.  -> dict of arrays in the reference's order."""
+    mt, mb, dt, db = [], [], [], []
+    n_cand = 0
+    for kt, kb, et, eb in zip(kp_top, kp_bot, desc_top, desc_bot):
+        if len(kt) == 0 or len(kb) == 0:  # :3039
+            continue
+        q, t, _ = match_sorted(eb, et)  # query = bottom, train = top (:3042)
+        good = int(rig.pct_good_matches * len(q))  # :3045
+        q, t = q[:good], t[:good]
+        n_cand += good
+        mt.append(kt[t])
+        mb.append(kb[q])
+        dt.append(et[t])
+        db.append(eb[q])
+    if not mt:
+        e2, e3, e32 = np.zeros((0, 2), np.float32), np.zeros((0, 3)), np.zeros((0, 32), np.uint8)
+        return dict(m_top=e2, m_bot=e2, d_top=e32, d_bot=e32, X=e3, b_top=e3, b_bot=e3, n_cand=0)
+    mt, mb = np.concatenate(mt).astype(np.float32), np.concatenate(mb).astype(np.float32)
+    dt, db = np.concatenate(dt), np.concatenate(db)
+    ok = oracle.pixel_gates(mt.astype(np.float64), mb.astype(np.float64), rig.stereo_min_disp,
+                            rig.stereo_max_hdiff)  # :3086
+    mt, mb, dt, db = mt[ok], mb[ok], dt[ok], db[ok]
+    az1, el1 = oracle.pano_to_angles(mt[:, 0], mt[:, 1], *rig.pano_top)  # pose_est_tools.py:344
+    az2, el2 = oracle.pano_to_angles(mb[:, 0], mb[:, 1], *rig.pano_bot)  # :345
+    bt, bb = oracle.angles_to_bearing(az1, el1), oracle.angles_to_bearing(az2, el2)  # :348-349
+    X = oracle.triangulate_midpoint(az1, el1, az2, el2, rig.F_top, rig.F_bot)  # :365
+    good = oracle.range_filter_homo(X, rig.min_range, rig.max_range)  # :372
+    return dict(m_top=mt[good], m_bot=mb[good], d_top=dt[good], d_bot=db[good], X=X[good], b_top=bt[good],
+                b_bot=bb[good], n_cand=n_cand)
+
+
+def f2f_view(rig, m_train, d_train, m_query, d_query):
+    """match_features_frame_to_frame (pose_est_tools.py:211-269) for one view -> (train_idx, query_idx)."""
+    q, t, _ = match_sorted(d_query, d_train)  # query = current, train = reference (:215)
+    good = int(rig.pct_good_matches * len(q))  # :225
+    q, t = q[:good], t[:good]
+    if good > 0 and rig.f2f_max_hdiff >= 0:  # :245
+        pt = np.zeros((good, 2))
+        pq = np.zeros((good, 2))
+        pt[:, 0] = m_train[t, 0]
+        pq[:, 0] = m_query[q, 0]
+        ok = oracle.pixel_gates(pt, pq, -1, rig.f2f_max_hdiff)  # :247
+        q, t = q[ok], t[ok]
+    return t, q
+
+
+def track_inputs(rig, ref, cur):
+    """Correspondence stacking of TrackerStereoSE3.track_frame (pose_est_tools.py:741-778).
+    ref / cur: dicts from stereo_frame.  -> f [n,3], p [n,3], cam [n], (q, t) index arrays, n_top."""
+    t_top, q_top = f2f_view(rig, ref["m_top"], ref["d_top"], cur["m_top"], cur["d_top"])
+    t_bot, q_bot = f2f_view(rig, ref["m_bot"], ref["d_bot"], cur["m_bot"], cur["d_bot"])
+    f = np.vstack([cur["b_top"][q_top], cur["b_bot"][q_bot]])
+    p = np.vstack([ref["X"][t_top], ref["X"][t_bot]])
+    cam = np.concatenate([np.zeros(len(q_top), np.int32), np.ones(len(q_bot), np.int32)])
+    return dict(f=f, p=p, cam=cam, q=np.concatenate([q_top, q_bot]), t=np.concatenate([t_top, t_bot]),
+                n_top=len(q_top))
+
+
+def track_pair(rig, ref, cur, thr, max_iter, seed, adaptive=False, lm_iter=30):
+    """track_frame steps 3-4 (pose_est_tools.py:785, :830) on the oracle: RANSAC + LM on the inliers."""
+    c = track_inputs(rig, ref, cur)
+    cam_off = np.stack([rig.F_top, rig.F_bot])
+    cam_rot = np.stack([np.eye(3), np.eye(3)])
+    r = oracle.ransac_abs_pose(c["f"], c["p"], thr, max_iter, seed=seed, adaptive=adaptive, cam=c["cam"],
+                               cam_off=cam_off, cam_rot=cam_rot)
+    idx = np.nonzero(r["mask"])[0].astype(np.int32)
+    T = r["T"]
+    if r["status"] == 0:
+        T, _, _ = oracle.refine_abs_pose(c["f"], c["p"], r["T"], idx=idx, cam=c["cam"], cam_off=cam_off,
+                                         cam_rot=cam_rot, max_lm_iter=lm_iter)
+    return dict(corr=c, ransac=r, T=T)

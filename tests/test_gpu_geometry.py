@@ -1,0 +1,210 @@
+"""GPU parity of the geometry stages and of the two assemble kernels, through the C ABI.
+
+* elementwise geometry: against the golden vectors captured from the reference's numpy code
+  (tests/golden/geometry_c2.npz) AND against the oracle, rel-tol 1e-12 (FP64, device libm vs glibc);
+  boolean outputs (NaN pattern, range filter, gates) bit-exact;
+* assemble kernels: against the reference's control flow restated on the oracle (tests/refflow.py):
+  selected indices / ordering / descriptors / counts bit-exact, FP64 values rel-tol 1e-12."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import refflow
+import synth
+from vo_single_camera_sos_amd.device import make_rig
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "geometry_c2.npz"))
+RT = dict(rtol=1e-12, atol=1e-12)
+
+
+def _to(dev, *arrs):
+    return [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in arrs]
+
+
+def _pano(name):
+    rows, cols, px, hmax, hmin, _ = G[name + "_pano"]
+    return cols, rows, px, hmax
+
+
+def test_pano_to_bearing_vs_reference_fixture(ctx):
+    for name in ("top", "bot"):
+        m = G["m_" + name]
+        (uv,) = _to(ctx.device, m[:, :2])
+        az, el, b = ctx.pano_to_bearing(uv, *_pano(name))
+        ctx.synchronize()
+        az, el, b = az.cpu().numpy(), el.cpu().numpy(), b.cpu().numpy()
+        assert np.array_equal(np.isnan(az), np.isnan(G["az_" + name]))
+        assert np.array_equal(np.isnan(el), np.isnan(G["el_" + name]))
+        assert np.allclose(az, G["az_" + name], equal_nan=True, **RT)
+        assert np.allclose(el, G["el_" + name], equal_nan=True, **RT)
+        assert np.allclose(b, G["bearing_" + name][:, :3], equal_nan=True, **RT)
+        oaz, oel = oracle.pano_to_angles(m[:, 0], m[:, 1], *_pano(name))
+        assert np.allclose(az, oaz, equal_nan=True, **RT) and np.allclose(el, oel, equal_nan=True, **RT)
+
+
+def test_triangulation_and_range_filter_vs_reference_fixture(ctx):
+    a1, e1, a2, e2 = _to(ctx.device, G["az_top"], G["el_top"], G["az_bot"], G["el_bot"])
+    X = ctx.triangulate_midpoint(a1, e1, a2, e2, G["top_F"], G["bot_F"])
+    ok = ctx.range_filter(X, 500.0, 7000.0)
+    ok2 = ctx.range_filter(X, 900.0, 0.0)
+    ctx.synchronize()
+    Xn = X.cpu().numpy()
+    want = G["tri_X_homo"][:, :3]
+    assert np.array_equal(np.isnan(Xn).any(1), np.isnan(want).any(1))
+    assert np.allclose(Xn, want, equal_nan=True, rtol=1e-9, atol=1e-7)  # Cramer vs LAPACK solve
+    assert np.allclose(Xn, oracle.triangulate_midpoint(G["az_top"], G["el_top"], G["az_bot"], G["el_bot"],
+                                                       G["top_F"], G["bot_F"]), equal_nan=True, rtol=1e-11, atol=1e-9)
+    assert np.array_equal(ok.cpu().numpy().astype(bool), G["range_ok_500_7000"])
+    assert np.array_equal(ok2.cpu().numpy().astype(bool), G["range_ok_min_only"])
+
+
+@pytest.mark.parametrize("tag,is_z", [("z", True), ("radial", False)])
+def test_rgbd_backproject_vs_reference_fixture(ctx, tag, is_z):
+    depth, u, v = _to(ctx.device, G["rgbd_depth"], G["rgbd_u"].astype(np.int32), G["rgbd_v"].astype(np.int32))
+    fx, fy, cx, cy, fl = G["rgbd_intrinsics"]
+    xyz, b = ctx.rgbd_backproject(depth, u, v, fx, fy, cx, cy, fl, is_z)
+    ctx.synchronize()
+    xyz, b = xyz.cpu().numpy(), b.cpu().numpy()
+    want = G["rgbd_xyz_" + tag][0]
+    assert np.array_equal(np.isnan(xyz), np.isnan(want))
+    assert np.allclose(xyz, want, equal_nan=True, **RT)
+    good = ~np.isnan(want[:, 2])
+    assert np.allclose(b[good], G["rgbd_bearing_" + tag], **RT)
+
+
+def _rigs(f2f=75.0):
+    kw = dict(pano_top=synth.PANO_C2, pano_bot=synth.PANO_C2, F_top=synth.F_TOP, F_bot=synth.F_BOT,
+              min_range=500.0, max_range=7000.0, stereo_min_disp=1.0, stereo_max_hdiff=2.5, f2f_max_hdiff=f2f,
+              pct_good_matches=1.0)
+    return make_rig(**kw), refflow.RigParams(**kw)
+
+
+def _gpu_stereo(ctx, rig, packed, nframes, nmask, out_cap):
+    dev = ctx.device
+    t = {k: torch.from_numpy(v).to(dev) for k, v in packed.items()}
+    keys = ctx.match_hamming(t["desc_bot"], t["desc_top"], t["n_bot"], t["n_top"], k=1)  # query = bottom
+    order = ctx.sort_matches(keys, t["n_bot"])
+    return ctx.stereo_assemble(rig, t["kp_top"], t["kp_bot"], t["desc_top"], t["desc_bot"], t["n_top"], t["n_bot"],
+                               keys, order, nframes, nmask, out_cap)
+
+
+def _check_frames(out, want_frames):
+    got = {k: v.cpu().numpy() for k, v in out.items()}
+    for fi, w in enumerate(want_frames):
+        M = len(w["X"])
+        assert got["M"][fi] == M, "frame %d: count %d != %d" % (fi, got["M"][fi], M)
+        assert got["n_cand"][fi] == w["n_cand"]
+        assert np.array_equal(got["m_top"][fi, :M], w["m_top"]) and np.array_equal(got["m_bot"][fi, :M], w["m_bot"])
+        assert np.array_equal(got["d_top"][fi, :M], w["d_top"]) and np.array_equal(got["d_bot"][fi, :M], w["d_bot"])
+        assert np.allclose(got["X"][fi, :M], w["X"], rtol=1e-11, atol=1e-9)
+        assert np.allclose(got["b_top"][fi, :M], w["b_top"], **RT) and np.allclose(got["b_bot"][fi, :M], w["b_bot"], **RT)
+    return got
+
+
+def test_stereo_assemble_matches_reference_flow(ctx):
+    rng = np.random.default_rng(21)
+    nmask, cap = 12, 256
+    rig, rp = _rigs()
+    P, desc = synth.make_scene(rng, 2500)
+    frames = []
+    for k in range(3):
+        R, t = synth.random_pose(rng) if k else (np.eye(3), np.zeros(3))
+        frames.append(synth.observe_frame(rng, P, desc, R, t, nmask=nmask, cap=cap))
+    # edge cases: an empty top bucket, an empty bottom bucket, a bucket with a single keypoint
+    frames[1]["kp_top"][3] = frames[1]["kp_top"][3][:0]
+    frames[1]["desc_top"][3] = frames[1]["desc_top"][3][:0]
+    frames[1]["kp_bot"][7] = frames[1]["kp_bot"][7][:0]
+    frames[1]["desc_bot"][7] = frames[1]["desc_bot"][7][:0]
+    frames[2]["kp_bot"][0] = frames[2]["kp_bot"][0][:1]
+    frames[2]["desc_bot"][0] = frames[2]["desc_bot"][0][:1]
+    packed = synth.pack_buckets(frames, nmask, cap)
+    out = _gpu_stereo(ctx, rig, packed, 3, nmask, nmask * cap)
+    ctx.synchronize()
+    want = [refflow.stereo_frame(rp, fr["kp_top"], fr["kp_bot"], fr["desc_top"], fr["desc_bot"]) for fr in frames]
+    got = _check_frames(out, want)
+    assert got["M"].min() > 500  # the scene really produces stereo-validated points
+
+
+def test_stereo_assemble_output_capacity_and_empty_frame(ctx):
+    rng = np.random.default_rng(22)
+    nmask, cap = 12, 64
+    rig, rp = _rigs()
+    P, desc = synth.make_scene(rng, 600)
+    fr = synth.observe_frame(rng, P, desc, np.eye(3), np.zeros(3), nmask=nmask, cap=cap)
+    empty = dict(kp_top=[np.zeros((0, 2), np.float32)] * nmask, kp_bot=[np.zeros((0, 2), np.float32)] * nmask,
+                 desc_top=[np.zeros((0, 32), np.uint8)] * nmask, desc_bot=[np.zeros((0, 32), np.uint8)] * nmask)
+    packed = synth.pack_buckets([fr, empty], nmask, cap)
+    out = _gpu_stereo(ctx, rig, packed, 2, nmask, 50)  # too small on purpose: output is clipped, never overrun
+    ctx.synchronize()
+    want = refflow.stereo_frame(rp, fr["kp_top"], fr["kp_bot"], fr["desc_top"], fr["desc_bot"])
+    got = {k: v.cpu().numpy() for k, v in out.items()}
+    assert len(want["X"]) > 50 and got["M"][0] == 50 and got["M"][1] == 0
+    assert np.array_equal(got["m_top"][0], want["m_top"][:50])
+
+
+@pytest.mark.parametrize("f2f_gate", [75.0, -1.0, 0.0])
+def test_f2f_assemble_and_full_tracking_chain(ctx, f2f_gate):
+    """stereo -> f2f match -> assemble -> RANSAC -> LM for several pairs, against refflow.track_pair."""
+    rng = np.random.default_rng(23)
+    nmask, cap = 12, 256
+    rig, rp = _rigs(f2f_gate)
+    P, desc = synth.make_scene(rng, 2600)
+    poses = [(np.eye(3), np.zeros(3))] + [synth.random_pose(rng) for _ in range(3)]
+    frames = [synth.observe_frame(rng, P, desc, R, t, nmask=nmask, cap=cap) for R, t in poses]
+    packed = synth.pack_buckets(frames, nmask, cap)
+    frame_cap = 3072
+    st = _gpu_stereo(ctx, rig, packed, 4, nmask, frame_cap)
+    dev = ctx.device
+    pairs = [(0, 1), (0, 2), (0, 3), (1, 2)]
+    ref_f, cur_f = _to(dev, np.array([a for a, b in pairs], np.int32), np.array([b for a, b in pairs], np.int32))
+    kt = ctx.match_hamming(st["d_top"], st["d_top"], st["M"], st["M"], k=1, q_slot=cur_f, t_slot=ref_f)
+    ot = ctx.sort_matches(kt, st["M"], q_slot=cur_f)
+    kb = ctx.match_hamming(st["d_bot"], st["d_bot"], st["M"], st["M"], k=1, q_slot=cur_f, t_slot=ref_f)
+    ob = ctx.sort_matches(kb, st["M"], q_slot=cur_f)
+    corr = ctx.f2f_assemble(rig, st, ref_f, cur_f, kt, ot, kb, ob, 2 * frame_cap)
+    off, rot = _to(dev, np.stack([synth.F_TOP, synth.F_BOT]), np.stack([np.eye(3), np.eye(3)]))
+    rs = ctx.ransac_abs_pose(corr["f"], corr["p"], corr["n"], synth.THR_5DEG, 300, seed=31, cam=corr["cam"],
+                             cam_off=off, cam_rot=rot, cam_rot_identity=True)
+    T = rs["T"].clone()
+    ctx.refine_abs_pose(corr["f"], corr["p"], corr["n"], T, idx=rs["idx"], m=rs["n_inliers"], cam=corr["cam"],
+                        cam_off=off, cam_rot=rot)
+    ctx.synchronize()
+    want_frames = [refflow.stereo_frame(rp, fr["kp_top"], fr["kp_bot"], fr["desc_top"], fr["desc_bot"])
+                   for fr in frames]
+    _check_frames(st, want_frames)
+    c = {k: v.cpu().numpy() for k, v in corr.items()}
+    r = {k: v.cpu().numpy() for k, v in rs.items()}
+    T = T.cpu().numpy()
+    gotX = st["X"].cpu().numpy()
+    gotb = {0: st["b_top"].cpu().numpy(), 1: st["b_bot"].cpu().numpy()}
+    for pi, (a, b) in enumerate(pairs):
+        w = refflow.track_inputs(rp, want_frames[a], want_frames[b])
+        n = len(w["cam"])
+        assert c["n"][pi] == n and c["n_top"][pi] == w["n_top"]
+        assert np.array_equal(c["cam"][pi, :n], w["cam"])
+        assert np.array_equal(c["q"][pi, :n], w["q"]) and np.array_equal(c["t"][pi, :n], w["t"])
+        assert np.allclose(c["f"][pi, :n], w["f"], **RT) and np.allclose(c["p"][pi, :n], w["p"], rtol=1e-11, atol=1e-9)
+        # the gathered rows are exact copies of the GPU's own frame arrays
+        for k in range(n):
+            assert np.array_equal(c["p"][pi, k], gotX[a, w["t"][k]])
+            assert np.array_equal(c["f"][pi, k], gotb[int(w["cam"][k])][b, w["q"][k]])
+        # RANSAC + LM on the GPU's own correspondences == oracle on the same arrays, bit for bit
+        cam_off, cam_rot = np.stack([synth.F_TOP, synth.F_BOT]), np.stack([np.eye(3), np.eye(3)])
+        o = oracle.ransac_abs_pose(c["f"][pi, :n], c["p"][pi, :n], synth.THR_5DEG, 300, seed=31 + pi,
+                                   cam=c["cam"][pi, :n], cam_off=cam_off, cam_rot=cam_rot)
+        assert np.array_equal(r["mask"][pi, :n].astype(bool), o["mask"]) and np.array_equal(r["T"][pi], o["T"])
+        idx = np.nonzero(o["mask"])[0].astype(np.int32)
+        To, _, _ = oracle.refine_abs_pose(c["f"][pi, :n], c["p"][pi, :n], o["T"], idx=idx, cam=c["cam"][pi, :n],
+                                          cam_off=cam_off, cam_rot=cam_rot)
+        assert np.array_equal(T[pi], To)
+        # and the estimate is the planted motion (loose: 5 degree threshold, bearing-only)
+        Ra, ta = poses[a]
+        Rb, tb = poses[b]
+        R_rel, t_rel = Ra.T @ Rb, Ra.T @ (tb - ta)
+        ang, _ = synth.pose_error(T[pi], R_rel, t_rel)
+        assert ang < np.deg2rad(1.0) and np.linalg.norm(T[pi][:, 3] - t_rel) < 60.0
+        assert o["n_inliers"] > 0.5 * n

@@ -42,8 +42,15 @@ SIGNATURES = {
     "sosvo_timer_start": (c_i32, [c_p]),
     "sosvo_timer_stop": (c_i32, [c_p]),
     "sosvo_timer_elapsed_ms": (c_i32, [c_p, ctypes.POINTER(c_f32)]),
-    "sosvo_match_hamming": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p]),
-    "sosvo_sort_matches": (c_i32, [c_p, c_p, c_p, c_i32, c_i32, c_p]),
+    "sosvo_match_hamming": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p]),
+    "sosvo_sort_matches": (c_i32, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_p]),
+    "sosvo_pano_to_bearing": (c_i32, [c_p, c_p, c_i32, c_f64, c_f64, c_f64, c_f64, c_p, c_p, c_p]),
+    "sosvo_triangulate_midpoint": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_i32, c_p, c_p, c_p]),
+    "sosvo_range_filter": (c_i32, [c_p, c_p, c_i32, c_f64, c_f64, c_p]),
+    "sosvo_rgbd_backproject": (c_i32, [c_p, c_p, c_i32, c_i32, c_p, c_p, c_i32, c_f64, c_f64, c_f64, c_f64, c_f64,
+                                       c_i32, c_p, c_p]),
+    "sosvo_stereo_assemble": (c_i32, [c_p] + [c_p] * 9 + [c_i32] * 4 + [c_p] * 9),
+    "sosvo_f2f_assemble": (c_i32, [c_p] + [c_p] * 7 + [c_i32] + [c_p] * 6 + [c_i32, c_i32] + [c_p] * 7),
     "sosvo_ransac_abs_pose": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_p, c_i32, c_i32, c_f64,
                                       c_i32, c_i32, c_u64, c_p, c_p, c_p, c_p, c_p, c_p]),
     "sosvo_refine_abs_pose": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_p, c_i32, c_i32, c_p, c_p, c_i32,
@@ -51,6 +58,13 @@ SIGNATURES = {
 }
 
 FLAG_CAM_ROT_IDENTITY = 1
+
+
+class Rig(ctypes.Structure):
+    """Mirror of `struct sosvo_rig` (include/sosvo.h)."""
+    _fields_ = [("pano_top", c_f64 * 4), ("pano_bot", c_f64 * 4), ("F_top", c_f64 * 3), ("F_bot", c_f64 * 3),
+                ("min_range", c_f64), ("max_range", c_f64), ("stereo_min_disp", c_f64),
+                ("stereo_max_hdiff", c_f64), ("f2f_max_hdiff", c_f64), ("pct_good_matches", c_f64)]
 
 _lib = None
 

@@ -1,0 +1,68 @@
+// Device-side restatement of the reference's numpy geometry on the hot path.
+//   omnistereo/panorama.py:635-641, :616-622   pano pixel -> (azimuth, elevation), NaN outside
+//   omnistereo/camera_models.py:1049-1065      angles -> unit bearing
+//   omnistereo/camera_models.py:3333-3340, :2437-2490  rays on the unit cylinder, midpoint triangulation
+//   omnistereo/camera_models.py:3309-3319      range filter on the homogeneous row (norm includes the 1)
+//   omnistereo/common_cv.py:177-186            pixel gates
+// FP64 throughout; sin/cos/tan/atan2 come from the device math library (the CPU oracle uses
+// libm), so values are compared with rel-tol 1e-12, not bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "sosvo.h"
+
+#define SV_TWO_PI (2 * 3.14159265358979323846 * 1.0) /* cyl_circumference, panorama.py:152 */
+
+__device__ __forceinline__ static double sv_nan() { return __longlong_as_double(0x7FF8000000000000LL); }
+
+// pano = {cols, rows, pixel_size, cyl_height_max}
+__device__ __forceinline__ static void sv_pano_angles(double u, double v, const double* pano, double* az, double* el) {
+  *az = (0.0 <= u && u < pano[0]) ? SV_TWO_PI - pano[2] * u : sv_nan();
+  *el = (0.0 <= v && v < pano[1]) ? atan2(pano[3] - pano[2] * v, 1.0) : sv_nan();
+}
+
+__device__ __forceinline__ static void sv_bearing(double az, double el, double* b3) {
+  const double b = cos(el), z = sin(el);
+  b3[0] = b * cos(az);
+  b3[1] = b * sin(az);
+  b3[2] = z;
+}
+
+__device__ __forceinline__ static void sv_triangulate(double az1, double el1, double az2, double el2, const double* F1,
+                                                       const double* F2, double* X) {
+  const double v1[3] = {cos(az1), sin(az1), tan(el1)};
+  const double v2[3] = {cos(az2), sin(az2), tan(el2)};
+  const double pv[3] = {v1[1] * v2[2] - v1[2] * v2[1], v1[2] * v2[0] - v1[0] * v2[2], v1[0] * v2[1] - v1[1] * v2[0]};
+  const double mag = sqrt(pv[0] * pv[0] + pv[1] * pv[1] + pv[2] * pv[2]);
+  const double nh[3] = {pv[0] / mag, pv[1] / mag, pv[2] / mag};
+  const double a[3] = {v1[0], v1[1], v1[2]}, b[3] = {-v2[0], -v2[1], -v2[2]}, c[3] = {nh[0], nh[1], nh[2]};
+  const double d[3] = {F2[0] - F1[0], F2[1] - F1[1], F2[2] - F1[2]};
+  const double bxc[3] = {b[1] * c[2] - b[2] * c[1], b[2] * c[0] - b[0] * c[2], b[0] * c[1] - b[1] * c[0]};
+  const double det = a[0] * bxc[0] + a[1] * bxc[1] + a[2] * bxc[2];
+  const double l1 = (d[0] * bxc[0] + d[1] * bxc[1] + d[2] * bxc[2]) / det;
+  const double bxd[3] = {b[1] * d[2] - b[2] * d[1], b[2] * d[0] - b[0] * d[2], b[0] * d[1] - b[1] * d[0]};
+  const double lp = (a[0] * bxd[0] + a[1] * bxd[1] + a[2] * bxd[2]) / det;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double G1 = F1[k] + l1 * v1[k];
+    X[k] = G1 + lp / 2.0 * nh[k];
+  }
+}
+
+__device__ __forceinline__ static bool sv_range_ok(const double* X, double min_range, double max_range) {
+  const double nrm = sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2] + 1.0);
+  bool good = true;
+  if (min_range > 0) good = good && (nrm >= min_range);
+  if (max_range > 0) good = good && (nrm <= max_range);
+  return good;
+}
+
+__device__ __forceinline__ static bool sv_pixel_gate(double ut, double vt, double ub, double vb, double min_disp,
+                                                      double max_hdiff) {
+  bool good = true;
+  if (max_hdiff > 0) good = fabs(ut - ub) <= max_hdiff;
+  if (min_disp >= 0) good = good && (vt - vb >= min_disp);
+  return good;
+}

@@ -34,12 +34,15 @@ __device__ __forceinline__ uint32_t hamming256(const uint4& a0, const uint4& a1,
 template <int QPT, int K>
 __global__ __launch_bounds__(kThreads) void match_hamming_kernel(
     const uint4* __restrict__ q_desc, const uint4* __restrict__ t_desc, const int32_t* __restrict__ nq,
-    const int32_t* __restrict__ nt, int q_stride, int t_stride, int nsplit, uint32_t* __restrict__ keys) {
+    const int32_t* __restrict__ nt, const int32_t* __restrict__ q_slot, const int32_t* __restrict__ t_slot,
+    int q_stride, int t_stride, int nsplit, uint32_t* __restrict__ keys) {
   __shared__ uint4 tile[kTrainTile * 2];
   const int tid = threadIdx.x;
   const int p = blockIdx.y;
-  const int nqp = min(nq[p], q_stride);
-  const int ntp = min(nt[p], t_stride);
+  const int qs = q_slot ? q_slot[p] : p;  // which block of query rows / counts this problem uses
+  const int ts = t_slot ? t_slot[p] : p;
+  const int nqp = min(nq[qs], q_stride);
+  const int ntp = min(nt[ts], t_stride);
   const int q0 = blockIdx.x * (kThreads * QPT);
   if (q0 >= nqp) return;  // uniform over the workgroup
 
@@ -56,14 +59,14 @@ __global__ __launch_bounds__(kThreads) void match_hamming_kernel(
   for (int r = 0; r < QPT; ++r) {
     const int qi = q0 + r * kThreads + tid;
     const bool valid = qi < nqp;
-    const size_t row = (size_t)p * q_stride + (valid ? qi : q0);
+    const size_t row = (size_t)qs * q_stride + (valid ? qi : q0);
     qa[r] = q_desc[row * 2 + 0];
     qb[r] = q_desc[row * 2 + 1];
     best[r] = SOSVO_KEY_NONE;
     second[r] = SOSVO_KEY_NONE;
   }
 
-  const uint4* tsrc = t_desc + (size_t)p * t_stride * 2;
+  const uint4* tsrc = t_desc + (size_t)ts * t_stride * 2;
   for (int t0 = tb; t0 < te; t0 += kTrainTile) {
     const int lim = min(kTrainTile, te - t0);
     __syncthreads();
@@ -103,11 +106,12 @@ __global__ __launch_bounds__(kThreads) void match_hamming_kernel(
 // keep query order (stable), as Python's sorted() does at camera_models.py:444.
 __global__ __launch_bounds__(kThreads) void sort_matches_kernel(const uint32_t* __restrict__ keys,
                                                                 const int32_t* __restrict__ nq,
-                                                                int q_stride, int32_t* __restrict__ order) {
+                                                                const int32_t* __restrict__ q_slot, int q_stride,
+                                                                int32_t* __restrict__ order) {
   extern __shared__ uint32_t sk[];
   const int tid = threadIdx.x;
   const int p = blockIdx.y;
-  const int n = min(nq[p], q_stride);
+  const int n = min(nq[q_slot ? q_slot[p] : p], q_stride);
   const int i0 = blockIdx.x * kThreads;
   if (i0 >= n) return;
   const int n4 = (n + 3) & ~3;
@@ -131,8 +135,9 @@ __global__ __launch_bounds__(kThreads) void sort_matches_kernel(const uint32_t* 
 extern "C" {
 
 int32_t sosvo_match_hamming(sosvo_ctx* ctx, const uint8_t* q_desc, const uint8_t* t_desc,
-                            const int32_t* nq, const int32_t* nt, int32_t nprob, int32_t q_stride,
-                            int32_t t_stride, int32_t k, uint32_t* keys) {
+                            const int32_t* nq, const int32_t* nt, const int32_t* q_slot,
+                            const int32_t* t_slot, int32_t nprob, int32_t q_stride, int32_t t_stride, int32_t k,
+                            uint32_t* keys) {
   SOSVO_ENTER(ctx);
   SOSVO_REQUIRE(ctx, q_desc && t_desc && nq && nt && keys, "null pointer");
   SOSVO_REQUIRE(ctx, k == 1 || k == 2, "k must be 1 or 2");
@@ -164,24 +169,24 @@ int32_t sosvo_match_hamming(sosvo_ctx* ctx, const uint8_t* q_desc, const uint8_t
   if (k == 1) {
     if (qpt == 4)
       hipLaunchKernelGGL((match_hamming_kernel<4, 1>), grid, block, 0, ctx->stream, q4, t4, nq, nt,
-                         q_stride, t_stride, nsplit, keys);
+                         q_slot, t_slot, q_stride, t_stride, nsplit, keys);
     else
       hipLaunchKernelGGL((match_hamming_kernel<1, 1>), grid, block, 0, ctx->stream, q4, t4, nq, nt,
-                         q_stride, t_stride, nsplit, keys);
+                         q_slot, t_slot, q_stride, t_stride, nsplit, keys);
   } else {
     if (qpt == 4)
       hipLaunchKernelGGL((match_hamming_kernel<4, 2>), grid, block, 0, ctx->stream, q4, t4, nq, nt,
-                         q_stride, t_stride, nsplit, keys);
+                         q_slot, t_slot, q_stride, t_stride, nsplit, keys);
     else
       hipLaunchKernelGGL((match_hamming_kernel<1, 2>), grid, block, 0, ctx->stream, q4, t4, nq, nt,
-                         q_stride, t_stride, nsplit, keys);
+                         q_slot, t_slot, q_stride, t_stride, nsplit, keys);
   }
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
 }
 
-int32_t sosvo_sort_matches(sosvo_ctx* ctx, const uint32_t* keys, const int32_t* nq, int32_t nprob,
-                           int32_t q_stride, int32_t* order) {
+int32_t sosvo_sort_matches(sosvo_ctx* ctx, const uint32_t* keys, const int32_t* nq, const int32_t* q_slot,
+                           int32_t nprob, int32_t q_stride, int32_t* order) {
   SOSVO_ENTER(ctx);
   SOSVO_REQUIRE(ctx, keys && nq && order, "null pointer");
   SOSVO_REQUIRE(ctx, nprob >= 0 && nprob <= 65535, "nprob out of range");
@@ -189,7 +194,7 @@ int32_t sosvo_sort_matches(sosvo_ctx* ctx, const uint32_t* keys, const int32_t* 
   if (nprob == 0) return SOSVO_OK;
   const size_t lds = (size_t)((q_stride + 3) & ~3) * sizeof(uint32_t);
   dim3 grid(cdiv(q_stride, kThreads), nprob), block(kThreads);
-  hipLaunchKernelGGL(sort_matches_kernel, grid, block, lds, ctx->stream, keys, nq, q_stride, order);
+  hipLaunchKernelGGL(sort_matches_kernel, grid, block, lds, ctx->stream, keys, nq, q_slot, q_stride, order);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
 }

@@ -8,9 +8,11 @@ import torch
 from . import _lib
 from ._lib import SosvoError, c_f32, c_p
 
+NULL = c_p(0)
+
 
 def _ptr(t):
-    return c_p(t.data_ptr())
+    return c_p(t.data_ptr()) if t is not None else NULL
 
 
 def _check(t, dtype, name, shape=None, ndim=None):
@@ -28,6 +30,22 @@ def _check(t, dtype, name, shape=None, ndim=None):
         if len(shape) != t.dim() or any(s is not None and s != d for s, d in zip(shape, t.shape)):
             raise SosvoError("%s: shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
     return t
+
+
+def make_rig(pano_top, pano_bot, F_top, F_bot, min_range, max_range, stereo_min_disp=1.0, stereo_max_hdiff=2.5,
+             f2f_max_hdiff=-1.0, pct_good_matches=1.0):
+    """Host-side sosvo_rig.  pano_* = (cols, rows, pixel_size, cyl_height_max)."""
+    r = _lib.Rig()
+    for k in range(4):
+        r.pano_top[k] = float(pano_top[k])
+        r.pano_bot[k] = float(pano_bot[k])
+    for k in range(3):
+        r.F_top[k] = float(F_top[k])
+        r.F_bot[k] = float(F_bot[k])
+    r.min_range, r.max_range = float(min_range), float(max_range)
+    r.stereo_min_disp, r.stereo_max_hdiff = float(stereo_min_disp), float(stereo_max_hdiff)
+    r.f2f_max_hdiff, r.pct_good_matches = float(f2f_max_hdiff), float(pct_good_matches)
+    return r
 
 
 class Context(object):
@@ -82,38 +100,52 @@ class Context(object):
         return float(ms.value)
 
     # ---- K7 ----------------------------------------------------------------------------
-    def match_hamming(self, q_desc, t_desc, nq, nt, k=1, keys=None):
-        """q_desc [P, Sq, 32] u8, t_desc [P, St, 32] u8, nq/nt [P] i32 -> keys [P, Sq, k] u32
-        (stored as int32 bit patterns are NOT used: the tensor dtype is torch.uint32)."""
+    def match_hamming(self, q_desc, t_desc, nq, nt, k=1, keys=None, q_slot=None, t_slot=None):
+        """q_desc [Bq, Sq, 32] u8, t_desc [Bt, St, 32] u8, nq [Bq] / nt [Bt] i32 -> keys [P, Sq, k] u32.
+        Without slots P = Bq = Bt; with q_slot / t_slot [P] i32, problem p uses blocks q_slot[p] / t_slot[p]."""
         _check(q_desc, torch.uint8, "q_desc", (None, None, _lib.DESC_BYTES))
-        _check(t_desc, torch.uint8, "t_desc", (q_desc.shape[0], None, _lib.DESC_BYTES))
-        P, Sq = q_desc.shape[0], q_desc.shape[1]
-        St = t_desc.shape[1]
-        _check(nq, torch.int32, "nq", (P,))
-        _check(nt, torch.int32, "nt", (P,))
+        _check(t_desc, torch.uint8, "t_desc", (None, None, _lib.DESC_BYTES))
+        Bq, Sq = q_desc.shape[0], q_desc.shape[1]
+        Bt, St = t_desc.shape[0], t_desc.shape[1]
+        _check(nq, torch.int32, "nq", (Bq,))
+        _check(nt, torch.int32, "nt", (Bt,))
+        if (q_slot is None) != (t_slot is None):
+            raise SosvoError("q_slot and t_slot go together")
+        if q_slot is not None:
+            P = q_slot.shape[0]
+            _check(q_slot, torch.int32, "q_slot", (P,))
+            _check(t_slot, torch.int32, "t_slot", (P,))
+        else:
+            if Bq != Bt:
+                raise SosvoError("q_desc and t_desc must have the same number of blocks without slots")
+            P = Bq
         if keys is None:
             keys = torch.empty((P, Sq, k), dtype=torch.uint32, device=q_desc.device)
         _check(keys, torch.uint32, "keys", (P, Sq, k))
-        self._call(self._lib.sosvo_match_hamming, _ptr(q_desc), _ptr(t_desc), _ptr(nq), _ptr(nt),
-                   P, Sq, St, int(k), _ptr(keys))
+        self._call(self._lib.sosvo_match_hamming, _ptr(q_desc), _ptr(t_desc), _ptr(nq), _ptr(nt), _ptr(q_slot),
+                   _ptr(t_slot), P, Sq, St, int(k), _ptr(keys))
         return keys
 
-    def sort_matches(self, keys, nq, order=None):
-        """keys [P, Sq, 1] u32 (1-NN), nq [P] i32 -> order [P, Sq] i32 (query index by rank)."""
+    def sort_matches(self, keys, nq, order=None, q_slot=None):
+        """keys [P, Sq, 1] u32 (1-NN), nq i32 (per block) -> order [P, Sq] i32 (query index by rank)."""
         _check(keys, torch.uint32, "keys", (None, None, 1))
         P, Sq = keys.shape[0], keys.shape[1]
-        _check(nq, torch.int32, "nq", (P,))
+        _check(nq, torch.int32, "nq", ndim=1)
+        if q_slot is not None:
+            _check(q_slot, torch.int32, "q_slot", (P,))
+        elif nq.shape[0] != P:
+            raise SosvoError("nq must have one entry per problem without q_slot")
         if order is None:
             order = torch.full((P, Sq), -1, dtype=torch.int32, device=keys.device)
         _check(order, torch.int32, "order", (P, Sq))
-        self._call(self._lib.sosvo_sort_matches, _ptr(keys), _ptr(nq), P, Sq, _ptr(order))
+        self._call(self._lib.sosvo_sort_matches, _ptr(keys), _ptr(nq), _ptr(q_slot), P, Sq, _ptr(order))
         return order
 
     # ---- K8 / K10 / K9 -----------------------------------------------------------------
-    def _rig(self, cam, cam_off, cam_rot, P, S):
+    def _rig_cams(self, cam, cam_off, cam_rot, P, S):
         """Validate the optional non-central rig description; returns (cam_ptr, off_ptr, rot_ptr, ncam)."""
         if cam is None:
-            return c_p(0), c_p(0), c_p(0), 1
+            return NULL, NULL, NULL, 1
         _check(cam, torch.int32, "cam", (P, S))
         _check(cam_off, torch.float64, "cam_off", (None, 3))
         ncam = cam_off.shape[0]
@@ -123,48 +155,181 @@ class Context(object):
         return _ptr(cam), _ptr(cam_off), _ptr(cam_rot), ncam
 
     def ransac_abs_pose(self, f, p, n, thr, max_iter, seed=0, adaptive=False, cam=None, cam_off=None,
-                        cam_rot=None, cam_rot_identity=False, want_counts=False):
+                        cam_rot=None, cam_rot_identity=False, want_counts=False, out=None):
         """f, p [P, S, 3] f64, n [P] i32 (+ cam [P, S] i32, cam_off [C,3], cam_rot [C,3,3]) ->
-        dict(T [P,3,4], mask [P,S] u8, idx [P,S] i32, n_inliers [P] i32, info [P,4] i32[, counts [P,max_iter]])."""
+        dict(T [P,3,4], mask [P,S] u8, idx [P,S] i32, n_inliers [P] i32, info [P,4] i32[, counts [P,max_iter]]).
+        `out` may carry preallocated result tensors (same keys) to avoid allocations in a hot loop."""
         _check(f, torch.float64, "f", (None, None, 3))
         P, S = f.shape[0], f.shape[1]
         _check(p, torch.float64, "p", (P, S, 3))
         _check(n, torch.int32, "n", (P,))
-        cam_p, off_p, rot_p, ncam = self._rig(cam, cam_off, cam_rot, P, S)
+        cam_p, off_p, rot_p, ncam = self._rig_cams(cam, cam_off, cam_rot, P, S)
         dev = f.device
-        T = torch.empty((P, 3, 4), dtype=torch.float64, device=dev)
-        mask = torch.zeros((P, S), dtype=torch.uint8, device=dev)
-        idx = torch.full((P, S), -1, dtype=torch.int32, device=dev)
-        n_inl = torch.empty((P,), dtype=torch.int32, device=dev)
-        info = torch.empty((P, 4), dtype=torch.int32, device=dev)
-        counts = torch.empty((P, int(max_iter)), dtype=torch.int32, device=dev) if want_counts else None
+        if out is None:
+            out = dict(T=torch.empty((P, 3, 4), dtype=torch.float64, device=dev),
+                       mask=torch.zeros((P, S), dtype=torch.uint8, device=dev),
+                       idx=torch.full((P, S), -1, dtype=torch.int32, device=dev),
+                       n_inliers=torch.empty((P,), dtype=torch.int32, device=dev),
+                       info=torch.empty((P, 4), dtype=torch.int32, device=dev))
+            if want_counts:
+                out["counts"] = torch.empty((P, int(max_iter)), dtype=torch.int32, device=dev)
+        _check(out["T"], torch.float64, "T", (P, 3, 4))
+        _check(out["mask"], torch.uint8, "mask", (P, S))
+        _check(out["idx"], torch.int32, "idx", (P, S))
+        _check(out["n_inliers"], torch.int32, "n_inliers", (P,))
+        _check(out["info"], torch.int32, "info", (P, 4))
+        counts = out.get("counts")
+        if counts is not None:
+            _check(counts, torch.int32, "counts", (P, int(max_iter)))
         flags = _lib.FLAG_CAM_ROT_IDENTITY if cam_rot_identity else 0
         self._call(self._lib.sosvo_ransac_abs_pose, _ptr(f), _ptr(p), cam_p, off_p, rot_p, ncam, flags,
                    _ptr(n), P, S, float(thr), int(max_iter), 1 if adaptive else 0, int(seed) & (2 ** 64 - 1),
-                   _ptr(T), _ptr(mask), _ptr(idx), _ptr(n_inl), _ptr(info),
-                   _ptr(counts) if counts is not None else c_p(0))
-        out = dict(T=T, mask=mask, idx=idx, n_inliers=n_inl, info=info)
-        if want_counts:
-            out["counts"] = counts
+                   _ptr(out["T"]), _ptr(out["mask"]), _ptr(out["idx"]), _ptr(out["n_inliers"]), _ptr(out["info"]),
+                   _ptr(counts))
         return out
 
     def refine_abs_pose(self, f, p, n, T, idx=None, m=None, cam=None, cam_off=None, cam_rot=None,
-                        max_lm_iter=30):
+                        max_lm_iter=30, cost=None, iters=None):
         """In-place LM refinement of T [P,3,4]; returns (T, cost [P] f64, iters [P] i32)."""
         _check(f, torch.float64, "f", (None, None, 3))
         P, S = f.shape[0], f.shape[1]
         _check(p, torch.float64, "p", (P, S, 3))
         _check(n, torch.int32, "n", (P,))
         _check(T, torch.float64, "T", (P, 3, 4))
-        cam_p, off_p, rot_p, ncam = self._rig(cam, cam_off, cam_rot, P, S)
+        cam_p, off_p, rot_p, ncam = self._rig_cams(cam, cam_off, cam_rot, P, S)
         if (idx is None) != (m is None):
             raise SosvoError("idx and m go together")
         if idx is not None:
             _check(idx, torch.int32, "idx", (P, S))
             _check(m, torch.int32, "m", (P,))
-        cost = torch.empty((P,), dtype=torch.float64, device=f.device)
-        iters = torch.empty((P,), dtype=torch.int32, device=f.device)
+        if cost is None:
+            cost = torch.empty((P,), dtype=torch.float64, device=f.device)
+        if iters is None:
+            iters = torch.empty((P,), dtype=torch.int32, device=f.device)
+        _check(cost, torch.float64, "cost", (P,))
+        _check(iters, torch.int32, "iters", (P,))
         self._call(self._lib.sosvo_refine_abs_pose, _ptr(f), _ptr(p), cam_p, off_p, rot_p, ncam, _ptr(n), P, S,
-                   _ptr(idx) if idx is not None else c_p(0), _ptr(m) if m is not None else c_p(0),
-                   int(max_lm_iter), _ptr(T), _ptr(cost), _ptr(iters))
+                   _ptr(idx), _ptr(m), int(max_lm_iter), _ptr(T), _ptr(cost), _ptr(iters))
         return T, cost, iters
+
+    # ---- geometry ----------------------------------------------------------------------
+    def pano_to_bearing(self, uv, cols, rows, pixel_size, cyl_height_max):
+        """uv [n,2] f64 -> (az [n], el [n], bearing [n,3]) f64."""
+        _check(uv, torch.float64, "uv", (None, 2))
+        n = uv.shape[0]
+        az = torch.empty((n,), dtype=torch.float64, device=uv.device)
+        el = torch.empty((n,), dtype=torch.float64, device=uv.device)
+        b = torch.empty((n, 3), dtype=torch.float64, device=uv.device)
+        self._call(self._lib.sosvo_pano_to_bearing, _ptr(uv), n, float(cols), float(rows), float(pixel_size),
+                   float(cyl_height_max), _ptr(az), _ptr(el), _ptr(b))
+        return az, el, b
+
+    def triangulate_midpoint(self, az_top, el_top, az_bot, el_bot, F_top, F_bot):
+        n = az_top.shape[0]
+        for name, t in (("az_top", az_top), ("el_top", el_top), ("az_bot", az_bot), ("el_bot", el_bot)):
+            _check(t, torch.float64, name, (n,))
+        X = torch.empty((n, 3), dtype=torch.float64, device=az_top.device)
+        f1 = (ctypes.c_double * 3)(*[float(v) for v in F_top])
+        f2 = (ctypes.c_double * 3)(*[float(v) for v in F_bot])
+        self._call(self._lib.sosvo_triangulate_midpoint, _ptr(az_top), _ptr(el_top), _ptr(az_bot), _ptr(el_bot), n,
+                   ctypes.cast(f1, c_p), ctypes.cast(f2, c_p), _ptr(X))
+        return X
+
+    def range_filter(self, X, min_range, max_range):
+        _check(X, torch.float64, "X", (None, 3))
+        ok = torch.empty((X.shape[0],), dtype=torch.uint8, device=X.device)
+        self._call(self._lib.sosvo_range_filter, _ptr(X), X.shape[0], float(min_range), float(max_range), _ptr(ok))
+        return ok
+
+    def rgbd_backproject(self, depth, u, v, fx, fy, cx, cy, focal_length_m, depth_is_Z):
+        _check(depth, torch.float32, "depth", ndim=2)
+        n = u.shape[0]
+        _check(u, torch.int32, "u", (n,))
+        _check(v, torch.int32, "v", (n,))
+        xyz = torch.empty((n, 3), dtype=torch.float64, device=depth.device)
+        b = torch.empty((n, 3), dtype=torch.float64, device=depth.device)
+        self._call(self._lib.sosvo_rgbd_backproject, _ptr(depth), depth.shape[0], depth.shape[1], _ptr(u), _ptr(v), n,
+                   float(fx), float(fy), float(cx), float(cy), float(focal_length_m), 1 if depth_is_Z else 0,
+                   _ptr(xyz), _ptr(b))
+        return xyz, b
+
+    def stereo_assemble(self, rig, kp_top, kp_bot, desc_top, desc_bot, n_top, n_bot, keys, order, nframes, nmask,
+                        out_cap, out=None):
+        """Per-bucket stereo matches -> per-frame correspondences (see include/sosvo.h).
+        kp_* [F*NM, cap, 2] f32, desc_* [F*NM, cap, 32] u8, n_* [F*NM] i32, keys [F*NM, cap, 1] u32,
+        order [F*NM, cap] i32 -> dict(m_top, m_bot [F,out_cap,2] f32, d_top, d_bot [F,out_cap,32] u8,
+        X, b_top, b_bot [F,out_cap,3] f64, M [F] i32, n_cand [F] i32)."""
+        P = nframes * nmask
+        _check(kp_top, torch.float32, "kp_top", (P, None, 2))
+        cap = kp_top.shape[1]
+        _check(kp_bot, torch.float32, "kp_bot", (P, cap, 2))
+        _check(desc_top, torch.uint8, "desc_top", (P, cap, 32))
+        _check(desc_bot, torch.uint8, "desc_bot", (P, cap, 32))
+        _check(n_top, torch.int32, "n_top", (P,))
+        _check(n_bot, torch.int32, "n_bot", (P,))
+        _check(keys, torch.uint32, "keys", (P, cap, 1))
+        _check(order, torch.int32, "order", (P, cap))
+        dev = kp_top.device
+        F = nframes
+        if out is None:
+            out = dict(m_top=torch.zeros((F, out_cap, 2), dtype=torch.float32, device=dev),
+                       m_bot=torch.zeros((F, out_cap, 2), dtype=torch.float32, device=dev),
+                       d_top=torch.zeros((F, out_cap, 32), dtype=torch.uint8, device=dev),
+                       d_bot=torch.zeros((F, out_cap, 32), dtype=torch.uint8, device=dev),
+                       X=torch.zeros((F, out_cap, 3), dtype=torch.float64, device=dev),
+                       b_top=torch.zeros((F, out_cap, 3), dtype=torch.float64, device=dev),
+                       b_bot=torch.zeros((F, out_cap, 3), dtype=torch.float64, device=dev),
+                       M=torch.zeros((F,), dtype=torch.int32, device=dev),
+                       n_cand=torch.zeros((F,), dtype=torch.int32, device=dev))
+        _check(out["m_top"], torch.float32, "m_top", (F, out_cap, 2))
+        _check(out["m_bot"], torch.float32, "m_bot", (F, out_cap, 2))
+        _check(out["d_top"], torch.uint8, "d_top", (F, out_cap, 32))
+        _check(out["d_bot"], torch.uint8, "d_bot", (F, out_cap, 32))
+        for k in ("X", "b_top", "b_bot"):
+            _check(out[k], torch.float64, k, (F, out_cap, 3))
+        _check(out["M"], torch.int32, "M", (F,))
+        _check(out["n_cand"], torch.int32, "n_cand", (F,))
+        self._call(self._lib.sosvo_stereo_assemble, ctypes.cast(ctypes.pointer(rig), c_p), _ptr(kp_top), _ptr(kp_bot),
+                   _ptr(desc_top), _ptr(desc_bot), _ptr(n_top), _ptr(n_bot), _ptr(keys), _ptr(order), F, nmask, cap,
+                   out_cap, _ptr(out["m_top"]), _ptr(out["m_bot"]), _ptr(out["d_top"]), _ptr(out["d_bot"]),
+                   _ptr(out["X"]), _ptr(out["b_top"]), _ptr(out["b_bot"]), _ptr(out["M"]), _ptr(out["n_cand"]))
+        return out
+
+    def f2f_assemble(self, rig, frames, ref_frame, cur_frame, keys_top, order_top, keys_bot, order_bot, corr_cap,
+                     out=None):
+        """frames = dict from stereo_assemble; ref_frame / cur_frame [NP] i32; keys_* [NP, frame_cap, 1] u32,
+        order_* [NP, frame_cap] i32 -> dict(f, p [NP,corr_cap,3] f64, cam, q, t [NP,corr_cap] i32, n, n_top [NP])."""
+        F, frame_cap = frames["m_top"].shape[0], frames["m_top"].shape[1]
+        NP = ref_frame.shape[0]
+        _check(ref_frame, torch.int32, "ref_frame", (NP,))
+        _check(cur_frame, torch.int32, "cur_frame", (NP,))
+        _check(frames["m_top"], torch.float32, "m_top", (F, frame_cap, 2))
+        _check(frames["m_bot"], torch.float32, "m_bot", (F, frame_cap, 2))
+        for k in ("X", "b_top", "b_bot"):
+            _check(frames[k], torch.float64, k, (F, frame_cap, 3))
+        _check(frames["M"], torch.int32, "M", (F,))
+        for name, t in (("keys_top", keys_top), ("keys_bot", keys_bot)):
+            _check(t, torch.uint32, name, (NP, frame_cap, 1))
+        for name, t in (("order_top", order_top), ("order_bot", order_bot)):
+            _check(t, torch.int32, name, (NP, frame_cap))
+        dev = ref_frame.device
+        if out is None:
+            out = dict(f=torch.zeros((NP, corr_cap, 3), dtype=torch.float64, device=dev),
+                       p=torch.zeros((NP, corr_cap, 3), dtype=torch.float64, device=dev),
+                       cam=torch.zeros((NP, corr_cap), dtype=torch.int32, device=dev),
+                       q=torch.zeros((NP, corr_cap), dtype=torch.int32, device=dev),
+                       t=torch.zeros((NP, corr_cap), dtype=torch.int32, device=dev),
+                       n=torch.zeros((NP,), dtype=torch.int32, device=dev),
+                       n_top=torch.zeros((NP,), dtype=torch.int32, device=dev))
+        _check(out["f"], torch.float64, "f", (NP, corr_cap, 3))
+        _check(out["p"], torch.float64, "p", (NP, corr_cap, 3))
+        for k in ("cam", "q", "t"):
+            _check(out[k], torch.int32, k, (NP, corr_cap))
+        _check(out["n"], torch.int32, "n", (NP,))
+        _check(out["n_top"], torch.int32, "n_top", (NP,))
+        self._call(self._lib.sosvo_f2f_assemble, ctypes.cast(ctypes.pointer(rig), c_p), _ptr(frames["m_top"]),
+                   _ptr(frames["m_bot"]), _ptr(frames["X"]), _ptr(frames["b_top"]), _ptr(frames["b_bot"]),
+                   _ptr(frames["M"]), frame_cap, _ptr(ref_frame), _ptr(cur_frame), _ptr(keys_top), _ptr(order_top),
+                   _ptr(keys_bot), _ptr(order_bot), NP, corr_cap, _ptr(out["f"]), _ptr(out["p"]), _ptr(out["cam"]),
+                   _ptr(out["q"]), _ptr(out["t"]), _ptr(out["n"]), _ptr(out["n_top"]))
+        return out
