@@ -67,6 +67,14 @@ int32_t sosvo_timer_start(sosvo_ctx* ctx);
 int32_t sosvo_timer_stop(sosvo_ctx* ctx);
 int32_t sosvo_timer_elapsed_ms(sosvo_ctx* ctx, float* ms);
 
+/* Per-kernel HIP-event profile on the context's stream: while enabled, every kernel launch of
+ * every entry point is bracketed by an event pair (up to 16384 launches since the last enable).
+ * sosvo_profile_enable(on) also clears the record.  sosvo_profile_get synchronises on entry i and
+ * returns the kernel's label and its duration in ms.                                            */
+int32_t sosvo_profile_enable(sosvo_ctx* ctx, int32_t on);
+int32_t sosvo_profile_count(sosvo_ctx* ctx);
+int32_t sosvo_profile_get(sosvo_ctx* ctx, int32_t i, char* name_out, int32_t name_cap, float* ms);
+
 /* ---- K7: brute-force Hamming matching ------------------------------------------------
  * Replaces cv2.BFMatcher(NORM_HAMMING).match / .knnMatch as called from
  * omnistereo/camera_models.py:442 and :420 (FeatureMatcher.match, :404-446).

@@ -1,0 +1,47 @@
+"""GPU: the batched FramePairPipeline (everything after detection) against the reference's control
+flow on the CPU oracle (tests/refflow.py), end to end: stereo correspondences, frame-to-frame
+correspondences, inlier masks (bit-exact) and the refined pose (rel-tol 1e-6, BASELINE north_star)."""
+import numpy as np
+import pytest
+
+import refflow
+import synth
+from vo_single_camera_sos_amd.pipeline import FramePairPipeline, RigConfig
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pipeline_end_to_end_parity(ctx):
+    B, NM, cap = 5, 12, 192
+    rig_kw = dict(pano_top=synth.PANO_C2, pano_bot=synth.PANO_C2, F_top=synth.F_TOP, F_bot=synth.F_BOT,
+                  min_range=500.0, max_range=7000.0, stereo_min_disp=1.0, stereo_max_hdiff=2.5,
+                  f2f_max_hdiff=75.0, pct_good_matches=1.0)
+    frames = []
+    for i in range(B):
+        rng = np.random.default_rng(500 + i)
+        P, desc = synth.make_scene(rng, 1500 if i else 40)  # pair 0: too few points to track well
+        R, t = synth.random_pose(rng)
+        frames.append(synth.observe_frame(rng, P, desc, np.eye(3), np.zeros(3), nmask=NM, cap=cap))
+        frames.append(synth.observe_frame(rng, P, desc, R, t, nmask=NM, cap=cap))
+    pipe = FramePairPipeline(ctx, RigConfig(**rig_kw), B, nmask=NM, bucket_cap=cap, frame_cap=2048, max_iter=400,
+                             seed=77)
+    pipe.load_keypoints(synth.pack_buckets(frames, NM, cap))
+    pipe.step()
+    rec = pipe.results()
+    ctx.synchronize()
+    rec = rec.cpu().numpy()
+    mask = pipe.ransac["mask"].cpu().numpy()
+    M = pipe.frames["M"].cpu().numpy()
+    rp = refflow.RigParams(**rig_kw)
+    for i in range(B):
+        ref = refflow.stereo_frame(rp, *[frames[2 * i][k] for k in ("kp_top", "kp_bot", "desc_top", "desc_bot")])
+        cur = refflow.stereo_frame(rp, *[frames[2 * i + 1][k] for k in ("kp_top", "kp_bot", "desc_top", "desc_bot")])
+        assert M[2 * i] == len(ref["X"]) and M[2 * i + 1] == len(cur["X"])
+        w = refflow.track_pair(rp, ref, cur, pipe.thr, 400, seed=77 + i)
+        n = len(w["corr"]["cam"])
+        assert rec[i, 13] == n
+        assert rec[i, 14] == w["ransac"]["status"] and rec[i, 15] == w["ransac"]["best_iter"]
+        assert rec[i, 12] == w["ransac"]["n_inliers"]
+        assert np.array_equal(mask[i, :n].astype(bool), w["ransac"]["mask"])
+        assert np.allclose(rec[i, :12].reshape(3, 4), w["T"], rtol=1e-6, atol=1e-9)
+    assert (rec[1:, 14] == 0).all() and (rec[1:, 12] > 1000).all()

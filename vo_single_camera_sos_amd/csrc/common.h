@@ -7,6 +7,13 @@
 
 #include "sosvo.h"
 
+struct sosvo_prof_entry {
+  const char* name;  // string literal
+  hipEvent_t a, b;
+};
+
+constexpr int kSosvoProfMax = 16384;
+
 struct sosvo_ctx {
   int32_t device;
   hipStream_t stream;
@@ -15,7 +22,42 @@ struct sosvo_ctx {
   // scratch workspace owned by the context (grown on demand, never inside a capture)
   void* ws;
   size_t ws_bytes;
+  // optional per-kernel HIP-event profile (sosvo_profile_*): one event pair per launch
+  int32_t prof_on;
+  int32_t prof_n;        // entries recorded since the last enable/reset
+  int32_t prof_created;  // event pairs that exist
+  sosvo_prof_entry* prof;
 };
+
+// Brackets the kernel launches of the enclosing scope with a HIP event pair when profiling is on.
+struct SosvoProfScope {
+  sosvo_ctx* ctx;
+  bool active;
+  SosvoProfScope(sosvo_ctx* c, const char* name) : ctx(c), active(false) {
+    if (!c->prof_on || !c->prof || c->prof_n >= kSosvoProfMax) return;
+    sosvo_prof_entry& e = c->prof[c->prof_n];
+    if (c->prof_n >= c->prof_created) {
+      if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+      c->prof_created = c->prof_n + 1;
+    }
+    e.name = name;
+    if (hipEventRecord(e.a, c->stream) != hipSuccess) return;
+    active = true;
+  }
+  ~SosvoProfScope() {
+    if (!active) return;
+    (void)hipEventRecord(ctx->prof[ctx->prof_n].b, ctx->stream);
+    ctx->prof_n++;
+  }
+};
+#define SOSVO_PROFILE(ctx, name) SosvoProfScope sosvo_prof_scope_(ctx, name)
+
+// Kernel launch on the context's stream, labelled with the kernel's name for the profile.
+#define SOSVO_LAUNCH(ctx, kernel, ...)            \
+  do {                                            \
+    SOSVO_PROFILE(ctx, #kernel);                  \
+    hipLaunchKernelGGL(kernel, __VA_ARGS__);      \
+  } while (0)
 
 #define SOSVO_WAVE 64
 

@@ -35,6 +35,13 @@ int32_t sosvo_destroy(sosvo_ctx* ctx) {
   if (!ctx) return SOSVO_OK;
   (void)hipSetDevice(ctx->device);
   if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->prof) {
+    for (int i = 0; i < ctx->prof_created; ++i) {
+      (void)hipEventDestroy(ctx->prof[i].a);
+      (void)hipEventDestroy(ctx->prof[i].b);
+    }
+    free(ctx->prof);
+  }
   (void)hipEventDestroy(ctx->ev_start);
   (void)hipEventDestroy(ctx->ev_stop);
   free(ctx);
@@ -64,6 +71,29 @@ int32_t sosvo_timer_start(sosvo_ctx* ctx) {
 int32_t sosvo_timer_stop(sosvo_ctx* ctx) {
   SOSVO_ENTER(ctx);
   SOSVO_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+  return SOSVO_OK;
+}
+
+int32_t sosvo_profile_enable(sosvo_ctx* ctx, int32_t on) {
+  SOSVO_ENTER(ctx);
+  if (on && !ctx->prof) {
+    ctx->prof = (sosvo_prof_entry*)calloc(kSosvoProfMax, sizeof(sosvo_prof_entry));
+    if (!ctx->prof) return sosvo_fail(ctx, SOSVO_ERR_HIP, __func__, "out of host memory");
+  }
+  ctx->prof_on = on ? 1 : 0;
+  ctx->prof_n = 0;
+  return SOSVO_OK;
+}
+
+int32_t sosvo_profile_count(sosvo_ctx* ctx) { return ctx ? ctx->prof_n : 0; }
+
+int32_t sosvo_profile_get(sosvo_ctx* ctx, int32_t i, char* name_out, int32_t name_cap, float* ms) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, ctx->prof && i >= 0 && i < ctx->prof_n && name_out && name_cap > 0 && ms, "bad arguments");
+  const sosvo_prof_entry& e = ctx->prof[i];
+  SOSVO_HIP(ctx, hipEventSynchronize(e.b));
+  SOSVO_HIP(ctx, hipEventElapsedTime(ms, e.a, e.b));
+  snprintf(name_out, (size_t)name_cap, "%s", e.name ? e.name : "");
   return SOSVO_OK;
 }
 

@@ -238,7 +238,7 @@ int32_t sosvo_pano_to_bearing(sosvo_ctx* ctx, const double* uv, int32_t n, doubl
   SOSVO_ENTER(ctx);
   SOSVO_REQUIRE(ctx, uv && n >= 0, "bad arguments");
   if (n == 0) return SOSVO_OK;
-  hipLaunchKernelGGL(pano_to_bearing_kernel, dim3(cdiv(n, kThreads)), dim3(kThreads), 0, ctx->stream, uv, n, cols, rows,
+  SOSVO_LAUNCH(ctx,pano_to_bearing_kernel, dim3(cdiv(n, kThreads)), dim3(kThreads), 0, ctx->stream, uv, n, cols, rows,
                      pixel_size, cyl_height_max, az, el, bearing);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
@@ -255,7 +255,7 @@ int32_t sosvo_triangulate_midpoint(sosvo_ctx* ctx, const double* az_top, const d
     foci.F1[k] = F_top_host[k];
     foci.F2[k] = F_bot_host[k];
   }
-  hipLaunchKernelGGL(triangulate_kernel, dim3(cdiv(n, kThreads)), dim3(kThreads), 0, ctx->stream, az_top, el_top, az_bot,
+  SOSVO_LAUNCH(ctx,triangulate_kernel, dim3(cdiv(n, kThreads)), dim3(kThreads), 0, ctx->stream, az_top, el_top, az_bot,
                      el_bot, n, foci, X);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
@@ -266,7 +266,7 @@ int32_t sosvo_range_filter(sosvo_ctx* ctx, const double* X, int32_t n, double mi
   SOSVO_ENTER(ctx);
   SOSVO_REQUIRE(ctx, X && ok && n >= 0, "bad arguments");
   if (n == 0) return SOSVO_OK;
-  hipLaunchKernelGGL(range_filter_kernel, dim3(cdiv(n, kThreads)), dim3(kThreads), 0, ctx->stream, X, n, min_range,
+  SOSVO_LAUNCH(ctx,range_filter_kernel, dim3(cdiv(n, kThreads)), dim3(kThreads), 0, ctx->stream, X, n, min_range,
                      max_range, ok);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
@@ -279,7 +279,7 @@ int32_t sosvo_rgbd_backproject(sosvo_ctx* ctx, const float* depth, int32_t rows,
   SOSVO_REQUIRE(ctx, depth && u && v && xyz && bearing && n >= 0 && rows > 0 && cols > 0, "bad arguments");
   if (n == 0) return SOSVO_OK;
   Intr k{fx, fy, cx, cy, focal_length_m};
-  hipLaunchKernelGGL(rgbd_backproject_kernel, dim3(cdiv(n, kThreads)), dim3(kThreads), 0, ctx->stream, depth, rows, cols,
+  SOSVO_LAUNCH(ctx,rgbd_backproject_kernel, dim3(cdiv(n, kThreads)), dim3(kThreads), 0, ctx->stream, depth, rows, cols,
                      u, v, n, k, depth_is_Z, xyz, bearing);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
@@ -297,7 +297,7 @@ int32_t sosvo_stereo_assemble(sosvo_ctx* ctx, const sosvo_rig* rig_host, const f
   SOSVO_REQUIRE(ctx, nframes >= 0 && nframes <= (1 << 20) && nmask > 0 && cap > 0 && out_cap > 0, "sizes out of range");
   SOSVO_REQUIRE(ctx, cap <= (1 << SOSVO_KEY_SHIFT), "cap out of range");
   if (nframes == 0) return SOSVO_OK;
-  hipLaunchKernelGGL(stereo_assemble_kernel, dim3(nframes), dim3(kThreads), 0, ctx->stream, *rig_host, kp_top, kp_bot,
+  SOSVO_LAUNCH(ctx,stereo_assemble_kernel, dim3(nframes), dim3(kThreads), 0, ctx->stream, *rig_host, kp_top, kp_bot,
                      reinterpret_cast<const uint4*>(desc_top), reinterpret_cast<const uint4*>(desc_bot), n_top, n_bot,
                      keys, order, nmask, cap, out_cap, m_top, m_bot, reinterpret_cast<uint4*>(d_top),
                      reinterpret_cast<uint4*>(d_bot), X, b_top, b_bot, M, n_cand);
@@ -318,7 +318,7 @@ int32_t sosvo_f2f_assemble(sosvo_ctx* ctx, const sosvo_rig* rig_host, const floa
                 "null pointer");
   SOSVO_REQUIRE(ctx, npairs >= 0 && npairs <= (1 << 20) && frame_cap > 0 && corr_cap > 0, "sizes out of range");
   if (npairs == 0) return SOSVO_OK;
-  hipLaunchKernelGGL(f2f_assemble_kernel, dim3(npairs), dim3(kThreads), 0, ctx->stream, *rig_host, m_top, m_bot, X,
+  SOSVO_LAUNCH(ctx,f2f_assemble_kernel, dim3(npairs), dim3(kThreads), 0, ctx->stream, *rig_host, m_top, m_bot, X,
                      b_top, b_bot, M, frame_cap, ref_frame, cur_frame, keys_top, order_top, keys_bot, order_bot,
                      corr_cap, f, p, cam, corr_q, corr_t, n, n_topview);
   SOSVO_LAUNCH_CHECK(ctx);

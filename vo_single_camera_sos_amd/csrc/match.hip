@@ -168,17 +168,17 @@ int32_t sosvo_match_hamming(sosvo_ctx* ctx, const uint8_t* q_desc, const uint8_t
   dim3 grid(gx, nprob, nsplit), block(kThreads);
   if (k == 1) {
     if (qpt == 4)
-      hipLaunchKernelGGL((match_hamming_kernel<4, 1>), grid, block, 0, ctx->stream, q4, t4, nq, nt,
+      SOSVO_LAUNCH(ctx,(match_hamming_kernel<4, 1>), grid, block, 0, ctx->stream, q4, t4, nq, nt,
                          q_slot, t_slot, q_stride, t_stride, nsplit, keys);
     else
-      hipLaunchKernelGGL((match_hamming_kernel<1, 1>), grid, block, 0, ctx->stream, q4, t4, nq, nt,
+      SOSVO_LAUNCH(ctx,(match_hamming_kernel<1, 1>), grid, block, 0, ctx->stream, q4, t4, nq, nt,
                          q_slot, t_slot, q_stride, t_stride, nsplit, keys);
   } else {
     if (qpt == 4)
-      hipLaunchKernelGGL((match_hamming_kernel<4, 2>), grid, block, 0, ctx->stream, q4, t4, nq, nt,
+      SOSVO_LAUNCH(ctx,(match_hamming_kernel<4, 2>), grid, block, 0, ctx->stream, q4, t4, nq, nt,
                          q_slot, t_slot, q_stride, t_stride, nsplit, keys);
     else
-      hipLaunchKernelGGL((match_hamming_kernel<1, 2>), grid, block, 0, ctx->stream, q4, t4, nq, nt,
+      SOSVO_LAUNCH(ctx,(match_hamming_kernel<1, 2>), grid, block, 0, ctx->stream, q4, t4, nq, nt,
                          q_slot, t_slot, q_stride, t_stride, nsplit, keys);
   }
   SOSVO_LAUNCH_CHECK(ctx);
@@ -194,7 +194,7 @@ int32_t sosvo_sort_matches(sosvo_ctx* ctx, const uint32_t* keys, const int32_t* 
   if (nprob == 0) return SOSVO_OK;
   const size_t lds = (size_t)((q_stride + 3) & ~3) * sizeof(uint32_t);
   dim3 grid(cdiv(q_stride, kThreads), nprob), block(kThreads);
-  hipLaunchKernelGGL(sort_matches_kernel, grid, block, lds, ctx->stream, keys, nq, q_slot, q_stride, order);
+  SOSVO_LAUNCH(ctx,sort_matches_kernel, grid, block, lds, ctx->stream, keys, nq, q_slot, q_stride, order);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
 }

@@ -557,10 +557,10 @@ int32_t sosvo_ransac_abs_pose(sosvo_ctx* ctx, const double* f, const double* p, 
   double* hyp = (double*)(ws + o_hyp);
   int32_t* counts = hyp_counts ? hyp_counts : (int32_t*)(ws + o_counts);
 
-  hipLaunchKernelGGL(ransac_prepare_kernel, dim3(nprob), dim3(kThreads), 0, ctx->stream, cam, n, stride,
+  SOSVO_LAUNCH(ctx,ransac_prepare_kernel, dim3(nprob), dim3(kThreads), 0, ctx->stream, cam, n, stride,
                      cam ? ncam : 1, perm, cinfo);
   SOSVO_LAUNCH_CHECK(ctx);
-  hipLaunchKernelGGL(ransac_hyp_kernel, dim3(cdiv(H, 64), nprob), dim3(64), 0, ctx->stream, f, p, cam, cam_off,
+  SOSVO_LAUNCH(ctx,ransac_hyp_kernel, dim3(cdiv(H, 64), nprob), dim3(64), 0, ctx->stream, f, p, cam, cam_off,
                      cam_rot, n, stride, H, seed, perm, cinfo, hyp, counts);
   SOSVO_LAUNCH_CHECK(ctx);
 
@@ -577,18 +577,18 @@ int32_t sosvo_ransac_abs_pose(sosvo_ctx* ctx, const double* f, const double* p, 
   hchunks = cdiv(H, hchunk);
   dim3 grid(gx, hchunks, nprob);
   if (ident)
-    hipLaunchKernelGGL((ransac_score_kernel<true, 2>), grid, dim3(kThreads), 0, ctx->stream, f, p, cam, cam_off,
+    SOSVO_LAUNCH(ctx,(ransac_score_kernel<true, 2>), grid, dim3(kThreads), 0, ctx->stream, f, p, cam, cam_off,
                        cam_rot, n, stride, H, hchunk, thr, fast_ok, hyp, counts);
   else
-    hipLaunchKernelGGL((ransac_score_kernel<false, 1>), grid, dim3(kThreads), 0, ctx->stream, f, p, cam, cam_off,
+    SOSVO_LAUNCH(ctx,(ransac_score_kernel<false, 1>), grid, dim3(kThreads), 0, ctx->stream, f, p, cam, cam_off,
                        cam_rot, n, stride, H, hchunk, thr, fast_ok, hyp, counts);
   SOSVO_LAUNCH_CHECK(ctx);
   if (ident)
-    hipLaunchKernelGGL((ransac_select_kernel<true>), dim3(nprob), dim3(kThreads), 0, ctx->stream, f, p, cam,
+    SOSVO_LAUNCH(ctx,(ransac_select_kernel<true>), dim3(nprob), dim3(kThreads), 0, ctx->stream, f, p, cam,
                        cam_off, cam_rot, n, stride, H, thr, adaptive, hyp, counts, T_out, inlier_mask, inlier_idx,
                        n_inliers, info);
   else
-    hipLaunchKernelGGL((ransac_select_kernel<false>), dim3(nprob), dim3(kThreads), 0, ctx->stream, f, p, cam,
+    SOSVO_LAUNCH(ctx,(ransac_select_kernel<false>), dim3(nprob), dim3(kThreads), 0, ctx->stream, f, p, cam,
                        cam_off, cam_rot, n, stride, H, thr, adaptive, hyp, counts, T_out, inlier_mask, inlier_idx,
                        n_inliers, info);
   SOSVO_LAUNCH_CHECK(ctx);
@@ -608,7 +608,7 @@ int32_t sosvo_refine_abs_pose(sosvo_ctx* ctx, const double* f, const double* p, 
   SOSVO_REQUIRE(ctx, stride > 0 && stride <= (1 << 20), "stride out of range");
   SOSVO_REQUIRE(ctx, max_lm_iter > 0 && max_lm_iter <= 10000, "max_lm_iter out of range");
   if (nprob == 0) return SOSVO_OK;
-  hipLaunchKernelGGL(refine_kernel, dim3(nprob), dim3(kThreads), 0, ctx->stream, f, p, cam, cam_off, cam_rot, n,
+  SOSVO_LAUNCH(ctx,refine_kernel, dim3(nprob), dim3(kThreads), 0, ctx->stream, f, p, cam, cam_off, cam_rot, n,
                      stride, idx, m, max_lm_iter, T_io, cost_out, iters_out);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;

@@ -99,6 +99,21 @@ class Context(object):
         self._call(self._lib.sosvo_timer_elapsed_ms, ctypes.byref(ms))
         return float(ms.value)
 
+    def profile_enable(self, on=True):
+        """Start (and clear) / stop the per-kernel HIP-event record."""
+        self._call(self._lib.sosvo_profile_enable, 1 if on else 0)
+
+    def profile_read(self):
+        """-> list of (kernel label, milliseconds) for every launch since profile_enable(True)."""
+        n = self._lib.sosvo_profile_count(self._h)
+        buf = ctypes.create_string_buffer(128)
+        ms = c_f32()
+        out = []
+        for i in range(n):
+            self._call(self._lib.sosvo_profile_get, i, buf, 128, ctypes.byref(ms))
+            out.append((buf.value.decode(), float(ms.value)))
+        return out
+
     # ---- K7 ----------------------------------------------------------------------------
     def match_hamming(self, q_desc, t_desc, nq, nt, k=1, keys=None, q_slot=None, t_slot=None):
         """q_desc [Bq, Sq, 32] u8, t_desc [Bt, St, 32] u8, nq [Bq] / nt [Bt] i32 -> keys [P, Sq, k] u32.

@@ -1,0 +1,118 @@
+"""Batched frame-pair front end: the order of operations of one reference VO step
+(StereoPanoramicFrame.__init__ -> TrackerStereoSE3.track_frame, omnistereo/pose_est_tools.py:271-402,
+:736-847) for B independent frame pairs at once, every buffer resident in HBM, every stage one or two
+asynchronous C-ABI calls on one stream, no host synchronisation inside a step.
+
+Pair i tracks frame 2i+1 (current) against frame 2i (reference / keyframe)."""
+import numpy as np
+import torch
+
+from .device import Context, make_rig
+
+
+class RigConfig(object):
+    """What the hot path needs to know about one calibrated omnistereo rig (host numbers)."""
+
+    def __init__(self, pano_top, pano_bot, F_top, F_bot, min_range, max_range, stereo_min_disp=1.0,
+                 stereo_max_hdiff=2.5, f2f_max_hdiff=None, pct_good_matches=1.0):
+        self.pano_top, self.pano_bot = tuple(pano_top), tuple(pano_bot)
+        self.F_top, self.F_bot = np.asarray(F_top, np.float64), np.asarray(F_bot, np.float64)
+        self.min_range, self.max_range = float(min_range), float(max_range)
+        self.stereo_min_disp, self.stereo_max_hdiff = float(stereo_min_disp), float(stereo_max_hdiff)
+        # TrackerStereoSE3.bootstrap_tracker (pose_est_tools.py:866): 0.125 * 0.5 * pano cols
+        self.f2f_max_hdiff = 0.125 * 0.5 * self.pano_top[0] if f2f_max_hdiff is None else float(f2f_max_hdiff)
+        self.pct_good_matches = float(pct_good_matches)
+
+    def as_struct(self):
+        return make_rig(self.pano_top, self.pano_bot, self.F_top, self.F_bot, self.min_range, self.max_range,
+                        self.stereo_min_disp, self.stereo_max_hdiff, self.f2f_max_hdiff, self.pct_good_matches)
+
+
+class FramePairPipeline(object):
+    def __init__(self, ctx, rig, n_pairs, nmask=12, bucket_cap=192, frame_cap=2048, thr=None, max_iter=2000,
+                 adaptive=False, seed=0, lm_iter=30):
+        assert isinstance(ctx, Context)
+        self.ctx, self.rig_cfg, self.rig = ctx, rig, rig.as_struct()
+        self.B, self.F, self.NM = int(n_pairs), 2 * int(n_pairs), int(nmask)
+        self.bucket_cap, self.frame_cap, self.corr_cap = int(bucket_cap), int(frame_cap), 2 * int(frame_cap)
+        # TrackerSE3.set_global_parameters_for_tracking (pose_est_tools.py:675-676)
+        self.thr = float(1.0 - np.cos(np.deg2rad(5.0))) if thr is None else float(thr)
+        self.max_iter, self.adaptive, self.seed, self.lm_iter = int(max_iter), bool(adaptive), int(seed), int(lm_iter)
+        dev = ctx.device
+        P = self.F * self.NM
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
+        self.kp_top, self.kp_bot = z((P, bucket_cap, 2), torch.float32), z((P, bucket_cap, 2), torch.float32)
+        self.desc_top, self.desc_bot = z((P, bucket_cap, 32), torch.uint8), z((P, bucket_cap, 32), torch.uint8)
+        self.n_top, self.n_bot = z((P,), torch.int32), z((P,), torch.int32)
+        self.s_keys, self.s_order = z((P, bucket_cap, 1), torch.uint32), z((P, bucket_cap), torch.int32)
+        Fc, Cc = self.frame_cap, self.corr_cap
+        self.frames = dict(m_top=z((self.F, Fc, 2), torch.float32), m_bot=z((self.F, Fc, 2), torch.float32),
+                           d_top=z((self.F, Fc, 32), torch.uint8), d_bot=z((self.F, Fc, 32), torch.uint8),
+                           X=z((self.F, Fc, 3), torch.float64), b_top=z((self.F, Fc, 3), torch.float64),
+                           b_bot=z((self.F, Fc, 3), torch.float64), M=z((self.F,), torch.int32),
+                           n_cand=z((self.F,), torch.int32))
+        self.ref_frame = torch.arange(0, self.F, 2, dtype=torch.int32, device=dev)
+        self.cur_frame = torch.arange(1, self.F, 2, dtype=torch.int32, device=dev)
+        self.k_top, self.k_bot = z((self.B, Fc, 1), torch.uint32), z((self.B, Fc, 1), torch.uint32)
+        self.o_top, self.o_bot = z((self.B, Fc), torch.int32), z((self.B, Fc), torch.int32)
+        self.corr = dict(f=z((self.B, Cc, 3), torch.float64), p=z((self.B, Cc, 3), torch.float64),
+                         cam=z((self.B, Cc), torch.int32), q=z((self.B, Cc), torch.int32),
+                         t=z((self.B, Cc), torch.int32), n=z((self.B,), torch.int32), n_top=z((self.B,), torch.int32))
+        self.ransac = dict(T=z((self.B, 3, 4), torch.float64), mask=z((self.B, Cc), torch.uint8),
+                           idx=z((self.B, Cc), torch.int32), n_inliers=z((self.B,), torch.int32),
+                           info=z((self.B, 4), torch.int32))
+        self.T = z((self.B, 3, 4), torch.float64)
+        self.lm_cost, self.lm_iters = z((self.B,), torch.float64), z((self.B,), torch.int32)
+        self.cam_off = torch.from_numpy(np.stack([rig.F_top, rig.F_bot])).to(dev)
+        self.cam_rot = torch.from_numpy(np.stack([np.eye(3), np.eye(3)])).to(dev)
+
+    # ---- inputs ------------------------------------------------------------------------------
+    def load_keypoints(self, packed):
+        """Image-free entry: per-bucket keypoints/descriptors as numpy arrays (tests/synth.pack_buckets)."""
+        dev = self.ctx.device
+        for name in ("kp_top", "kp_bot", "desc_top", "desc_bot", "n_top", "n_bot"):
+            getattr(self, name).copy_(torch.from_numpy(packed[name]).to(dev))
+
+    # ---- one step ----------------------------------------------------------------------------
+    def stereo(self):
+        c = self.ctx
+        c.match_hamming(self.desc_bot, self.desc_top, self.n_bot, self.n_top, k=1, keys=self.s_keys)
+        c.sort_matches(self.s_keys, self.n_bot, order=self.s_order)
+        c.stereo_assemble(self.rig, self.kp_top, self.kp_bot, self.desc_top, self.desc_bot, self.n_top, self.n_bot,
+                          self.s_keys, self.s_order, self.F, self.NM, self.frame_cap, out=self.frames)
+
+    def track(self):
+        c, fr = self.ctx, self.frames
+        c.match_hamming(fr["d_top"], fr["d_top"], fr["M"], fr["M"], k=1, keys=self.k_top, q_slot=self.cur_frame,
+                        t_slot=self.ref_frame)
+        c.sort_matches(self.k_top, fr["M"], order=self.o_top, q_slot=self.cur_frame)
+        c.match_hamming(fr["d_bot"], fr["d_bot"], fr["M"], fr["M"], k=1, keys=self.k_bot, q_slot=self.cur_frame,
+                        t_slot=self.ref_frame)
+        c.sort_matches(self.k_bot, fr["M"], order=self.o_bot, q_slot=self.cur_frame)
+        c.f2f_assemble(self.rig, fr, self.ref_frame, self.cur_frame, self.k_top, self.o_top, self.k_bot, self.o_bot,
+                       self.corr_cap, out=self.corr)
+        co = self.corr
+        c.ransac_abs_pose(co["f"], co["p"], co["n"], self.thr, self.max_iter, seed=self.seed, adaptive=self.adaptive,
+                          cam=co["cam"], cam_off=self.cam_off, cam_rot=self.cam_rot, cam_rot_identity=True,
+                          out=self.ransac)
+        self.T.copy_(self.ransac["T"])
+        c.refine_abs_pose(co["f"], co["p"], co["n"], self.T, idx=self.ransac["idx"], m=self.ransac["n_inliers"],
+                          cam=co["cam"], cam_off=self.cam_off, cam_rot=self.cam_rot, max_lm_iter=self.lm_iter,
+                          cost=self.lm_cost, iters=self.lm_iters)
+
+    def step(self):
+        """Everything after detection for all B pairs (asynchronous)."""
+        self.stereo()
+        self.track()
+        return self.T
+
+    def results(self):
+        """[B,16] f64 rows: 3x4 refined pose, n_inliers, n_correspondences, status, RANSAC best iteration
+        (the per-pair record gathered over ranks in the multi-GPU configuration)."""
+        out = torch.empty((self.B, 16), dtype=torch.float64, device=self.ctx.device)
+        out[:, :12] = self.T.reshape(self.B, 12)
+        out[:, 12] = self.ransac["n_inliers"].to(torch.float64)
+        out[:, 13] = self.corr["n"].to(torch.float64)
+        out[:, 14] = self.ransac["info"][:, 2].to(torch.float64)
+        out[:, 15] = self.ransac["info"][:, 0].to(torch.float64)
+        return out
