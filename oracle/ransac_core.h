@@ -496,15 +496,56 @@ static inline double orc_residual(const double* x, const double* f, const double
 
 static inline void orc_residual_jac(const double* x, const double* f, const double* p, const double* o,
                                     const double* Rc, double* r, double* J) {
-  const double r0 = orc_residual(x, f, p, o, Rc);
-  *r = r0;
-  for (int j = 0; j < 6; ++j) {
-    double xp[6];
-    for (int u = 0; u < 6; ++u) xp[u] = x[u];
-    double h = ORC_SQRT_EPS * fabs(x[j]);
-    if (h == 0.0) h = ORC_SQRT_EPS;
-    xp[j] = x[j] + h;
-    J[j] = (orc_residual(xp, f, p, o, Rc) - r0) / h;
+  /* Analytic Jacobian of r = 1 - f . u/|u|, u = Rc^T (R(c)^T (p - t) - o), wrt (t, Cayley c).
+   * (OpenGV differentiates numerically; the forward-difference noise stalls LM ~1e-5 short of the
+   * minimum and makes the result depend on last-bit input noise, so the exact gradient is used.) */
+  *r = orc_residual(x, f, p, o, Rc);
+  double R[9];
+  orc_cayley2rot(x + 3, R);
+  const double c0 = x[3], c1 = x[4], c2 = x[5];
+  const double s = 1.0 + (((c0 * c0) + (c1 * c1)) + (c2 * c2));
+  const double d0 = p[0] - x[0], d1 = p[1] - x[1], d2 = p[2] - x[2];
+  const double w0 = ((R[0] * d0) + (R[3] * d1)) + (R[6] * d2);
+  const double w1 = ((R[1] * d0) + (R[4] * d1)) + (R[7] * d2);
+  const double w2 = ((R[2] * d0) + (R[5] * d1)) + (R[8] * d2);
+  const double e0 = w0 - o[0], e1 = w1 - o[1], e2 = w2 - o[2];
+  const double u0 = ((Rc[0] * e0) + (Rc[3] * e1)) + (Rc[6] * e2);
+  const double u1 = ((Rc[1] * e0) + (Rc[4] * e1)) + (Rc[7] * e2);
+  const double u2 = ((Rc[2] * e0) + (Rc[5] * e1)) + (Rc[8] * e2);
+  const double nrm = sqrt(((u0 * u0) + (u1 * u1)) + (u2 * u2));
+  const double g0 = u0 / nrm, g1 = u1 / nrm, g2 = u2 / nrm;
+  const double fg = ((f[0] * g0) + (f[1] * g1)) + (f[2] * g2);
+  const double a0 = (f[0] - (fg * g0)) / nrm, a1 = (f[1] - (fg * g1)) / nrm, a2 = (f[2] - (fg * g2)) / nrm;
+  const double b0 = ((Rc[0] * a0) + (Rc[1] * a1)) + (Rc[2] * a2);
+  const double b1 = ((Rc[3] * a0) + (Rc[4] * a1)) + (Rc[5] * a2);
+  const double b2 = ((Rc[6] * a0) + (Rc[7] * a1)) + (Rc[8] * a2);
+  /* dr/dt = R b */
+  J[0] = ((R[0] * b0) + (R[1] * b1)) + (R[2] * b2);
+  J[1] = ((R[3] * b0) + (R[4] * b1)) + (R[5] * b2);
+  J[2] = ((R[6] * b0) + (R[7] * b1)) + (R[8] * b2);
+  /* dr/dc_k = -b . dw/dc_k,  dw/dc_k = ((dN/dc_k)^T d - 2 c_k w) / s,
+   * (dN/dc_k)^T d = -2 c_k d - 2 e_k x d + 2 (c d_k + e_k (c . d)) */
+  const double cd = ((c0 * d0) + (c1 * d1)) + (c2 * d2);
+  {
+    const double m0 = ((-2.0 * c0) * d0) + (2.0 * ((c0 * d0) + cd));
+    const double m1 = (((-2.0 * c0) * d1) - (2.0 * (-d2))) + (2.0 * (c1 * d0));
+    const double m2 = (((-2.0 * c0) * d2) - (2.0 * d1)) + (2.0 * (c2 * d0));
+    const double q0 = (m0 - ((2.0 * c0) * w0)) / s, q1 = (m1 - ((2.0 * c0) * w1)) / s, q2 = (m2 - ((2.0 * c0) * w2)) / s;
+    J[3] = -(((b0 * q0) + (b1 * q1)) + (b2 * q2));
+  }
+  {
+    const double m0 = (((-2.0 * c1) * d0) - (2.0 * d2)) + (2.0 * (c0 * d1));
+    const double m1 = ((-2.0 * c1) * d1) + (2.0 * ((c1 * d1) + cd));
+    const double m2 = (((-2.0 * c1) * d2) - (2.0 * (-d0))) + (2.0 * (c2 * d1));
+    const double q0 = (m0 - ((2.0 * c1) * w0)) / s, q1 = (m1 - ((2.0 * c1) * w1)) / s, q2 = (m2 - ((2.0 * c1) * w2)) / s;
+    J[4] = -(((b0 * q0) + (b1 * q1)) + (b2 * q2));
+  }
+  {
+    const double m0 = (((-2.0 * c2) * d0) - (2.0 * (-d1))) + (2.0 * (c0 * d2));
+    const double m1 = (((-2.0 * c2) * d1) - (2.0 * d0)) + (2.0 * (c1 * d2));
+    const double m2 = ((-2.0 * c2) * d2) + (2.0 * ((c2 * d2) + cd));
+    const double q0 = (m0 - ((2.0 * c2) * w0)) / s, q1 = (m1 - ((2.0 * c2) * w1)) / s, q2 = (m2 - ((2.0 * c2) * w2)) / s;
+    J[5] = -(((b0 * q0) + (b1 * q1)) + (b2 * q2));
   }
 }
 
