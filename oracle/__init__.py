@@ -229,3 +229,81 @@ def unwrap_lut(gum13, cols, rows, pixel_size, h_max, h_min, elev_low, elev_high)
     my = np.empty((int(rows), int(cols)), dtype=np.float64)
     lib().orc_unwrap_lut(_p(gum13), _p(pano), _p(elev), _p(mx), _p(my))
     return mx, my
+
+
+# ---- image stages (OpenCV semantics restated, see oracle/image.c) ---------------------------------
+def unwrap(omni, mask, map_x, map_y):
+    """omni [H,W,3] u8, mask [H,W] u8 or None, map_x/map_y [rows,cols] f32 -> pano [rows,cols,3] u8."""
+    omni = _c(omni, np.uint8)
+    H, W = omni.shape[:2]
+    map_x = _c(map_x, np.float32)
+    map_y = _c(map_y, np.float32)
+    rows, cols = map_x.shape
+    if mask is not None:
+        mask = _c(mask, np.uint8)
+    pano = np.empty((rows, cols, 3), dtype=np.uint8)
+    lib().orc_unwrap(_p(omni), _pn(mask), ctypes.c_int32(H), ctypes.c_int32(W), _p(map_x), _p(map_y),
+                     ctypes.c_int32(rows), ctypes.c_int32(cols), _p(pano))
+    return pano
+
+
+def median_gray(pano, ksize, want_bgr=False):
+    pano = _c(pano, np.uint8)
+    rows, cols = pano.shape[:2]
+    gray = np.empty((rows, cols), dtype=np.uint8)
+    bgr = np.empty((rows, cols, 3), dtype=np.uint8) if want_bgr else None
+    lib().orc_median_gray(_p(pano), ctypes.c_int32(rows), ctypes.c_int32(cols), ctypes.c_int32(ksize), _p(gray),
+                          _pn(bgr))
+    return (gray, bgr) if want_bgr else gray
+
+
+def min_eigen(gray):
+    gray = _c(gray, np.uint8)
+    eig = np.empty(gray.shape, dtype=np.float32)
+    lib().orc_min_eigen(_p(gray), ctypes.c_int32(gray.shape[0]), ctypes.c_int32(gray.shape[1]), _p(eig))
+    return eig
+
+
+def gft_select(eig, mask_id, which, quality=0.01, min_distance=5.0, max_corners=1000):
+    eig = _c(eig, np.float32)
+    mask_id = _c(mask_id, np.uint8)
+    rows, cols = eig.shape
+    kp = np.zeros((rows * cols, 2), dtype=np.float32)
+    maxv = ctypes.c_float(0)
+    L = lib()
+    L.orc_gft_select.restype = ctypes.c_int32
+    n = L.orc_gft_select(_p(eig), _p(mask_id), ctypes.c_int32(which), ctypes.c_int32(rows), ctypes.c_int32(cols),
+                         ctypes.c_double(quality), ctypes.c_double(min_distance), ctypes.c_int32(max_corners), _p(kp),
+                         ctypes.byref(maxv))
+    return kp[:n].copy(), maxv.value
+
+
+def gauss7(gray):
+    gray = _c(gray, np.uint8)
+    out = np.empty_like(gray)
+    lib().orc_gauss7(_p(gray), ctypes.c_int32(gray.shape[0]), ctypes.c_int32(gray.shape[1]), _p(out))
+    return out
+
+
+def orb_pattern():
+    pts = np.empty((512, 2), dtype=np.int8)
+    lib().orc_orb_pattern(_p(pts))
+    return pts
+
+
+def orb_describe(blurred, kp_xy, cos_a, sin_a, pattern=None, edge=31):
+    """-> (desc [m,32] u8, kept_idx [m] i32): keypoints within `edge` px of the border are dropped."""
+    blurred = _c(blurred, np.uint8)
+    kp_xy = _c(kp_xy, np.float32).reshape(-1, 2)
+    if pattern is None:
+        pattern = orb_pattern()
+    pattern = _c(pattern, np.int8)
+    n = kp_xy.shape[0]
+    desc = np.zeros((max(n, 1), 32), dtype=np.uint8)
+    kept = np.zeros(max(n, 1), dtype=np.int32)
+    L = lib()
+    L.orc_orb_describe.restype = ctypes.c_int32
+    m = L.orc_orb_describe(_p(blurred), ctypes.c_int32(blurred.shape[0]), ctypes.c_int32(blurred.shape[1]), _p(kp_xy),
+                           ctypes.c_int32(n), ctypes.c_float(cos_a), ctypes.c_float(sin_a), _p(pattern),
+                           ctypes.c_int32(edge), _p(desc), _p(kept))
+    return desc[:m].copy(), kept[:m].copy()
