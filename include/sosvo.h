@@ -75,6 +75,31 @@ int32_t sosvo_profile_enable(sosvo_ctx* ctx, int32_t on);
 int32_t sosvo_profile_count(sosvo_ctx* ctx);
 int32_t sosvo_profile_get(sosvo_ctx* ctx, int32_t i, char* name_out, int32_t name_cap, float* ms);
 
+/* ---- K1: unwrap (a1 + a2) ---------------------------------------------------------------------
+ * Replaces Panorama.get_panoramic_image's cv2.remap(omni, map_x, map_y, INTER_LINEAR,
+ * BORDER_CONSTANT, 0) (omnistereo/panorama.py:293) for both mirrors of every frame, with
+ * OmniStereoModel.get_fully_masked_images' bitwise_and (camera_models.py:2991-2996) folded into
+ * the bilinear taps (a masked-out source pixel reads 0, exactly as masking the image first).
+ *   omni  [nframes, H, W, 3] u8 (BGR)
+ *   masks [2, H, W] u8, non-zero = pixel belongs to that mirror's annulus; NULL = no masking
+ *   map_x, map_y [2, rows, cols] f32: Panorama.world2cam_LUT_map_x/y cast to float32 (:291-292);
+ *       NaN entries give the border colour 0
+ *   pano  [2, nframes, rows, cols, 3] u8 -- VIEW-MAJOR: image i = view * nframes + frame
+ * Arithmetic: coordinates rounded to 1/32 px (ties to even), weights (32-fx)(32-fy),
+ * (sum + 512) >> 10; taps outside the image read 0.                                            */
+int32_t sosvo_unwrap(sosvo_ctx* ctx, const uint8_t* omni, const uint8_t* masks, const float* map_x,
+                     const float* map_y, int32_t nframes, int32_t H, int32_t W, int32_t rows,
+                     int32_t cols, uint8_t* pano);
+
+/* ---- K2 + K3: median blur + gray --------------------------------------------------------------
+ * Replaces cv2.medianBlur(pano, ksize) (omnistereo/camera_models.py:1711, pose_est_tools.py:528;
+ * ksize 11 for the SOS frames, 0 = none for RGB-D) followed by cv2.cvtColor(BGR2GRAY)
+ * (camera_models.py:1714, or the conversion ORB does internally).  Exact k x k median per channel
+ * with replicated border, then (1868 B + 9617 G + 4899 R + 8192) >> 14.
+ *   img [nimg, rows, cols, 3] u8 -> gray [nimg, rows, cols] u8.  ksize in {0, 1, 3, 5, 11}.       */
+int32_t sosvo_median_gray(sosvo_ctx* ctx, const uint8_t* img, int32_t nimg, int32_t rows,
+                          int32_t cols, int32_t ksize, uint8_t* gray);
+
 /* ---- K7: brute-force Hamming matching ------------------------------------------------
  * Replaces cv2.BFMatcher(NORM_HAMMING).match / .knnMatch as called from
  * omnistereo/camera_models.py:442 and :420 (FeatureMatcher.match, :404-446).

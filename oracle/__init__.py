@@ -264,15 +264,15 @@ def min_eigen(gray):
     return eig
 
 
-def gft_select(eig, mask_id, which, quality=0.01, min_distance=5.0, max_corners=1000):
+def gft_select(eig, mask_bits, which, quality=0.01, min_distance=5.0, max_corners=1000):
     eig = _c(eig, np.float32)
-    mask_id = _c(mask_id, np.uint8)
+    mask_bits = _c(mask_bits, np.uint32)
     rows, cols = eig.shape
     kp = np.zeros((rows * cols, 2), dtype=np.float32)
     maxv = ctypes.c_float(0)
     L = lib()
     L.orc_gft_select.restype = ctypes.c_int32
-    n = L.orc_gft_select(_p(eig), _p(mask_id), ctypes.c_int32(which), ctypes.c_int32(rows), ctypes.c_int32(cols),
+    n = L.orc_gft_select(_p(eig), _p(mask_bits), ctypes.c_int32(which), ctypes.c_int32(rows), ctypes.c_int32(cols),
                          ctypes.c_double(quality), ctypes.c_double(min_distance), ctypes.c_int32(max_corners), _p(kp),
                          ctypes.byref(maxv))
     return kp[:n].copy(), maxv.value

@@ -170,7 +170,7 @@ void orc_min_eigen(const uint8_t* gray, int32_t rows, int32_t cols, float* eig) 
 }
 
 /* ---- K4b: goodFeaturesToTrack selection for one mask ---------------------------------------------
- * mask_id[y*cols+x] == which (0..254) selects this mask's pixels, 255 = no mask.  Returns the number of
+ * Bit `which` of mask_bits[y*cols+x] set = the pixel belongs to this mask (masks may overlap).  Returns the number of
  * corners written to kp_xy (x, y as float, in acceptance order = descending quality). */
 typedef struct {
   float v;
@@ -185,13 +185,13 @@ static int cand_cmp(const void* pa, const void* pb) {
   return (a->idx > b->idx) ? -1 : (a->idx < b->idx ? 1 : 0); /* ties: higher address first */
 }
 
-int32_t orc_gft_select(const float* eig, const uint8_t* mask_id, int32_t which, int32_t rows, int32_t cols,
+int32_t orc_gft_select(const float* eig, const uint32_t* mask_bits, int32_t which, int32_t rows, int32_t cols,
                        double quality, double min_distance, int32_t max_corners, float* kp_xy,
                        float* max_val_out) {
   float maxv = -INFINITY;
   int any = 0;
   for (int64_t i = 0; i < (int64_t)rows * cols; ++i)
-    if (mask_id[i] == which) {
+    if ((mask_bits[i] >> which) & 1u) {
       if (!any || eig[i] > maxv) maxv = eig[i];
       any = 1;
     }
@@ -203,7 +203,7 @@ int32_t orc_gft_select(const float* eig, const uint8_t* mask_id, int32_t which, 
   for (int y = 1; y < rows - 1; ++y)
     for (int x = 1; x < cols - 1; ++x) {
       const int64_t i = (int64_t)y * cols + x;
-      if (mask_id[i] != which) continue;
+      if (!((mask_bits[i] >> which) & 1u)) continue;
       const float v = eig[i] > thr ? eig[i] : 0.0f;
       if (v == 0.0f) continue;
       float dil = v; /* 3x3 dilation of the thresholded map */

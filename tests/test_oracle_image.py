@@ -60,7 +60,7 @@ def test_min_eigen_against_float64_structure_tensor():
 
 def test_gft_selection_rules():
     eig = np.zeros((30, 40), dtype=np.float32)
-    mask = np.zeros((30, 40), dtype=np.uint8)       # one mask (id 0) everywhere
+    mask = np.ones((30, 40), dtype=np.uint32)       # bit 0: one mask everywhere
     eig[10, 10] = 1.0
     eig[10, 13] = 0.9                               # 3 px from the first: suppressed by min distance 5
     eig[10, 16] = 0.8                               # 6 px: kept
@@ -74,7 +74,8 @@ def test_gft_selection_rules():
     kp2, _ = oracle.gft_select(eig, mask, 0, max_corners=2)
     assert kp2.tolist() == [[10.0, 10.0], [16.0, 10.0]]
     # a second mask sees only its own pixels for max / candidates, but dilation looks at all pixels
-    mask[:, 20:] = 1
+    mask[:, 20:] = 2                                # bit 1 only
+    mask[:, 19] = 3                                 # masks may share a column
     kp3, maxv3 = oracle.gft_select(eig, mask, 1)
     assert maxv3 == 0.5 and kp3.tolist() == [[31.0, 5.0], [20.0, 20.0]]
     kp4, _ = oracle.gft_select(eig, mask, 7)

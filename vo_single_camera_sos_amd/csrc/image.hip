@@ -1,0 +1,199 @@
+// Image stages of the hot path, batched over NI = 2 * nframes images (view-major: image i is
+// view i / nframes of frame i % nframes).
+//
+//   K1 unwrap        cv2.remap at omnistereo/panorama.py:293 (+ the annulus masks of
+//                    camera_models.py:2991-2996 folded into the bilinear taps)
+//   K2+K3 median     cv2.medianBlur(pano, 11) at camera_models.py:1711 and cv2.cvtColor(BGR2GRAY) at :1714
+//
+// Both are integer/byte work.  K1 is a gather (HBM/L2-bound, coalesced on the pano rows).  K2 is the
+// heavy one: 121-element medians for every pixel and channel.  It is computed WITHOUT sorting and
+// without LDS: a wave owns a 54-column strip and walks down the rows; each new source row is turned
+// into 8 bit-planes with 64-bit wave ballots (one SGPR pair per plane), every lane cuts its 11-bit
+// horizontal window out of the ballot, and the 11 x 11 window lives in a register shift-register of
+// packed bit-plane words (two rows per VGPR).  The median is then a radix select from the MSB down:
+// AND + popcount on 6 words per bit decide whether the 61st smallest value has that bit set.
+// ~940 VALU ops per output pixel (3 channels) instead of ~5800 for compare-and-count.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ---- K1 ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void unwrap_kernel(const uint8_t* __restrict__ omni,
+                                                          const uint8_t* __restrict__ masks,
+                                                          const float* __restrict__ map_x,
+                                                          const float* __restrict__ map_y, int nframes, int H, int W,
+                                                          int rows, int cols, uint8_t* __restrict__ pano) {
+  const int npix = rows * cols;
+  const int pix = blockIdx.x * kThreads + threadIdx.x;
+  const int img = blockIdx.y;  // view-major
+  if (pix >= npix) return;
+  const int view = img / nframes, frame = img - view * nframes;
+  const float mx = map_x[(size_t)view * npix + pix], my = map_y[(size_t)view * npix + pix];
+  int acc0 = 0, acc1 = 0, acc2 = 0;
+  if (mx == mx && my == my && mx > -4.0f && mx < (float)W + 4.0f && my > -4.0f && my < (float)H + 4.0f) {
+    const int sx = __float2int_rn(mx * 32.0f), sy = __float2int_rn(my * 32.0f);  // ties to even
+    const int ix = sx >> 5, iy = sy >> 5, fx = sx & 31, fy = sy & 31;
+    const uint8_t* src = omni + (size_t)frame * H * W * 3;
+    const uint8_t* msk = masks ? masks + (size_t)view * H * W : nullptr;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int x = ix + (t & 1), y = iy + (t >> 1);
+      const int w = ((t & 1) ? fx : 32 - fx) * ((t >> 1) ? fy : 32 - fy);
+      if (x < 0 || x >= W || y < 0 || y >= H) continue;
+      const size_t o = (size_t)y * W + x;
+      if (msk && !msk[o]) continue;
+      acc0 += w * src[3 * o + 0];
+      acc1 += w * src[3 * o + 1];
+      acc2 += w * src[3 * o + 2];
+    }
+  }
+  uint8_t* out = pano + ((size_t)img * npix + pix) * 3;
+  out[0] = (uint8_t)((acc0 + 512) >> 10);
+  out[1] = (uint8_t)((acc1 + 512) >> 10);
+  out[2] = (uint8_t)((acc2 + 512) >> 10);
+}
+
+__device__ __forceinline__ uint8_t bgr2gray(int b, int g, int r) {
+  return (uint8_t)((1868 * b + 9617 * g + 4899 * r + 8192) >> 14);
+}
+
+__global__ __launch_bounds__(kThreads) void gray_kernel(const uint8_t* __restrict__ img, size_t npix_total,
+                                                        uint8_t* __restrict__ gray) {
+  const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= npix_total) return;
+  gray[i] = bgr2gray(img[3 * i], img[3 * i + 1], img[3 * i + 2]);
+}
+
+// ---- K2 + K3 ----------------------------------------------------------------------------------------
+// K x K median per channel (replicated border) followed by BGR->gray.  K odd, 3 <= K <= 15.
+template <int K>
+__global__ __launch_bounds__(kThreads) void median_gray_kernel(const uint8_t* __restrict__ img, int nimg, int rows,
+                                                               int cols, int strips, uint8_t* __restrict__ gray) {
+  constexpr int R = K / 2;
+  constexpr int NW = (K + 1) / 2;       // packed words per bit-plane, two rows (16-bit halves) per word
+  constexpr int OUTW = 64 - 2 * R;      // output columns per wave
+  constexpr uint32_t FIELD = (1u << K) - 1u;
+  constexpr int HALF = (K * K) / 2 + 1;  // rank of the median, 1-based
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * kThreads + threadIdx.x) >> 6;
+  if (wave >= nimg * strips) return;  // wave-uniform
+  const int im = wave / strips, strip = wave - im * strips;
+  const int x0 = strip * OUTW;
+  const int x_src = clampi(x0 - R + lane, 0, cols - 1);
+  const int x_out = x0 + lane;
+  const bool out_ok = lane < OUTW && x_out < cols;
+  const uint8_t* src = img + (size_t)im * rows * cols * 3;
+  uint8_t* dst = gray + (size_t)im * rows * cols;
+
+  uint32_t Wp[3][8][NW];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+      for (int j = 0; j < NW; ++j) Wp[c][b][j] = 0u;
+
+  for (int r_src = -R; r_src < rows + R; ++r_src) {
+    const int rr = clampi(r_src, 0, rows - 1);
+    const uint8_t* px = src + ((size_t)rr * cols + x_src) * 3;
+    const uint32_t pix[3] = {px[0], px[1], px[2]};
+    // shift the window up by one row and append the new row's 8 bit-plane fields
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const unsigned long long bal = __ballot((pix[c] >> b) & 1u);
+        const uint32_t field = (uint32_t)(bal >> lane) & FIELD;
+#pragma unroll
+        for (int j = 0; j + 1 < NW; ++j) Wp[c][b][j] = __funnelshift_r(Wp[c][b][j], Wp[c][b][j + 1], 16);
+        if (K & 1)
+          Wp[c][b][NW - 1] = field;  // odd K: the newest row sits alone in the low half of the last word
+        else
+          Wp[c][b][NW - 1] = (Wp[c][b][NW - 1] >> 16) | (field << 16);
+      }
+    }
+    const int r_out = r_src - R;
+    if (r_out < 0) continue;  // window not complete yet (uniform)
+    int med[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      uint32_t C[NW];
+#pragma unroll
+      for (int j = 0; j < NW; ++j) C[j] = (FIELD << 16) | FIELD;
+      if (K & 1) C[NW - 1] = FIELD;
+      int k = HALF, cntC = K * K, res = 0;
+#pragma unroll
+      for (int b = 7; b >= 0; --b) {
+        uint32_t t[NW];
+        int n1 = 0;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+          t[j] = C[j] & Wp[c][b][j];
+          n1 += __popc(t[j]);
+        }
+        const int nz = cntC - n1;           // candidates whose bit b is 0
+        const bool take0 = k <= nz;          // the k-th smallest is among them
+        res |= take0 ? 0 : (1 << b);
+        k = take0 ? k : k - nz;
+        cntC = take0 ? nz : n1;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) C[j] = take0 ? (C[j] ^ t[j]) : t[j];
+      }
+      med[c] = res;
+    }
+    if (out_ok) dst[(size_t)r_out * cols + x_out] = bgr2gray(med[0], med[1], med[2]);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t sosvo_unwrap(sosvo_ctx* ctx, const uint8_t* omni, const uint8_t* masks, const float* map_x,
+                     const float* map_y, int32_t nframes, int32_t H, int32_t W, int32_t rows, int32_t cols,
+                     uint8_t* pano) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, omni && map_x && map_y && pano, "null pointer");
+  SOSVO_REQUIRE(ctx, nframes >= 0 && nframes <= 32767, "nframes out of range");
+  SOSVO_REQUIRE(ctx, H > 0 && W > 0 && H <= 16384 && W <= 16384 && rows > 0 && cols > 0 && rows * (int64_t)cols < (1 << 28),
+                "image sizes out of range");
+  if (nframes == 0) return SOSVO_OK;
+  SOSVO_LAUNCH(ctx, unwrap_kernel, dim3(cdiv(rows * cols, kThreads), 2 * nframes), dim3(kThreads), 0, ctx->stream, omni,
+               masks, map_x, map_y, nframes, H, W, rows, cols, pano);
+  SOSVO_LAUNCH_CHECK(ctx);
+  return SOSVO_OK;
+}
+
+int32_t sosvo_median_gray(sosvo_ctx* ctx, const uint8_t* img, int32_t nimg, int32_t rows, int32_t cols,
+                          int32_t ksize, uint8_t* gray) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, img && gray, "null pointer");
+  SOSVO_REQUIRE(ctx, nimg >= 0 && nimg <= 65535 && rows > 0 && cols > 0 && rows * (int64_t)cols < (1 << 28),
+                "sizes out of range");
+  SOSVO_REQUIRE(ctx, ksize <= 1 || ksize == 3 || ksize == 5 || ksize == 11, "ksize must be 0/1 (none), 3, 5 or 11");
+  if (nimg == 0) return SOSVO_OK;
+  if (ksize <= 1) {
+    const size_t n = (size_t)nimg * rows * cols;
+    SOSVO_LAUNCH(ctx, gray_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream, img, n,
+                 gray);
+  } else {
+    const int outw = 64 - 2 * (ksize / 2);
+    const int strips = cdiv(cols, outw);
+    const int waves = nimg * strips;
+    dim3 grid(cdiv(waves, kThreads / 64)), block(kThreads);
+    if (ksize == 11)
+      SOSVO_LAUNCH(ctx, median_gray_kernel<11>, grid, block, 0, ctx->stream, img, nimg, rows, cols, strips, gray);
+    else if (ksize == 5)
+      SOSVO_LAUNCH(ctx, median_gray_kernel<5>, grid, block, 0, ctx->stream, img, nimg, rows, cols, strips, gray);
+    else
+      SOSVO_LAUNCH(ctx, median_gray_kernel<3>, grid, block, 0, ctx->stream, img, nimg, rows, cols, strips, gray);
+  }
+  SOSVO_LAUNCH_CHECK(ctx);
+  return SOSVO_OK;
+}
+
+}  // extern "C"

@@ -114,6 +114,37 @@ class Context(object):
             out.append((buf.value.decode(), float(ms.value)))
         return out
 
+    # ---- K1 / K2 / K3 ------------------------------------------------------------------
+    def unwrap(self, omni, masks, map_x, map_y, pano=None):
+        """omni [F,H,W,3] u8, masks [2,H,W] u8 or None, map_x/map_y [2,rows,cols] f32 ->
+        pano [2,F,rows,cols,3] u8 (view-major)."""
+        _check(omni, torch.uint8, "omni", (None, None, None, 3))
+        F, H, W = omni.shape[0], omni.shape[1], omni.shape[2]
+        if masks is not None:
+            _check(masks, torch.uint8, "masks", (2, H, W))
+        _check(map_x, torch.float32, "map_x", (2, None, None))
+        rows, cols = map_x.shape[1], map_x.shape[2]
+        _check(map_y, torch.float32, "map_y", (2, rows, cols))
+        if pano is None:
+            pano = torch.empty((2, F, rows, cols, 3), dtype=torch.uint8, device=omni.device)
+        _check(pano, torch.uint8, "pano", (2, F, rows, cols, 3))
+        self._call(self._lib.sosvo_unwrap, _ptr(omni), _ptr(masks), _ptr(map_x), _ptr(map_y), F, H, W, rows, cols,
+                   _ptr(pano))
+        return pano
+
+    def median_gray(self, img, ksize, gray=None):
+        """img [..., rows, cols, 3] u8 -> gray [..., rows, cols] u8 (k x k median per channel, then BGR2GRAY)."""
+        _check(img, torch.uint8, "img")
+        if img.dim() < 3 or img.shape[-1] != 3:
+            raise SosvoError("img: expected [..., rows, cols, 3]")
+        rows, cols = img.shape[-3], img.shape[-2]
+        nimg = int(img.numel() // (rows * cols * 3))
+        if gray is None:
+            gray = torch.empty(tuple(img.shape[:-1]), dtype=torch.uint8, device=img.device)
+        _check(gray, torch.uint8, "gray", tuple(img.shape[:-1]))
+        self._call(self._lib.sosvo_median_gray, _ptr(img), nimg, rows, cols, int(ksize), _ptr(gray))
+        return gray
+
     # ---- K7 ----------------------------------------------------------------------------
     def match_hamming(self, q_desc, t_desc, nq, nt, k=1, keys=None, q_slot=None, t_slot=None):
         """q_desc [Bq, Sq, 32] u8, t_desc [Bt, St, 32] u8, nq [Bq] / nt [Bt] i32 -> keys [P, Sq, k] u32.
