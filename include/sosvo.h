@@ -100,6 +100,36 @@ int32_t sosvo_unwrap(sosvo_ctx* ctx, const uint8_t* omni, const uint8_t* masks, 
 int32_t sosvo_median_gray(sosvo_ctx* ctx, const uint8_t* img, int32_t nimg, int32_t rows,
                           int32_t cols, int32_t ksize, uint8_t* gray);
 
+/* ---- K4: goodFeaturesToTrack per azimuthal mask (a4, the reference's default detector) ---------
+ * Replaces cv2.goodFeaturesToTrack(image, maxCorners, qualityLevel, minDistance, mask, useHarris=False)
+ * as called per mask from OmniCamModel.detect_sparse_features_on_panorama
+ * (omnistereo/camera_models.py:1739, :1778) and RGBDFrame.detect_sparse_features (pose_est_tools.py:544).
+ *   gray      [nimg, rows, cols] u8 (the median-blurred gray panorama, camera_models.py:1711-1714)
+ *   mask_bits [nsets, rows, cols] u32: bit m set = the pixel belongs to azimuthal mask m (masks may
+ *             overlap); image i uses set i / images_per_maskset (one set per mirror)
+ * Problem p = image * nmask + mask.  Per problem: min-eigenvalue map (Sobel 3, block 3, reflect-101,
+ * float32), maxVal over the mask, threshold quality * maxVal, 3x3 dilation NMS excluding the 1-px
+ * image border, descending sort (ties: higher address first), greedy min-distance on a cell grid,
+ * stop at max_corners (<= 0: no limit) or at the output capacity `cap`.
+ *   kp [nimg*nmask, cap, 2] f32 (x, y) in acceptance order, n [nimg*nmask] i32,
+ *   status [nimg*nmask] i32 (optional): bit 0 = more than 4096 candidates (result then depends on
+ *   which were kept), bit 1 = mask too large for the on-chip grid and more than 1024 corners wanted. */
+int32_t sosvo_detect_gft(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* mask_bits, int32_t nimg,
+                         int32_t images_per_maskset, int32_t rows, int32_t cols, int32_t nmask,
+                         double quality, double min_distance, int32_t max_corners, int32_t cap,
+                         float* kp, int32_t* n, int32_t* status);
+
+/* ---- K6: ORB descriptors on provided keypoints (a4) --------------------------------------------
+ * Replaces ORB_create(nfeatures).compute(image, keypoints) (omnistereo/camera_models.py:1765, :1785;
+ * pose_est_tools.py:553): keypoints nearer than `edge` (31) px to the border are REMOVED (kp and n
+ * are compacted in place, order kept), the image is blurred 7x7 sigma 2 (8.8 fixed point), and the
+ * 256 pair tests of `pattern` [512,2] i8 (device) are evaluated at offsets rotated by the keypoint
+ * angle (cos_a, sin_a as float32: the GFT path gives every keypoint angle -1 degree) and rounded.
+ * Problem p = image * nmask + mask as above.  desc [nimg*nmask, cap, 32] u8, 8 tests per byte, LSB first. */
+int32_t sosvo_describe_orb(sosvo_ctx* ctx, const uint8_t* gray, int32_t nimg, int32_t rows, int32_t cols,
+                           int32_t nmask, int32_t cap, float* kp, int32_t* n, float cos_a, float sin_a,
+                           const int8_t* pattern, int32_t edge, uint8_t* desc);
+
 /* ---- K7: brute-force Hamming matching ------------------------------------------------
  * Replaces cv2.BFMatcher(NORM_HAMMING).match / .knnMatch as called from
  * omnistereo/camera_models.py:442 and :420 (FeatureMatcher.match, :404-446).

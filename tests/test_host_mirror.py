@@ -49,6 +49,14 @@ def test_pixel_to_angles_bearings_and_projection():
     assert np.allclose([u_t.item(), v_t.item(), u_b.item(), v_b.item()], G["roundtrip_px"], rtol=1e-14)
 
 
+def test_product_orb_pattern_equals_oracle_pattern():
+    import oracle
+    from vo_single_camera_sos_amd import orb_pattern
+    assert np.array_equal(orb_pattern.orb_pattern(), oracle.orb_pattern())
+    ca, sa = orb_pattern.angle_cos_sin(-1.0)
+    assert ca.dtype == np.float32 and np.isclose(ca, np.cos(np.deg2rad(1.0))) and sa < 0
+
+
 def test_annulus_masks_and_bucket_columns():
     gs = _rig()
     top, bot = gs.make_annulus_masks((480, 640))

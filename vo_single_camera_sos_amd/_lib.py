@@ -47,6 +47,10 @@ SIGNATURES = {
     "sosvo_profile_get": (c_i32, [c_p, c_i32, ctypes.c_char_p, c_i32, ctypes.POINTER(c_f32)]),
     "sosvo_unwrap": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]),
     "sosvo_median_gray": (c_i32, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p]),
+    "sosvo_detect_gft": (c_i32, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_f64, c_f64, c_i32, c_i32, c_p,
+                                 c_p, c_p]),
+    "sosvo_describe_orb": (c_i32, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_f32, c_f32, c_p, c_i32,
+                                   c_p]),
     "sosvo_match_hamming": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p]),
     "sosvo_sort_matches": (c_i32, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_p]),
     "sosvo_pano_to_bearing": (c_i32, [c_p, c_p, c_i32, c_f64, c_f64, c_f64, c_f64, c_p, c_p, c_p]),

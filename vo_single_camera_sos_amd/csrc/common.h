@@ -100,3 +100,35 @@ static inline int32_t sosvo_ws_reserve(sosvo_ctx* ctx, size_t bytes) {
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Order-preserving map float -> uint32 (larger float <=> larger uint), for atomicMax and sort keys.
+__host__ __device__ static inline uint32_t sosvo_float_ordered(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ static inline float sosvo_ordered_float(uint32_t u) {
+  u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+#ifdef __HIPCC__
+// Stable position of a lane's element among the valid elements of a 256-thread workgroup round:
+// wave ballot prefix + running base (*s_running is advanced by the round's total).  wave_off: 5 ints of LDS.
+__device__ __forceinline__ int sosvo_block_compact_pos(bool valid, int* wave_off, int* s_running, int tid) {
+  const int lane = tid & 63, wid = tid >> 6;
+  const unsigned long long bal = __ballot(valid);
+  __syncthreads();
+  if (lane == 0) wave_off[wid + 1] = __popcll(bal);
+  __syncthreads();
+  if (tid == 0) {
+    wave_off[0] = *s_running;
+    for (int w = 0; w < 4; ++w) wave_off[w + 1] += wave_off[w];
+    *s_running = wave_off[4];
+  }
+  __syncthreads();
+  return wave_off[wid] + __popcll(bal & ((1ULL << lane) - 1ULL));
+}
+#endif

@@ -1,0 +1,429 @@
+// K4 -- goodFeaturesToTrack (the reference's default detector) and K6 -- ORB descriptors on given keypoints.
+//
+//   cv2.goodFeaturesToTrack(pano, maxCorners=N, qualityLevel=0.01, minDistance=5, mask=m, useHarris=False)
+//        omnistereo/camera_models.py:1739 (per azimuthal mask), :1778 (no masks), pose_est_tools.py:544 (RGB-D)
+//   ORB_create(nfeatures=N).compute(pano, keypoints)     camera_models.py:1765, :1785, pose_est_tools.py:553
+//
+// Batched over images (view-major) and azimuthal masks; problem p = image * nmask + mask.
+//   eig      min-eigenvalue map in float32 with a fixed operation order (identical to the oracle's), the
+//            per-mask maximum folded in through an order-preserving atomicMax;
+//   cand     3x3 non-maximum suppression of the thresholded map -> unordered candidate keys
+//            (ordered(value) << 32 | pixel index) per problem;
+//   select   one workgroup per problem: rank sort of the keys in LDS (descending value, higher address first),
+//            then the greedy minimum-distance pass on an LDS cell grid, first wave only: 18 lanes test the
+//            9 neighbour cells x 2 slots of a candidate at once and vote with __ballot;
+//   blur     7x7 sigma=2 Gaussian in 8.8 fixed point (separable, LDS tile);
+//   describe one workgroup per problem: border rule + stable compaction, then one wave per keypoint:
+//            lane l evaluates tests l, 64+l, 128+l, 192+l; four 64-bit ballots ARE the 32 descriptor bytes.
+// Everything is integer work or float32 with a pinned evaluation order -> bit-exact against the oracle.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kCandCap = 4096;   // candidates kept per (image, mask)
+constexpr int kMaxMasks = 32;
+
+__device__ __forceinline__ int refl101(int i, int n) {
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
+  return i;
+}
+
+// Products of the scaled Sobel derivatives at IMAGE position (y, x) (already inside the image).
+__device__ __forceinline__ void sobel_products(const uint8_t* __restrict__ g, int rows, int cols, int y, int x,
+                                               float* xx, float* xy, float* yy) {
+  const float scale = (float)(1.0 / 3060.0);
+  const uint8_t* r0 = g + (size_t)refl101(y - 1, rows) * cols;
+  const uint8_t* r1 = g + (size_t)y * cols;
+  const uint8_t* r2 = g + (size_t)refl101(y + 1, rows) * cols;
+  const int xl = refl101(x - 1, cols), xr = refl101(x + 1, cols);
+  const int dxi = ((int)r0[xr] + 2 * (int)r1[xr] + (int)r2[xr]) - ((int)r0[xl] + 2 * (int)r1[xl] + (int)r2[xl]);
+  const int dyi = ((int)r2[xl] + 2 * (int)r2[x] + (int)r2[xr]) - ((int)r0[xl] + 2 * (int)r0[x] + (int)r0[xr]);
+  const float dx = (float)dxi * scale, dy = (float)dyi * scale;
+  *xx = dx * dx;
+  *xy = dx * dy;
+  *yy = dy * dy;
+}
+
+constexpr int kEigTW = 64, kEigTH = 4;  // output tile per workgroup (256 threads, one pixel each)
+
+__global__ __launch_bounds__(kThreads) void min_eigen_kernel(const uint8_t* __restrict__ gray,
+                                                             const uint32_t* __restrict__ mask_bits,
+                                                             int images_per_maskset, int rows, int cols, int nmask,
+                                                             float* __restrict__ eig, uint32_t* __restrict__ maxbits) {
+  __shared__ float sxx[kEigTH + 2][kEigTW + 2], sxy[kEigTH + 2][kEigTW + 2], syy[kEigTH + 2][kEigTW + 2];
+  __shared__ uint32_t smax[kMaxMasks];
+  const int tid = threadIdx.x, img = blockIdx.z;
+  const int x0 = blockIdx.x * kEigTW, y0 = blockIdx.y * kEigTH;
+  const uint8_t* g = gray + (size_t)img * rows * cols;
+  if (tid < kMaxMasks) smax[tid] = 0u;
+  // products on the (TH+2) x (TW+2) halo tile; a position outside the image takes the product AT the
+  // reflected position (box filter with reflect-101 on the covariance images)
+  for (int i = tid; i < (kEigTH + 2) * (kEigTW + 2); i += kThreads) {
+    const int ty = i / (kEigTW + 2), tx = i - ty * (kEigTW + 2);
+    const int y = refl101(y0 + ty - 1, rows), x = refl101(x0 + tx - 1, cols);
+    sobel_products(g, rows, cols, y, x, &sxx[ty][tx], &sxy[ty][tx], &syy[ty][tx]);
+  }
+  __syncthreads();
+  const int ty = tid / kEigTW, tx = tid - ty * kEigTW;
+  const int y = y0 + ty, x = x0 + tx;
+  if (y < rows && x < cols) {
+    float s[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float(*v)[kEigTW + 2] = k == 0 ? sxx : (k == 1 ? sxy : syy);
+      const float ha = (v[ty][tx] + v[ty][tx + 1]) + v[ty][tx + 2];
+      const float hc = (v[ty + 1][tx] + v[ty + 1][tx + 1]) + v[ty + 1][tx + 2];
+      const float hb = (v[ty + 2][tx] + v[ty + 2][tx + 1]) + v[ty + 2][tx + 2];
+      s[k] = (ha + hc) + hb;
+    }
+    const float a = s[0] * 0.5f, b = s[1], c = s[2] * 0.5f;
+    const float e = (a + c) - sqrtf(((a - c) * (a - c)) + (b * b));
+    eig[((size_t)img * rows + y) * cols + x] = e;
+    uint32_t bits = mask_bits[((size_t)(img / images_per_maskset) * rows + y) * cols + x];
+    const uint32_t o = sosvo_float_ordered(e);
+    while (bits) {
+      const int m = __ffs(bits) - 1;
+      bits &= bits - 1;
+      if (m < nmask) atomicMax(&smax[m], o);
+    }
+  }
+  __syncthreads();
+  if (tid < nmask && smax[tid]) atomicMax(&maxbits[(size_t)img * nmask + tid], smax[tid]);
+}
+
+__global__ __launch_bounds__(kThreads) void gft_candidates_kernel(const float* __restrict__ eig,
+                                                                  const uint32_t* __restrict__ mask_bits,
+                                                                  int images_per_maskset, int rows, int cols, int nmask,
+                                                                  double quality, const uint32_t* __restrict__ maxbits,
+                                                                  int32_t* __restrict__ cand_count,
+                                                                  unsigned long long* __restrict__ cand) {
+  const int img = blockIdx.y;
+  const int pix = blockIdx.x * kThreads + threadIdx.x;
+  if (pix >= rows * cols) return;
+  const int y = pix / cols, x = pix - y * cols;
+  if (y < 1 || y > rows - 2 || x < 1 || x > cols - 2) return;
+  uint32_t bits = mask_bits[((size_t)(img / images_per_maskset) * rows) * cols + pix];
+  if (!bits) return;
+  const float* e = eig + (size_t)img * rows * cols;
+  float nb[9];
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) nb[(dy + 1) * 3 + dx + 1] = e[pix + dy * cols + dx];
+  while (bits) {
+    const int m = __ffs(bits) - 1;
+    bits &= bits - 1;
+    if (m >= nmask) break;
+    const uint32_t mb = maxbits[(size_t)img * nmask + m];
+    if (!mb) continue;
+    const float thr = (float)((double)sosvo_ordered_float(mb) * quality);
+    const float v = nb[4] > thr ? nb[4] : 0.0f;
+    if (v == 0.0f) continue;
+    float dil = v;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const float t = nb[k] > thr ? nb[k] : 0.0f;
+      dil = t > dil ? t : dil;
+    }
+    if (v != dil) continue;
+    const size_t p = (size_t)img * nmask + m;
+    const int slot = atomicAdd(&cand_count[p], 1);
+    if (slot < kCandCap) cand[p * kCandCap + slot] = ((unsigned long long)sosvo_float_ordered(v) << 32) | (uint32_t)pix;
+  }
+}
+
+// One workgroup per problem.  LDS (32 KB) is used twice: first for the candidate keys of the rank sort,
+// then -- the sorted order lives in global memory by then -- for the cell grid of the greedy pass.
+constexpr int kSelLdsBytes = kCandCap * 8;
+constexpr int kSelGridCells = (kSelLdsBytes - 1024 * 4) / 8;  // 2 slots (u32) per cell, 1024 u32 left for the list
+
+__global__ __launch_bounds__(kThreads) void gft_select_kernel(const unsigned long long* __restrict__ cand,
+                                                              const int32_t* __restrict__ cand_count, int rows, int cols,
+                                                              float min_distance, int cell, int max_corners, int cap,
+                                                              uint32_t* __restrict__ sorted_g, float* __restrict__ kp,
+                                                              int32_t* __restrict__ n_out, int32_t* __restrict__ status) {
+  __shared__ unsigned long long lds_u64[kCandCap];
+  __shared__ int s_bbox[4];
+  __shared__ int s_accepted;
+  unsigned long long* keys = lds_u64;
+  uint32_t* grid = reinterpret_cast<uint32_t*>(lds_u64);     // phase 2: 2 slots per cell, pixel index + 1 (0 = empty)
+  uint32_t* acc = grid + 2 * kSelGridCells;                   // phase 2 fallback: accepted pixel indices (<= 1024)
+  const int tid = threadIdx.x, p = blockIdx.x;
+  const int total = cand_count[p];
+  const int n = min(total, kCandCap);
+  uint32_t* sorted = sorted_g + (size_t)p * kCandCap;
+  if (tid == 0) {
+    s_bbox[0] = 1 << 30;
+    s_bbox[1] = 1 << 30;
+    s_bbox[2] = -1;
+    s_bbox[3] = -1;
+    s_accepted = 0;
+  }
+  __syncthreads();
+  int xmin = 1 << 30, ymin = 1 << 30, xmax = -1, ymax = -1;
+  for (int i = tid; i < n; i += kThreads) {
+    const unsigned long long k = cand[(size_t)p * kCandCap + i];
+    keys[i] = k;
+    const int pix = (int)(uint32_t)k, y = pix / cols, x = pix - y * cols;
+    xmin = min(xmin, x);
+    xmax = max(xmax, x);
+    ymin = min(ymin, y);
+    ymax = max(ymax, y);
+  }
+  if (n > 0) {
+    atomicMin(&s_bbox[0], xmin);
+    atomicMin(&s_bbox[1], ymin);
+    atomicMax(&s_bbox[2], xmax);
+    atomicMax(&s_bbox[3], ymax);
+  }
+  __syncthreads();
+  // rank sort, descending: larger value first, ties -> higher pixel index first (keys are unique)
+  for (int i = tid; i < n; i += kThreads) {
+    const unsigned long long mine = keys[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += keys[j] > mine;
+    sorted[rank] = (uint32_t)mine;
+  }
+  int st = total > kCandCap ? 1 : 0;
+  const int cx0 = n > 0 ? s_bbox[0] / cell : 0, cy0 = n > 0 ? s_bbox[1] / cell : 0;
+  const int gw = n > 0 ? s_bbox[2] / cell - cx0 + 1 : 0, gh = n > 0 ? s_bbox[3] / cell - cy0 + 1 : 0;
+  const bool use_grid = gw * gh <= kSelGridCells;
+  const int limit_list = 1024;
+  __syncthreads();  // keys are dead from here on; sorted[] is visible to the whole workgroup
+  for (int i = tid; i < (use_grid ? gw * gh * 2 : 0); i += kThreads) grid[i] = 0u;
+  __syncthreads();
+  if (tid < 64) {  // greedy minimum-distance pass, first wave only
+    const float md2 = min_distance * min_distance;
+    const int lane = tid;
+    int accepted = 0;
+    bool stop = false;
+    for (int k0 = 0; k0 < n && !stop; k0 += 64) {
+      const uint32_t mypix = (k0 + lane < n) ? sorted[k0 + lane] : 0u;  // one coalesced read per 64 candidates
+      const int kend = min(64, n - k0);
+      for (int kk = 0; kk < kend; ++kk) {
+        const int pix = (int)__shfl(mypix, kk), y = pix / cols, x = pix - y * cols;
+        bool good = true;
+        if (min_distance >= 1.0f) {
+          bool conflict = false;
+          if (use_grid) {
+            const int xc = x / cell - cx0, yc = y / cell - cy0;
+            if (lane < 18) {
+              const int c9 = lane >> 1, slot = lane & 1;
+              const int xx = xc + (c9 % 3) - 1, yy = yc + (c9 / 3) - 1;
+              if (xx >= 0 && xx < gw && yy >= 0 && yy < gh) {
+                const uint32_t q = grid[(yy * gw + xx) * 2 + slot];
+                if (q) {
+                  const int qp = (int)q - 1, qy = qp / cols, qx = qp - qy * cols;
+                  const float dx = (float)(x - qx), dy = (float)(y - qy);
+                  conflict = dx * dx + dy * dy < md2;
+                }
+              }
+            }
+            good = __ballot(conflict) == 0ULL;
+            if (good && lane == 0) {
+              uint32_t* c = &grid[(yc * gw + xc) * 2];
+              if (c[0] == 0u)
+                c[0] = (uint32_t)pix + 1u;
+              else
+                c[1] = (uint32_t)pix + 1u;  // a 5x5 cell never holds a third point >= 5 px from two others
+            }
+          } else {  // large masks: scan the accepted list, 64 at a time
+            for (int a0 = 0; a0 < accepted; a0 += 64) {
+              if (a0 + lane < accepted) {
+                const int qp = (int)acc[a0 + lane], qy = qp / cols, qx = qp - qy * cols;
+                const float dx = (float)(x - qx), dy = (float)(y - qy);
+                conflict = conflict || (dx * dx + dy * dy < md2);
+              }
+            }
+            good = __ballot(conflict) == 0ULL;
+            if (good && lane == 0 && accepted < limit_list) acc[accepted] = (uint32_t)pix;
+          }
+        }
+        if (good) {
+          if (lane == 0 && accepted < cap) {
+            kp[((size_t)p * cap + accepted) * 2] = (float)x;
+            kp[((size_t)p * cap + accepted) * 2 + 1] = (float)y;
+          }
+          accepted++;
+          if (accepted == cap || (max_corners > 0 && accepted == max_corners) || (!use_grid && accepted == limit_list)) {
+            stop = true;
+            break;
+          }
+        }
+      }
+    }
+    if (!use_grid && accepted == limit_list && !(max_corners > 0 && max_corners <= limit_list) && cap > limit_list) st |= 2;
+    if (lane == 0) s_accepted = accepted;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    n_out[p] = min(s_accepted, cap);
+    if (status) status[p] = st;
+  }
+}
+
+// ---- K6a: 7x7 Gaussian, 8.8 fixed point ------------------------------------------------------------------
+constexpr int kBlurTW = 64, kBlurTH = 16;
+
+__global__ __launch_bounds__(kThreads) void gauss7_kernel(const uint8_t* __restrict__ gray, int rows, int cols,
+                                                          uint8_t* __restrict__ out) {
+  __shared__ uint8_t tile[kBlurTH + 6][kBlurTW + 6];
+  __shared__ uint16_t hrow[kBlurTH + 6][kBlurTW];
+  const int kw[7] = {18, 34, 49, 54, 49, 34, 18};
+  const int tid = threadIdx.x, img = blockIdx.z;
+  const int x0 = blockIdx.x * kBlurTW, y0 = blockIdx.y * kBlurTH;
+  const uint8_t* g = gray + (size_t)img * rows * cols;
+  for (int i = tid; i < (kBlurTH + 6) * (kBlurTW + 6); i += kThreads) {
+    const int ty = i / (kBlurTW + 6), tx = i - ty * (kBlurTW + 6);
+    tile[ty][tx] = g[(size_t)refl101(y0 + ty - 3, rows) * cols + refl101(x0 + tx - 3, cols)];
+  }
+  __syncthreads();
+  for (int i = tid; i < (kBlurTH + 6) * kBlurTW; i += kThreads) {
+    const int ty = i / kBlurTW, tx = i - ty * kBlurTW;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) s += kw[k] * tile[ty][tx + k];
+    hrow[ty][tx] = (uint16_t)s;
+  }
+  __syncthreads();
+  for (int i = tid; i < kBlurTH * kBlurTW; i += kThreads) {
+    const int ty = i / kBlurTW, tx = i - ty * kBlurTW;
+    const int y = y0 + ty, x = x0 + tx;
+    if (y >= rows || x >= cols) continue;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) s += (uint32_t)kw[k] * hrow[ty + k][tx];
+    out[((size_t)img * rows + y) * cols + x] = (uint8_t)((s + 32768u) >> 16);
+  }
+}
+
+// ---- K6b: border rule + descriptors ---------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void orb_describe_kernel(const uint8_t* __restrict__ blurred, int rows, int cols,
+                                                                int nmask, int cap, float* __restrict__ kp,
+                                                                int32_t* __restrict__ n_io, float cos_a, float sin_a,
+                                                                const int8_t* __restrict__ pattern, int edge,
+                                                                uint8_t* __restrict__ desc) {
+  extern __shared__ float lds_kp[];  // [cap][2] compacted keypoints
+  __shared__ int off[512];
+  __shared__ int wave_off[5];
+  __shared__ int s_running;
+  const int tid = threadIdx.x, p = blockIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int img = p / nmask;
+  const int n = min(n_io[p], cap);
+  if (tid == 0) s_running = 0;
+  for (int i = tid; i < 512; i += kThreads) {
+    const float px = (float)pattern[2 * i], py = (float)pattern[2 * i + 1];
+    const float xr = (px * cos_a) - (py * sin_a), yr = (px * sin_a) + (py * cos_a);
+    off[i] = __float2int_rn(yr) * cols + __float2int_rn(xr);
+  }
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += kThreads) {
+    const int i = i0 + tid;
+    float x = 0.f, y = 0.f;
+    bool keep = false;
+    if (i < n) {
+      x = kp[((size_t)p * cap + i) * 2];
+      y = kp[((size_t)p * cap + i) * 2 + 1];
+      keep = x >= (float)edge && x < (float)(cols - edge) && y >= (float)edge && y < (float)(rows - edge);
+    }
+    const int pos = sosvo_block_compact_pos(keep, wave_off, &s_running, tid);
+    if (keep) {
+      lds_kp[2 * pos] = x;
+      lds_kp[2 * pos + 1] = y;
+    }
+  }
+  __syncthreads();
+  const int m = s_running;
+  for (int i = tid; i < 2 * m; i += kThreads) kp[(size_t)p * cap * 2 + i] = lds_kp[i];
+  if (tid == 0) n_io[p] = m;
+  const uint8_t* im = blurred + (size_t)img * rows * cols;
+  for (int j = wid; j < m; j += kThreads / 64) {
+    const uint8_t* c = im + (size_t)__float2int_rn(lds_kp[2 * j + 1]) * cols + __float2int_rn(lds_kp[2 * j]);
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(desc + ((size_t)p * cap + j) * 32);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = 64 * r + lane;
+      const unsigned long long bal = __ballot(c[off[2 * t]] < c[off[2 * t + 1]]);
+      if (lane == 0) d[r] = bal;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t sosvo_detect_gft(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* mask_bits, int32_t nimg,
+                         int32_t images_per_maskset, int32_t rows, int32_t cols, int32_t nmask, double quality,
+                         double min_distance, int32_t max_corners, int32_t cap, float* kp, int32_t* n,
+                         int32_t* status) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, gray && mask_bits && kp && n, "null pointer");
+  SOSVO_REQUIRE(ctx, nimg >= 0 && nimg <= 65535 && images_per_maskset > 0, "nimg out of range");
+  SOSVO_REQUIRE(ctx, rows >= 3 && cols >= 3 && rows * (int64_t)cols < (1 << 28), "image sizes out of range");
+  SOSVO_REQUIRE(ctx, nmask >= 1 && nmask <= kMaxMasks, "nmask out of range (1..32)");
+  SOSVO_REQUIRE(ctx, cap > 0 && cap <= 4096 && quality > 0 && min_distance >= 0, "bad detector parameters");
+  if (nimg == 0) return SOSVO_OK;
+  const size_t P = (size_t)nimg * nmask;
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    size_t o = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return o;
+  };
+  const size_t o_eig = carve(sizeof(float) * (size_t)nimg * rows * cols);
+  const size_t o_max = carve(sizeof(uint32_t) * P);
+  const size_t o_cnt = carve(sizeof(int32_t) * P);
+  const size_t o_cand = carve(sizeof(unsigned long long) * P * kCandCap);
+  const size_t o_sorted = carve(sizeof(uint32_t) * P * kCandCap);
+  int32_t rc = sosvo_ws_reserve(ctx, off);
+  if (rc != SOSVO_OK) return rc;
+  char* ws = (char*)ctx->ws;
+  float* eig = (float*)(ws + o_eig);
+  uint32_t* maxbits = (uint32_t*)(ws + o_max);
+  int32_t* cnt = (int32_t*)(ws + o_cnt);
+  unsigned long long* cand = (unsigned long long*)(ws + o_cand);
+  uint32_t* sorted_g = (uint32_t*)(ws + o_sorted);
+  SOSVO_HIP(ctx, hipMemsetAsync(ws + o_max, 0, (o_cand - o_max), ctx->stream));  // maxbits and counts
+
+  SOSVO_LAUNCH(ctx, min_eigen_kernel, dim3(cdiv(cols, kEigTW), cdiv(rows, kEigTH), nimg), dim3(kThreads), 0, ctx->stream,
+               gray, mask_bits, images_per_maskset, rows, cols, nmask, eig, maxbits);
+  SOSVO_LAUNCH_CHECK(ctx);
+  SOSVO_LAUNCH(ctx, gft_candidates_kernel, dim3(cdiv(rows * cols, kThreads), nimg), dim3(kThreads), 0, ctx->stream, eig,
+               mask_bits, images_per_maskset, rows, cols, nmask, quality, maxbits, cnt, cand);
+  SOSVO_LAUNCH_CHECK(ctx);
+  const int cell = min_distance >= 1 ? (int)lrint(min_distance) : 1;
+  SOSVO_LAUNCH(ctx, gft_select_kernel, dim3((unsigned)P), dim3(kThreads), 0, ctx->stream, cand, cnt, rows, cols,
+               (float)min_distance, cell, max_corners, cap, sorted_g, kp, n, status);
+  SOSVO_LAUNCH_CHECK(ctx);
+  return SOSVO_OK;
+}
+
+int32_t sosvo_describe_orb(sosvo_ctx* ctx, const uint8_t* gray, int32_t nimg, int32_t rows, int32_t cols,
+                           int32_t nmask, int32_t cap, float* kp, int32_t* n, float cos_a, float sin_a,
+                           const int8_t* pattern, int32_t edge, uint8_t* desc) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, gray && kp && n && pattern && desc, "null pointer");
+  SOSVO_REQUIRE(ctx, nimg >= 0 && nimg <= 65535 && nmask >= 1, "nimg / nmask out of range");
+  SOSVO_REQUIRE(ctx, rows >= 1 && cols >= 1 && rows * (int64_t)cols < (1 << 28), "image sizes out of range");
+  SOSVO_REQUIRE(ctx, cap > 0 && cap <= 4096, "cap out of range");
+  SOSVO_REQUIRE(ctx, edge >= 19, "edge must cover the rotated 31x31 patch (>= 19)");
+  SOSVO_REQUIRE(ctx, ((uintptr_t)desc & 7) == 0, "desc must be 8-byte aligned");
+  if (nimg == 0) return SOSVO_OK;
+  const size_t bytes = (size_t)nimg * rows * cols;
+  int32_t rc = sosvo_ws_reserve(ctx, bytes);
+  if (rc != SOSVO_OK) return rc;
+  uint8_t* blurred = (uint8_t*)ctx->ws;
+  SOSVO_LAUNCH(ctx, gauss7_kernel, dim3(cdiv(cols, kBlurTW), cdiv(rows, kBlurTH), nimg), dim3(kThreads), 0, ctx->stream,
+               gray, rows, cols, blurred);
+  SOSVO_LAUNCH_CHECK(ctx);
+  SOSVO_LAUNCH(ctx, orb_describe_kernel, dim3((unsigned)((size_t)nimg * nmask)), dim3(kThreads),
+               (size_t)cap * 2 * sizeof(float), ctx->stream, blurred, rows, cols, nmask, cap, kp, n, cos_a, sin_a, pattern,
+               edge, desc);
+  SOSVO_LAUNCH_CHECK(ctx);
+  return SOSVO_OK;
+}
+
+}  // extern "C"

@@ -145,6 +145,48 @@ class Context(object):
         self._call(self._lib.sosvo_median_gray, _ptr(img), nimg, rows, cols, int(ksize), _ptr(gray))
         return gray
 
+    # ---- K4 / K6 -----------------------------------------------------------------------
+    def detect_gft(self, gray, mask_bits, images_per_maskset, nmask, cap, quality=0.01, min_distance=5.0,
+                   max_corners=1000, kp=None, n=None, status=None):
+        """gray [NI,rows,cols] u8, mask_bits [nsets,rows,cols] u32 (as int32 bit patterns are not accepted: use
+        torch.uint32) -> kp [NI*nmask, cap, 2] f32, n [NI*nmask] i32, status [NI*nmask] i32."""
+        _check(gray, torch.uint8, "gray", ndim=3)
+        NI, rows, cols = gray.shape
+        _check(mask_bits, torch.uint32, "mask_bits", (None, rows, cols))
+        if mask_bits.shape[0] * images_per_maskset < NI:
+            raise SosvoError("mask_bits has too few sets for %d images" % NI)
+        P = NI * nmask
+        dev = gray.device
+        if kp is None:
+            kp = torch.zeros((P, cap, 2), dtype=torch.float32, device=dev)
+        if n is None:
+            n = torch.zeros((P,), dtype=torch.int32, device=dev)
+        if status is None:
+            status = torch.zeros((P,), dtype=torch.int32, device=dev)
+        _check(kp, torch.float32, "kp", (P, cap, 2))
+        _check(n, torch.int32, "n", (P,))
+        _check(status, torch.int32, "status", (P,))
+        self._call(self._lib.sosvo_detect_gft, _ptr(gray), _ptr(mask_bits), NI, int(images_per_maskset), rows, cols,
+                   int(nmask), float(quality), float(min_distance), int(max_corners), int(cap), _ptr(kp), _ptr(n),
+                   _ptr(status))
+        return kp, n, status
+
+    def describe_orb(self, gray, kp, n, nmask, pattern, cos_a, sin_a, edge=31, desc=None):
+        """Compacts kp/n in place (border rule) and returns desc [NI*nmask, cap, 32] u8."""
+        _check(gray, torch.uint8, "gray", ndim=3)
+        NI, rows, cols = gray.shape
+        P = NI * nmask
+        _check(kp, torch.float32, "kp", (P, None, 2))
+        cap = kp.shape[1]
+        _check(n, torch.int32, "n", (P,))
+        _check(pattern, torch.int8, "pattern", (512, 2))
+        if desc is None:
+            desc = torch.zeros((P, cap, 32), dtype=torch.uint8, device=gray.device)
+        _check(desc, torch.uint8, "desc", (P, cap, 32))
+        self._call(self._lib.sosvo_describe_orb, _ptr(gray), NI, rows, cols, int(nmask), cap, _ptr(kp), _ptr(n),
+                   float(cos_a), float(sin_a), _ptr(pattern), int(edge), _ptr(desc))
+        return desc
+
     # ---- K7 ----------------------------------------------------------------------------
     def match_hamming(self, q_desc, t_desc, nq, nt, k=1, keys=None, q_slot=None, t_slot=None):
         """q_desc [Bq, Sq, 32] u8, t_desc [Bt, St, 32] u8, nq [Bq] / nt [Bt] i32 -> keys [P, Sq, k] u32.
