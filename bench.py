@@ -3,10 +3,12 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of B independent synthetic frame pairs per GPU
-(inputs resident in HBM).  For N > 1 the driver launches one rank per GPU through
-torch.distributed.run; ranks shard the pairs (no data-path collective) and all-gather the per-pair
-pose records (16 doubles each) over RCCL at the end of every step.  Rank 0 prints ONE JSON line.
+A "step" is one pass of the WHOLE hot path (unwrap -> median -> gray -> detect -> describe -> stereo
+match -> triangulate -> frame-to-frame match -> RANSAC -> LM) over one batch of B independent synthetic
+frame pairs per GPU; the omni frames are resident in HBM when the timed region starts.  For N > 1 the
+driver launches one rank per GPU through torch.distributed.run; ranks shard the pairs (no data-path
+collective) and all-gather the per-pair pose records (16 doubles each) over RCCL at the end of every
+step.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -22,8 +24,12 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
-# compulsory HBM bytes per C2 frame pair (two BGR frames in, match/inlier/pose out)
-B_ALG_C2 = 2 * 640 * 480 * 3 + 4 * 2000 * 12 + 2 * 2000 + 96
+
+
+def b_alg_c2(H, W, kpts):
+    """compulsory HBM bytes per frame pair: two BGR frames in; match index + distance out for
+    4 matchings; inlier mask; pose."""
+    return 2 * H * W * 3 + 4 * kpts * 12 + 2 * kpts + 96
 
 
 def parse():
@@ -32,37 +38,22 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs-per-gpu", type=int, default=64, help="B: frame pairs per GPU per step (C4: 512/8)")
-    ap.add_argument("--kpts", type=int, default=2000, help="keypoints per view (C2: 2000)")
+    ap.add_argument("--features-per-mask", type=int, default=330, help="detector budget per azimuthal mask")
     ap.add_argument("--iters", type=int, default=2000, help="RANSAC iterations, fixed (C2: 2000)")
-    ap.add_argument("--cpu-pairs", type=int, default=24, help="frame pairs timed on the host for cpu_baseline")
+    ap.add_argument("--cpu-pairs", type=int, default=32, help="frame pairs timed on the host for cpu_baseline")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--seed", type=int, default=1234)
     return ap.parse_args()
 
 
-def make_inputs(seed, n_pairs, kpts, nmask, bucket_cap):
-    """Synthetic image-free inputs (SURVEY.md 8d 'stage-level' inputs): per pair one random scene seen
-    from two viewpoints; keypoints + 256-bit descriptors per azimuthal bucket of both panoramas."""
-    import synth
-    frames = []
-    n_scene = int(kpts / 1.12)
-    for i in range(n_pairs):
-        rng = np.random.default_rng(seed + i)
-        P, desc = synth.make_scene(rng, n_scene)
-        R, t = synth.random_pose(rng)
-        frames.append(synth.observe_frame(rng, P, desc, np.eye(3), np.zeros(3), nmask=nmask, cap=bucket_cap))
-        frames.append(synth.observe_frame(rng, P, desc, R, t, nmask=nmask, cap=bucket_cap))
-    return frames, synth.pack_buckets(frames, nmask, bucket_cap)
-
-
-def cpu_baseline(frames, rig_kw, thr, iters, seed, n_pairs):
+def cpu_baseline(omni, im, rig_kw, thr, iters, seed, n_pairs):
     """The reference's control flow on the CPU oracle (kind 'port'), one host core."""
     import refflow
     rp = refflow.RigParams(**rig_kw)
     t0 = time.perf_counter()
     for i in range(n_pairs):
-        ref = refflow.stereo_frame(rp, *[frames[2 * i][k] for k in ("kp_top", "kp_bot", "desc_top", "desc_bot")])
-        cur = refflow.stereo_frame(rp, *[frames[2 * i + 1][k] for k in ("kp_top", "kp_bot", "desc_top", "desc_bot")])
+        ref = refflow.frame_from_image(rp, im, omni[2 * i])
+        cur = refflow.frame_from_image(rp, im, omni[2 * i + 1])
         refflow.track_pair(rp, ref, cur, thr, iters, seed=seed + i)
     dt = time.perf_counter() - t0
     return n_pairs / dt, dt
@@ -84,21 +75,31 @@ def main():
     if args.gpus != n_gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d; using %d" % (args.gpus, world, n_gpus), file=sys.stderr)
 
-    import synth
+    from vo_single_camera_sos_amd import synthetic
     from vo_single_camera_sos_amd.device import Context
+    from vo_single_camera_sos_amd.frontend import DeviceImageModel, ImageFrontEnd
+    from vo_single_camera_sos_amd.omnistereo.gum import synthetic_gums
+    from vo_single_camera_sos_amd.omnistereo.panorama import Panorama
     from vo_single_camera_sos_amd.pipeline import FramePairPipeline, RigConfig
 
-    B, NM = args.pairs_per_gpu, 12
-    bucket_cap = int(np.ceil(args.kpts * 1.25 / NM / 64.0)) * 64
-    frame_cap = int(np.ceil(args.kpts * 1.05 / 256.0)) * 256
-    rig_kw = dict(pano_top=synth.PANO_C2, pano_bot=synth.PANO_C2, F_top=synth.F_TOP, F_bot=synth.F_BOT,
+    B = args.pairs_per_gpu
+    H, W = 480, 640
+    gs = synthetic_gums()
+    for m in (gs.top_model, gs.bot_model):
+        m.panorama = Panorama(m, width=1200)  # reference default (camera_models.py:3107) -> 1200 x 122
+    gs.make_annulus_masks((H, W))
+    pano = gs.top_model.panorama
+    geo = (pano.cols, pano.rows, pano.pixel_size, pano.cyl_height_max)
+    rig_kw = dict(pano_top=geo, pano_bot=geo, F_top=gs.top_model.F[:3, 0], F_bot=gs.bot_model.F[:3, 0],
                   min_range=500.0, max_range=7000.0, stereo_min_disp=1.0, stereo_max_hdiff=2.5,
-                  f2f_max_hdiff=0.125 * 0.5 * synth.PANO_C2[0], pct_good_matches=1.0)
+                  f2f_max_hdiff=0.125 * 0.5 * pano.cols, pct_good_matches=1.0)
     ctx = Context(local_rank)
-    pipe = FramePairPipeline(ctx, RigConfig(**rig_kw), B, nmask=NM, bucket_cap=bucket_cap, frame_cap=frame_cap,
-                             max_iter=args.iters, adaptive=False, seed=args.seed)
-    frames, packed = make_inputs(args.seed + 100000 * rank, B, args.kpts, NM, bucket_cap)
-    pipe.load_keypoints(packed)
+    model = DeviceImageModel(ctx, gs, (H, W))
+    fe = ImageFrontEnd(ctx, model, 2 * B, detection_method="GFT", num_of_features=args.features_per_mask)
+    pipe = FramePairPipeline(ctx, RigConfig(**rig_kw), B, frame_cap=2048, max_iter=args.iters, adaptive=False,
+                             seed=args.seed, front_end=fe)
+    omni, poses = synthetic.make_frame_pairs(gs, B, seed=args.seed + 100000 * rank)
+    fe.load_frames(omni)
     gathered = torch.empty((n_gpus * B, 16), dtype=torch.float64, device=ctx.device) if dist else None
 
     def step():
@@ -132,6 +133,8 @@ def main():
 
     if rank == 0:
         rec = rec.cpu().numpy()
+        n_kp = fe.n.cpu().numpy().reshape(2, 2 * B, model.nmask).sum(-1)  # [view, frame]
+        M = pipe.frames["M"].cpu().numpy()
         per_kernel = {}
         for name, ms in prof:
             s = per_kernel.setdefault(name, [0, 0.0])
@@ -139,9 +142,15 @@ def main():
             s[1] += ms
         dom = max(per_kernel.items(), key=lambda kv: kv[1][1])
         dom_avg_s = dom[1][1] / dom[1][0] / 1e3
-        kernel_ms_per_step = sum(v[1] for v in per_kernel.values()) / args.steps
-        b_alg_launch = B_ALG_C2 * B  # one launch of the dominant kernel processes the whole batch of B pairs
+        kpts = int(round(float(n_kp.mean())))
+        b_alg = b_alg_c2(H, W, kpts)
+        b_alg_launch = b_alg * B  # one launch of the dominant kernel covers the whole batch of B pairs
         achieved = b_alg_launch / dom_avg_s / 1e9
+        ok = rec[:, 14] == 0
+        rot_err = []
+        for i in range(B):
+            dR = rec[i, :12].reshape(3, 4)[:, :3].T @ poses[i][0]
+            rot_err.append(np.degrees(np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1))))
         out = {
             "metric": "frame-pairs/sec (detect+match+triangulate+RANSAC) on 640x480 omni, 2000 kpts",
             "value": n_gpus * B * args.steps / elapsed,
@@ -149,26 +158,34 @@ def main():
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8/u32 (Hamming) + f64 (geometry, RANSAC)", "data": "synthetic",
-            "config": {"workload": "C2 without the image stages (unwrap/median/detect/describe not built yet): "
-                                   "per pair 2 frames x 2 views x ~%d keypoints resident in HBM -> 24 bucket "
-                                   "matchings + 2 frame-to-frame matchings -> triangulation -> non-central P3P "
-                                   "RANSAC %d iterations fixed -> LM" % (args.kpts, args.iters),
-                       "pairs_per_gpu": B, "global_pairs_per_step": n_gpus * B, "parallelism": "pairs sharded, dp%d" % n_gpus,
-                       "mean_correspondences": float(rec[:, 13].mean()), "mean_inliers": float(rec[:, 12].mean()),
-                       "tracked_ok": int((rec[:, 14] == 0).sum())},
+            "dtype": "u8 (images, Hamming) + f32 (corner response) + f64 (geometry, RANSAC)", "data": "synthetic",
+            "config": {"workload": "C2: 640x480 BGR omni frame pair -> 2 x 1200x122 panoramas per frame, 11x11 median, "
+                                   "GFT (reference default detector, %d per azimuthal mask x 12 masks) + ORB descriptors, "
+                                   "24 bucket + 2 frame-to-frame BF Hamming matchings, midpoint triangulation, "
+                                   "non-central P3P RANSAC %d iterations fixed, LM" % (args.features_per_mask, args.iters),
+                       "pairs_per_gpu": B, "global_pairs_per_step": n_gpus * B,
+                       "parallelism": "pairs sharded over ranks, dp%d" % n_gpus,
+                       "keypoints_per_view_mean": float(n_kp.mean()), "stereo_points_per_frame_mean": float(M.mean()),
+                       "correspondences_per_pair_mean": float(rec[:, 13].mean()),
+                       "inliers_per_pair_mean": float(rec[:, 12].mean()), "tracked_ok": int(ok.sum()),
+                       "rotation_error_deg_median": float(np.median(rot_err))},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "avg_launch_ms": dom_avg_s * 1e3, "launches": dom[1][0],
-                         "algorithmic_bytes_per_launch": b_alg_launch,
-                         "note": "dominant kernel is FP64-VALU bound (no contraction, no MFMA); HBM fraction is "
-                                 "reported as SURVEY 8(d) prescribes and is expected to be small"},
+                         "algorithmic_bytes_per_pair": b_alg, "algorithmic_bytes_per_launch": b_alg_launch,
+                         "note": "no contraction anywhere (no MFMA); the dominant kernel is VALU-bound integer/bit work, "
+                                 "so the HBM fraction is small by construction (SURVEY 8d)"},
             "kernels_ms_per_step": {k: v[1] / args.steps for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])},
-            "kernel_ms_per_step_total": kernel_ms_per_step,
+            "kernel_ms_per_step_total": sum(v[1] for v in per_kernel.values()) / args.steps,
         }
         if n_gpus == 1 and not args.no_cpu:
+            import refflow
+            from vo_single_camera_sos_amd import orb_pattern
+            ca, sa = orb_pattern.angle_cos_sin(-1.0)
+            im = refflow.ImageModel(model.map_x.cpu().numpy(), model.map_y.cpu().numpy(), model.omni_masks.cpu().numpy(),
+                                    model.mask_bits_host, model.nmask, args.features_per_mask, model.pattern_host, ca, sa)
             n_cpu = min(args.cpu_pairs, B)
-            v, dt = cpu_baseline(frames, rig_kw, pipe.thr, args.iters, args.seed, n_cpu)
+            v, dt = cpu_baseline(omni, im, rig_kw, pipe.thr, args.iters, args.seed, n_cpu)
             out["cpu_baseline"] = {"value": v, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
                                    "sample": "%d of the same frame pairs through the C oracle (oracle/*.c) driven by "
                                              "tests/refflow.py, %.1f s" % (n_cpu, dt)}

@@ -65,6 +65,44 @@ def stereo_frame(rig, kp_top, kp_bot, desc_top, desc_bot):
                 b_bot=bb[good], n_cand=n_cand)
 
 
+class ImageModel(object):
+    """Per-model constants of the image front end (host arrays): float32 unwrap maps and annulus mask per
+    view, azimuthal mask bit fields per view, detector settings."""
+
+    def __init__(self, map_x, map_y, omni_masks, mask_bits, nmask, max_corners, pattern, cos_a, sin_a,
+                 median_ksize=11, quality=0.01, min_distance=5.0, edge=31):
+        self.map_x, self.map_y, self.omni_masks, self.mask_bits = map_x, map_y, omni_masks, mask_bits
+        self.nmask, self.max_corners, self.pattern = nmask, max_corners, pattern
+        self.cos_a, self.sin_a = cos_a, sin_a
+        self.median_ksize, self.quality, self.min_distance, self.edge = median_ksize, quality, min_distance, edge
+
+
+def detect_view(im, omni, view):
+    """set_current_omni_image (camera_models.py:3107) + detect_sparse_features_on_panorama with GFT
+    (camera_models.py:1708-1797) for one mirror: lists over azimuthal masks of keypoints / descriptors."""
+    pano = oracle.unwrap(omni, im.omni_masks[view], im.map_x[view], im.map_y[view])  # :3114 + panorama.py:293
+    gray = oracle.median_gray(pano, im.median_ksize)                                  # :1711, :1714
+    eig = oracle.min_eigen(gray)
+    blurred = oracle.gauss7(gray)
+    kps, descs = [], []
+    for m in range(im.nmask):                                                         # :1730
+        kp, _ = oracle.gft_select(eig, im.mask_bits[view], m, im.quality, im.min_distance, im.max_corners)  # :1739
+        d, kept = oracle.orb_describe(blurred, kp, im.cos_a, im.sin_a, im.pattern, im.edge)                 # :1765
+        kps.append(kp[kept])
+        descs.append(d)
+    return kps, descs, pano, gray
+
+
+def frame_from_image(rig, im, omni):
+    """StereoPanoramicFrame.__init__ for one omni image (pose_est_tools.py:271-402)."""
+    kt, dt, _, _ = detect_view(im, omni, 0)
+    kb, db, _, _ = detect_view(im, omni, 1)
+    fr = stereo_frame(rig, kt, kb, dt, db)
+    fr["n_kp_top"] = sum(len(k) for k in kt)
+    fr["n_kp_bot"] = sum(len(k) for k in kb)
+    return fr
+
+
 def f2f_view(rig, m_train, d_train, m_query, d_query):
     """match_features_frame_to_frame (pose_est_tools.py:211-269) for one view -> (train_idx, query_idx)."""
     q, t, _ = match_sorted(d_query, d_train)  # query = current, train = reference (:215)

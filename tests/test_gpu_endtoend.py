@@ -1,0 +1,92 @@
+"""GPU: the complete hot path from omni frames to refined pose (ImageFrontEnd + FramePairPipeline) against
+the reference's control flow on the CPU oracle (tests/refflow.py) on the same rendered frames:
+panoramas, gray images, keypoints, descriptors, stereo correspondences, frame-to-frame correspondences and
+inlier masks bit-exact; refined pose rel-tol 1e-6 (BASELINE north_star)."""
+import numpy as np
+import pytest
+
+import oracle
+import refflow
+import synth
+from vo_single_camera_sos_amd import orb_pattern, synthetic
+from vo_single_camera_sos_amd.frontend import DeviceImageModel, ImageFrontEnd
+from vo_single_camera_sos_amd.omnistereo.gum import synthetic_gums
+from vo_single_camera_sos_amd.omnistereo.panorama import Panorama
+from vo_single_camera_sos_amd.pipeline import FramePairPipeline, RigConfig
+
+pytestmark = pytest.mark.gpu
+
+
+def test_full_hot_path_from_images(ctx):
+    B = 3
+    gs = synthetic_gums()
+    for m in (gs.top_model, gs.bot_model):
+        m.panorama = Panorama(m, width=1200)
+    gs.make_annulus_masks((480, 640))
+    omni, poses = synthetic.make_frame_pairs(gs, B, seed=99)
+    omni[5] = 0  # a black current frame: nothing to detect -> tracking of pair 2 must fail cleanly
+    model = DeviceImageModel(ctx, gs, (480, 640))
+    assert model.nmask == 12
+    fe = ImageFrontEnd(ctx, model, 2 * B, num_of_features=330)
+    pano = gs.top_model.panorama
+    rig_kw = dict(pano_top=(pano.cols, pano.rows, pano.pixel_size, pano.cyl_height_max),
+                  pano_bot=(pano.cols, pano.rows, pano.pixel_size, pano.cyl_height_max),
+                  F_top=gs.top_model.F[:3, 0], F_bot=gs.bot_model.F[:3, 0], min_range=500.0, max_range=7000.0,
+                  stereo_min_disp=1.0, stereo_max_hdiff=2.5, f2f_max_hdiff=0.125 * 0.5 * pano.cols,
+                  pct_good_matches=1.0)
+    assert rig_kw["pano_top"] == synth.PANO_C2
+    pipe = FramePairPipeline(ctx, RigConfig(**rig_kw), B, frame_cap=2048, max_iter=500, seed=5, front_end=fe)
+    fe.load_frames(omni)
+    pipe.step()
+    rec = pipe.results()
+    ctx.synchronize()
+
+    # ---- model constants: the GPU-built azimuthal masks equal masks built with the oracle's unwrap
+    mx, my = model.map_x.cpu().numpy(), model.map_y.cpu().numpy()
+    for vi, m in enumerate((gs.top_model, gs.bot_model)):
+        gpu_bits = m.panorama.mask_bits()
+        m.panorama.generate_azimuthal_masks(
+            30, 0, elev_mask_padding=10, stand_masks_azimuth_coord_in_degrees_list=[50, 170, 290],
+            stand_masks_width_in_degrees=10,
+            unwrap_fn=lambda om, vi=vi: oracle.unwrap(np.repeat(om[..., None], 3, 2), None, mx[vi], my[vi])[..., 0])
+        assert np.array_equal(m.panorama.mask_bits(), gpu_bits)
+        assert np.array_equal(gpu_bits, model.mask_bits_host[vi])
+
+    ca, sa = orb_pattern.angle_cos_sin(-1.0)
+    im = refflow.ImageModel(mx, my, model.omni_masks.cpu().numpy(), model.mask_bits_host, 12, 330,
+                            orb_pattern.orb_pattern(), ca, sa)
+    rp = refflow.RigParams(**rig_kw)
+    g_pano, g_gray = fe.pano.cpu().numpy(), fe.gray.cpu().numpy()
+    g_kp, g_n, g_desc = fe.kp.cpu().numpy(), fe.n.cpu().numpy(), fe.desc.cpu().numpy()
+    assert not fe.status.cpu().numpy().any()
+    F = 2 * B
+    frames = []
+    for f in range(F):
+        per_view = []
+        for v in range(2):
+            kps, descs, pano_o, gray_o = refflow.detect_view(im, omni[f], v)
+            assert np.array_equal(g_pano[v, f], pano_o), ("pano", f, v)
+            assert np.array_equal(g_gray[v * F + f], gray_o), ("gray", f, v)
+            for m in range(12):
+                p = (v * F + f) * 12 + m
+                assert g_n[p] == len(kps[m]), ("count", f, v, m)
+                assert np.array_equal(g_kp[p, : g_n[p]], kps[m]), ("kp", f, v, m)
+                assert np.array_equal(g_desc[p, : g_n[p]], descs[m]), ("desc", f, v, m)
+            per_view.append((kps, descs))
+        frames.append(refflow.stereo_frame(rp, per_view[0][0], per_view[1][0], per_view[0][1], per_view[1][1]))
+    M = pipe.frames["M"].cpu().numpy()
+    assert [int(x) for x in M] == [len(fr["X"]) for fr in frames]
+    assert M[:5].min() > 300 and M[5] == 0
+    rec = rec.cpu().numpy()
+    mask = pipe.ransac["mask"].cpu().numpy()
+    for i in range(B):
+        w = refflow.track_pair(rp, frames[2 * i], frames[2 * i + 1], pipe.thr, 500, seed=5 + i)
+        n = len(w["corr"]["cam"])
+        assert rec[i, 13] == n and rec[i, 14] == w["ransac"]["status"] and rec[i, 12] == w["ransac"]["n_inliers"]
+        assert np.array_equal(mask[i, :n].astype(bool), w["ransac"]["mask"])
+        assert np.allclose(rec[i, :12].reshape(3, 4), w["T"], rtol=1e-6, atol=1e-9)
+    assert rec[2, 14] == 1 and rec[2, 13] == 0           # black frame: no correspondences, status "no model"
+    for i in range(2):                                    # the planted motion is recovered (loosely: 5 deg threshold)
+        R, t = poses[i]
+        ang, _ = synth.pose_error(rec[i, :12].reshape(3, 4), R, t)
+        assert ang < np.deg2rad(2.0)

@@ -125,7 +125,9 @@ class Panorama(object):
     # ---- azimuthal bucket masks (panorama.py:520-589) ----
     def generate_azimuthal_masks(self, azimuth_mask_degrees, overlap_degrees=0, mask_also_on_elev=True,
                                  elev_mask_padding=0, stand_masks_azimuth_coord_in_degrees_list=(),
-                                 stand_masks_width_in_degrees=1, show=False, omni_shape=None):
+                                 stand_masks_width_in_degrees=1, show=False, omni_shape=None, unwrap_fn=None):
+        """`unwrap_fn(omni_mask) -> pano_mask` overrides the GPU unwrap of the elevation mask (tests use it to
+        build the masks without a GPU); default is self.get_panoramic_image."""
         azimuth_mask_radians = np.deg2rad(azimuth_mask_degrees)
         overlap_radians = np.deg2rad(overlap_degrees)
         self.azimuthal_masks = []
@@ -137,7 +139,10 @@ class Panorama(object):
                 omni_img_mask = self.model.make_mask(mask_shape=omni_shape, radius_pixel_shrinking=elev_mask_padding)
             else:
                 omni_img_mask = self.model.mask if self.model.mask is not None else self.model.make_mask(omni_shape)
-            pano_img_mask = self.get_panoramic_image(omni_img_mask, set_own=False)
+            if unwrap_fn is not None:
+                pano_img_mask = unwrap_fn(omni_img_mask)
+            else:
+                pano_img_mask = self.get_panoramic_image(omni_img_mask, set_own=False)
 
         def paint(mask, c1, c2, value):  # cv2.rectangle(..., thickness=-1): both corner columns included
             lo, hi = (c1, c2) if c1 <= c2 else (c2, c1)

@@ -30,9 +30,15 @@ class RigConfig(object):
 
 class FramePairPipeline(object):
     def __init__(self, ctx, rig, n_pairs, nmask=12, bucket_cap=192, frame_cap=2048, thr=None, max_iter=2000,
-                 adaptive=False, seed=0, lm_iter=30):
+                 adaptive=False, seed=0, lm_iter=30, front_end=None):
+        """front_end: an ImageFrontEnd over 2 * n_pairs frames; its keypoint/descriptor buffers are used in
+        place (no copy).  Without it, keypoints are loaded with load_keypoints()."""
         assert isinstance(ctx, Context)
         self.ctx, self.rig_cfg, self.rig = ctx, rig, rig.as_struct()
+        self.front_end = front_end
+        if front_end is not None:
+            assert front_end.F == 2 * int(n_pairs)
+            nmask, bucket_cap = front_end.model.nmask, front_end.kp_cap
         self.B, self.F, self.NM = int(n_pairs), 2 * int(n_pairs), int(nmask)
         self.bucket_cap, self.frame_cap, self.corr_cap = int(bucket_cap), int(frame_cap), 2 * int(frame_cap)
         # TrackerSE3.set_global_parameters_for_tracking (pose_est_tools.py:675-676)
@@ -41,9 +47,14 @@ class FramePairPipeline(object):
         dev = ctx.device
         P = self.F * self.NM
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
-        self.kp_top, self.kp_bot = z((P, bucket_cap, 2), torch.float32), z((P, bucket_cap, 2), torch.float32)
-        self.desc_top, self.desc_bot = z((P, bucket_cap, 32), torch.uint8), z((P, bucket_cap, 32), torch.uint8)
-        self.n_top, self.n_bot = z((P,), torch.int32), z((P,), torch.int32)
+        if front_end is not None:
+            v = front_end.view_arrays()
+            self.kp_top, self.kp_bot, self.desc_top, self.desc_bot = v["kp_top"], v["kp_bot"], v["desc_top"], v["desc_bot"]
+            self.n_top, self.n_bot = v["n_top"], v["n_bot"]
+        else:
+            self.kp_top, self.kp_bot = z((P, bucket_cap, 2), torch.float32), z((P, bucket_cap, 2), torch.float32)
+            self.desc_top, self.desc_bot = z((P, bucket_cap, 32), torch.uint8), z((P, bucket_cap, 32), torch.uint8)
+            self.n_top, self.n_bot = z((P,), torch.int32), z((P,), torch.int32)
         self.s_keys, self.s_order = z((P, bucket_cap, 1), torch.uint32), z((P, bucket_cap), torch.int32)
         Fc, Cc = self.frame_cap, self.corr_cap
         self.frames = dict(m_top=z((self.F, Fc, 2), torch.float32), m_bot=z((self.F, Fc, 2), torch.float32),
@@ -101,7 +112,10 @@ class FramePairPipeline(object):
                           cost=self.lm_cost, iters=self.lm_iters)
 
     def step(self):
-        """Everything after detection for all B pairs (asynchronous)."""
+        """The whole hot path for all B pairs (asynchronous): image front end (when attached), stereo
+        correspondences, frame-to-frame tracking."""
+        if self.front_end is not None:
+            self.front_end.run()
         self.stereo()
         self.track()
         return self.T

@@ -1,0 +1,112 @@
+"""Synthetic omnistereo frames for benchmarks and end-to-end tests (there is no network
+for datasets).  A textured room is ray-cast through the GUM model of both mirrors: every omni pixel of
+each mirror's annulus is lifted to its viewing ray (closed-form inverse of the distortion-free GUM),
+the ray is intersected with the room's planes, and the hit point is coloured by a multi-scale
+procedural checker texture hashed from its world coordinates.  Frames of one pair see the same room
+from two poses, so stereo disparity and frame-to-frame motion are geometrically exact.  numpy only."""
+import numpy as np
+
+
+def lift_pixels(model, u, v):
+    """Omni pixels -> unit viewing directions in the mirror frame (distortion-free GUM only).
+    Inverse of GUM.get_pixel_from_3D_point_wrt_M: q = Ps - Cp = lambda * (x, y, sigma), |Ps| = 1."""
+    p = model.precalib_params
+    if p.use_distortion and (p.k1 or p.k2 or p.k3):
+        raise NotImplementedError("closed-form lifting needs k1 = k2 = k3 = 0")
+    y = (v - p.v_center) / p.gamma2
+    x = (u - p.u_center - p.gamma1 * p.alpha_c * y) / p.gamma1
+    sigma = -1.0 if p.xi3 > 0 else 1.0  # sign of (Ps_z - xi3) for the visible half
+    d = np.stack([x, y, np.full_like(x, sigma)], axis=-1)
+    cp = np.array([p.xi1, p.xi2, p.xi3])
+    a = np.sum(d * d, axis=-1)
+    b = 2.0 * (d @ cp)
+    c = cp @ cp - 1.0
+    lam = (-b + np.sqrt(b * b - 4 * a * c)) / (2 * a)
+    return cp + lam[..., None] * d
+
+
+def _hash3(ix, iy, iz, salt):
+    h = (ix.astype(np.int64) * 73856093) ^ (iy.astype(np.int64) * 19349663) ^ (iz.astype(np.int64) * 83492791) ^ salt
+    h = (h ^ (h >> 13)) * 1274126177
+    h = h ^ (h >> 16)
+    return h & 0xFFFFFF
+
+
+class Room(object):
+    """Axis-aligned room (mm) with a few interior pillars, textured by hashed multi-scale cells."""
+
+    def __init__(self, seed=0, half_x=(2600.0, 3400.0), half_y=(2100.0, 3900.0), z_floor=-1400.0, z_ceil=1500.0,
+                 cells=(260.0, 65.0)):
+        rng = np.random.default_rng(seed)
+        self.seed = int(seed)
+        self.planes = [(0, -rng.uniform(*half_x)), (0, rng.uniform(*half_x)), (1, -rng.uniform(*half_y)),
+                       (1, rng.uniform(*half_y)), (2, z_floor), (2, z_ceil)]
+        self.cells = cells
+
+    def cast(self, origins, dirs):
+        """origins [3], dirs [n,3] -> hit points [n,3] (nearest plane in front of the ray)."""
+        t_best = np.full(dirs.shape[0], np.inf)
+        for axis, val in self.planes:
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t = (val - origins[axis]) / dirs[:, axis]
+            t = np.where(t > 1e-6, t, np.inf)
+            t_best = np.minimum(t_best, t)
+        return origins + dirs * t_best[:, None], t_best
+
+    def colour(self, P):
+        """World points [n,3] -> BGR uint8 [n,3]."""
+        out = np.zeros((P.shape[0], 3), dtype=np.float64)
+        weights = (0.62, 0.38)
+        for lvl, (cell, w) in enumerate(zip(self.cells, weights)):
+            idx = np.floor(P / cell + 0.5 * lvl).astype(np.int64)
+            h = _hash3(idx[:, 0], idx[:, 1], idx[:, 2], 0x5bd1e995 * (self.seed + 1) + lvl)
+            col = np.stack([(h >> s) & 0xFF for s in (0, 8, 16)], axis=-1).astype(np.float64)
+            out += w * col
+        return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def render_omni(gums, room, R, t, noise_sigma=2.0, rng=None):
+    """One 8-bit BGR omni frame seen from the viewpoint X_world = R x + t (x in the rig frame [C], mm)."""
+    W, H = gums.top_model.image_size
+    img = np.zeros((H, W, 3), dtype=np.uint8)
+    if gums.top_model.mask is None:
+        gums.make_annulus_masks((H, W))
+    for m in (gums.top_model, gums.bot_model):
+        vv, uu = np.nonzero(m.mask)
+        dirs = lift_pixels(m, uu.astype(np.float64), vv.astype(np.float64))  # mirror frame = [C] orientation
+        origin = R @ m.F[:3, 0] + t
+        P, _ = room.cast(origin, dirs @ R.T)
+        img[vv, uu] = room.colour(P)
+    if noise_sigma > 0:
+        rng = rng or np.random.default_rng(0)
+        img = np.clip(img.astype(np.float64) + rng.normal(0, noise_sigma, img.shape), 0, 255).astype(np.uint8)
+        img[(gums.top_model.mask == 0) & (gums.bot_model.mask == 0)] = 0
+    return img
+
+
+def random_step(rng, max_t=100.0, max_deg=5.0):
+    """Random SE(3) step (|t| <= max_t mm, angle <= max_deg): pose of the second viewpoint in the first."""
+    axis = rng.normal(size=3)
+    axis /= np.linalg.norm(axis)
+    ang = np.deg2rad(rng.uniform(0.2, max_deg))
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+    t = rng.normal(size=3)
+    t = t / np.linalg.norm(t) * rng.uniform(0.1 * max_t, max_t)
+    return R, t
+
+
+def make_frame_pairs(gums, n_pairs, seed=1234, noise_sigma=2.0):
+    """-> (omni [2*n_pairs, H, W, 3] u8, poses list of (R, t)): pair i = frames 2i (reference, identity pose)
+    and 2i+1 (current, pose (R, t) in the reference frame); one room per pair."""
+    W, H = gums.top_model.image_size
+    omni = np.zeros((2 * n_pairs, H, W, 3), dtype=np.uint8)
+    poses = []
+    for i in range(n_pairs):
+        rng = np.random.default_rng(seed + i)
+        room = Room(seed=seed + i)
+        R, t = random_step(rng)
+        omni[2 * i] = render_omni(gums, room, np.eye(3), np.zeros(3), noise_sigma, rng)
+        omni[2 * i + 1] = render_omni(gums, room, R, t, noise_sigma, rng)
+        poses.append((R, t))
+    return omni, poses
