@@ -100,37 +100,61 @@ __global__ __launch_bounds__(kThreads) void gft_candidates_kernel(const float* _
                                                                   int32_t* __restrict__ cand_count,
                                                                   unsigned long long* __restrict__ cand) {
   const int img = blockIdx.y;
+  const int lane = threadIdx.x & 63;
   const int pix = blockIdx.x * kThreads + threadIdx.x;
-  if (pix >= rows * cols) return;
   const int y = pix / cols, x = pix - y * cols;
-  if (y < 1 || y > rows - 2 || x < 1 || x > cols - 2) return;
-  uint32_t bits = mask_bits[((size_t)(img / images_per_maskset) * rows) * cols + pix];
-  if (!bits) return;
+  const bool inside = pix < rows * cols && y >= 1 && y <= rows - 2 && x >= 1 && x <= cols - 2;
+  uint32_t bits = inside ? mask_bits[((size_t)(img / images_per_maskset) * rows) * cols + pix] : 0u;
+  if (nmask < 32) bits &= (1u << nmask) - 1u;
   const float* e = eig + (size_t)img * rows * cols;
   float nb[9];
 #pragma unroll
-  for (int dy = -1; dy <= 1; ++dy)
+  for (int k = 0; k < 9; ++k) nb[k] = 0.0f;
+  if (bits) {
 #pragma unroll
-    for (int dx = -1; dx <= 1; ++dx) nb[(dy + 1) * 3 + dx + 1] = e[pix + dy * cols + dx];
-  while (bits) {
-    const int m = __ffs(bits) - 1;
-    bits &= bits - 1;
-    if (m >= nmask) break;
-    const uint32_t mb = maxbits[(size_t)img * nmask + m];
-    if (!mb) continue;
-    const float thr = (float)((double)sosvo_ordered_float(mb) * quality);
-    const float v = nb[4] > thr ? nb[4] : 0.0f;
-    if (v == 0.0f) continue;
-    float dil = v;
+    for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const float t = nb[k] > thr ? nb[k] : 0.0f;
-      dil = t > dil ? t : dil;
+      for (int dx = -1; dx <= 1; ++dx) nb[(dy + 1) * 3 + dx + 1] = e[pix + dy * cols + dx];
+  }
+  // every lane walks its mask bits; the slot reservation is aggregated per (wave, mask): one atomic each
+  while (__ballot(bits != 0u)) {
+    int m = -1;
+    bool is_cand = false;
+    float v = 0.0f;
+    if (bits) {
+      m = __ffs(bits) - 1;
+      bits &= bits - 1;
+      const uint32_t mb = maxbits[(size_t)img * nmask + m];
+      if (mb) {
+        const float thr = (float)((double)sosvo_ordered_float(mb) * quality);
+        v = nb[4] > thr ? nb[4] : 0.0f;
+        if (v != 0.0f) {
+          float dil = v;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) {
+            const float t = nb[k] > thr ? nb[k] : 0.0f;
+            dil = t > dil ? t : dil;
+          }
+          is_cand = v == dil;
+        }
+      }
     }
-    if (v != dil) continue;
-    const size_t p = (size_t)img * nmask + m;
-    const int slot = atomicAdd(&cand_count[p], 1);
-    if (slot < kCandCap) cand[p * kCandCap + slot] = ((unsigned long long)sosvo_float_ordered(v) << 32) | (uint32_t)pix;
+    unsigned long long todo = __ballot(is_cand);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int mm = __shfl(m, leader);
+      const unsigned long long same = __ballot(is_cand && m == mm);
+      const size_t p = (size_t)img * nmask + mm;
+      int base = 0;
+      if (lane == leader) base = atomicAdd(&cand_count[p], __popcll(same));
+      base = __shfl(base, leader);
+      if (is_cand && m == mm) {
+        const int slot = base + __popcll(same & ((1ULL << lane) - 1ULL));
+        if (slot < kCandCap)
+          cand[p * kCandCap + slot] = ((unsigned long long)sosvo_float_ordered(v) << 32) | (uint32_t)pix;
+      }
+      todo &= ~same;
+    }
   }
 }
 

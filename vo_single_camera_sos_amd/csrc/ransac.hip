@@ -27,7 +27,7 @@ namespace {
 constexpr int kMaxCam = 8;
 constexpr int kHypDoubles = 16;  // R[9], t[3], -R^T t [3], pad
 constexpr int kThreads = 256;
-constexpr int kScoreHypChunkMax = 512;
+constexpr int kScoreHypChunkMax = 128;
 
 __device__ const double kEye9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
 __device__ const double kZero3[3] = {0, 0, 0};
@@ -159,6 +159,7 @@ __global__ __launch_bounds__(kThreads) void ransac_score_kernel(
     int stride, int H, int hchunk, double thr, int fast_ok, const double* __restrict__ hyp,
     int32_t* __restrict__ counts) {
   __shared__ int lcnt[kScoreHypChunkMax];
+  __shared__ double shyp[kScoreHypChunkMax][12];
   const int tid = threadIdx.x, b = blockIdx.z;
   const int n = min(n_arr[b], stride);
   const int p0 = blockIdx.x * (kThreads * PPT);
@@ -196,15 +197,21 @@ __global__ __launch_bounds__(kThreads) void ransac_score_kernel(
   const double c1 = 1.0 - thr;
   const double c2 = c1 * c1;
   const double c2hi = c2 * (1.0 + 1e-9), c2lo = c2 * (1.0 - 1e-9);
+  // stage this chunk's hypotheses (R and -R^T t, 12 doubles each) in LDS with coalesced loads; the scoring
+  // loop then reads them as wave-wide LDS broadcasts instead of dependent scalar loads from L2
+  const double* hb = hyp + ((size_t)b * H + h0) * kHypDoubles;
+  for (int k = tid; k < (h1 - h0) * 12; k += kThreads) {
+    const int hh = k / 12, e = k - hh * 12;
+    shyp[hh][e] = hb[(size_t)hh * kHypDoubles + (e < 9 ? e : e + 3)];
+  }
   __syncthreads();
 
-  const double* hb = hyp + (size_t)b * H * kHypDoubles;
   for (int h = h0; h < h1; ++h) {
-    const double* hp = hb + (size_t)h * kHypDoubles;  // wave-uniform address -> scalar loads
+    const double* hp = shyp[h - h0];
     const double r0 = hp[0];
     if (r0 != r0) continue;  // failed minimal solve
     const double r1 = hp[1], r2 = hp[2], r3 = hp[3], r4 = hp[4], r5 = hp[5], r6 = hp[6], r7 = hp[7], r8 = hp[8];
-    const double ix = hp[12], iy = hp[13], iz = hp[14];
+    const double ix = hp[9], iy = hp[10], iz = hp[11];
     int wave_total = 0;
 #pragma unroll
     for (int r = 0; r < PPT; ++r) {
@@ -387,6 +394,7 @@ __global__ __launch_bounds__(kThreads) void refine_kernel(
     int stride, const int32_t* __restrict__ idx, const int32_t* __restrict__ m_arr, int max_lm_iter,
     double* __restrict__ T_io, double* __restrict__ cost_out, int32_t* __restrict__ iters_out) {
   __shared__ double scratch[4];
+  __shared__ double sred[28][4];
   __shared__ double sx[6], sxn[6], sdx[6];
   __shared__ double sA[21], sg[6];
   __shared__ int s_flag;  // 0 continue tries, 1 accepted, 2 accepted+converged, 3 give up
@@ -433,16 +441,26 @@ __global__ __launch_bounds__(kThreads) void refine_kernel(
         for (int v = u; v < 6; ++v) A[a++] += J[u] * J[v];
       }
     }
-    cost = block_sum(c, scratch, tid);
+    // one fused reduction of the 28 sums (same order as block_sum: wave tree, then w0 + w1 + w2 + w3)
+    {
+      double wv[28];
+      wv[27] = c;
 #pragma unroll
-    for (int a = 0; a < 21; ++a) {
-      const double s = block_sum(A[a], scratch, tid);
-      if (tid == 0) sA[a] = s;
-    }
+      for (int a = 0; a < 21; ++a) wv[a] = A[a];
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
-      const double s = block_sum(g[a], scratch, tid);
-      if (tid == 0) sg[a] = s;
+      for (int a = 0; a < 6; ++a) wv[21 + a] = g[a];
+#pragma unroll
+      for (int a = 0; a < 28; ++a)
+        for (int o = 32; o > 0; o >>= 1) wv[a] = wv[a] + __shfl_down(wv[a], o);
+      __syncthreads();
+      if ((tid & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 28; ++a) sred[a][tid >> 6] = wv[a];
+      }
+      __syncthreads();
+      if (tid < 21) sA[tid] = ((sred[tid][0] + sred[tid][1]) + sred[tid][2]) + sred[tid][3];
+      if (tid >= 21 && tid < 27) sg[tid - 21] = ((sred[tid][0] + sred[tid][1]) + sred[tid][2]) + sred[tid][3];
+      cost = ((sred[27][0] + sred[27][1]) + sred[27][2]) + sred[27][3];
     }
     __syncthreads();
     int accepted = 0, converged = 0;
