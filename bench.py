@@ -80,6 +80,7 @@ def main():
     from vo_single_camera_sos_amd.frontend import DeviceImageModel, ImageFrontEnd
     from vo_single_camera_sos_amd.omnistereo.gum import synthetic_gums
     from vo_single_camera_sos_amd.omnistereo.panorama import Panorama
+    from vo_single_camera_sos_amd.parallel import gather_records, max_over_ranks
     from vo_single_camera_sos_amd.pipeline import FramePairPipeline, RigConfig
 
     B = args.pairs_per_gpu
@@ -106,7 +107,7 @@ def main():
         pipe.step()
         rec = pipe.results()
         if dist:
-            dist.all_gather_into_tensor(gathered, rec)  # 16 doubles per pair: latency-bound, one flat gather
+            gather_records(rec, out=gathered)  # 16 doubles per pair: latency-bound, one flat RCCL all-gather
         return rec
 
     for _ in range(args.warmup):
@@ -126,10 +127,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_read()
     ctx.profile_enable(False)
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, ctx.device)
 
     if rank == 0:
         rec = rec.cpu().numpy()
