@@ -130,6 +130,32 @@ int32_t sosvo_describe_orb(sosvo_ctx* ctx, const uint8_t* gray, int32_t nimg, in
                            int32_t nmask, int32_t cap, float* kp, int32_t* n, float cos_a, float sin_a,
                            const int8_t* pattern, int32_t edge, uint8_t* desc);
 
+/* ---- K5: ORB keypoint detection per azimuthal mask (a4, feature_detection_method "ORB") ----------
+ * Replaces cv2.ORB_create(nfeatures=N).detect(image, mask) (omnistereo/camera_models.py:1640, :1755;
+ * pose_est_tools.py:478, :547) for all azimuthal masks of all images at once: 8 levels x 1.2, per-level
+ * quotas, FAST-9/16 (threshold 20) with 3x3 NMS, 31-px border, (resized) mask, best 2 n_l by FAST score,
+ * Harris response, best n_l, intensity-centroid orientation; see vo_single_camera_sos_amd/csrc/orb.hip.
+ *   sosvo_orb_pyramid_pixels(rows, cols): pixels of one image's 8-level pyramid (host helper)
+ *   sosvo_orb_mask_pyramid: mask_bits [nsets, rows, cols] u32 -> mask_pyr [nsets, pyramid_pixels] u32,
+ *       every mask resized level by level (kept where > 254); call once per model
+ *   sosvo_detect_orb: gray [nimg, rows, cols] u8 -> kp4 [nimg*nmask, cap, 4] f32 = (x, y in level-0
+ *       coordinates, angle in degrees, level), resp [nimg*nmask, cap] f32 (Harris), n [nimg*nmask] i32;
+ *       keypoints ordered by level, then response descending, then (y, x).
+ * ---- K6': ORB descriptors for oriented multi-level keypoints
+ * Replaces .compute(image, keypoints) on ORB's own keypoints (camera_models.py:1765): keypoints within
+ * 31 px of the level-0 border are removed (kp4 / n compacted in place), each level is blurred 7x7 sigma 2,
+ * the pattern is rotated by the keypoint's angle.  desc [nimg*nmask, cap, 32] u8; kp_xy (optional)
+ * [nimg*nmask, cap, 2] f32 receives the compacted (x, y) for the matching stages.                 */
+int64_t sosvo_orb_pyramid_pixels(int32_t rows, int32_t cols);
+int32_t sosvo_orb_mask_pyramid(sosvo_ctx* ctx, const uint32_t* mask_bits, int32_t nsets, int32_t rows,
+                               int32_t cols, int32_t nmask, uint32_t* mask_pyr);
+int32_t sosvo_detect_orb(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* mask_pyr, int32_t nimg,
+                         int32_t images_per_maskset, int32_t rows, int32_t cols, int32_t nmask,
+                         int32_t nfeatures, int32_t cap, float* kp4, float* resp, int32_t* n);
+int32_t sosvo_describe_orb_levels(sosvo_ctx* ctx, const uint8_t* gray, int32_t nimg, int32_t rows,
+                                  int32_t cols, int32_t nmask, int32_t cap, float* kp4, int32_t* n,
+                                  const int8_t* pattern, uint8_t* desc, float* kp_xy);
+
 /* ---- K7: brute-force Hamming matching ------------------------------------------------
  * Replaces cv2.BFMatcher(NORM_HAMMING).match / .knnMatch as called from
  * omnistereo/camera_models.py:442 and :420 (FeatureMatcher.match, :404-446).

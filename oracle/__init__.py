@@ -291,6 +291,65 @@ def orb_pattern():
     return pts
 
 
+def orb_level_size(rows, cols, level):
+    r, c = ctypes.c_int32(0), ctypes.c_int32(0)
+    lib().orc_orb_level_size(ctypes.c_int32(rows), ctypes.c_int32(cols), ctypes.c_int32(level), ctypes.byref(r),
+                             ctypes.byref(c))
+    return r.value, c.value
+
+
+def resize_linear(src, h1, w1):
+    src = _c(src, np.uint8)
+    dst = np.empty((h1, w1), dtype=np.uint8)
+    lib().orc_resize_linear(_p(src), ctypes.c_int32(src.shape[0]), ctypes.c_int32(src.shape[1]), _p(dst),
+                            ctypes.c_int32(h1), ctypes.c_int32(w1))
+    return dst
+
+
+def fast_score_map(img, thr=20):
+    img = _c(img, np.uint8)
+    out = np.empty_like(img)
+    lib().orc_fast_score_map(_p(img), ctypes.c_int32(img.shape[0]), ctypes.c_int32(img.shape[1]), ctypes.c_int32(thr),
+                             _p(out))
+    return out
+
+
+def orb_quotas(nfeatures):
+    q = np.zeros(8, dtype=np.int32)
+    lib().orc_orb_quotas(ctypes.c_int32(nfeatures), _p(q))
+    return q
+
+
+def orb_detect(gray, mask_bits, nmask, nfeatures, cap=1024):
+    """-> list over masks of (kp [n,4] = x, y, angle_deg, level; resp [n])."""
+    gray = _c(gray, np.uint8)
+    mask_bits = _c(mask_bits, np.uint32)
+    rows, cols = gray.shape
+    kp = np.zeros((nmask, cap, 4), dtype=np.float32)
+    resp = np.zeros((nmask, cap), dtype=np.float32)
+    n = np.zeros(nmask, dtype=np.int32)
+    lib().orc_orb_detect(_p(gray), ctypes.c_int32(rows), ctypes.c_int32(cols), _p(mask_bits), ctypes.c_int32(nmask),
+                         ctypes.c_int32(nfeatures), ctypes.c_int32(cap), _p(kp), _p(resp), _p(n))
+    return [(kp[m, : n[m]].copy(), resp[m, : n[m]].copy()) for m in range(nmask)]
+
+
+def orb_describe_levels(gray, kp4, pattern=None):
+    """kp4 [n,4] = (x, y, angle_deg, level) -> (desc [m,32], kept_idx [m])."""
+    gray = _c(gray, np.uint8)
+    kp4 = _c(kp4, np.float32).reshape(-1, 4)
+    if pattern is None:
+        pattern = orb_pattern()
+    pattern = _c(pattern, np.int8)
+    n = kp4.shape[0]
+    desc = np.zeros((max(n, 1), 32), dtype=np.uint8)
+    kept = np.zeros(max(n, 1), dtype=np.int32)
+    L = lib()
+    L.orc_orb_describe_levels.restype = ctypes.c_int32
+    m = L.orc_orb_describe_levels(_p(gray), ctypes.c_int32(gray.shape[0]), ctypes.c_int32(gray.shape[1]), _p(kp4),
+                                  ctypes.c_int32(n), _p(pattern), _p(desc), _p(kept))
+    return desc[:m].copy(), kept[:m].copy()
+
+
 def orb_describe(blurred, kp_xy, cos_a, sin_a, pattern=None, edge=31):
     """-> (desc [m,32] u8, kept_idx [m] i32): keypoints within `edge` px of the border are dropped."""
     blurred = _c(blurred, np.uint8)

@@ -51,6 +51,10 @@ SIGNATURES = {
                                  c_p, c_p]),
     "sosvo_describe_orb": (c_i32, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_f32, c_f32, c_p, c_i32,
                                    c_p]),
+    "sosvo_orb_pyramid_pixels": (ctypes.c_int64, [c_i32, c_i32]),
+    "sosvo_orb_mask_pyramid": (c_i32, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p]),
+    "sosvo_detect_orb": (c_i32, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p]),
+    "sosvo_describe_orb_levels": (c_i32, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p, c_p]),
     "sosvo_match_hamming": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p]),
     "sosvo_sort_matches": (c_i32, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_p]),
     "sosvo_pano_to_bearing": (c_i32, [c_p, c_p, c_i32, c_f64, c_f64, c_f64, c_f64, c_p, c_p, c_p]),

@@ -1,0 +1,564 @@
+// K5 -- ORB keypoint detection per azimuthal mask, and K6' -- ORB descriptors for oriented multi-level keypoints.
+//
+//   cv2.ORB_create(nfeatures=N).detect(pano, mask)   omnistereo/camera_models.py:1640, :1755; pose_est_tools.py:478, :547
+//   .compute(pano, keypoints)                        camera_models.py:1765; pose_est_tools.py:553
+//
+// Batched over images (view-major) x azimuthal masks; problem p = image * nmask + mask.
+//   pyramid   8 levels x 1.2, each level bilinear (11-bit fixed point) from the previous one; all levels of one
+//             image live back to back in one workspace row (level offsets in a by-value struct);
+//   fast      FAST-9/16 score for every pyramid pixel in one launch (16 ring loads per lane from L1/L2);
+//   select    one workgroup per problem walks the levels: 3x3 NMS + 31-px border + mask -> candidates in LDS,
+//             keep the best 2 n_l by FAST score through a 256-bin LDS histogram (ties kept), Harris response
+//             per candidate, rank sort (response desc, then y, x), keep n_l (+ ties), intensity-centroid angle
+//             with one wave per keypoint (lanes = patch rows, shuffle reduction), fastAtan2 polynomial in
+//             float32 with a pinned operation order;
+//   describe  border rule on level-0 coordinates + stable compaction, then one wave per keypoint: the rotated
+//             offsets are evaluated per lane in float32, four 64-bit ballots are the 32 descriptor bytes.
+// Integer work except the Harris/angle float32 arithmetic, whose operation order is pinned -> bit-exact against
+// the oracle (cos/sin of the angle are double-precision library calls rounded to float32 on both sides).
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kLevels = 8;
+constexpr int kEdge = 31;
+constexpr int kHalfPatch = 15;
+constexpr int kFastThr = 20;
+constexpr int kCandMax = 2048;  // candidates per (problem, level) held in LDS
+
+struct Pyr {
+  int h[kLevels], w[kLevels];
+  long long off[kLevels];
+  float scale[kLevels];
+  int quota[kLevels];
+  int nlev;          // levels that exist (h, w >= 1)
+  long long total;   // pixels of one image's pyramid
+};
+
+__device__ __forceinline__ int refl101(int i, int n) {
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
+  return i;
+}
+
+// ---- pyramid -------------------------------------------------------------------------------------------
+struct ResizeTap {
+  int i0, i1, w0, w1;
+};
+
+__device__ __forceinline__ ResizeTap resize_tap(int d, double scale, int n0) {
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  int i = (int)floorf(f);
+  f -= (float)i;
+  if (i < 0) {
+    i = 0;
+    f = 0.f;
+  }
+  if (i >= n0 - 1) {
+    i = n0 - 1;
+    f = 0.f;
+  }
+  ResizeTap t;
+  t.i0 = i;
+  t.i1 = i + 1 < n0 ? i + 1 : n0 - 1;
+  t.w1 = __float2int_rn(f * 2048.f);
+  t.w0 = 2048 - t.w1;
+  return t;
+}
+
+__global__ __launch_bounds__(kThreads) void copy_level0_kernel(const uint8_t* __restrict__ gray, int npix,
+                                                               long long total, uint8_t* __restrict__ pyr) {
+  const int i = blockIdx.x * kThreads + threadIdx.x, img = blockIdx.y;
+  if (i < npix) pyr[(size_t)img * total + i] = gray[(size_t)img * npix + i];
+}
+
+__global__ __launch_bounds__(kThreads) void resize_level_kernel(uint8_t* __restrict__ pyr, long long total,
+                                                                long long off0, int h0, int w0, long long off1, int h1,
+                                                                int w1) {
+  const int i = blockIdx.x * kThreads + threadIdx.x, img = blockIdx.y;
+  if (i >= h1 * w1) return;
+  const int dy = i / w1, dx = i - dy * w1;
+  const ResizeTap ty = resize_tap(dy, (double)h0 / h1, h0), tx = resize_tap(dx, (double)w0 / w1, w0);
+  const uint8_t* s = pyr + (size_t)img * total + off0;
+  const long long top = (long long)tx.w0 * s[(size_t)ty.i0 * w0 + tx.i0] + (long long)tx.w1 * s[(size_t)ty.i0 * w0 + tx.i1];
+  const long long bot = (long long)tx.w0 * s[(size_t)ty.i1 * w0 + tx.i0] + (long long)tx.w1 * s[(size_t)ty.i1 * w0 + tx.i1];
+  pyr[(size_t)img * total + off1 + i] = (uint8_t)((ty.w0 * top + ty.w1 * bot + (1 << 21)) >> 22);
+}
+
+// mask level l from level l-1: every mask bit is resized as a 0/255 image and kept where the result is > 254
+__global__ __launch_bounds__(kThreads) void mask_level_kernel(uint32_t* __restrict__ mp, long long total, long long off0,
+                                                              int h0, int w0, long long off1, int h1, int w1, int nmask) {
+  const int i = blockIdx.x * kThreads + threadIdx.x, set = blockIdx.y;
+  if (i >= h1 * w1) return;
+  const int dy = i / w1, dx = i - dy * w1;
+  const ResizeTap ty = resize_tap(dy, (double)h0 / h1, h0), tx = resize_tap(dx, (double)w0 / w1, w0);
+  const uint32_t* s = mp + (size_t)set * total + off0;
+  const uint32_t b00 = s[(size_t)ty.i0 * w0 + tx.i0], b01 = s[(size_t)ty.i0 * w0 + tx.i1];
+  const uint32_t b10 = s[(size_t)ty.i1 * w0 + tx.i0], b11 = s[(size_t)ty.i1 * w0 + tx.i1];
+  uint32_t out = 0;
+  for (int m = 0; m < nmask; ++m) {
+    const long long top = (long long)tx.w0 * (((b00 >> m) & 1u) * 255) + (long long)tx.w1 * (((b01 >> m) & 1u) * 255);
+    const long long bot = (long long)tx.w0 * (((b10 >> m) & 1u) * 255) + (long long)tx.w1 * (((b11 >> m) & 1u) * 255);
+    const int v = (int)((ty.w0 * top + ty.w1 * bot + (1 << 21)) >> 22);
+    if (v > 254) out |= 1u << m;
+  }
+  mp[(size_t)set * total + off1 + i] = out;
+}
+
+// ---- FAST-9/16 score map over the whole pyramid ------------------------------------------------------------
+__device__ __forceinline__ int fast_score(const uint8_t* __restrict__ im, int w, int y, int x) {
+  const int v = im[(size_t)y * w + x];
+  int d[16];
+  const int rx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+  const int ry[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+#pragma unroll
+  for (int k = 0; k < 16; ++k) d[k] = (int)im[(size_t)(y + ry[k]) * w + x + rx[k]] - v;
+  int best = 0;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    int mn_b = 1 << 20, mn_d = 1 << 20;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const int dd = d[(s + j) & 15];
+      mn_b = min(mn_b, dd);
+      mn_d = min(mn_d, -dd);
+    }
+    best = max(best, max(mn_b, mn_d));
+  }
+  return best > kFastThr ? best - 1 : 0;
+}
+
+__global__ __launch_bounds__(kThreads) void fast_score_kernel(const uint8_t* __restrict__ pyr, Pyr P,
+                                                              uint8_t* __restrict__ score) {
+  const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+  const int img = blockIdx.y;
+  if (i >= P.total) return;
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < kLevels; ++k)
+    if (k < P.nlev && i >= P.off[k]) l = k;
+  const int h = P.h[l], w = P.w[l];
+  const int j = (int)(i - P.off[l]), y = j / w, x = j - y * w;
+  int s = 0;
+  // only levels that can hold a keypoint (31-px border) and have a quota are scored
+  if (P.quota[l] > 0 && h > 2 * kEdge && w > 2 * kEdge && y >= 3 && y < h - 3 && x >= 3 && x < w - 3)
+    s = fast_score(pyr + (size_t)img * P.total + P.off[l], w, y, x);
+  score[(size_t)img * P.total + i] = (uint8_t)s;
+}
+
+// ---- selection ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+  const float scale = (float)(180.0 / 3.14159265358979323846);
+  const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale;
+  const float p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
+  const float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = ay / (ax + 2.220446049250313e-16f);
+    c2 = c * c;
+    a = ((((p7 * c2) + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c = ax / (ay + 2.220446049250313e-16f);
+    c2 = c * c;
+    a = 90.f - ((((p7 * c2) + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+__device__ __forceinline__ float harris_response(const uint8_t* __restrict__ im, int h, int w, int cx, int cy) {
+  int a = 0, b = 0, c = 0;
+  for (int dy = -3; dy <= 3; ++dy)
+    for (int dx = -3; dx <= 3; ++dx) {
+      const int y = cy + dy, x = cx + dx;
+#define PX(yy, xx) ((int)im[(size_t)refl101((yy), h) * w + refl101((xx), w)])
+      const int Ix = (PX(y, x + 1) - PX(y, x - 1)) * 2 + (PX(y - 1, x + 1) - PX(y - 1, x - 1)) + (PX(y + 1, x + 1) - PX(y + 1, x - 1));
+      const int Iy = (PX(y + 1, x) - PX(y - 1, x)) * 2 + (PX(y + 1, x - 1) - PX(y - 1, x - 1)) + (PX(y + 1, x + 1) - PX(y - 1, x + 1));
+#undef PX
+      a += Ix * Ix;
+      b += Iy * Iy;
+      c += Ix * Iy;
+    }
+  const float scale = 1.f / (4 * 7 * 255.f);
+  const float s4 = (scale * scale) * (scale * scale);
+  const float fa = (float)a, fb = (float)b, fc = (float)c;
+  return (((fa * fb) - (fc * fc)) - ((0.04f * (fa + fb)) * (fa + fb))) * s4;
+}
+
+__global__ __launch_bounds__(kThreads) void orb_select_kernel(const uint8_t* __restrict__ pyr,
+                                                              const uint8_t* __restrict__ score,
+                                                              const uint32_t* __restrict__ mask_pyr, Pyr P,
+                                                              int images_per_maskset, int nmask, int cap,
+                                                              float* __restrict__ kp4, float* __restrict__ resp_out,
+                                                              int32_t* __restrict__ n_out) {
+  __shared__ uint32_t cxy[kCandMax];            // (y << 16) | x
+  __shared__ uint8_t cfast[kCandMax];
+  __shared__ unsigned long long ckey[kCandMax];  // ordered(harris) << 32 | (0xFFFFFFFF - linear index)
+  __shared__ uint32_t sxy[kCandMax];
+  __shared__ float sresp[kCandMax];
+  __shared__ int hist[256];
+  __shared__ int s_nc, s_thr, s_keep, s_nout;
+  __shared__ int wave_off[5];
+  __shared__ int s_running;
+  const int tid = threadIdx.x, p = blockIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int img = p / nmask, m = p - img * nmask;
+  const int kumax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+  if (tid == 0) s_nout = 0;
+  __syncthreads();
+  for (int l = 0; l < P.nlev; ++l) {
+    const int h = P.h[l], w = P.w[l], quota = P.quota[l];
+    if (quota <= 0 || h <= 2 * kEdge || w <= 2 * kEdge) continue;  // uniform
+    const uint8_t* im = pyr + (size_t)img * P.total + P.off[l];
+    const uint8_t* sc = score + (size_t)img * P.total + P.off[l];
+    const uint32_t* mk = mask_pyr + (size_t)(img / images_per_maskset) * P.total + P.off[l];
+    if (tid == 0) s_nc = 0;
+    for (int k = tid; k < 256; k += kThreads) hist[k] = 0;
+    __syncthreads();
+    // 1. NMS + border + mask -> candidates (unordered)
+    const int rw = w - 2 * kEdge, rh = h - 2 * kEdge;
+    for (int i = tid; i < rw * rh; i += kThreads) {
+      const int y = kEdge + i / rw, x = kEdge + i % rw;
+      const int s = sc[(size_t)y * w + x];
+      if (!s || !((mk[(size_t)y * w + x] >> m) & 1u)) continue;
+      bool is_max = true;
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx)
+          if ((dy || dx) && sc[(size_t)(y + dy) * w + x + dx] >= s) is_max = false;
+      if (is_max) {
+        const int slot = atomicAdd(&s_nc, 1);
+        if (slot < kCandMax) {
+          cxy[slot] = ((uint32_t)y << 16) | (uint32_t)x;
+          cfast[slot] = (uint8_t)s;
+          atomicAdd(&hist[s], 1);
+        }
+      }
+    }
+    __syncthreads();
+    const int nc0 = min(s_nc, kCandMax);
+    // 2. retainBest(2 * quota) by FAST score, ties kept: threshold from the histogram
+    if (tid == 0) {
+      int thr = 0;
+      if (nc0 > 2 * quota) {
+        int acc = 0;
+        for (thr = 255; thr >= 0; --thr) {
+          acc += hist[thr];
+          if (acc >= 2 * quota) break;
+        }
+      }
+      s_thr = thr;
+      s_running = 0;
+    }
+    __syncthreads();
+    const int thr = s_thr;
+    // 3. Harris response of the survivors -> sort keys (compacted, order irrelevant: keys are unique)
+    for (int i0 = 0; i0 < nc0; i0 += kThreads) {
+      const int i = i0 + tid;
+      const bool keep = i < nc0 && cfast[i] >= thr;
+      uint32_t xy = 0;
+      float r = 0.f;
+      if (keep) {
+        xy = cxy[i];
+        r = harris_response(im, h, w, (int)(xy & 0xFFFFu), (int)(xy >> 16));
+      }
+      const int pos = sosvo_block_compact_pos(keep, wave_off, &s_running, tid);
+      if (keep) {
+        const uint32_t lin = (xy >> 16) * (uint32_t)w + (xy & 0xFFFFu);
+        ckey[pos] = ((unsigned long long)sosvo_float_ordered(r) << 32) | (0xFFFFFFFFu - lin);
+      }
+    }
+    __syncthreads();
+    const int nc = s_running;
+    // 4. rank sort: response descending, then (y, x) ascending
+    for (int i = tid; i < nc; i += kThreads) {
+      const unsigned long long mine = ckey[i];
+      int rank = 0;
+      for (int j = 0; j < nc; ++j) rank += ckey[j] > mine;
+      const uint32_t lin = 0xFFFFFFFFu - (uint32_t)mine;
+      sxy[rank] = ((lin / (uint32_t)w) << 16) | (lin % (uint32_t)w);
+      sresp[rank] = sosvo_ordered_float((uint32_t)(mine >> 32));
+    }
+    __syncthreads();
+    // 5. retainBest(quota) by Harris response, ties kept
+    if (tid == 0) {
+      int keep = nc;
+      if (nc > quota) {
+        const float amb = sresp[quota - 1];
+        keep = quota;
+        while (keep < nc && sresp[keep] >= amb) keep++;
+      }
+      s_keep = keep;
+    }
+    __syncthreads();
+    const int keep = s_keep, base_out = s_nout;
+    // 6. orientation: one wave per keypoint, lanes 0..30 take the patch rows v = -15..15
+    for (int j = wid; j < keep && base_out + j < cap; j += kThreads / 64) {
+      const int cx = (int)(sxy[j] & 0xFFFFu), cy = (int)(sxy[j] >> 16);
+      int m10 = 0, m01 = 0;
+      if (lane < 2 * kHalfPatch + 1) {
+        const int v = lane - kHalfPatch, d = kumax[v < 0 ? -v : v];
+        const uint8_t* row = im + (size_t)refl101(cy + v, h) * w;
+        int rs = 0;
+        for (int u = -d; u <= d; ++u) {
+          const int val = row[refl101(cx + u, w)];
+          m10 += u * val;
+          rs += val;
+        }
+        m01 = v * rs;
+      }
+      for (int o = 32; o > 0; o >>= 1) {
+        m10 += __shfl_down(m10, o);
+        m01 += __shfl_down(m01, o);
+      }
+      if (lane == 0) {
+        const size_t o = (size_t)p * cap + base_out + j;
+        kp4[4 * o + 0] = (float)cx * P.scale[l];
+        kp4[4 * o + 1] = (float)cy * P.scale[l];
+        kp4[4 * o + 2] = fast_atan2_deg((float)m01, (float)m10);
+        kp4[4 * o + 3] = (float)l;
+        resp_out[o] = sresp[j];
+      }
+    }
+    __syncthreads();
+    if (tid == 0) s_nout = min(cap, base_out + keep);
+    __syncthreads();
+  }
+  if (tid == 0) n_out[p] = s_nout;
+}
+
+// ---- blur of every level (7x7 sigma 2, 8.8 fixed point) -----------------------------------------------------
+constexpr int kBlurTW = 64, kBlurTH = 16;
+
+__global__ __launch_bounds__(kThreads) void gauss7_level_kernel(const uint8_t* __restrict__ pyr, long long total,
+                                                                long long off, int rows, int cols,
+                                                                uint8_t* __restrict__ out) {
+  __shared__ uint8_t tile[kBlurTH + 6][kBlurTW + 6];
+  __shared__ uint16_t hrow[kBlurTH + 6][kBlurTW];
+  const int kw[7] = {18, 34, 49, 54, 49, 34, 18};
+  const int tid = threadIdx.x, img = blockIdx.z;
+  const int x0 = blockIdx.x * kBlurTW, y0 = blockIdx.y * kBlurTH;
+  const uint8_t* g = pyr + (size_t)img * total + off;
+  for (int i = tid; i < (kBlurTH + 6) * (kBlurTW + 6); i += kThreads) {
+    const int ty = i / (kBlurTW + 6), tx = i - ty * (kBlurTW + 6);
+    tile[ty][tx] = g[(size_t)refl101(y0 + ty - 3, rows) * cols + refl101(x0 + tx - 3, cols)];
+  }
+  __syncthreads();
+  for (int i = tid; i < (kBlurTH + 6) * kBlurTW; i += kThreads) {
+    const int ty = i / kBlurTW, tx = i - ty * kBlurTW;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) s += kw[k] * tile[ty][tx + k];
+    hrow[ty][tx] = (uint16_t)s;
+  }
+  __syncthreads();
+  for (int i = tid; i < kBlurTH * kBlurTW; i += kThreads) {
+    const int ty = i / kBlurTW, tx = i - ty * kBlurTW;
+    const int y = y0 + ty, x = x0 + tx;
+    if (y >= rows || x >= cols) continue;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) s += (uint32_t)kw[k] * hrow[ty + k][tx];
+    out[(size_t)img * total + off + (size_t)y * cols + x] = (uint8_t)((s + 32768u) >> 16);
+  }
+}
+
+// ---- descriptors of oriented multi-level keypoints ------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void orb_describe_levels_kernel(const uint8_t* __restrict__ blur, Pyr P, int rows,
+                                                                       int cols, int nmask, int cap,
+                                                                       float* __restrict__ kp4, int32_t* __restrict__ n_io,
+                                                                       const int8_t* __restrict__ pattern,
+                                                                       uint8_t* __restrict__ desc,
+                                                                       float* __restrict__ kp_xy) {
+  extern __shared__ float lds_kp[];  // [cap][4]
+  __shared__ int8_t spat[1024];
+  __shared__ int wave_off[5];
+  __shared__ int s_running;
+  const int tid = threadIdx.x, p = blockIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int img = p / nmask;
+  const int n = min(n_io[p], cap);
+  if (tid == 0) s_running = 0;
+  for (int i = tid; i < 1024; i += kThreads) spat[i] = pattern[i];
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += kThreads) {
+    const int i = i0 + tid;
+    float k0 = 0.f, k1 = 0.f, k2 = 0.f, k3 = 0.f;
+    bool keep = false;
+    if (i < n) {
+      const float* s = kp4 + ((size_t)p * cap + i) * 4;
+      k0 = s[0];
+      k1 = s[1];
+      k2 = s[2];
+      k3 = s[3];
+      const int l = (int)k3;
+      keep = k0 >= (float)kEdge && k0 < (float)(cols - kEdge) && k1 >= (float)kEdge && k1 < (float)(rows - kEdge) &&
+             l >= 0 && l < P.nlev;
+    }
+    const int pos = sosvo_block_compact_pos(keep, wave_off, &s_running, tid);
+    if (keep) {
+      lds_kp[4 * pos + 0] = k0;
+      lds_kp[4 * pos + 1] = k1;
+      lds_kp[4 * pos + 2] = k2;
+      lds_kp[4 * pos + 3] = k3;
+    }
+  }
+  __syncthreads();
+  const int mkept = s_running;
+  for (int i = tid; i < 4 * mkept; i += kThreads) kp4[(size_t)p * cap * 4 + i] = lds_kp[i];
+  if (kp_xy)
+    for (int i = tid; i < mkept; i += kThreads) {
+      kp_xy[((size_t)p * cap + i) * 2] = lds_kp[4 * i];
+      kp_xy[((size_t)p * cap + i) * 2 + 1] = lds_kp[4 * i + 1];
+    }
+  if (tid == 0) n_io[p] = mkept;
+  for (int j = wid; j < mkept; j += kThreads / 64) {
+    const int l = (int)lds_kp[4 * j + 3];
+    const int hh = P.h[l], ww = P.w[l];
+    const float inv = 1.f / P.scale[l];
+    float angle = lds_kp[4 * j + 2];
+    angle *= (float)(3.14159265358979323846 / 180.0);
+    const float ca = (float)cos((double)angle), sa = (float)sin((double)angle);
+    const int cx = __float2int_rn(lds_kp[4 * j] * inv), cy = __float2int_rn(lds_kp[4 * j + 1] * inv);
+    const uint8_t* im = blur + (size_t)img * P.total + P.off[l];
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(desc + ((size_t)p * cap + j) * 32);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = 64 * r + lane;
+      int val[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float px = (float)spat[2 * (2 * t + e)], py = (float)spat[2 * (2 * t + e) + 1];
+        const float xr = (px * ca) - (py * sa), yr = (px * sa) + (py * ca);
+        const int xx = refl101(cx + __float2int_rn(xr), ww), yy = refl101(cy + __float2int_rn(yr), hh);
+        val[e] = im[(size_t)yy * ww + xx];
+      }
+      const unsigned long long bal = __ballot(val[0] < val[1]);
+      if (lane == 0) d[r] = bal;
+    }
+  }
+}
+
+Pyr make_pyr(int rows, int cols, int nfeatures) {
+  Pyr P;
+  memset(&P, 0, sizeof(P));
+  long long off = 0;
+  for (int l = 0; l < kLevels; ++l) {
+    const double s = pow(1.2, (double)l);
+    const int w = (int)lrint((double)cols / s), h = (int)lrint((double)rows / s);
+    if (h < 1 || w < 1) break;
+    P.h[l] = h;
+    P.w[l] = w;
+    P.off[l] = off;
+    P.scale[l] = (float)s;
+    off += (long long)h * w;
+    P.nlev = l + 1;
+  }
+  P.total = off;
+  const double f = 1.0 / 1.2;
+  double nd = nfeatures * (1.0 - f) / (1.0 - pow(f, (double)kLevels));
+  int sum = 0;
+  for (int l = 0; l < kLevels - 1; ++l) {
+    P.quota[l] = (int)lrint(nd);
+    sum += P.quota[l];
+    nd *= f;
+  }
+  P.quota[kLevels - 1] = nfeatures - sum > 0 ? nfeatures - sum : 0;
+  return P;
+}
+
+int32_t build_pyramid(sosvo_ctx* ctx, const uint8_t* gray, int nimg, int rows, int cols, const Pyr& P, uint8_t* pyr) {
+  SOSVO_LAUNCH(ctx, copy_level0_kernel, dim3(cdiv(rows * cols, kThreads), nimg), dim3(kThreads), 0, ctx->stream, gray,
+               rows * cols, P.total, pyr);
+  SOSVO_LAUNCH_CHECK(ctx);
+  for (int l = 1; l < P.nlev; ++l) {
+    SOSVO_LAUNCH(ctx, resize_level_kernel, dim3(cdiv(P.h[l] * P.w[l], kThreads), nimg), dim3(kThreads), 0, ctx->stream, pyr,
+                 P.total, P.off[l - 1], P.h[l - 1], P.w[l - 1], P.off[l], P.h[l], P.w[l]);
+    SOSVO_LAUNCH_CHECK(ctx);
+  }
+  return SOSVO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t sosvo_orb_pyramid_pixels(int32_t rows, int32_t cols) {
+  if (rows < 1 || cols < 1) return 0;
+  return make_pyr(rows, cols, 0).total;
+}
+
+int32_t sosvo_orb_mask_pyramid(sosvo_ctx* ctx, const uint32_t* mask_bits, int32_t nsets, int32_t rows, int32_t cols,
+                               int32_t nmask, uint32_t* mask_pyr) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, mask_bits && mask_pyr, "null pointer");
+  SOSVO_REQUIRE(ctx, nsets >= 1 && nsets <= 65535 && rows >= 1 && cols >= 1 && nmask >= 1 && nmask <= 32, "bad sizes");
+  const Pyr P = make_pyr(rows, cols, 0);
+  SOSVO_HIP(ctx, hipMemcpy2DAsync(mask_pyr, (size_t)P.total * 4, mask_bits, (size_t)rows * cols * 4,
+                                  (size_t)rows * cols * 4, nsets, hipMemcpyDeviceToDevice, ctx->stream));
+  for (int l = 1; l < P.nlev; ++l) {
+    SOSVO_LAUNCH(ctx, mask_level_kernel, dim3(cdiv(P.h[l] * P.w[l], kThreads), nsets), dim3(kThreads), 0, ctx->stream,
+                 mask_pyr, P.total, P.off[l - 1], P.h[l - 1], P.w[l - 1], P.off[l], P.h[l], P.w[l], nmask);
+    SOSVO_LAUNCH_CHECK(ctx);
+  }
+  return SOSVO_OK;
+}
+
+int32_t sosvo_detect_orb(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* mask_pyr, int32_t nimg,
+                         int32_t images_per_maskset, int32_t rows, int32_t cols, int32_t nmask, int32_t nfeatures,
+                         int32_t cap, float* kp4, float* resp, int32_t* n) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, gray && mask_pyr && kp4 && resp && n, "null pointer");
+  SOSVO_REQUIRE(ctx, nimg >= 0 && nimg <= 65535 && images_per_maskset > 0, "nimg out of range");
+  SOSVO_REQUIRE(ctx, rows >= 1 && cols >= 1 && cols < 65536 && rows < 65536 && rows * (int64_t)cols < (1 << 28),
+                "image sizes out of range");
+  SOSVO_REQUIRE(ctx, nmask >= 1 && nmask <= 32 && nfeatures >= 1 && cap >= 1 && cap <= 4096, "bad detector parameters");
+  if (nimg == 0) return SOSVO_OK;
+  const Pyr P = make_pyr(rows, cols, nfeatures);
+  const size_t bytes = (size_t)nimg * P.total;
+  int32_t rc = sosvo_ws_reserve(ctx, 2 * ((bytes + 255) & ~(size_t)255));
+  if (rc != SOSVO_OK) return rc;
+  uint8_t* pyr = (uint8_t*)ctx->ws;
+  uint8_t* score = pyr + ((bytes + 255) & ~(size_t)255);
+  rc = build_pyramid(ctx, gray, nimg, rows, cols, P, pyr);
+  if (rc != SOSVO_OK) return rc;
+  SOSVO_LAUNCH(ctx, fast_score_kernel, dim3((unsigned)((P.total + kThreads - 1) / kThreads), nimg), dim3(kThreads), 0,
+               ctx->stream, pyr, P, score);
+  SOSVO_LAUNCH_CHECK(ctx);
+  SOSVO_LAUNCH(ctx, orb_select_kernel, dim3((unsigned)((size_t)nimg * nmask)), dim3(kThreads), 0, ctx->stream, pyr, score,
+               mask_pyr, P, images_per_maskset, nmask, cap, kp4, resp, n);
+  SOSVO_LAUNCH_CHECK(ctx);
+  return SOSVO_OK;
+}
+
+int32_t sosvo_describe_orb_levels(sosvo_ctx* ctx, const uint8_t* gray, int32_t nimg, int32_t rows, int32_t cols,
+                                  int32_t nmask, int32_t cap, float* kp4, int32_t* n, const int8_t* pattern,
+                                  uint8_t* desc, float* kp_xy) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, gray && kp4 && n && pattern && desc, "null pointer");
+  SOSVO_REQUIRE(ctx, nimg >= 0 && nimg <= 65535 && nmask >= 1, "nimg / nmask out of range");
+  SOSVO_REQUIRE(ctx, rows >= 1 && cols >= 1 && rows * (int64_t)cols < (1 << 28), "image sizes out of range");
+  SOSVO_REQUIRE(ctx, cap > 0 && cap <= 2048, "cap out of range");
+  SOSVO_REQUIRE(ctx, ((uintptr_t)desc & 7) == 0, "desc must be 8-byte aligned");
+  if (nimg == 0) return SOSVO_OK;
+  const Pyr P = make_pyr(rows, cols, 0);
+  const size_t bytes = (size_t)nimg * P.total;
+  int32_t rc = sosvo_ws_reserve(ctx, 2 * ((bytes + 255) & ~(size_t)255));
+  if (rc != SOSVO_OK) return rc;
+  uint8_t* pyr = (uint8_t*)ctx->ws;
+  uint8_t* blur = pyr + ((bytes + 255) & ~(size_t)255);
+  rc = build_pyramid(ctx, gray, nimg, rows, cols, P, pyr);
+  if (rc != SOSVO_OK) return rc;
+  for (int l = 0; l < P.nlev; ++l) {
+    SOSVO_LAUNCH(ctx, gauss7_level_kernel, dim3(cdiv(P.w[l], kBlurTW), cdiv(P.h[l], kBlurTH), nimg), dim3(kThreads), 0,
+                 ctx->stream, pyr, P.total, P.off[l], P.h[l], P.w[l], blur);
+    SOSVO_LAUNCH_CHECK(ctx);
+  }
+  SOSVO_LAUNCH(ctx, orb_describe_levels_kernel, dim3((unsigned)((size_t)nimg * nmask)), dim3(kThreads),
+               (size_t)cap * 4 * sizeof(float), ctx->stream, blur, P, rows, cols, nmask, cap, kp4, n, pattern, desc, kp_xy);
+  SOSVO_LAUNCH_CHECK(ctx);
+  return SOSVO_OK;
+}
+
+}  // extern "C"

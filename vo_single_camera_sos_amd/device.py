@@ -187,6 +187,60 @@ class Context(object):
                    float(cos_a), float(sin_a), _ptr(pattern), int(edge), _ptr(desc))
         return desc
 
+    # ---- K5 / K6' ----------------------------------------------------------------------
+    def orb_pyramid_pixels(self, rows, cols):
+        return int(self._lib.sosvo_orb_pyramid_pixels(int(rows), int(cols)))
+
+    def orb_mask_pyramid(self, mask_bits, nmask):
+        """mask_bits [nsets, rows, cols] u32 -> mask_pyr [nsets, pyramid_pixels] u32 (once per model)."""
+        _check(mask_bits, torch.uint32, "mask_bits", ndim=3)
+        nsets, rows, cols = mask_bits.shape
+        out = torch.zeros((nsets, self.orb_pyramid_pixels(rows, cols)), dtype=torch.uint32, device=mask_bits.device)
+        self._call(self._lib.sosvo_orb_mask_pyramid, _ptr(mask_bits), nsets, rows, cols, int(nmask), _ptr(out))
+        return out
+
+    def detect_orb(self, gray, mask_pyr, images_per_maskset, nmask, nfeatures, cap, kp4=None, resp=None, n=None):
+        """gray [NI,rows,cols] u8 -> kp4 [NI*nmask, cap, 4] f32 (x, y, angle_deg, level), resp [NI*nmask, cap] f32,
+        n [NI*nmask] i32."""
+        _check(gray, torch.uint8, "gray", ndim=3)
+        NI, rows, cols = gray.shape
+        _check(mask_pyr, torch.uint32, "mask_pyr", (None, self.orb_pyramid_pixels(rows, cols)))
+        if mask_pyr.shape[0] * images_per_maskset < NI:
+            raise SosvoError("mask_pyr has too few sets for %d images" % NI)
+        P = NI * nmask
+        dev = gray.device
+        if kp4 is None:
+            kp4 = torch.zeros((P, cap, 4), dtype=torch.float32, device=dev)
+        if resp is None:
+            resp = torch.zeros((P, cap), dtype=torch.float32, device=dev)
+        if n is None:
+            n = torch.zeros((P,), dtype=torch.int32, device=dev)
+        _check(kp4, torch.float32, "kp4", (P, cap, 4))
+        _check(resp, torch.float32, "resp", (P, cap))
+        _check(n, torch.int32, "n", (P,))
+        self._call(self._lib.sosvo_detect_orb, _ptr(gray), _ptr(mask_pyr), NI, int(images_per_maskset), rows, cols,
+                   int(nmask), int(nfeatures), int(cap), _ptr(kp4), _ptr(resp), _ptr(n))
+        return kp4, resp, n
+
+    def describe_orb_levels(self, gray, kp4, n, nmask, pattern, desc=None, kp_xy=None):
+        """Compacts kp4 / n in place (31-px border rule); returns (desc [P,cap,32] u8, kp_xy [P,cap,2] f32)."""
+        _check(gray, torch.uint8, "gray", ndim=3)
+        NI, rows, cols = gray.shape
+        P = NI * nmask
+        _check(kp4, torch.float32, "kp4", (P, None, 4))
+        cap = kp4.shape[1]
+        _check(n, torch.int32, "n", (P,))
+        _check(pattern, torch.int8, "pattern", (512, 2))
+        if desc is None:
+            desc = torch.zeros((P, cap, 32), dtype=torch.uint8, device=gray.device)
+        if kp_xy is None:
+            kp_xy = torch.zeros((P, cap, 2), dtype=torch.float32, device=gray.device)
+        _check(desc, torch.uint8, "desc", (P, cap, 32))
+        _check(kp_xy, torch.float32, "kp_xy", (P, cap, 2))
+        self._call(self._lib.sosvo_describe_orb_levels, _ptr(gray), NI, rows, cols, int(nmask), cap, _ptr(kp4), _ptr(n),
+                   _ptr(pattern), _ptr(desc), _ptr(kp_xy))
+        return desc, kp_xy
+
     # ---- K7 ----------------------------------------------------------------------------
     def match_hamming(self, q_desc, t_desc, nq, nt, k=1, keys=None, q_slot=None, t_slot=None):
         """q_desc [Bq, Sq, 32] u8, t_desc [Bt, St, 32] u8, nq [Bq] / nt [Bt] i32 -> keys [P, Sq, k] u32.
