@@ -38,7 +38,15 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs-per-gpu", type=int, default=64, help="B: frame pairs per GPU per step (C4: 512/8)")
-    ap.add_argument("--features-per-mask", type=int, default=330, help="detector budget per azimuthal mask")
+    ap.add_argument("--detector", default="GFT", choices=["GFT", "ORB"],
+                    help="GFT: the reference's default detector (pose_est_tools.py:684), always with ORB descriptors; "
+                         "ORB: FAST/Harris pyramid detector (finds few corners on an 11x11-median-blurred panorama)")
+    ap.add_argument("--features-per-mask", type=int, default=1000,
+                    help="detector budget per azimuthal mask (reference default 1000, pose_est_tools.py:862)")
+    ap.add_argument("--pano-width", type=int, default=1440,
+                    help="panorama columns.  The reference default (camera_models.py:3107) is 1200 -> 1200 x 122, where "
+                         "GFT's minDistance 5 and ORB.compute's 31-px border cap the count at ~1250 keypoints per view; "
+                         "1440 -> 1440 x 146 gives the ~2000 keypoints per view BASELINE's metric is quoted on")
     ap.add_argument("--iters", type=int, default=2000, help="RANSAC iterations, fixed (C2: 2000)")
     ap.add_argument("--cpu-pairs", type=int, default=32, help="frame pairs timed on the host for cpu_baseline")
     ap.add_argument("--no-cpu", action="store_true")
@@ -87,7 +95,7 @@ def main():
     H, W = 480, 640
     gs = synthetic_gums()
     for m in (gs.top_model, gs.bot_model):
-        m.panorama = Panorama(m, width=1200)  # reference default (camera_models.py:3107) -> 1200 x 122
+        m.panorama = Panorama(m, width=args.pano_width)
     gs.make_annulus_masks((H, W))
     pano = gs.top_model.panorama
     geo = (pano.cols, pano.rows, pano.pixel_size, pano.cyl_height_max)
@@ -96,7 +104,8 @@ def main():
                   f2f_max_hdiff=0.125 * 0.5 * pano.cols, pct_good_matches=1.0)
     ctx = Context(local_rank)
     model = DeviceImageModel(ctx, gs, (H, W))
-    fe = ImageFrontEnd(ctx, model, 2 * B, detection_method="GFT", num_of_features=args.features_per_mask)
+    fe = ImageFrontEnd(ctx, model, 2 * B, detection_method=args.detector, num_of_features=args.features_per_mask,
+                       kp_cap=512)
     pipe = FramePairPipeline(ctx, RigConfig(**rig_kw), B, frame_cap=2048, max_iter=args.iters, adaptive=False,
                              seed=args.seed, front_end=fe)
     omni, poses = synthetic.make_frame_pairs(gs, B, seed=args.seed + 100000 * rank)
@@ -157,10 +166,13 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 (images, Hamming) + f32 (corner response) + f64 (geometry, RANSAC)", "data": "synthetic",
-            "config": {"workload": "C2: 640x480 BGR omni frame pair -> 2 x 1200x122 panoramas per frame, 11x11 median, "
-                                   "GFT (reference default detector, %d per azimuthal mask x 12 masks) + ORB descriptors, "
-                                   "24 bucket + 2 frame-to-frame BF Hamming matchings, midpoint triangulation, "
-                                   "non-central P3P RANSAC %d iterations fixed, LM" % (args.features_per_mask, args.iters),
+            "config": {"workload": "C2: 640x480 BGR omni frame pair -> 2 x %dx%d panoramas per frame, 11x11 median, "
+                                   "%s detector (budget %d per azimuthal mask x %d masks) + ORB descriptors, "
+                                   "%d bucket + 2 frame-to-frame BF Hamming matchings, midpoint triangulation, "
+                                   "non-central P3P RANSAC %d iterations fixed, LM"
+                                   % (pano.cols, pano.rows, args.detector, args.features_per_mask, model.nmask,
+                                      2 * model.nmask, args.iters),
+                       "keypoint_capacity_hit": bool(int(fe.n.max().item()) >= fe.kp_cap),
                        "pairs_per_gpu": B, "global_pairs_per_step": n_gpus * B,
                        "parallelism": "pairs sharded over ranks, dp%d" % n_gpus,
                        "keypoints_per_view_mean": float(n_kp.mean()), "stereo_points_per_frame_mean": float(M.mean()),
@@ -181,7 +193,8 @@ def main():
             from vo_single_camera_sos_amd import orb_pattern
             ca, sa = orb_pattern.angle_cos_sin(-1.0)
             im = refflow.ImageModel(model.map_x.cpu().numpy(), model.map_y.cpu().numpy(), model.omni_masks.cpu().numpy(),
-                                    model.mask_bits_host, model.nmask, args.features_per_mask, model.pattern_host, ca, sa)
+                                    model.mask_bits_host, model.nmask, args.features_per_mask, model.pattern_host, ca, sa,
+                                    method=args.detector, kp_cap=fe.kp_cap)
             n_cpu = min(args.cpu_pairs, B)
             v, dt = cpu_baseline(omni, im, rig_kw, pipe.thr, args.iters, args.seed, n_cpu)
             out["cpu_baseline"] = {"value": v, "unit": "frame-pairs/s", "cores": 1, "kind": "port",

@@ -70,11 +70,12 @@ class ImageModel(object):
     view, azimuthal mask bit fields per view, detector settings."""
 
     def __init__(self, map_x, map_y, omni_masks, mask_bits, nmask, max_corners, pattern, cos_a, sin_a,
-                 median_ksize=11, quality=0.01, min_distance=5.0, edge=31):
+                 median_ksize=11, quality=0.01, min_distance=5.0, edge=31, method="GFT", kp_cap=1024):
         self.map_x, self.map_y, self.omni_masks, self.mask_bits = map_x, map_y, omni_masks, mask_bits
         self.nmask, self.max_corners, self.pattern = nmask, max_corners, pattern
         self.cos_a, self.sin_a = cos_a, sin_a
         self.median_ksize, self.quality, self.min_distance, self.edge = median_ksize, quality, min_distance, edge
+        self.method, self.kp_cap = method.upper(), kp_cap
 
 
 def detect_view(im, omni, view):
@@ -82,6 +83,13 @@ def detect_view(im, omni, view):
     (camera_models.py:1708-1797) for one mirror: lists over azimuthal masks of keypoints / descriptors."""
     pano = oracle.unwrap(omni, im.omni_masks[view], im.map_x[view], im.map_y[view])  # :3114 + panorama.py:293
     gray = oracle.median_gray(pano, im.median_ksize)                                  # :1711, :1714
+    if im.method == "ORB":                                                            # :1640, :1755, :1765
+        kps, descs = [], []
+        for kp4, _ in oracle.orb_detect(gray, im.mask_bits[view], im.nmask, im.max_corners, im.kp_cap):
+            d, kept = oracle.orb_describe_levels(gray, kp4, im.pattern)
+            kps.append(np.ascontiguousarray(kp4[kept][:, :2]))
+            descs.append(d)
+        return kps, descs, pano, gray
     eig = oracle.min_eigen(gray)
     blurred = oracle.gauss7(gray)
     kps, descs = [], []

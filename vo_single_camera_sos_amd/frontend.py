@@ -52,14 +52,19 @@ class ImageFrontEnd(object):
     def __init__(self, ctx, model, nframes, detection_method="GFT", num_of_features=1000, kp_cap=None,
                  median_win_size=11, quality=0.01, min_distance=5.0, edge=31):
         """num_of_features: per azimuthal mask (FeatureMatcher.num_of_features, pose_est_tools.py:862)."""
-        if detection_method.upper() != "GFT":
-            raise NotImplementedError("detection method %r: only GFT (the reference default, pose_est_tools.py:684) "
-                                      "is built so far" % detection_method)
+        if detection_method.upper() not in ("GFT", "ORB"):
+            raise NotImplementedError("detection method %r: GFT (the reference default, pose_est_tools.py:684) and "
+                                      "ORB are built" % detection_method)
         self.ctx, self.model, self.F = ctx, model, int(nframes)
         self.method = detection_method.upper()
         self.num_of_features, self.median_win_size = int(num_of_features), int(median_win_size)
         self.quality, self.min_distance, self.edge = float(quality), float(min_distance), int(edge)
-        self.kp_cap = int(kp_cap) if kp_cap else int(min(1024, max(64, -(-self.num_of_features // 64) * 64)))
+        if kp_cap:
+            self.kp_cap = int(kp_cap)
+        elif self.method == "ORB":  # retainBest keeps ties beyond the quota: leave head room
+            self.kp_cap = int(min(2048, max(64, -(-int(self.num_of_features * 1.25) // 64) * 64)))
+        else:
+            self.kp_cap = int(min(1024, max(64, -(-self.num_of_features // 64) * 64)))
         dev, m = ctx.device, model
         NI, P = 2 * self.F, 2 * self.F * m.nmask
         self.omni = torch.zeros((self.F, m.H, m.W, 3), dtype=torch.uint8, device=dev)
@@ -70,6 +75,11 @@ class ImageFrontEnd(object):
         self.status = torch.zeros((P,), dtype=torch.int32, device=dev)
         self.desc = torch.zeros((P, self.kp_cap, 32), dtype=torch.uint8, device=dev)
         self.cos_a, self.sin_a = orb_pattern.angle_cos_sin(orb_pattern.GFT_KEYPOINT_ANGLE)
+        if self.method == "ORB":
+            self.kp4 = torch.zeros((P, self.kp_cap, 4), dtype=torch.float32, device=dev)
+            self.resp = torch.zeros((P, self.kp_cap), dtype=torch.float32, device=dev)
+            if getattr(model, "mask_pyr", None) is None:
+                model.mask_pyr = ctx.orb_mask_pyramid(model.mask_bits, model.nmask)
 
     def load_frames(self, omni):
         """omni: numpy or torch uint8 [F, H, W, 3] (BGR) -> resident in HBM."""
@@ -80,6 +90,11 @@ class ImageFrontEnd(object):
         c, m = self.ctx, self.model
         c.unwrap(self.omni, m.omni_masks, m.map_x, m.map_y, pano=self.pano)                       # K1 (a1 + a2)
         c.median_gray(self.pano.view(2 * self.F, m.rows, m.cols, 3), self.median_win_size, gray=self.gray)  # K2 + K3
+        if self.method == "ORB":
+            c.detect_orb(self.gray, m.mask_pyr, self.F, m.nmask, self.num_of_features, self.kp_cap, kp4=self.kp4,
+                         resp=self.resp, n=self.n)                                                # K5
+            c.describe_orb_levels(self.gray, self.kp4, self.n, m.nmask, m.pattern, desc=self.desc, kp_xy=self.kp)  # K6'
+            return
         c.detect_gft(self.gray, m.mask_bits, self.F, m.nmask, self.kp_cap, quality=self.quality,
                      min_distance=self.min_distance, max_corners=self.num_of_features, kp=self.kp, n=self.n,
                      status=self.status)                                                          # K4
