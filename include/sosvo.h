@@ -91,6 +91,15 @@ int32_t sosvo_unwrap(sosvo_ctx* ctx, const uint8_t* omni, const uint8_t* masks, 
                      const float* map_y, int32_t nframes, int32_t H, int32_t W, int32_t rows,
                      int32_t cols, uint8_t* pano);
 
+/* Table-driven form of K1 for the batched path (identical results): sosvo_unwrap_prepare folds the
+ * float maps, the 1/32-px rounding, the border test and the annulus masks into a packed table
+ * [2, rows, cols, 2] u32 once per model; sosvo_unwrap_table then unwraps nframes frames with one 8-byte
+ * table load and four 4-byte tap loads per panorama pixel.                                       */
+int32_t sosvo_unwrap_prepare(sosvo_ctx* ctx, const uint8_t* masks, const float* map_x, const float* map_y,
+                             int32_t H, int32_t W, int32_t rows, int32_t cols, uint32_t* table);
+int32_t sosvo_unwrap_table(sosvo_ctx* ctx, const uint8_t* omni, const uint32_t* table, int32_t nframes,
+                           int32_t H, int32_t W, int32_t rows, int32_t cols, uint8_t* pano);
+
 /* ---- K2 + K3: median blur + gray --------------------------------------------------------------
  * Replaces cv2.medianBlur(pano, ksize) (omnistereo/camera_models.py:1711, pose_est_tools.py:528;
  * ksize 11 for the SOS frames, 0 = none for RGB-D) followed by cv2.cvtColor(BGR2GRAY)

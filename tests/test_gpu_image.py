@@ -75,6 +75,27 @@ def test_unwrap_random_maps_border_and_nan(ctx):
             assert np.array_equal(pano[v, f], oracle.unwrap(omni[f], masks[v], mx[v], my[v]))
 
 
+@pytest.mark.parametrize("pshape", [(40, 72), (41, 71), (1, 5)])
+def test_unwrap_table_form_equals_map_form(ctx, pshape):
+    """The batched path's table-driven K1 (sosvo_unwrap_prepare + sosvo_unwrap_table) is bit-identical to the
+    map-driven one (and hence to the oracle), also for panorama sizes that defeat the aligned 4-pixel stores."""
+    rng = np.random.default_rng(pshape[1])
+    omni = rng.integers(0, 256, (3, 37, 53, 3), dtype=np.uint8)
+    mx = rng.uniform(-6, 59, (2,) + pshape).astype(np.float32)
+    my = rng.uniform(-6, 43, (2,) + pshape).astype(np.float32)
+    mx[0, 0, :3] = [np.nan, 52.0, 51.99]
+    my[0, 0, :3] = [3.0, 36.0, 35.99]       # the very last source pixel as a tap
+    masks = (rng.random((2, 37, 53)) < 0.7).astype(np.uint8) * 255
+    masks[:, 36, 52] = 255
+    t_omni, t_masks, t_mx, t_my = _to(ctx.device, omni, masks, mx, my)
+    for tm in (t_masks, None):
+        want = ctx.unwrap(t_omni, tm, t_mx, t_my)
+        got = ctx.unwrap_table(t_omni, ctx.unwrap_prepare(tm, t_mx, t_my, (37, 53)))
+        ctx.synchronize()
+        assert torch.equal(got, want)
+    assert np.array_equal(got[0, 2].cpu().numpy(), oracle.unwrap(omni[2], None, mx[0], my[0]))
+
+
 @pytest.mark.parametrize("shape,k", [((122, 1200), 11), ((37, 53), 11), ((64, 54), 11), ((30, 109), 5),
                                      ((20, 63), 3), ((11, 11), 11), ((5, 200), 11)])
 def test_median_gray_exact(ctx, shape, k):

@@ -46,6 +46,8 @@ SIGNATURES = {
     "sosvo_profile_count": (c_i32, [c_p]),
     "sosvo_profile_get": (c_i32, [c_p, c_i32, ctypes.c_char_p, c_i32, ctypes.POINTER(c_f32)]),
     "sosvo_unwrap": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]),
+    "sosvo_unwrap_prepare": (c_i32, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p]),
+    "sosvo_unwrap_table": (c_i32, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]),
     "sosvo_median_gray": (c_i32, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p]),
     "sosvo_detect_gft": (c_i32, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_f64, c_f64, c_i32, c_i32, c_p,
                                  c_p, c_p]),

@@ -7,11 +7,10 @@
 // Batched over images (view-major) and azimuthal masks; problem p = image * nmask + mask.
 //   eig      min-eigenvalue map in float32 with a fixed operation order (identical to the oracle's), the
 //            per-mask maximum folded in through an order-preserving atomicMax;
-//   cand     3x3 non-maximum suppression of the thresholded map -> unordered candidate keys
-//            (ordered(value) << 32 | pixel index) per problem;
-//   select   one workgroup per problem: rank sort of the keys in LDS (descending value, higher address first),
-//            then the greedy minimum-distance pass on an LDS cell grid, first wave only: 18 lanes test the
-//            9 neighbour cells x 2 slots of a candidate at once and vote with __ballot;
+//   select   one workgroup per problem: 3x3 non-maximum suppression of the thresholded map inside the mask's
+//            bounding box -> sort keys (ordered(value) << 32 | pixel index) in LDS, rank sort (descending value,
+//            higher address first), then the greedy minimum-distance pass on an LDS cell grid by the first wave,
+//            64 candidates per step with an exact replay of the sequential acceptance rule;
 //   blur     7x7 sigma=2 Gaussian in 8.8 fixed point (separable, LDS tile);
 //   describe one workgroup per problem: border rule + stable compaction, then one wave per keypoint:
 //            lane l evaluates tests l, 64+l, 128+l, 192+l; four 64-bit ballots ARE the 32 descriptor bytes.
@@ -51,13 +50,15 @@ constexpr int kEigTW = 64, kEigTH = 4;  // output tile per workgroup (256 thread
 __global__ __launch_bounds__(kThreads) void min_eigen_kernel(const uint8_t* __restrict__ gray,
                                                              const uint32_t* __restrict__ mask_bits,
                                                              int images_per_maskset, int rows, int cols, int nmask,
-                                                             float* __restrict__ eig, uint32_t* __restrict__ maxbits) {
+                                                             float* __restrict__ eig, uint32_t* __restrict__ mstat) {
+  // mstat[p][5] (zero-initialised, all fields grow by atomicMax): ordered(max eig) over the mask,
+  // 0xFFFFFFFF - xmin, 0xFFFFFFFF - ymin, xmax + 1, ymax + 1 of the mask's pixels
   __shared__ float sxx[kEigTH + 2][kEigTW + 2], sxy[kEigTH + 2][kEigTW + 2], syy[kEigTH + 2][kEigTW + 2];
-  __shared__ uint32_t smax[kMaxMasks];
+  __shared__ uint32_t smax[5][kMaxMasks];
   const int tid = threadIdx.x, img = blockIdx.z;
   const int x0 = blockIdx.x * kEigTW, y0 = blockIdx.y * kEigTH;
   const uint8_t* g = gray + (size_t)img * rows * cols;
-  if (tid < kMaxMasks) smax[tid] = 0u;
+  if (tid < 5 * kMaxMasks) (&smax[0][0])[tid] = 0u;
   // products on the (TH+2) x (TW+2) halo tile; a position outside the image takes the product AT the
   // reflected position (box filter with reflect-101 on the covariance images)
   for (int i = tid; i < (kEigTH + 2) * (kEigTW + 2); i += kThreads) {
@@ -66,8 +67,9 @@ __global__ __launch_bounds__(kThreads) void min_eigen_kernel(const uint8_t* __re
     sobel_products(g, rows, cols, y, x, &sxx[ty][tx], &sxy[ty][tx], &syy[ty][tx]);
   }
   __syncthreads();
-  const int ty = tid / kEigTW, tx = tid - ty * kEigTW;
+  const int ty = tid / kEigTW, tx = tid - ty * kEigTW;  // a wave is one 64-pixel row of the tile
   const int y = y0 + ty, x = x0 + tx;
+  uint32_t bits = 0u, o = 0u;
   if (y < rows && x < cols) {
     float s[3];
 #pragma unroll
@@ -81,210 +83,225 @@ __global__ __launch_bounds__(kThreads) void min_eigen_kernel(const uint8_t* __re
     const float a = s[0] * 0.5f, b = s[1], c = s[2] * 0.5f;
     const float e = (a + c) - sqrtf(((a - c) * (a - c)) + (b * b));
     eig[((size_t)img * rows + y) * cols + x] = e;
-    uint32_t bits = mask_bits[((size_t)(img / images_per_maskset) * rows + y) * cols + x];
-    const uint32_t o = sosvo_float_ordered(e);
-    while (bits) {
-      const int m = __ffs(bits) - 1;
-      bits &= bits - 1;
-      if (m < nmask) atomicMax(&smax[m], o);
-    }
+    bits = mask_bits[((size_t)(img / images_per_maskset) * rows + y) * cols + x];
+    if (nmask < 32) bits &= (1u << nmask) - 1u;
+    o = sosvo_float_ordered(e);
   }
-  __syncthreads();
-  if (tid < nmask && smax[tid]) atomicMax(&maxbits[(size_t)img * nmask + tid], smax[tid]);
-}
-
-__global__ __launch_bounds__(kThreads) void gft_candidates_kernel(const float* __restrict__ eig,
-                                                                  const uint32_t* __restrict__ mask_bits,
-                                                                  int images_per_maskset, int rows, int cols, int nmask,
-                                                                  double quality, const uint32_t* __restrict__ maxbits,
-                                                                  int32_t* __restrict__ cand_count,
-                                                                  unsigned long long* __restrict__ cand) {
-  const int img = blockIdx.y;
-  const int lane = threadIdx.x & 63;
-  const int pix = blockIdx.x * kThreads + threadIdx.x;
-  const int y = pix / cols, x = pix - y * cols;
-  const bool inside = pix < rows * cols && y >= 1 && y <= rows - 2 && x >= 1 && x <= cols - 2;
-  uint32_t bits = inside ? mask_bits[((size_t)(img / images_per_maskset) * rows) * cols + pix] : 0u;
-  if (nmask < 32) bits &= (1u << nmask) - 1u;
-  const float* e = eig + (size_t)img * rows * cols;
-  float nb[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) nb[k] = 0.0f;
-  if (bits) {
-#pragma unroll
-    for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-      for (int dx = -1; dx <= 1; ++dx) nb[(dy + 1) * 3 + dx + 1] = e[pix + dy * cols + dx];
-  }
-  // every lane walks its mask bits; the slot reservation is aggregated per (wave, mask): one atomic each
-  while (__ballot(bits != 0u)) {
-    int m = -1;
-    bool is_cand = false;
-    float v = 0.0f;
-    if (bits) {
-      m = __ffs(bits) - 1;
-      bits &= bits - 1;
-      const uint32_t mb = maxbits[(size_t)img * nmask + m];
-      if (mb) {
-        const float thr = (float)((double)sosvo_ordered_float(mb) * quality);
-        v = nb[4] > thr ? nb[4] : 0.0f;
-        if (v != 0.0f) {
-          float dil = v;
-#pragma unroll
-          for (int k = 0; k < 9; ++k) {
-            const float t = nb[k] > thr ? nb[k] : 0.0f;
-            dil = t > dil ? t : dil;
+  // per-mask statistics: one set of LDS atomics per wave when all its in-image lanes carry the same mask bits
+  // (the common case), per lane at sector boundaries
+  {
+    // the bounding box depends only on the mask set: the first image of every set records it
+    const bool do_bbox = (img % images_per_maskset) == 0;
+    const bool in_img = y < rows && x < cols;
+    const unsigned long long act = __ballot(in_img);
+    const int first = act ? __ffsll((long long)act) - 1 : 0;
+    const uint32_t b0 = __shfl(bits, first);
+    const bool uniform = __ballot(in_img && bits != b0) == 0ULL;
+    if (uniform) {
+      uint32_t om = in_img ? o : 0u;
+      for (int s = 32; s > 0; s >>= 1) om = max(om, (uint32_t)__shfl_down((int)om, s));
+      if ((tid & 63) == 0 && act) {
+        const int xlo = x0, xhi = min(x0 + kEigTW - 1, cols - 1);
+        uint32_t b = b0;
+        while (b) {
+          const int m = __ffs(b) - 1;
+          b &= b - 1;
+          atomicMax(&smax[0][m], om);
+          if (do_bbox) {
+            atomicMax(&smax[1][m], 0xFFFFFFFFu - (uint32_t)xlo);
+            atomicMax(&smax[2][m], 0xFFFFFFFFu - (uint32_t)y);
+            atomicMax(&smax[3][m], (uint32_t)xhi + 1u);
+            atomicMax(&smax[4][m], (uint32_t)y + 1u);
           }
-          is_cand = v == dil;
+        }
+      }
+    } else {
+      uint32_t b = bits;
+      while (b) {
+        const int m = __ffs(b) - 1;
+        b &= b - 1;
+        atomicMax(&smax[0][m], o);
+        if (do_bbox) {
+          atomicMax(&smax[1][m], 0xFFFFFFFFu - (uint32_t)x);
+          atomicMax(&smax[2][m], 0xFFFFFFFFu - (uint32_t)y);
+          atomicMax(&smax[3][m], (uint32_t)x + 1u);
+          atomicMax(&smax[4][m], (uint32_t)y + 1u);
         }
       }
     }
-    unsigned long long todo = __ballot(is_cand);
-    while (todo) {
-      const int leader = __ffsll((long long)todo) - 1;
-      const int mm = __shfl(m, leader);
-      const unsigned long long same = __ballot(is_cand && m == mm);
-      const size_t p = (size_t)img * nmask + mm;
-      int base = 0;
-      if (lane == leader) base = atomicAdd(&cand_count[p], __popcll(same));
-      base = __shfl(base, leader);
-      if (is_cand && m == mm) {
-        const int slot = base + __popcll(same & ((1ULL << lane) - 1ULL));
-        if (slot < kCandCap)
-          cand[p * kCandCap + slot] = ((unsigned long long)sosvo_float_ordered(v) << 32) | (uint32_t)pix;
-      }
-      todo &= ~same;
-    }
+  }
+  __syncthreads();
+  if (tid < 5 * kMaxMasks) {
+    const int f = tid / kMaxMasks, m = tid - f * kMaxMasks;
+    if (m < nmask && smax[f][m]) atomicMax(&mstat[((size_t)img * nmask + m) * 5 + f], smax[f][m]);
   }
 }
 
-// One workgroup per problem.  LDS (32 KB) is used twice: first for the candidate keys of the rank sort,
-// then -- the sorted order lives in global memory by then -- for the cell grid of the greedy pass.
-constexpr int kSelLdsBytes = kCandCap * 8;
-constexpr int kSelGridCells = (kSelLdsBytes - 1024 * 4) / 8;  // 2 slots (u32) per cell, 1024 u32 left for the list
+// One workgroup per problem (image, mask).  Phase 1 scans the mask's bounding box for 3x3 maxima of the
+// thresholded response and builds the sort keys in LDS; phase 2 rank-sorts them (descending value, higher
+// address first) into global memory; phase 3 -- the keys are dead, the 32 KB of LDS become the cell grid --
+// is the greedy minimum-distance pass by the first wave, 64 candidates at a time: every lane tests its
+// candidate against the grid of already accepted points (9 cells x 2 slots) and against the earlier lanes
+// of its batch (64 shuffles -> a 64-bit conflict mask); a short scalar pass over the batch then replays the
+// sequential acceptance rule exactly (accept iff no conflict with anything accepted before).
+constexpr int kSelGridCells = (kCandCap * 8 - 1024 * 4) / 8;  // 2 slots (u32) per cell, 1024 u32 left for the list
 
-__global__ __launch_bounds__(kThreads) void gft_select_kernel(const unsigned long long* __restrict__ cand,
-                                                              const int32_t* __restrict__ cand_count, int rows, int cols,
+__global__ __launch_bounds__(kThreads) void gft_select_kernel(const float* __restrict__ eig,
+                                                              const uint32_t* __restrict__ mask_bits,
+                                                              const uint32_t* __restrict__ mstat, int images_per_maskset,
+                                                              int nmask, int rows, int cols, double quality,
                                                               float min_distance, int cell, int max_corners, int cap,
                                                               uint32_t* __restrict__ sorted_g, float* __restrict__ kp,
                                                               int32_t* __restrict__ n_out, int32_t* __restrict__ status) {
   __shared__ unsigned long long lds_u64[kCandCap];
-  __shared__ int s_bbox[4];
-  __shared__ int s_accepted;
+  __shared__ int s_count, s_accepted;
   unsigned long long* keys = lds_u64;
-  uint32_t* grid = reinterpret_cast<uint32_t*>(lds_u64);     // phase 2: 2 slots per cell, pixel index + 1 (0 = empty)
-  uint32_t* acc = grid + 2 * kSelGridCells;                   // phase 2 fallback: accepted pixel indices (<= 1024)
+  uint32_t* grid = reinterpret_cast<uint32_t*>(lds_u64);  // phase 3: 2 slots per cell, pixel index + 1 (0 = empty)
+  uint32_t* acc_list = grid + 2 * kSelGridCells;          // phase 3 fallback: accepted pixel indices (<= 1024)
   const int tid = threadIdx.x, p = blockIdx.x;
-  const int total = cand_count[p];
-  const int n = min(total, kCandCap);
+  const int img = p / nmask, m = p - img * nmask;
+  const uint32_t* st = mstat + (size_t)p * 5;                                                              // [0]: max
+  const uint32_t* sb = mstat + ((size_t)(img / images_per_maskset) * images_per_maskset * nmask + m) * 5;  // bbox
   uint32_t* sorted = sorted_g + (size_t)p * kCandCap;
   if (tid == 0) {
-    s_bbox[0] = 1 << 30;
-    s_bbox[1] = 1 << 30;
-    s_bbox[2] = -1;
-    s_bbox[3] = -1;
+    s_count = 0;
     s_accepted = 0;
   }
   __syncthreads();
-  int xmin = 1 << 30, ymin = 1 << 30, xmax = -1, ymax = -1;
-  for (int i = tid; i < n; i += kThreads) {
-    const unsigned long long k = cand[(size_t)p * kCandCap + i];
-    keys[i] = k;
-    const int pix = (int)(uint32_t)k, y = pix / cols, x = pix - y * cols;
-    xmin = min(xmin, x);
-    xmax = max(xmax, x);
-    ymin = min(ymin, y);
-    ymax = max(ymax, y);
-  }
-  if (n > 0) {
-    atomicMin(&s_bbox[0], xmin);
-    atomicMin(&s_bbox[1], ymin);
-    atomicMax(&s_bbox[2], xmax);
-    atomicMax(&s_bbox[3], ymax);
+  // ---- phase 1: candidates ------------------------------------------------------------------------------
+  const bool any = st[0] != 0u;
+  const int bx0 = any ? max(1, (int)(0xFFFFFFFFu - sb[1])) : 0, by0 = any ? max(1, (int)(0xFFFFFFFFu - sb[2])) : 0;
+  const int bx1 = any ? min(cols - 2, (int)sb[3] - 1) : -1, by1 = any ? min(rows - 2, (int)sb[4] - 1) : -1;
+  const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+  if (any && bw > 0 && bh > 0) {
+    const float thr = (float)((double)sosvo_ordered_float(st[0]) * quality);
+    const float* e = eig + (size_t)img * rows * cols;
+    const uint32_t* mb = mask_bits + (size_t)(img / images_per_maskset) * rows * cols;
+    for (int i = tid; i < bw * bh; i += kThreads) {
+      const int y = by0 + i / bw, x = bx0 + i % bw;
+      const int pix = y * cols + x;
+      if (!((mb[pix] >> m) & 1u)) continue;
+      const float c = e[pix];
+      const float v = c > thr ? c : 0.0f;
+      if (v == 0.0f) continue;
+      float dil = v;
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+          const float q = e[pix + dy * cols + dx];
+          const float t = q > thr ? q : 0.0f;
+          dil = t > dil ? t : dil;
+        }
+      if (v != dil) continue;
+      const int slot = atomicAdd(&s_count, 1);
+      if (slot < kCandCap) keys[slot] = ((unsigned long long)sosvo_float_ordered(v) << 32) | (uint32_t)pix;
+    }
   }
   __syncthreads();
-  // rank sort, descending: larger value first, ties -> higher pixel index first (keys are unique)
+  const int total = s_count;
+  const int n = min(total, kCandCap);
+  // ---- phase 2: rank sort (keys are unique) --------------------------------------------------------------
   for (int i = tid; i < n; i += kThreads) {
     const unsigned long long mine = keys[i];
     int rank = 0;
     for (int j = 0; j < n; ++j) rank += keys[j] > mine;
     sorted[rank] = (uint32_t)mine;
   }
-  int st = total > kCandCap ? 1 : 0;
-  const int cx0 = n > 0 ? s_bbox[0] / cell : 0, cy0 = n > 0 ? s_bbox[1] / cell : 0;
-  const int gw = n > 0 ? s_bbox[2] / cell - cx0 + 1 : 0, gh = n > 0 ? s_bbox[3] / cell - cy0 + 1 : 0;
+  int stt = total > kCandCap ? 1 : 0;
+  const int cx0 = bx0 / cell, cy0 = by0 / cell;
+  const int gw = bw > 0 ? bx1 / cell - cx0 + 1 : 0, gh = bh > 0 ? by1 / cell - cy0 + 1 : 0;
   const bool use_grid = gw * gh <= kSelGridCells;
   const int limit_list = 1024;
   __syncthreads();  // keys are dead from here on; sorted[] is visible to the whole workgroup
   for (int i = tid; i < (use_grid ? gw * gh * 2 : 0); i += kThreads) grid[i] = 0u;
   __syncthreads();
-  if (tid < 64) {  // greedy minimum-distance pass, first wave only
+  // ---- phase 3: greedy minimum-distance pass, first wave ----------------------------------------------------
+  if (tid < 64) {
     const float md2 = min_distance * min_distance;
     const int lane = tid;
+    const bool spaced = min_distance >= 1.0f;
+    int limit = cap;
+    if (max_corners > 0 && max_corners < limit) limit = max_corners;
+    if (!use_grid && limit_list < limit) {
+      limit = limit_list;
+      stt |= 2;
+    }
     int accepted = 0;
-    bool stop = false;
-    for (int k0 = 0; k0 < n && !stop; k0 += 64) {
-      const uint32_t mypix = (k0 + lane < n) ? sorted[k0 + lane] : 0u;  // one coalesced read per 64 candidates
+    for (int k0 = 0; k0 < n && accepted < limit; k0 += 64) {
       const int kend = min(64, n - k0);
-      for (int kk = 0; kk < kend; ++kk) {
-        const int pix = (int)__shfl(mypix, kk), y = pix / cols, x = pix - y * cols;
-        bool good = true;
-        if (min_distance >= 1.0f) {
-          bool conflict = false;
-          if (use_grid) {
-            const int xc = x / cell - cx0, yc = y / cell - cy0;
-            if (lane < 18) {
-              const int c9 = lane >> 1, slot = lane & 1;
-              const int xx = xc + (c9 % 3) - 1, yy = yc + (c9 / 3) - 1;
-              if (xx >= 0 && xx < gw && yy >= 0 && yy < gh) {
-                const uint32_t q = grid[(yy * gw + xx) * 2 + slot];
-                if (q) {
-                  const int qp = (int)q - 1, qy = qp / cols, qx = qp - qy * cols;
-                  const float dx = (float)(x - qx), dy = (float)(y - qy);
-                  conflict = dx * dx + dy * dy < md2;
-                }
-              }
-            }
-            good = __ballot(conflict) == 0ULL;
-            if (good && lane == 0) {
-              uint32_t* c = &grid[(yc * gw + xc) * 2];
-              if (c[0] == 0u)
-                c[0] = (uint32_t)pix + 1u;
-              else
-                c[1] = (uint32_t)pix + 1u;  // a 5x5 cell never holds a third point >= 5 px from two others
-            }
-          } else {  // large masks: scan the accepted list, 64 at a time
-            for (int a0 = 0; a0 < accepted; a0 += 64) {
-              if (a0 + lane < accepted) {
-                const int qp = (int)acc[a0 + lane], qy = qp / cols, qx = qp - qy * cols;
+      const bool active = lane < kend;
+      const int pix = active ? (int)sorted[k0 + lane] : 0;  // one coalesced read per 64 candidates
+      const int y = pix / cols, x = pix - y * cols;
+      bool prior = false;  // conflict with a point accepted in an earlier batch
+      if (active && spaced) {
+        if (use_grid) {
+          const int xc = x / cell - cx0, yc = y / cell - cy0;
+#pragma unroll
+          for (int c9 = 0; c9 < 9; ++c9) {
+            const int xx = xc + (c9 % 3) - 1, yy = yc + (c9 / 3) - 1;
+            if (xx < 0 || xx >= gw || yy < 0 || yy >= gh) continue;
+#pragma unroll
+            for (int slot = 0; slot < 2; ++slot) {
+              const uint32_t q = grid[(yy * gw + xx) * 2 + slot];
+              if (q) {
+                const int qp = (int)q - 1, qy = qp / cols, qx = qp - qy * cols;
                 const float dx = (float)(x - qx), dy = (float)(y - qy);
-                conflict = conflict || (dx * dx + dy * dy < md2);
+                prior = prior || (dx * dx + dy * dy < md2);
               }
             }
-            good = __ballot(conflict) == 0ULL;
-            if (good && lane == 0 && accepted < limit_list) acc[accepted] = (uint32_t)pix;
           }
-        }
-        if (good) {
-          if (lane == 0 && accepted < cap) {
-            kp[((size_t)p * cap + accepted) * 2] = (float)x;
-            kp[((size_t)p * cap + accepted) * 2 + 1] = (float)y;
-          }
-          accepted++;
-          if (accepted == cap || (max_corners > 0 && accepted == max_corners) || (!use_grid && accepted == limit_list)) {
-            stop = true;
-            break;
+        } else {
+          for (int a = 0; a < accepted; ++a) {
+            const int qp = (int)acc_list[a], qy = qp / cols, qx = qp - qy * cols;
+            const float dx = (float)(x - qx), dy = (float)(y - qy);
+            prior = prior || (dx * dx + dy * dy < md2);
           }
         }
       }
+      // conflicts with earlier lanes of this batch
+      unsigned long long cm = 0ULL;
+      if (spaced) {
+        for (int j = 0; j < kend; ++j) {
+          const int xj = __shfl(x, j), yj = __shfl(y, j);
+          const float dx = (float)(x - xj), dy = (float)(y - yj);
+          if (j < lane && (dx * dx + dy * dy < md2)) cm |= 1ULL << j;
+        }
+      }
+      const unsigned long long okmask = __ballot(active && !prior);
+      // replay of the sequential rule over the batch (wave-uniform)
+      unsigned long long acc = 0ULL;
+      int room = limit - accepted;
+      const uint32_t cm_lo = (uint32_t)cm, cm_hi = (uint32_t)(cm >> 32);
+      for (int j = 0; j < kend && room > 0; ++j) {
+        if (!((okmask >> j) & 1ULL)) continue;
+        const unsigned long long cmj = ((unsigned long long)(uint32_t)__shfl((int)cm_hi, j) << 32) | (uint32_t)__shfl((int)cm_lo, j);
+        if ((cmj & acc) == 0ULL) {
+          acc |= 1ULL << j;
+          room--;
+        }
+      }
+      if ((acc >> lane) & 1ULL) {
+        const int pos = accepted + __popcll(acc & ((1ULL << lane) - 1ULL));
+        kp[((size_t)p * cap + pos) * 2] = (float)x;
+        kp[((size_t)p * cap + pos) * 2 + 1] = (float)y;
+        if (spaced) {
+          if (use_grid) {
+            uint32_t* c = &grid[((y / cell - cy0) * gw + (x / cell - cx0)) * 2];
+            if (atomicCAS(&c[0], 0u, (uint32_t)pix + 1u) != 0u) c[1] = (uint32_t)pix + 1u;
+          } else {
+            acc_list[pos] = (uint32_t)pix;
+          }
+        }
+      }
+      accepted += __popcll(acc);
     }
-    if (!use_grid && accepted == limit_list && !(max_corners > 0 && max_corners <= limit_list) && cap > limit_list) st |= 2;
     if (lane == 0) s_accepted = accepted;
   }
   __syncthreads();
   if (tid == 0) {
     n_out[p] = min(s_accepted, cap);
-    if (status) status[p] = st;
+    if (status) status[p] = stt;
   }
 }
 
@@ -398,29 +415,23 @@ int32_t sosvo_detect_gft(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* ma
     return o;
   };
   const size_t o_eig = carve(sizeof(float) * (size_t)nimg * rows * cols);
-  const size_t o_max = carve(sizeof(uint32_t) * P);
-  const size_t o_cnt = carve(sizeof(int32_t) * P);
-  const size_t o_cand = carve(sizeof(unsigned long long) * P * kCandCap);
+  const size_t o_stat = carve(sizeof(uint32_t) * P * 5);
   const size_t o_sorted = carve(sizeof(uint32_t) * P * kCandCap);
   int32_t rc = sosvo_ws_reserve(ctx, off);
   if (rc != SOSVO_OK) return rc;
   char* ws = (char*)ctx->ws;
   float* eig = (float*)(ws + o_eig);
-  uint32_t* maxbits = (uint32_t*)(ws + o_max);
-  int32_t* cnt = (int32_t*)(ws + o_cnt);
-  unsigned long long* cand = (unsigned long long*)(ws + o_cand);
+  uint32_t* mstat = (uint32_t*)(ws + o_stat);
   uint32_t* sorted_g = (uint32_t*)(ws + o_sorted);
-  SOSVO_HIP(ctx, hipMemsetAsync(ws + o_max, 0, (o_cand - o_max), ctx->stream));  // maxbits and counts
+  SOSVO_HIP(ctx, hipMemsetAsync(mstat, 0, sizeof(uint32_t) * P * 5, ctx->stream));
 
   SOSVO_LAUNCH(ctx, min_eigen_kernel, dim3(cdiv(cols, kEigTW), cdiv(rows, kEigTH), nimg), dim3(kThreads), 0, ctx->stream,
-               gray, mask_bits, images_per_maskset, rows, cols, nmask, eig, maxbits);
-  SOSVO_LAUNCH_CHECK(ctx);
-  SOSVO_LAUNCH(ctx, gft_candidates_kernel, dim3(cdiv(rows * cols, kThreads), nimg), dim3(kThreads), 0, ctx->stream, eig,
-               mask_bits, images_per_maskset, rows, cols, nmask, quality, maxbits, cnt, cand);
+               gray, mask_bits, images_per_maskset, rows, cols, nmask, eig, mstat);
   SOSVO_LAUNCH_CHECK(ctx);
   const int cell = min_distance >= 1 ? (int)lrint(min_distance) : 1;
-  SOSVO_LAUNCH(ctx, gft_select_kernel, dim3((unsigned)P), dim3(kThreads), 0, ctx->stream, cand, cnt, rows, cols,
-               (float)min_distance, cell, max_corners, cap, sorted_g, kp, n, status);
+  SOSVO_LAUNCH(ctx, gft_select_kernel, dim3((unsigned)P), dim3(kThreads), 0, ctx->stream, eig, mask_bits, mstat,
+               images_per_maskset, nmask, rows, cols, quality, (float)min_distance, cell, max_corners, cap, sorted_g, kp, n,
+               status);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
 }

@@ -57,6 +57,106 @@ __global__ __launch_bounds__(kThreads) void unwrap_kernel(const uint8_t* __restr
   out[2] = (uint8_t)((acc2 + 512) >> 10);
 }
 
+// ---- K1, table-driven form -----------------------------------------------------------------------------
+// The float maps, the 1/32-px rounding, the border test and the annulus mask depend only on the model, so
+// they are folded once into a packed table: word0 = (iy << 16) | (ix & 0xFFFF) (int16 each), word1 =
+// fx | fy << 5 | valid << 10 (4 bits: tap t in-bounds and unmasked).  The per-frame kernel then does no
+// float work and no mask loads: one 8-byte table load and four 4-byte tap loads per pixel, four pixels per
+// lane so that the 12 output bytes leave as three aligned dwords.
+__global__ __launch_bounds__(kThreads) void unwrap_table_kernel(const uint8_t* __restrict__ masks,
+                                                                const float* __restrict__ map_x,
+                                                                const float* __restrict__ map_y, int H, int W, int npix,
+                                                                uint2* __restrict__ table) {
+  const int pix = blockIdx.x * kThreads + threadIdx.x, view = blockIdx.y;
+  if (pix >= npix) return;
+  const float mx = map_x[(size_t)view * npix + pix], my = map_y[(size_t)view * npix + pix];
+  uint2 e = make_uint2(0u, 0u);
+  if (mx == mx && my == my && mx > -4.0f && mx < (float)W + 4.0f && my > -4.0f && my < (float)H + 4.0f) {
+    const int sx = __float2int_rn(mx * 32.0f), sy = __float2int_rn(my * 32.0f);
+    const int ix = sx >> 5, iy = sy >> 5, fx = sx & 31, fy = sy & 31;
+    const uint8_t* msk = masks ? masks + (size_t)view * H * W : nullptr;
+    uint32_t valid = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int x = ix + (t & 1), y = iy + (t >> 1);
+      if (x >= 0 && x < W && y >= 0 && y < H && (!msk || msk[(size_t)y * W + x])) valid |= 1u << t;
+    }
+    e.x = ((uint32_t)(iy & 0xFFFF) << 16) | (uint32_t)(ix & 0xFFFF);
+    e.y = (uint32_t)fx | ((uint32_t)fy << 5) | (valid << 10);
+  }
+  table[(size_t)view * npix + pix] = e;
+}
+
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+typedef unsigned long long __attribute__((aligned(1))) u64_unaligned;
+
+// One panorama pixel per lane (neighbouring lanes = neighbouring pixels, so a wave's taps fall on a short arc
+// of the omni image: few cache lines per load instruction).  The two taps of a source row are adjacent pixels
+// = 6 consecutive bytes: ONE unaligned 8-byte load per row.  The 768 output bytes of a workgroup are staged
+// in LDS and leave as 192 aligned dwords.
+__global__ __launch_bounds__(kThreads) void unwrap_lut_kernel(const uint8_t* __restrict__ omni,
+                                                              const uint2* __restrict__ table, int nframes, int H, int W,
+                                                              int npix, uint8_t* __restrict__ pano) {
+  __shared__ uint32_t stage[kThreads * 3 / 4];
+  const int tid = threadIdx.x;
+  const int pix = blockIdx.x * kThreads + tid;
+  const int img = blockIdx.y;
+  const int view = img / nframes, frame = img - view * nframes;
+  const uint8_t* src = omni + (size_t)frame * H * W * 3;
+  const size_t npx_src = (size_t)H * W;
+  int acc0 = 0, acc1 = 0, acc2 = 0;
+  if (pix < npix) {
+    const uint2 e = table[(size_t)view * npix + pix];
+    const uint32_t valid = e.y >> 10;
+    if (valid) {
+      const int ix = (int)(int16_t)(e.x & 0xFFFFu), iy = (int)(int16_t)(e.x >> 16);
+      const int fx = (int)(e.y & 31u), fy = (int)((e.y >> 5) & 31u);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const uint32_t vr = (valid >> (2 * r)) & 3u;  // bit 0: tap (ix, iy + r), bit 1: tap (ix + 1, iy + r)
+        if (!vr) continue;
+        const int wy = r ? fy : 32 - fy;
+        const long long o = (long long)(iy + r) * W + ix;  // may be -1 when only the right tap is inside
+        unsigned long long v = 0ULL;
+        if (o >= 0 && (size_t)o + 3 <= npx_src) {  // 8 bytes from 3 * o stay inside the frame
+          v = *reinterpret_cast<const u64_unaligned*>(src + 3 * o);
+        } else {
+          if (vr & 1u) v |= (unsigned long long)src[3 * o] | ((unsigned long long)src[3 * o + 1] << 8) | ((unsigned long long)src[3 * o + 2] << 16);
+          if (vr & 2u) v |= ((unsigned long long)src[3 * o + 3] << 24) | ((unsigned long long)src[3 * o + 4] << 32) | ((unsigned long long)src[3 * o + 5] << 40);
+        }
+        if (vr & 1u) {
+          const int w = (32 - fx) * wy;
+          acc0 += w * (int)(v & 0xFFu);
+          acc1 += w * (int)((v >> 8) & 0xFFu);
+          acc2 += w * (int)((v >> 16) & 0xFFu);
+        }
+        if (vr & 2u) {
+          const int w = fx * wy;
+          acc0 += w * (int)((v >> 24) & 0xFFu);
+          acc1 += w * (int)((v >> 32) & 0xFFu);
+          acc2 += w * (int)((v >> 40) & 0xFFu);
+        }
+      }
+    }
+  }
+  const uint32_t b0 = (uint32_t)((acc0 + 512) >> 10), b1 = (uint32_t)((acc1 + 512) >> 10), b2 = (uint32_t)((acc2 + 512) >> 10);
+  const size_t out0 = ((size_t)img * npix + (size_t)blockIdx.x * kThreads) * 3;  // first output byte of this workgroup
+  const int nvalid = min(kThreads, npix - blockIdx.x * kThreads);
+  if ((out0 & 3) == 0 && nvalid == kThreads) {
+    uint8_t* sb = reinterpret_cast<uint8_t*>(stage);
+    sb[3 * tid + 0] = (uint8_t)b0;
+    sb[3 * tid + 1] = (uint8_t)b1;
+    sb[3 * tid + 2] = (uint8_t)b2;
+    __syncthreads();
+    if (tid < kThreads * 3 / 4) reinterpret_cast<uint32_t*>(pano + out0)[tid] = stage[tid];
+  } else if (pix < npix) {
+    uint8_t* out = pano + out0 + 3 * tid;
+    out[0] = (uint8_t)b0;
+    out[1] = (uint8_t)b1;
+    out[2] = (uint8_t)b2;
+  }
+}
+
 __device__ __forceinline__ uint8_t bgr2gray(int b, int g, int r) {
   return (uint8_t)((1868 * b + 9617 * g + 4899 * r + 8192) >> 14);
 }
@@ -164,6 +264,34 @@ int32_t sosvo_unwrap(sosvo_ctx* ctx, const uint8_t* omni, const uint8_t* masks, 
   if (nframes == 0) return SOSVO_OK;
   SOSVO_LAUNCH(ctx, unwrap_kernel, dim3(cdiv(rows * cols, kThreads), 2 * nframes), dim3(kThreads), 0, ctx->stream, omni,
                masks, map_x, map_y, nframes, H, W, rows, cols, pano);
+  SOSVO_LAUNCH_CHECK(ctx);
+  return SOSVO_OK;
+}
+
+int32_t sosvo_unwrap_prepare(sosvo_ctx* ctx, const uint8_t* masks, const float* map_x, const float* map_y, int32_t H,
+                             int32_t W, int32_t rows, int32_t cols, uint32_t* table) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, map_x && map_y && table, "null pointer");
+  SOSVO_REQUIRE(ctx, H > 0 && W > 0 && H <= 16384 && W <= 16384 && rows > 0 && cols > 0 && rows * (int64_t)cols < (1 << 28),
+                "image sizes out of range");
+  SOSVO_REQUIRE(ctx, ((uintptr_t)table & 7) == 0, "table must be 8-byte aligned");
+  SOSVO_LAUNCH(ctx, unwrap_table_kernel, dim3(cdiv(rows * cols, kThreads), 2), dim3(kThreads), 0, ctx->stream, masks, map_x,
+               map_y, H, W, rows * cols, reinterpret_cast<uint2*>(table));
+  SOSVO_LAUNCH_CHECK(ctx);
+  return SOSVO_OK;
+}
+
+int32_t sosvo_unwrap_table(sosvo_ctx* ctx, const uint8_t* omni, const uint32_t* table, int32_t nframes, int32_t H,
+                           int32_t W, int32_t rows, int32_t cols, uint8_t* pano) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, omni && table && pano, "null pointer");
+  SOSVO_REQUIRE(ctx, nframes >= 0 && nframes <= 32767, "nframes out of range");
+  SOSVO_REQUIRE(ctx, H > 0 && W > 0 && H <= 16384 && W <= 16384 && rows > 0 && cols > 0 && rows * (int64_t)cols < (1 << 28),
+                "image sizes out of range");
+  SOSVO_REQUIRE(ctx, ((uintptr_t)table & 7) == 0 && ((uintptr_t)pano & 3) == 0, "table / pano alignment");
+  if (nframes == 0) return SOSVO_OK;
+  SOSVO_LAUNCH(ctx, unwrap_lut_kernel, dim3(cdiv(rows * cols, kThreads), 2 * nframes), dim3(kThreads), 0,
+               ctx->stream, omni, reinterpret_cast<const uint2*>(table), nframes, H, W, rows * cols, pano);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
 }

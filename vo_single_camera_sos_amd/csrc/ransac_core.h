@@ -539,14 +539,21 @@ __device__ __forceinline__ static void sv_residual_jac(const double* x, const do
 /* Solve (A + lambda diag(A)) dx = -g for the packed upper triangle A (21) by LDL^T without
  * pivoting.  Returns 0 if a pivot is not positive. */
 __device__ __forceinline__ static int sv_solve_damped(const double* Apacked, const double* g, double lambda, double* dx) {
+  // Every loop is fully unrolled so that M, L, yv live in registers (runtime-indexed local arrays would go to
+  // scratch memory); a failed pivot only clears `ok`, the arithmetic of the successful case is unchanged.
   double M[36];
-  int a = 0;
-  for (int u = 0; u < 6; ++u)
-    for (int v = u; v < 6; ++v) {
-      M[6 * u + v] = Apacked[a];
-      M[6 * v + u] = Apacked[a];
-      a++;
-    }
+  {
+    int a = 0;
+#pragma unroll
+    for (int u = 0; u < 6; ++u)
+#pragma unroll
+      for (int v = u; v < 6; ++v) {
+        M[6 * u + v] = Apacked[a];
+        M[6 * v + u] = Apacked[a];
+        a++;
+      }
+  }
+#pragma unroll
   for (int u = 0; u < 6; ++u) {
     double dg = M[7 * u];
     if (dg < 1e-30) dg = 1e-30;
@@ -554,32 +561,42 @@ __device__ __forceinline__ static int sv_solve_damped(const double* Apacked, con
   }
   /* Cholesky M = L L^T */
   double L[36];
+#pragma unroll
   for (int i = 0; i < 36; ++i) L[i] = 0.0;
+  bool ok = true;
+#pragma unroll
   for (int j = 0; j < 6; ++j) {
     double s = M[7 * j];
+#pragma unroll
     for (int k = 0; k < j; ++k) s = s - (L[6 * j + k] * L[6 * j + k]);
-    if (!(s > 0.0)) return 0;
+    ok = ok && (s > 0.0);
     const double ljj = sqrt(s);
     L[7 * j] = ljj;
+#pragma unroll
     for (int i = j + 1; i < 6; ++i) {
       double t = M[6 * i + j];
+#pragma unroll
       for (int k = 0; k < j; ++k) t = t - (L[6 * i + k] * L[6 * j + k]);
       L[6 * i + j] = t / ljj;
     }
   }
   double yv[6];
+#pragma unroll
   for (int i = 0; i < 6; ++i) {
     double t = -g[i];
+#pragma unroll
     for (int k = 0; k < i; ++k) t = t - (L[6 * i + k] * yv[k]);
     yv[i] = t / L[7 * i];
   }
+#pragma unroll
   for (int i = 5; i >= 0; --i) {
     double t = yv[i];
+#pragma unroll
     for (int k = i + 1; k < 6; ++k) t = t - (L[6 * k + i] * dx[k]);
     dx[i] = t / L[7 * i];
   }
-  for (int i = 0; i < 6; ++i)
-    if (!isfinite(dx[i])) return 0;
-  return 1;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) ok = ok && isfinite(dx[i]);
+  return ok ? 1 : 0;
 }
 

@@ -132,6 +132,30 @@ class Context(object):
                    _ptr(pano))
         return pano
 
+    def unwrap_prepare(self, masks, map_x, map_y, omni_shape):
+        """Model constants -> packed unwrap table [2, rows, cols, 2] u32 (once per model)."""
+        H, W = omni_shape
+        if masks is not None:
+            _check(masks, torch.uint8, "masks", (2, H, W))
+        _check(map_x, torch.float32, "map_x", (2, None, None))
+        rows, cols = map_x.shape[1], map_x.shape[2]
+        _check(map_y, torch.float32, "map_y", (2, rows, cols))
+        table = torch.empty((2, rows, cols, 2), dtype=torch.uint32, device=map_x.device)
+        self._call(self._lib.sosvo_unwrap_prepare, _ptr(masks), _ptr(map_x), _ptr(map_y), H, W, rows, cols, _ptr(table))
+        return table
+
+    def unwrap_table(self, omni, table, pano=None):
+        """omni [F,H,W,3] u8, table from unwrap_prepare -> pano [2,F,rows,cols,3] u8 (view-major)."""
+        _check(omni, torch.uint8, "omni", (None, None, None, 3))
+        F, H, W = omni.shape[0], omni.shape[1], omni.shape[2]
+        _check(table, torch.uint32, "table", (2, None, None, 2))
+        rows, cols = table.shape[1], table.shape[2]
+        if pano is None:
+            pano = torch.empty((2, F, rows, cols, 3), dtype=torch.uint8, device=omni.device)
+        _check(pano, torch.uint8, "pano", (2, F, rows, cols, 3))
+        self._call(self._lib.sosvo_unwrap_table, _ptr(omni), _ptr(table), F, H, W, rows, cols, _ptr(pano))
+        return pano
+
     def median_gray(self, img, ksize, gray=None):
         """img [..., rows, cols, 3] u8 -> gray [..., rows, cols] u8 (k x k median per channel, then BGR2GRAY)."""
         _check(img, torch.uint8, "img")

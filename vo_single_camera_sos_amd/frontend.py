@@ -88,7 +88,9 @@ class ImageFrontEnd(object):
 
     def run(self):
         c, m = self.ctx, self.model
-        c.unwrap(self.omni, m.omni_masks, m.map_x, m.map_y, pano=self.pano)                       # K1 (a1 + a2)
+        if getattr(m, "unwrap_table", None) is None:  # once per model
+            m.unwrap_table = c.unwrap_prepare(m.omni_masks, m.map_x, m.map_y, (m.H, m.W))
+        c.unwrap_table(self.omni, m.unwrap_table, pano=self.pano)                                 # K1 (a1 + a2)
         c.median_gray(self.pano.view(2 * self.F, m.rows, m.cols, 3), self.median_win_size, gray=self.gray)  # K2 + K3
         if self.method == "ORB":
             c.detect_orb(self.gray, m.mask_pyr, self.F, m.nmask, self.num_of_features, self.kp_cap, kp4=self.kp4,
