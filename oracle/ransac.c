@@ -234,6 +234,18 @@ int32_t orc_refine_abs_pose(const double* f, const double* p, const int32_t* cam
         continue;
       }
       for (int u = 0; u < 6; ++u) xn[u] = x[u] + dx[u];
+      {
+        /* a step below the resolution we care about ends the refinement before it is evaluated */
+        double dxn = 0.0, xnn = 0.0;
+        for (int u = 0; u < 6; ++u) {
+          dxn += dx[u] * dx[u];
+          xnn += xn[u] * xn[u];
+        }
+        if (sqrt(dxn) <= ORC_LM_XTOL * (sqrt(xnn) + ORC_LM_XTOL)) {
+          converged = 1;
+          break;
+        }
+      }
       for (int l = 0; l < 256; ++l) part[0][l] = 0.0;
       for (int q = 0; q < cnt; ++q) {
         int i = idx ? idx[q] : q;
@@ -248,7 +260,9 @@ int32_t orc_refine_abs_pose(const double* f, const double* p, const int32_t* cam
           dxn += dx[u] * dx[u];
           xnn += xn[u] * xn[u];
         }
-        converged = ((cost - cn) <= ORC_LM_FTOL * cost) || (sqrt(dxn) <= ORC_LM_XTOL * (sqrt(xnn) + ORC_LM_XTOL));
+        converged = ((cost - cn) <= ORC_LM_FTOL * cost);
+        (void)dxn;
+        (void)xnn;
         for (int u = 0; u < 6; ++u) x[u] = xn[u];
         cost = cn;
         lambda *= 0.1;

@@ -10,9 +10,10 @@
 // without LDS: a wave owns a 54-column strip and walks down the rows; each new source row is turned
 // into 8 bit-planes with 64-bit wave ballots (one SGPR pair per plane), every lane cuts its 11-bit
 // horizontal window out of the ballot, and the 11 x 11 window lives in a register shift-register of
-// packed bit-plane words (two rows per VGPR).  The median is then a radix select from the MSB down:
-// AND + popcount on 6 words per bit decide whether the 61st smallest value has that bit set.
-// ~940 VALU ops per output pixel (3 channels) instead of ~5800 for compare-and-count.
+// packed bit-plane words (121 bits back to back in 4 VGPRs per plane, shifted with v_alignbit).  The median
+// is then a radix select from the MSB down: AND + popcount on 4 words per bit decide whether the 61st
+// smallest value has that bit set.  ~700 VALU ops per output pixel (3 channels) instead of ~5800 for
+// compare-and-count.
 #include "common.h"
 
 namespace {
@@ -174,10 +175,14 @@ template <int K>
 __global__ __launch_bounds__(kThreads) void median_gray_kernel(const uint8_t* __restrict__ img, int nimg, int rows,
                                                                int cols, int strips, uint8_t* __restrict__ gray) {
   constexpr int R = K / 2;
-  constexpr int NW = (K + 1) / 2;       // packed words per bit-plane, two rows (16-bit halves) per word
-  constexpr int OUTW = 64 - 2 * R;      // output columns per wave
+  constexpr int NB = K * K;               // window bits per bit-plane, rows packed back to back (oldest row first)
+  constexpr int NW = (NB + 31) / 32;      // words per bit-plane: 4 for 11 x 11
+  constexpr int POS = (K - 1) * K - 32 * (NW - 1);  // where the newest row goes inside the last word
+  static_assert(POS >= 0 && POS + K <= 32, "newest row must not straddle words");
+  constexpr int OUTW = 64 - 2 * R;        // output columns per wave
   constexpr uint32_t FIELD = (1u << K) - 1u;
-  constexpr int HALF = (K * K) / 2 + 1;  // rank of the median, 1-based
+  constexpr uint32_t LASTMASK = (NB - 32 * (NW - 1)) == 32 ? 0xFFFFFFFFu : ((1u << (NB - 32 * (NW - 1))) - 1u);
+  constexpr int HALF = NB / 2 + 1;        // rank of the median, 1-based
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * kThreads + threadIdx.x) >> 6;
   if (wave >= nimg * strips) return;  // wave-uniform
@@ -208,12 +213,10 @@ __global__ __launch_bounds__(kThreads) void median_gray_kernel(const uint8_t* __
       for (int b = 0; b < 8; ++b) {
         const unsigned long long bal = __ballot((pix[c] >> b) & 1u);
         const uint32_t field = (uint32_t)(bal >> lane) & FIELD;
+        // drop the oldest row (K bits) of the NB-bit window, append the new one at the top
 #pragma unroll
-        for (int j = 0; j + 1 < NW; ++j) Wp[c][b][j] = __funnelshift_r(Wp[c][b][j], Wp[c][b][j + 1], 16);
-        if (K & 1)
-          Wp[c][b][NW - 1] = field;  // odd K: the newest row sits alone in the low half of the last word
-        else
-          Wp[c][b][NW - 1] = (Wp[c][b][NW - 1] >> 16) | (field << 16);
+        for (int j = 0; j + 1 < NW; ++j) Wp[c][b][j] = __funnelshift_r(Wp[c][b][j], Wp[c][b][j + 1], K);
+        Wp[c][b][NW - 1] = (Wp[c][b][NW - 1] >> K) | (field << POS);
       }
     }
     const int r_out = r_src - R;
@@ -223,9 +226,9 @@ __global__ __launch_bounds__(kThreads) void median_gray_kernel(const uint8_t* __
     for (int c = 0; c < 3; ++c) {
       uint32_t C[NW];
 #pragma unroll
-      for (int j = 0; j < NW; ++j) C[j] = (FIELD << 16) | FIELD;
-      if (K & 1) C[NW - 1] = FIELD;
-      int k = HALF, cntC = K * K, res = 0;
+      for (int j = 0; j < NW; ++j) C[j] = 0xFFFFFFFFu;
+      C[NW - 1] = LASTMASK;
+      int k = HALF, cntC = NB, res = 0;
 #pragma unroll
       for (int b = 7; b >= 0; --b) {
         uint32_t t[NW];

@@ -473,7 +473,14 @@ __global__ __launch_bounds__(kThreads) void refine_kernel(
             sdx[u] = dx[u];
             sxn[u] = sx[u] + dx[u];
           }
-          s_flag = 0;
+          // a step below the resolution we care about ends the refinement before it is evaluated
+          double dxn = 0.0, xnn = 0.0;
+#pragma unroll
+          for (int u = 0; u < 6; ++u) {
+            dxn += dx[u] * dx[u];
+            xnn += sxn[u] * sxn[u];
+          }
+          s_flag = (sqrt(dxn) <= SV_LM_XTOL * (sqrt(xnn) + SV_LM_XTOL)) ? 4 : 0;
         } else {
           s_flag = 3;
         }
@@ -483,6 +490,11 @@ __global__ __launch_bounds__(kThreads) void refine_kernel(
         lambda *= 10.0;
         __syncthreads();
         continue;
+      }
+      if (s_flag == 4) {  // uniform
+        converged = 1;
+        __syncthreads();
+        break;
       }
       double xn[6];
 #pragma unroll
@@ -499,13 +511,7 @@ __global__ __launch_bounds__(kThreads) void refine_kernel(
       }
       cn = block_sum(cn, scratch, tid);
       if (cn < cost) {
-        double dxn = 0.0, xnn = 0.0;
-#pragma unroll
-        for (int u = 0; u < 6; ++u) {
-          dxn += sdx[u] * sdx[u];
-          xnn += xn[u] * xn[u];
-        }
-        converged = ((cost - cn) <= SV_LM_FTOL * cost) || (sqrt(dxn) <= SV_LM_XTOL * (sqrt(xnn) + SV_LM_XTOL));
+        converged = ((cost - cn) <= SV_LM_FTOL * cost);
         __syncthreads();
         if (tid == 0) {
 #pragma unroll
