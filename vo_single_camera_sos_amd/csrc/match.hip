@@ -38,12 +38,14 @@ __global__ __launch_bounds__(kThreads) void match_hamming_kernel(
     int q_stride, int t_stride, int nsplit, uint32_t* __restrict__ keys) {
   __shared__ uint4 tile[kTrainTile * 2];
   const int tid = threadIdx.x;
-  const int p = blockIdx.y;
+  // XCD-aware grid: workgroups go round-robin over the 8 XCDs by linear id, so the problem index (all
+  // workgroups busy) is the fastest dimension and the query tile (early exit beyond nq) the second.
+  const int p = blockIdx.x;
   const int qs = q_slot ? q_slot[p] : p;  // which block of query rows / counts this problem uses
   const int ts = t_slot ? t_slot[p] : p;
   const int nqp = min(nq[qs], q_stride);
   const int ntp = min(nt[ts], t_stride);
-  const int q0 = blockIdx.x * (kThreads * QPT);
+  const int q0 = blockIdx.y * (kThreads * QPT);
   if (q0 >= nqp) return;  // uniform over the workgroup
 
   // train range of this split, whole tiles
@@ -110,9 +112,9 @@ __global__ __launch_bounds__(kThreads) void sort_matches_kernel(const uint32_t* 
                                                                 int32_t* __restrict__ order) {
   extern __shared__ uint32_t sk[];
   const int tid = threadIdx.x;
-  const int p = blockIdx.y;
+  const int p = blockIdx.x;  // problem fastest, tile second (see match_hamming_kernel)
   const int n = min(nq[q_slot ? q_slot[p] : p], q_stride);
-  const int i0 = blockIdx.x * kThreads;
+  const int i0 = blockIdx.y * kThreads;
   if (i0 >= n) return;
   const int n4 = (n + 3) & ~3;
   const uint32_t* src = keys + (size_t)p * q_stride;
@@ -165,7 +167,7 @@ int32_t sosvo_match_hamming(sosvo_ctx* ctx, const uint8_t* q_desc, const uint8_t
   }
   if (nsplit > 1)
     SOSVO_HIP(ctx, hipMemsetAsync(keys, 0xFF, (size_t)nprob * q_stride * sizeof(uint32_t), ctx->stream));
-  dim3 grid(gx, nprob, nsplit), block(kThreads);
+  dim3 grid(nprob, gx, nsplit), block(kThreads);
   if (k == 1) {
     if (qpt == 4)
       SOSVO_LAUNCH(ctx,(match_hamming_kernel<4, 1>), grid, block, 0, ctx->stream, q4, t4, nq, nt,
@@ -193,7 +195,7 @@ int32_t sosvo_sort_matches(sosvo_ctx* ctx, const uint32_t* keys, const int32_t* 
   SOSVO_REQUIRE(ctx, q_stride > 0 && q_stride <= 16384, "q_stride out of range (max 16384)");
   if (nprob == 0) return SOSVO_OK;
   const size_t lds = (size_t)((q_stride + 3) & ~3) * sizeof(uint32_t);
-  dim3 grid(cdiv(q_stride, kThreads), nprob), block(kThreads);
+  dim3 grid(nprob, cdiv(q_stride, kThreads)), block(kThreads);
   SOSVO_LAUNCH(ctx,sort_matches_kernel, grid, block, lds, ctx->stream, keys, nq, q_slot, q_stride, order);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;

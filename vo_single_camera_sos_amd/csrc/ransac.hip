@@ -162,9 +162,11 @@ __global__ __launch_bounds__(kThreads) void ransac_score_kernel(
   __shared__ double shyp[kScoreHypChunkMax][12];
   const int tid = threadIdx.x, b = blockIdx.z;
   const int n = min(n_arr[b], stride);
-  const int p0 = blockIdx.x * (kThreads * PPT);
+  // XCD-aware grid: workgroups are dealt round-robin over the 8 XCDs by linear id, so the dimension with
+  // early-exiting workgroups (point blocks beyond n) must NOT be the fastest one: x = hypothesis chunk.
+  const int p0 = blockIdx.y * (kThreads * PPT);
   if (p0 >= n) return;
-  const int h0 = blockIdx.y * hchunk;
+  const int h0 = blockIdx.x * hchunk;
   const int h1 = min(H, h0 + hchunk);
   for (int k = tid; k < hchunk; k += kThreads) lcnt[k] = 0;
 
@@ -599,7 +601,7 @@ int32_t sosvo_ransac_abs_pose(sosvo_ctx* ctx, const double* f, const double* p, 
   if (hchunk > kScoreHypChunkMax) hchunk = kScoreHypChunkMax;
   if (hchunk < 16) hchunk = H < 16 ? H : 16;
   hchunks = cdiv(H, hchunk);
-  dim3 grid(gx, hchunks, nprob);
+  dim3 grid(hchunks, gx, nprob);
   if (ident)
     SOSVO_LAUNCH(ctx,(ransac_score_kernel<true, 2>), grid, dim3(kThreads), 0, ctx->stream, f, p, cam, cam_off,
                        cam_rot, n, stride, H, hchunk, thr, fast_ok, hyp, counts);
