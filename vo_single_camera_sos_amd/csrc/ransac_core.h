@@ -15,8 +15,9 @@
 
 #define SV_LM_LAMBDA0 1e-3
 #define SV_LM_MAX_TRIES 6
-#define SV_LM_FTOL 1e-12
-#define SV_LM_XTOL 1e-6 /* relative step size that ends the refinement (OpenGV sets xtol = 1e10 * eps = 2.2e-6) */
+/* OpenGV's optimize_nonlinear sets ftol = xtol = 1e10 * eps on Eigen's LevenbergMarquardt */
+#define SV_LM_FTOL 2.220446049250313e-6 /* relative cost decrease that ends the refinement */
+#define SV_LM_XTOL 2.220446049250313e-6 /* relative step size that ends the refinement */
 #define SV_SQRT_EPS 1.4901161193847656e-08
 #define SV_RANSAC_PROB_FAIL 0.01 /* 1 - 0.99, OpenGV sac::Ransac default probability */
 
