@@ -212,13 +212,16 @@ int32_t orc_refine_abs_pose(const double* f, const double* p, const int32_t* cam
       int i = idx ? idx[q] : q;
       int c = cam ? cam[i] : 0;
       int l = q & 255;
-      double r, J[6];
-      orc_residual_jac(x, f + 3 * i, p + 3 * i, cam_off + 3 * c, cam_rot + 9 * c, &r, J);
+      double r, J[6], Hq[21];
+      orc_residual_jac(x, f + 3 * i, p + 3 * i, cam_off + 3 * c, cam_rot + 9 * c, &r, J, Hq);
       part[27][l] += r * r;
       int a = 0;
       for (int u = 0; u < 6; ++u) {
         part[21 + u][l] += J[u] * r;
-        for (int v = u; v < 6; ++v) part[a++][l] += J[u] * J[v];
+        for (int v = u; v < 6; ++v) {
+          part[a][l] += (J[u] * J[v]) + Hq[a];
+          a++;
+        }
       }
     }
     cost = orc_tree_sum256(part[27]);

@@ -432,15 +432,18 @@ __global__ __launch_bounds__(kThreads) void refine_kernel(
       const int cc = cam ? cam[row] : 0;
       const double* o = cam ? cam_off + 3 * cc : kZero3;
       const double* rc = cam ? cam_rot + 9 * cc : kEye9;
-      double r, J[6];
-      sv_residual_jac(x, f + 3 * row, p + 3 * row, o, rc, &r, J);
+      double r, J[6], Hq[21];
+      sv_residual_jac(x, f + 3 * row, p + 3 * row, o, rc, &r, J, Hq);
       c += r * r;
       int a = 0;
 #pragma unroll
       for (int u = 0; u < 6; ++u) {
         g[u] += J[u] * r;
 #pragma unroll
-        for (int v = u; v < 6; ++v) A[a++] += J[u] * J[v];
+        for (int v = u; v < 6; ++v) {
+          A[a] += (J[u] * J[v]) + Hq[a];
+          a++;
+        }
       }
     }
     // one fused reduction of the 28 sums (same order as block_sum: wave tree, then w0 + w1 + w2 + w3)

@@ -483,7 +483,7 @@ __device__ __forceinline__ static double sv_residual(const double* x, const doub
 }
 
 __device__ __forceinline__ static void sv_residual_jac(const double* x, const double* f, const double* p, const double* o,
-                                    const double* Rc, double* r, double* J) {
+                                    const double* Rc, double* r, double* J, double* Hq) {
   /* Analytic Jacobian of r = 1 - f . u/|u|, u = Rc^T (R(c)^T (p - t) - o), wrt (t, Cayley c).
    * (OpenGV differentiates numerically; the forward-difference noise stalls LM ~1e-5 short of the
    * minimum and makes the result depend on last-bit input noise, so the exact gradient is used.) */
@@ -514,26 +514,61 @@ __device__ __forceinline__ static void sv_residual_jac(const double* x, const do
   /* dr/dc_k = -b . dw/dc_k,  dw/dc_k = ((dN/dc_k)^T d - 2 c_k w) / s,
    * (dN/dc_k)^T d = -2 c_k d - 2 e_k x d + 2 (c d_k + e_k (c . d)) */
   const double cd = ((c0 * d0) + (c1 * d1)) + (c2 * d2);
+  double Q[3][3];
   {
     const double m0 = ((-2.0 * c0) * d0) + (2.0 * ((c0 * d0) + cd));
     const double m1 = (((-2.0 * c0) * d1) - (2.0 * (-d2))) + (2.0 * (c1 * d0));
     const double m2 = (((-2.0 * c0) * d2) - (2.0 * d1)) + (2.0 * (c2 * d0));
-    const double q0 = (m0 - ((2.0 * c0) * w0)) / s, q1 = (m1 - ((2.0 * c0) * w1)) / s, q2 = (m2 - ((2.0 * c0) * w2)) / s;
-    J[3] = -(((b0 * q0) + (b1 * q1)) + (b2 * q2));
+    Q[0][0] = (m0 - ((2.0 * c0) * w0)) / s;
+    Q[0][1] = (m1 - ((2.0 * c0) * w1)) / s;
+    Q[0][2] = (m2 - ((2.0 * c0) * w2)) / s;
   }
   {
     const double m0 = (((-2.0 * c1) * d0) - (2.0 * d2)) + (2.0 * (c0 * d1));
     const double m1 = ((-2.0 * c1) * d1) + (2.0 * ((c1 * d1) + cd));
     const double m2 = (((-2.0 * c1) * d2) - (2.0 * (-d0))) + (2.0 * (c2 * d1));
-    const double q0 = (m0 - ((2.0 * c1) * w0)) / s, q1 = (m1 - ((2.0 * c1) * w1)) / s, q2 = (m2 - ((2.0 * c1) * w2)) / s;
-    J[4] = -(((b0 * q0) + (b1 * q1)) + (b2 * q2));
+    Q[1][0] = (m0 - ((2.0 * c1) * w0)) / s;
+    Q[1][1] = (m1 - ((2.0 * c1) * w1)) / s;
+    Q[1][2] = (m2 - ((2.0 * c1) * w2)) / s;
   }
   {
     const double m0 = (((-2.0 * c2) * d0) - (2.0 * (-d1))) + (2.0 * (c0 * d2));
     const double m1 = (((-2.0 * c2) * d1) - (2.0 * d0)) + (2.0 * (c1 * d2));
     const double m2 = ((-2.0 * c2) * d2) + (2.0 * ((c2 * d2) + cd));
-    const double q0 = (m0 - ((2.0 * c2) * w0)) / s, q1 = (m1 - ((2.0 * c2) * w1)) / s, q2 = (m2 - ((2.0 * c2) * w2)) / s;
-    J[5] = -(((b0 * q0) + (b1 * q1)) + (b2 * q2));
+    Q[2][0] = (m0 - ((2.0 * c2) * w0)) / s;
+    Q[2][1] = (m1 - ((2.0 * c2) * w1)) / s;
+    Q[2][2] = (m2 - ((2.0 * c2) * w2)) / s;
+  }
+  J[3] = -(((b0 * Q[0][0]) + (b1 * Q[0][1])) + (b2 * Q[0][2]));
+  J[4] = -(((b0 * Q[1][0]) + (b1 * Q[1][1])) + (b2 * Q[1][2]));
+  J[5] = -(((b0 * Q[2][0]) + (b1 * Q[2][1])) + (b2 * Q[2][2]));
+  /* Second-order term of the quartic cost: the cost is sum r^2 with r = 1 - cos(angle) ~ |e|^2 / 2 (e = tangent
+   * error), so its Hessian is sum (grad r grad r^T + r G^T G) up to O(|e|) relative, G = d(u/|u|)/dx.  Plain
+   * Gauss-Newton keeps only the first term and crawls (linear convergence); adding r G^T G makes the step a
+   * Newton step.  Hq = r G^T G, packed upper triangle like the normal matrix. */
+  double V[6][3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      V[j][i] = -(((Rc[i] * R[3 * j]) + (Rc[3 + i] * R[3 * j + 1])) + (Rc[6 + i] * R[3 * j + 2]));
+      V[3 + j][i] = ((Rc[i] * Q[j][0]) + (Rc[3 + i] * Q[j][1])) + (Rc[6 + i] * Q[j][2]);
+    }
+  double G[6][3];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const double gv = ((g0 * V[j][0]) + (g1 * V[j][1])) + (g2 * V[j][2]);
+    G[j][0] = (V[j][0] - (g0 * gv)) / nrm;
+    G[j][1] = (V[j][1] - (g1 * gv)) / nrm;
+    G[j][2] = (V[j][2] - (g2 * gv)) / nrm;
+  }
+  {
+    const double rr = *r;
+    int a = 0;
+#pragma unroll
+    for (int u = 0; u < 6; ++u)
+#pragma unroll
+      for (int v = u; v < 6; ++v) Hq[a++] = rr * (((G[u][0] * G[v][0]) + (G[u][1] * G[v][1])) + (G[u][2] * G[v][2]));
   }
 }
 
