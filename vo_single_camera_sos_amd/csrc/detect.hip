@@ -29,111 +29,156 @@ __device__ __forceinline__ int refl101(int i, int n) {
   return i;
 }
 
-// Products of the scaled Sobel derivatives at IMAGE position (y, x) (already inside the image).
-__device__ __forceinline__ void sobel_products(const uint8_t* __restrict__ g, int rows, int cols, int y, int x,
-                                               float* xx, float* xy, float* yy) {
-  const float scale = (float)(1.0 / 3060.0);
-  const uint8_t* r0 = g + (size_t)refl101(y - 1, rows) * cols;
-  const uint8_t* r1 = g + (size_t)y * cols;
-  const uint8_t* r2 = g + (size_t)refl101(y + 1, rows) * cols;
-  const int xl = refl101(x - 1, cols), xr = refl101(x + 1, cols);
-  const int dxi = ((int)r0[xr] + 2 * (int)r1[xr] + (int)r2[xr]) - ((int)r0[xl] + 2 * (int)r1[xl] + (int)r2[xl]);
-  const int dyi = ((int)r2[xl] + 2 * (int)r2[x] + (int)r2[xr]) - ((int)r0[xl] + 2 * (int)r0[x] + (int)r0[xr]);
-  const float dx = (float)dxi * scale, dy = (float)dyi * scale;
-  *xx = dx * dx;
-  *xy = dx * dy;
-  *yy = dy * dy;
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ---- K4a: min-eigenvalue map, rolling over rows ---------------------------------------------------------
+// One wave owns a 64-column strip (3 halo columns each side, 58 output columns) of one image and walks down a
+// chunk of rows; everything a 3x3 Sobel + 3x3 box sum + 3x3 local-maximum test needs from neighbouring columns
+// comes from neighbouring LANES (ds_bpermute), everything from neighbouring rows from three-deep register rings.
+// Per row and lane: one byte load, ten lane exchanges, ~70 VALU ops, one float store; no LDS, no barriers.
+//   gray row t  -> hd = g[x+1] - g[x-1], hs = g[x-1] + 2 g[x] + g[x+1]                  (integers, exact)
+//   P row v=t-1 -> dx = hd(v-1) + 2 hd(v) + hd(v+1), dy = hs(v+1) - hs(v-1), products dx*dx, dx*dy, dy*dy (f32)
+//                  and their horizontal 3-sums (a + b) + c in the oracle's order
+//   e row y=v-1 -> vertical sums (ha + hc) + hb, min eigenvalue, per-mask maximum, hm = max(e[x-1], e[x], e[x+1])
+//   flag row y-1-> e == max(hm(y-2), hm(y-1), hm(y)): 3x3 local maximum, one ballot (u64) per wave and row
+// Border rules (identical to the tile version it replaces): reflect-101 on the gray image, and a covariance
+// product outside the image is the product AT the reflected position.  In x both are "take the mirrored
+// lane".  In y a rolling reflect-101 of the gray rows evaluates the Sobel pair of the mirrored row with the
+// row order reversed, i.e. dx unchanged and dy negated -- the dx*dy product is negated back (exact).
+constexpr int kEigHalo = 3;
+constexpr int kEigStripW = 64 - 2 * kEigHalo;  // 58
+constexpr int kEigChunkRows = 64;
+
+__device__ __forceinline__ void eig_flush(uint32_t* __restrict__ mstat_img, uint32_t bits, uint32_t omax) {
+  while (bits) {
+    const int m = __ffs(bits) - 1;
+    bits &= bits - 1;
+    atomicMax(&mstat_img[m * 5], omax);
+  }
 }
 
-constexpr int kEigTW = 64, kEigTH = 4;  // output tile per workgroup (256 threads, one pixel each)
-
 __global__ __launch_bounds__(kThreads) void min_eigen_kernel(const uint8_t* __restrict__ gray,
-                                                             const uint32_t* __restrict__ mask_bits,
+                                                             const uint32_t* __restrict__ mask_bits, int nimg,
                                                              int images_per_maskset, int rows, int cols, int nmask,
-                                                             float* __restrict__ eig, uint32_t* __restrict__ mstat) {
-  // mstat[p][5] (zero-initialised, all fields grow by atomicMax): ordered(max eig) over the mask,
-  // 0xFFFFFFFF - xmin, 0xFFFFFFFF - ymin, xmax + 1, ymax + 1 of the mask's pixels
-  __shared__ float sxx[kEigTH + 2][kEigTW + 2], sxy[kEigTH + 2][kEigTW + 2], syy[kEigTH + 2][kEigTW + 2];
-  __shared__ uint32_t smax[5][kMaxMasks];
-  const int tid = threadIdx.x, img = blockIdx.z;
-  const int x0 = blockIdx.x * kEigTW, y0 = blockIdx.y * kEigTH;
+                                                             int strips, int nchunks, float* __restrict__ eig,
+                                                             unsigned long long* __restrict__ flags,
+                                                             uint32_t* __restrict__ mstat) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * kThreads + threadIdx.x) >> 6;
+  if (wave >= nimg * strips * nchunks) return;  // wave-uniform
+  const int img = wave / (strips * nchunks);
+  const int rem = wave - img * strips * nchunks;
+  const int chunk = rem / strips, strip = rem - chunk * strips;
+  const int xb = strip * kEigStripW - kEigHalo;  // column of lane 0
+  const int xc = xb + lane;
+  const int xs = clampi(xc, 0, cols - 1);
+  const int ll = clampi(refl101(xs - 1, cols) - xb, 0, 63);  // lane holding column x-1 (mirrored at the border)
+  const int lr = clampi(refl101(xs + 1, cols) - xb, 0, 63);
+  const bool out_lane = lane >= kEigHalo && lane < 64 - kEigHalo && xc < cols;  // xc >= 0 follows
+  const int ys = chunk * kEigChunkRows, ye = min(rows, ys + kEigChunkRows);
+  const int e_lo = max(ys - 1, 0), e_hi = min(ye, rows - 1);  // e rows this chunk evaluates
+  const int f_lo = max(ys, 1), f_hi = min(ye, rows - 1) - 1;   // flag rows this chunk owns
   const uint8_t* g = gray + (size_t)img * rows * cols;
-  if (tid < 5 * kMaxMasks) (&smax[0][0])[tid] = 0u;
-  // products on the (TH+2) x (TW+2) halo tile; a position outside the image takes the product AT the
-  // reflected position (box filter with reflect-101 on the covariance images)
-  for (int i = tid; i < (kEigTH + 2) * (kEigTW + 2); i += kThreads) {
-    const int ty = i / (kEigTW + 2), tx = i - ty * (kEigTW + 2);
-    const int y = refl101(y0 + ty - 1, rows), x = refl101(x0 + tx - 1, cols);
-    sobel_products(g, rows, cols, y, x, &sxx[ty][tx], &sxy[ty][tx], &syy[ty][tx]);
-  }
-  __syncthreads();
-  const int ty = tid / kEigTW, tx = tid - ty * kEigTW;  // a wave is one 64-pixel row of the tile
-  const int y = y0 + ty, x = x0 + tx;
-  uint32_t bits = 0u, o = 0u;
-  if (y < rows && x < cols) {
-    float s[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      float(*v)[kEigTW + 2] = k == 0 ? sxx : (k == 1 ? sxy : syy);
-      const float ha = (v[ty][tx] + v[ty][tx + 1]) + v[ty][tx + 2];
-      const float hc = (v[ty + 1][tx] + v[ty + 1][tx + 1]) + v[ty + 1][tx + 2];
-      const float hb = (v[ty + 2][tx] + v[ty + 2][tx + 1]) + v[ty + 2][tx + 2];
-      s[k] = (ha + hc) + hb;
+  float* eo = eig + (size_t)img * rows * cols;
+  unsigned long long* fo = flags + (size_t)img * rows * strips;
+  const uint32_t* mb = mask_bits + (size_t)(img / images_per_maskset) * rows * cols;
+  const uint32_t mask_all = nmask < 32 ? (1u << nmask) - 1u : 0xFFFFFFFFu;
+  uint32_t* mstat_img = mstat + (size_t)img * nmask * 5;
+  const float scale = (float)(1.0 / 3060.0);
+
+  int hd0 = 0, hd1 = 0, hd2 = 0, hs0 = 0, hs1 = 0, hs2 = 0;                     // gray rows t-2, t-1, t
+  float pxx0 = 0.f, pxx1 = 0.f, pxx2 = 0.f, pxy0 = 0.f, pxy1 = 0.f, pxy2 = 0.f;  // h-sums of P rows v-2, v-1, v
+  float pyy0 = 0.f, pyy1 = 0.f, pyy2 = 0.f;
+  float hm0 = 0.f, hm1 = 0.f, hm2 = 0.f, ec1 = 0.f, ec2 = 0.f;                   // e rows y-2, y-1, y
+  uint32_t cur_bits = 0u, cur_max = 0u;
+
+  for (int t = e_lo - 2; t <= e_hi + 2; ++t) {
+    {
+      const int c = (int)g[(size_t)refl101(t, rows) * cols + xs];
+      const int l = __shfl(c, ll), r = __shfl(c, lr);
+      hd0 = hd1; hd1 = hd2; hd2 = r - l;
+      hs0 = hs1; hs1 = hs2; hs2 = (l + 2 * c) + r;
     }
-    const float a = s[0] * 0.5f, b = s[1], c = s[2] * 0.5f;
-    const float e = (a + c) - sqrtf(((a - c) * (a - c)) + (b * b));
-    eig[((size_t)img * rows + y) * cols + x] = e;
-    bits = mask_bits[((size_t)(img / images_per_maskset) * rows + y) * cols + x];
-    if (nmask < 32) bits &= (1u << nmask) - 1u;
-    o = sosvo_float_ordered(e);
+    const int v = t - 1;
+    if (v < e_lo - 1) continue;  // uniform
+    {
+      const int dxi = (hd0 + 2 * hd1) + hd2, dyi = hs2 - hs0;
+      const float dx = (float)dxi * scale, dy = (float)dyi * scale;
+      const float xx = dx * dx, yy = dy * dy;
+      float xy = dx * dy;
+      if (v < 0 || v >= rows) xy = -xy;  // mirrored row: dy came out negated
+      pxx0 = pxx1; pxx1 = pxx2; pxx2 = (__shfl(xx, ll) + xx) + __shfl(xx, lr);
+      pxy0 = pxy1; pxy1 = pxy2; pxy2 = (__shfl(xy, ll) + xy) + __shfl(xy, lr);
+      pyy0 = pyy1; pyy1 = pyy2; pyy2 = (__shfl(yy, ll) + yy) + __shfl(yy, lr);
+    }
+    const int y = v - 1;
+    if (y < e_lo) continue;  // uniform
+    {
+      const float a = ((pxx0 + pxx1) + pxx2) * 0.5f, b = (pxy0 + pxy1) + pxy2, c = ((pyy0 + pyy1) + pyy2) * 0.5f;
+      const float e = (a + c) - sqrtf(((a - c) * (a - c)) + (b * b));
+      if (y >= ys && y < ye && out_lane) {
+        eo[(size_t)y * cols + xc] = e;
+        const uint32_t bits = mb[(size_t)y * cols + xc] & mask_all;
+        if (bits != cur_bits) {
+          eig_flush(mstat_img, cur_bits, cur_max);
+          cur_bits = bits;
+          cur_max = 0u;
+        }
+        cur_max = max(cur_max, sosvo_float_ordered(e));
+      }
+      const float el = __shfl(e, ll), er = __shfl(e, lr);
+      hm0 = hm1; hm1 = hm2; hm2 = fmaxf(fmaxf(el, e), er);
+      ec1 = ec2; ec2 = e;
+    }
+    const int f = y - 1;
+    if (f < f_lo || f > f_hi) continue;  // uniform
+    {
+      const bool is_max = out_lane && xc >= 1 && xc <= cols - 2 && ec1 == fmaxf(fmaxf(hm0, hm1), hm2);
+      const unsigned long long bal = __ballot(is_max);
+      if (lane == 0) fo[(size_t)f * strips + strip] = bal;
+    }
   }
-  // per-mask statistics: one set of LDS atomics per wave when all its in-image lanes carry the same mask bits
-  // (the common case), per lane at sector boundaries
-  {
-    // the bounding box depends only on the mask set: the first image of every set records it
-    const bool do_bbox = (img % images_per_maskset) == 0;
-    const bool in_img = y < rows && x < cols;
-    const unsigned long long act = __ballot(in_img);
-    const int first = act ? __ffsll((long long)act) - 1 : 0;
-    const uint32_t b0 = __shfl(bits, first);
-    const bool uniform = __ballot(in_img && bits != b0) == 0ULL;
-    if (uniform) {
-      uint32_t om = in_img ? o : 0u;
+  // per-mask maxima: one set of atomics per wave when all its output lanes saw a single mask word
+  const unsigned long long act = __ballot(out_lane && cur_bits != 0u);
+  if (act) {
+    const int first = __ffsll((long long)act) - 1;
+    const uint32_t b0 = __shfl(cur_bits, first);
+    if (__ballot(out_lane && cur_bits != 0u && cur_bits != b0) == 0ULL) {
+      uint32_t om = (out_lane && cur_bits != 0u) ? cur_max : 0u;
       for (int s = 32; s > 0; s >>= 1) om = max(om, (uint32_t)__shfl_down((int)om, s));
-      if ((tid & 63) == 0 && act) {
-        const int xlo = x0, xhi = min(x0 + kEigTW - 1, cols - 1);
-        uint32_t b = b0;
-        while (b) {
-          const int m = __ffs(b) - 1;
-          b &= b - 1;
-          atomicMax(&smax[0][m], om);
-          if (do_bbox) {
-            atomicMax(&smax[1][m], 0xFFFFFFFFu - (uint32_t)xlo);
-            atomicMax(&smax[2][m], 0xFFFFFFFFu - (uint32_t)y);
-            atomicMax(&smax[3][m], (uint32_t)xhi + 1u);
-            atomicMax(&smax[4][m], (uint32_t)y + 1u);
-          }
-        }
-      }
+      if (lane == 0) eig_flush(mstat_img, b0, om);
     } else {
-      uint32_t b = bits;
-      while (b) {
-        const int m = __ffs(b) - 1;
-        b &= b - 1;
-        atomicMax(&smax[0][m], o);
-        if (do_bbox) {
-          atomicMax(&smax[1][m], 0xFFFFFFFFu - (uint32_t)x);
-          atomicMax(&smax[2][m], 0xFFFFFFFFu - (uint32_t)y);
-          atomicMax(&smax[3][m], (uint32_t)x + 1u);
-          atomicMax(&smax[4][m], (uint32_t)y + 1u);
-        }
-      }
+      eig_flush(mstat_img, cur_bits, cur_max);
+    }
+  }
+}
+
+// Bounding box of every mask of every mask set (depends on the masks only): mstat fields 1..4 of the FIRST
+// image of the set, each grown by atomicMax: 0xFFFFFFFF - xmin, 0xFFFFFFFF - ymin, xmax + 1, ymax + 1.
+__global__ __launch_bounds__(kThreads) void mask_bbox_kernel(const uint32_t* __restrict__ mask_bits, int images_per_maskset,
+                                                             int rows, int cols, int nmask, uint32_t* __restrict__ mstat) {
+  __shared__ uint32_t sb[2][kMaxMasks];
+  const int tid = threadIdx.x, y = blockIdx.x, set = blockIdx.y;
+  if (tid < 2 * kMaxMasks) (&sb[0][0])[tid] = 0u;
+  __syncthreads();
+  const uint32_t* mb = mask_bits + ((size_t)set * rows + y) * cols;
+  const uint32_t mask_all = nmask < 32 ? (1u << nmask) - 1u : 0xFFFFFFFFu;
+  for (int x = tid; x < cols; x += kThreads) {
+    uint32_t b = mb[x] & mask_all;
+    while (b) {
+      const int m = __ffs(b) - 1;
+      b &= b - 1;
+      atomicMax(&sb[0][m], 0xFFFFFFFFu - (uint32_t)x);
+      atomicMax(&sb[1][m], (uint32_t)x + 1u);
     }
   }
   __syncthreads();
-  if (tid < 5 * kMaxMasks) {
-    const int f = tid / kMaxMasks, m = tid - f * kMaxMasks;
-    if (m < nmask && smax[f][m]) atomicMax(&mstat[((size_t)img * nmask + m) * 5 + f], smax[f][m]);
+  if (tid < nmask && sb[1][tid]) {
+    uint32_t* st = mstat + ((size_t)set * images_per_maskset * nmask + tid) * 5;
+    atomicMax(&st[1], sb[0][tid]);
+    atomicMax(&st[2], 0xFFFFFFFFu - (uint32_t)y);
+    atomicMax(&st[3], sb[1][tid]);
+    atomicMax(&st[4], (uint32_t)y + 1u);
   }
 }
 
@@ -147,6 +192,7 @@ __global__ __launch_bounds__(kThreads) void min_eigen_kernel(const uint8_t* __re
 constexpr int kSelGridCells = (kCandCap * 8 - 1024 * 4) / 8;  // 2 slots (u32) per cell, 1024 u32 left for the list
 
 __global__ __launch_bounds__(kThreads) void gft_select_kernel(const float* __restrict__ eig,
+                                                              const unsigned long long* __restrict__ flags, int strips,
                                                               const uint32_t* __restrict__ mask_bits,
                                                               const uint32_t* __restrict__ mstat, int images_per_maskset,
                                                               int nmask, int rows, int cols, double quality,
@@ -177,35 +223,58 @@ __global__ __launch_bounds__(kThreads) void gft_select_kernel(const float* __res
     const float thr = (float)((double)sosvo_ordered_float(st[0]) * quality);
     const float* e = eig + (size_t)img * rows * cols;
     const uint32_t* mb = mask_bits + (size_t)(img / images_per_maskset) * rows * cols;
-    for (int i = tid; i < bw * bh; i += kThreads) {
-      const int y = by0 + i / bw, x = bx0 + i % bw;
-      const int pix = y * cols + x;
-      if (!((mb[pix] >> m) & 1u)) continue;
-      const float c = e[pix];
-      const float v = c > thr ? c : 0.0f;
-      if (v == 0.0f) continue;
-      float dil = v;
+    // the local-maximum flags come from min_eigen_kernel: one u64 per (row, 58-column strip), bit = lane
+    const unsigned long long* fl = flags + (size_t)img * rows * strips;
+    const int s0 = bx0 / kEigStripW, ns = bx1 / kEigStripW - s0 + 1;
+    for (int i = tid; i < ns * bh; i += kThreads) {
+      const int ry = i / ns, sidx = s0 + (i - ry * ns);
+      const int y = by0 + ry;
+      unsigned long long w = fl[(size_t)y * strips + sidx];
+      while (w) {
+        const int l = __ffsll((long long)w) - 1;
+        w &= w - 1ULL;
+        const int x = sidx * kEigStripW - kEigHalo + l;
+        if (x < bx0 || x > bx1) continue;
+        const int pix = y * cols + x;
+        if (!((mb[pix] >> m) & 1u)) continue;
+        const float c = e[pix];
+        const float v = c > thr ? c : 0.0f;
+        if (v == 0.0f) continue;
+        if (v < 0.0f) {
+          // negative response above a negative threshold (all-negative mask): the thresholded neighbours
+          // (zeros) matter, evaluate the dilation as written
+          float dil = v;
 #pragma unroll
-      for (int dy = -1; dy <= 1; ++dy)
+          for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
-          const float q = e[pix + dy * cols + dx];
-          const float t = q > thr ? q : 0.0f;
-          dil = t > dil ? t : dil;
+            for (int dx = -1; dx <= 1; ++dx) {
+              const float q = e[pix + dy * cols + dx];
+              const float t = q > thr ? q : 0.0f;
+              dil = t > dil ? t : dil;
+            }
+          if (v != dil) continue;
         }
-      if (v != dil) continue;
-      const int slot = atomicAdd(&s_count, 1);
-      if (slot < kCandCap) keys[slot] = ((unsigned long long)sosvo_float_ordered(v) << 32) | (uint32_t)pix;
+        const int slot = atomicAdd(&s_count, 1);
+        if (slot < kCandCap) keys[slot] = ((unsigned long long)sosvo_float_ordered(v) << 32) | (uint32_t)pix;
+      }
     }
   }
   __syncthreads();
   const int total = s_count;
   const int n = min(total, kCandCap);
   // ---- phase 2: rank sort (keys are unique) --------------------------------------------------------------
+  const int n2 = (n + 1) & ~1;
+  if (tid == 0 && n2 > n) keys[n] = 0ULL;  // pad: never greater than a real key
+  __syncthreads();
   for (int i = tid; i < n; i += kThreads) {
     const unsigned long long mine = keys[i];
     int rank = 0;
-    for (int j = 0; j < n; ++j) rank += keys[j] > mine;
+    const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(keys);
+#pragma unroll 8
+    for (int j = 0; j < n2 / 2; ++j) {
+      const ulonglong2 kk = k2[j];
+      rank += (kk.x > mine) + (kk.y > mine);
+    }
     sorted[rank] = (uint32_t)mine;
   }
   int stt = total > kCandCap ? 1 : 0;
@@ -262,8 +331,8 @@ __global__ __launch_bounds__(kThreads) void gft_select_kernel(const float* __res
       // conflicts with earlier lanes of this batch
       unsigned long long cm = 0ULL;
       if (spaced) {
-        for (int j = 0; j < kend; ++j) {
-          const int xj = __shfl(x, j), yj = __shfl(y, j);
+        for (int j = 0; j < kend; ++j) {  // j is wave-uniform: v_readlane broadcasts through an SGPR
+          const int xj = __builtin_amdgcn_readlane(x, j), yj = __builtin_amdgcn_readlane(y, j);
           const float dx = (float)(x - xj), dy = (float)(y - yj);
           if (j < lane && (dx * dx + dy * dy < md2)) cm |= 1ULL << j;
         }
@@ -273,9 +342,10 @@ __global__ __launch_bounds__(kThreads) void gft_select_kernel(const float* __res
       unsigned long long acc = 0ULL;
       int room = limit - accepted;
       const uint32_t cm_lo = (uint32_t)cm, cm_hi = (uint32_t)(cm >> 32);
-      for (int j = 0; j < kend && room > 0; ++j) {
-        if (!((okmask >> j) & 1ULL)) continue;
-        const unsigned long long cmj = ((unsigned long long)(uint32_t)__shfl((int)cm_hi, j) << 32) | (uint32_t)__shfl((int)cm_lo, j);
+      for (unsigned long long todo = okmask; todo && room > 0; todo &= todo - 1ULL) {
+        const int j = __ffsll((long long)todo) - 1;
+        const unsigned long long cmj = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)cm_hi, j) << 32) |
+                                       (uint32_t)__builtin_amdgcn_readlane((int)cm_lo, j);
         if ((cmj & acc) == 0ULL) {
           acc |= 1ULL << j;
           room--;
@@ -414,23 +484,31 @@ int32_t sosvo_detect_gft(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* ma
     off += (bytes + 255) & ~(size_t)255;
     return o;
   };
+  const int strips = cdiv(cols, kEigStripW), nchunks = cdiv(rows, kEigChunkRows);
   const size_t o_eig = carve(sizeof(float) * (size_t)nimg * rows * cols);
+  const size_t o_flags = carve(sizeof(unsigned long long) * (size_t)nimg * rows * strips);
   const size_t o_stat = carve(sizeof(uint32_t) * P * 5);
   const size_t o_sorted = carve(sizeof(uint32_t) * P * kCandCap);
   int32_t rc = sosvo_ws_reserve(ctx, off);
   if (rc != SOSVO_OK) return rc;
   char* ws = (char*)ctx->ws;
   float* eig = (float*)(ws + o_eig);
+  unsigned long long* flags = (unsigned long long*)(ws + o_flags);
   uint32_t* mstat = (uint32_t*)(ws + o_stat);
   uint32_t* sorted_g = (uint32_t*)(ws + o_sorted);
   SOSVO_HIP(ctx, hipMemsetAsync(mstat, 0, sizeof(uint32_t) * P * 5, ctx->stream));
 
-  SOSVO_LAUNCH(ctx, min_eigen_kernel, dim3(cdiv(cols, kEigTW), cdiv(rows, kEigTH), nimg), dim3(kThreads), 0, ctx->stream,
-               gray, mask_bits, images_per_maskset, rows, cols, nmask, eig, mstat);
+  const int nsets = cdiv(nimg, images_per_maskset);
+  SOSVO_LAUNCH(ctx, mask_bbox_kernel, dim3(rows, nsets), dim3(kThreads), 0, ctx->stream, mask_bits, images_per_maskset, rows,
+               cols, nmask, mstat);
+  SOSVO_LAUNCH_CHECK(ctx);
+  const int waves = nimg * strips * nchunks;
+  SOSVO_LAUNCH(ctx, min_eigen_kernel, dim3(cdiv(waves, kThreads / 64)), dim3(kThreads), 0, ctx->stream, gray, mask_bits, nimg,
+               images_per_maskset, rows, cols, nmask, strips, nchunks, eig, flags, mstat);
   SOSVO_LAUNCH_CHECK(ctx);
   const int cell = min_distance >= 1 ? (int)lrint(min_distance) : 1;
-  SOSVO_LAUNCH(ctx, gft_select_kernel, dim3((unsigned)P), dim3(kThreads), 0, ctx->stream, eig, mask_bits, mstat,
-               images_per_maskset, nmask, rows, cols, quality, (float)min_distance, cell, max_corners, cap, sorted_g, kp, n,
+  SOSVO_LAUNCH(ctx, gft_select_kernel, dim3((unsigned)P), dim3(kThreads), 0, ctx->stream, eig, flags, strips, mask_bits,
+               mstat, images_per_maskset, nmask, rows, cols, quality, (float)min_distance, cell, max_corners, cap, sorted_g, kp, n,
                status);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
