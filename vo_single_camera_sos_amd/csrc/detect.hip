@@ -47,7 +47,6 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 // row order reversed, i.e. dx unchanged and dy negated -- the dx*dy product is negated back (exact).
 constexpr int kEigHalo = 3;
 constexpr int kEigStripW = 64 - 2 * kEigHalo;  // 58
-constexpr int kEigChunkRows = 64;
 
 __device__ __forceinline__ void eig_flush(uint32_t* __restrict__ mstat_img, uint32_t bits, uint32_t omax) {
   while (bits) {
@@ -60,7 +59,8 @@ __device__ __forceinline__ void eig_flush(uint32_t* __restrict__ mstat_img, uint
 __global__ __launch_bounds__(kThreads) void min_eigen_kernel(const uint8_t* __restrict__ gray,
                                                              const uint32_t* __restrict__ mask_bits, int nimg,
                                                              int images_per_maskset, int rows, int cols, int nmask,
-                                                             int strips, int nchunks, float* __restrict__ eig,
+                                                             int strips, int nchunks, int chunk_rows,
+                                                             float* __restrict__ eig,
                                                              unsigned long long* __restrict__ flags,
                                                              uint32_t* __restrict__ mstat) {
   const int lane = threadIdx.x & 63;
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kThreads) void min_eigen_kernel(const uint8_t* __re
   const int ll = clampi(refl101(xs - 1, cols) - xb, 0, 63);  // lane holding column x-1 (mirrored at the border)
   const int lr = clampi(refl101(xs + 1, cols) - xb, 0, 63);
   const bool out_lane = lane >= kEigHalo && lane < 64 - kEigHalo && xc < cols;  // xc >= 0 follows
-  const int ys = chunk * kEigChunkRows, ye = min(rows, ys + kEigChunkRows);
+  const int ys = chunk * chunk_rows, ye = min(rows, ys + chunk_rows);
   const int e_lo = max(ys - 1, 0), e_hi = min(ye, rows - 1);  // e rows this chunk evaluates
   const int f_lo = max(ys, 1), f_hi = min(ye, rows - 1) - 1;   // flag rows this chunk owns
   const uint8_t* g = gray + (size_t)img * rows * cols;
@@ -376,41 +376,44 @@ __global__ __launch_bounds__(kThreads) void gft_select_kernel(const float* __res
 }
 
 // ---- K6a: 7x7 Gaussian, 8.8 fixed point ------------------------------------------------------------------
-constexpr int kBlurTW = 64, kBlurTH = 16;
-
-__global__ __launch_bounds__(kThreads) void gauss7_kernel(const uint8_t* __restrict__ gray, int rows, int cols,
+// Same rolling layout as min_eigen_kernel: a wave owns a 64-column strip (58 output columns) and walks down a
+// chunk of rows; the six horizontal neighbours come from neighbouring lanes (mirrored lanes at the image
+// border = reflect-101), the seven rows of horizontal sums live in a register ring.
+__global__ __launch_bounds__(kThreads) void gauss7_kernel(const uint8_t* __restrict__ gray, int nimg, int rows, int cols,
+                                                          int strips, int nchunks, int chunk_rows,
                                                           uint8_t* __restrict__ out) {
-  __shared__ uint8_t tile[kBlurTH + 6][kBlurTW + 6];
-  __shared__ uint16_t hrow[kBlurTH + 6][kBlurTW];
-  const int kw[7] = {18, 34, 49, 54, 49, 34, 18};
-  const int tid = threadIdx.x, img = blockIdx.z;
-  const int x0 = blockIdx.x * kBlurTW, y0 = blockIdx.y * kBlurTH;
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * kThreads + threadIdx.x) >> 6;
+  if (wave >= nimg * strips * nchunks) return;  // wave-uniform
+  const int img = wave / (strips * nchunks);
+  const int rem = wave - img * strips * nchunks;
+  const int chunk = rem / strips, strip = rem - chunk * strips;
+  const int xb = strip * kEigStripW - kEigHalo;
+  const int xc = xb + lane;
+  const int xs = clampi(xc, 0, cols - 1);
+  int src[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) src[k] = clampi(refl101(xs + k - 3, cols) - xb, 0, 63);
+  const bool out_lane = lane >= kEigHalo && lane < 64 - kEigHalo && xc < cols;
+  const int ys = chunk * chunk_rows, ye = min(rows, ys + chunk_rows);
   const uint8_t* g = gray + (size_t)img * rows * cols;
-  for (int i = tid; i < (kBlurTH + 6) * (kBlurTW + 6); i += kThreads) {
-    const int ty = i / (kBlurTW + 6), tx = i - ty * (kBlurTW + 6);
-    tile[ty][tx] = g[(size_t)refl101(y0 + ty - 3, rows) * cols + refl101(x0 + tx - 3, cols)];
-  }
-  __syncthreads();
-  for (int i = tid; i < (kBlurTH + 6) * kBlurTW; i += kThreads) {
-    const int ty = i / kBlurTW, tx = i - ty * kBlurTW;
-    int s = 0;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) s += kw[k] * tile[ty][tx + k];
-    hrow[ty][tx] = (uint16_t)s;
-  }
-  __syncthreads();
-  for (int i = tid; i < kBlurTH * kBlurTW; i += kThreads) {
-    const int ty = i / kBlurTW, tx = i - ty * kBlurTW;
-    const int y = y0 + ty, x = x0 + tx;
-    if (y >= rows || x >= cols) continue;
-    uint32_t s = 0;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) s += (uint32_t)kw[k] * hrow[ty + k][tx];
-    out[((size_t)img * rows + y) * cols + x] = (uint8_t)((s + 32768u) >> 16);
+  uint8_t* o = out + (size_t)img * rows * cols;
+  uint32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, h6 = 0;
+  for (int t = ys - 3; t <= ye + 2; ++t) {
+    const int c = (int)g[(size_t)refl101(t, rows) * cols + xs];
+    const uint32_t s = 18u * (uint32_t)(__shfl(c, src[0]) + __shfl(c, src[6])) + 34u * (uint32_t)(__shfl(c, src[1]) + __shfl(c, src[5])) +
+                       49u * (uint32_t)(__shfl(c, src[2]) + __shfl(c, src[4])) + 54u * (uint32_t)c;
+    h0 = h1; h1 = h2; h2 = h3; h3 = h4; h4 = h5; h5 = h6; h6 = s;
+    const int y = t - 3;
+    if (y < ys) continue;  // uniform
+    const uint32_t vsum = 18u * (h0 + h6) + 34u * (h1 + h5) + 49u * (h2 + h4) + 54u * h3;
+    if (out_lane) o[(size_t)y * cols + xc] = (uint8_t)((vsum + 32768u) >> 16);
   }
 }
 
 // ---- K6b: border rule + descriptors ---------------------------------------------------------------------
+constexpr int kPatchMaxR = 23, kPatchRows = 48, kPatchStride = 64;
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 __global__ __launch_bounds__(kThreads) void orb_describe_kernel(const uint8_t* __restrict__ blurred, int rows, int cols,
                                                                 int nmask, int cap, float* __restrict__ kp,
                                                                 int32_t* __restrict__ n_io, float cos_a, float sin_a,
@@ -418,18 +421,37 @@ __global__ __launch_bounds__(kThreads) void orb_describe_kernel(const uint8_t* _
                                                                 uint8_t* __restrict__ desc) {
   extern __shared__ float lds_kp[];  // [cap][2] compacted keypoints
   __shared__ int off[512];
+  __shared__ uint16_t poff[512];
+  __shared__ uint32_t patch_lds[kThreads / 64][kPatchRows * kPatchStride / 4];
   __shared__ int wave_off[5];
-  __shared__ int s_running;
+  __shared__ int s_running, s_R;
   const int tid = threadIdx.x, p = blockIdx.x, lane = tid & 63, wid = tid >> 6;
   const int img = p / nmask;
   const int n = min(n_io[p], cap);
-  if (tid == 0) s_running = 0;
+  if (tid == 0) {
+    s_running = 0;
+    s_R = 0;
+  }
+  __syncthreads();
   for (int i = tid; i < 512; i += kThreads) {
     const float px = (float)pattern[2 * i], py = (float)pattern[2 * i + 1];
     const float xr = (px * cos_a) - (py * sin_a), yr = (px * sin_a) + (py * cos_a);
-    off[i] = __float2int_rn(yr) * cols + __float2int_rn(xr);
+    const int dx = __float2int_rn(xr), dy = __float2int_rn(yr);
+    off[i] = dy * cols + dx;
+    atomicMax(&s_R, max(abs(dx), abs(dy)));
   }
   __syncthreads();
+  const int R = s_R;
+  // Patch path: the (2R+1)^2 neighbourhood of a keypoint goes through LDS (rows of 64 bytes), fetched as
+  // unaligned dwords -- ~40 row segments per keypoint instead of 512 scattered byte loads.  The dword
+  // overrun past a patch row (<= 3 bytes) stays inside the image as long as the border rule keeps R + 1 px.
+  const bool patch_ok = R <= kPatchMaxR && edge >= R + 1;
+  if (patch_ok)
+    for (int i = tid; i < 512; i += kThreads) {
+      const int dy = (off[i] + R * cols + R) / cols - R;  // recover (dx, dy): |dx| <= R < cols
+      const int dx = off[i] - dy * cols;
+      poff[i] = (uint16_t)((dy + R) * kPatchStride + (dx + R));
+    }
   for (int i0 = 0; i0 < n; i0 += kThreads) {
     const int i = i0 + tid;
     float x = 0.f, y = 0.f;
@@ -450,6 +472,41 @@ __global__ __launch_bounds__(kThreads) void orb_describe_kernel(const uint8_t* _
   for (int i = tid; i < 2 * m; i += kThreads) kp[(size_t)p * cap * 2 + i] = lds_kp[i];
   if (tid == 0) n_io[p] = m;
   const uint8_t* im = blurred + (size_t)img * rows * cols;
+  if (patch_ok) {
+    uint32_t* patch32 = patch_lds[wid];
+    const uint8_t* patch = reinterpret_cast<const uint8_t*>(patch32);
+    const int prow = lane >> 4, pk = lane & 15;  // 16 lanes (dwords) per patch row, 4 rows per round
+    const int PR = 2 * R + 1, nit = (PR + 3) >> 2;
+    const bool ld_lane = 4 * pk < PR;
+    uint32_t reg[kPatchRows / 4];
+    auto issue = [&](int j) {
+      const uint8_t* base =
+          im + ((size_t)__float2int_rn(lds_kp[2 * j + 1]) - R) * cols + (__float2int_rn(lds_kp[2 * j]) - R) + 4 * pk;
+#pragma unroll
+      for (int it = 0; it < kPatchRows / 4; ++it) {
+        const int r = 4 * it + prow;
+        if (it < nit && ld_lane && r < PR) reg[it] = *reinterpret_cast<const u32_unaligned*>(base + (size_t)r * cols);
+      }
+    };
+    int j = wid;
+    if (j < m) issue(j);
+    for (; j < m; j += kThreads / 64) {
+#pragma unroll
+      for (int it = 0; it < kPatchRows / 4; ++it) {
+        const int r = 4 * it + prow;
+        if (it < nit && ld_lane && r < PR) patch32[r * (kPatchStride / 4) + pk] = reg[it];
+      }
+      if (j + kThreads / 64 < m) issue(j + kThreads / 64);  // next keypoint's rows fly while this one is tested
+      unsigned long long* d = reinterpret_cast<unsigned long long*>(desc + ((size_t)p * cap + j) * 32);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = 64 * r + lane;
+        const unsigned long long bal = __ballot(patch[poff[2 * t]] < patch[poff[2 * t + 1]]);
+        if (lane == 0) d[r] = bal;
+      }
+    }
+    return;
+  }
   for (int j = wid; j < m; j += kThreads / 64) {
     const uint8_t* c = im + (size_t)__float2int_rn(lds_kp[2 * j + 1]) * cols + __float2int_rn(lds_kp[2 * j]);
     unsigned long long* d = reinterpret_cast<unsigned long long*>(desc + ((size_t)p * cap + j) * 32);
@@ -460,6 +517,16 @@ __global__ __launch_bounds__(kThreads) void orb_describe_kernel(const uint8_t* _
       if (lane == 0) d[r] = bal;
     }
   }
+}
+
+// Row chunks of the rolling kernels: enough waves to fill 1024 SIMDs several times over, chunks of >= 24 rows
+// (6 halo rows each).
+static void rolling_chunks(int nimg, int rows, int strips, int* nchunks, int* chunk_rows) {
+  int nc = cdiv(16384, nimg * strips);
+  if (nc > rows / 24) nc = rows / 24;
+  if (nc < 1) nc = 1;
+  *chunk_rows = cdiv(rows, nc);
+  *nchunks = cdiv(rows, *chunk_rows);
 }
 
 }  // namespace
@@ -484,7 +551,9 @@ int32_t sosvo_detect_gft(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* ma
     off += (bytes + 255) & ~(size_t)255;
     return o;
   };
-  const int strips = cdiv(cols, kEigStripW), nchunks = cdiv(rows, kEigChunkRows);
+  const int strips = cdiv(cols, kEigStripW);
+  int nchunks, chunk_rows;
+  rolling_chunks(nimg, rows, strips, &nchunks, &chunk_rows);
   const size_t o_eig = carve(sizeof(float) * (size_t)nimg * rows * cols);
   const size_t o_flags = carve(sizeof(unsigned long long) * (size_t)nimg * rows * strips);
   const size_t o_stat = carve(sizeof(uint32_t) * P * 5);
@@ -504,7 +573,7 @@ int32_t sosvo_detect_gft(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* ma
   SOSVO_LAUNCH_CHECK(ctx);
   const int waves = nimg * strips * nchunks;
   SOSVO_LAUNCH(ctx, min_eigen_kernel, dim3(cdiv(waves, kThreads / 64)), dim3(kThreads), 0, ctx->stream, gray, mask_bits, nimg,
-               images_per_maskset, rows, cols, nmask, strips, nchunks, eig, flags, mstat);
+               images_per_maskset, rows, cols, nmask, strips, nchunks, chunk_rows, eig, flags, mstat);
   SOSVO_LAUNCH_CHECK(ctx);
   const int cell = min_distance >= 1 ? (int)lrint(min_distance) : 1;
   SOSVO_LAUNCH(ctx, gft_select_kernel, dim3((unsigned)P), dim3(kThreads), 0, ctx->stream, eig, flags, strips, mask_bits,
@@ -529,9 +598,14 @@ int32_t sosvo_describe_orb(sosvo_ctx* ctx, const uint8_t* gray, int32_t nimg, in
   int32_t rc = sosvo_ws_reserve(ctx, bytes);
   if (rc != SOSVO_OK) return rc;
   uint8_t* blurred = (uint8_t*)ctx->ws;
-  SOSVO_LAUNCH(ctx, gauss7_kernel, dim3(cdiv(cols, kBlurTW), cdiv(rows, kBlurTH), nimg), dim3(kThreads), 0, ctx->stream,
-               gray, rows, cols, blurred);
-  SOSVO_LAUNCH_CHECK(ctx);
+  {
+    const int strips = cdiv(cols, kEigStripW);
+    int nchunks, chunk_rows;
+    rolling_chunks(nimg, rows, strips, &nchunks, &chunk_rows);
+    SOSVO_LAUNCH(ctx, gauss7_kernel, dim3(cdiv(nimg * strips * nchunks, kThreads / 64)), dim3(kThreads), 0, ctx->stream, gray,
+                 nimg, rows, cols, strips, nchunks, chunk_rows, blurred);
+    SOSVO_LAUNCH_CHECK(ctx);
+  }
   SOSVO_LAUNCH(ctx, orb_describe_kernel, dim3((unsigned)((size_t)nimg * nmask)), dim3(kThreads),
                (size_t)cap * 2 * sizeof(float), ctx->stream, blurred, rows, cols, nmask, cap, kp, n, cos_a, sin_a, pattern,
                edge, desc);

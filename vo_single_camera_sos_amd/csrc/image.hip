@@ -100,8 +100,15 @@ __global__ __launch_bounds__(kThreads) void unwrap_lut_kernel(const uint8_t* __r
                                                               int npix, uint8_t* __restrict__ pano) {
   __shared__ uint32_t stage[kThreads * 3 / 4];
   const int tid = threadIdx.x;
-  const int pix = blockIdx.x * kThreads + tid;
-  const int img = blockIdx.y;
+  // XCD-aware 1-D grid: workgroups are dealt round-robin over the 8 XCDs by linear id, so image = 8 * group +
+  // (id % 8) keeps all blocks of one panorama (its annulus of the omni frame, its half of the table) on ONE
+  // XCD's L2 instead of pulling every frame through all eight.
+  const int gx = (npix + kThreads - 1) / kThreads;
+  const int q = blockIdx.x >> 3;
+  const int grp = q / gx, blk = q - grp * gx;
+  const int img = grp * 8 + (blockIdx.x & 7);
+  if (img >= 2 * nframes) return;  // uniform
+  const int pix = blk * kThreads + tid;
   const int view = img / nframes, frame = img - view * nframes;
   const uint8_t* src = omni + (size_t)frame * H * W * 3;
   const size_t npx_src = (size_t)H * W;
@@ -141,8 +148,8 @@ __global__ __launch_bounds__(kThreads) void unwrap_lut_kernel(const uint8_t* __r
     }
   }
   const uint32_t b0 = (uint32_t)((acc0 + 512) >> 10), b1 = (uint32_t)((acc1 + 512) >> 10), b2 = (uint32_t)((acc2 + 512) >> 10);
-  const size_t out0 = ((size_t)img * npix + (size_t)blockIdx.x * kThreads) * 3;  // first output byte of this workgroup
-  const int nvalid = min(kThreads, npix - blockIdx.x * kThreads);
+  const size_t out0 = ((size_t)img * npix + (size_t)blk * kThreads) * 3;  // first output byte of this workgroup
+  const int nvalid = min(kThreads, npix - blk * kThreads);
   if ((out0 & 3) == 0 && nvalid == kThreads) {
     uint8_t* sb = reinterpret_cast<uint8_t*>(stage);
     sb[3 * tid + 0] = (uint8_t)b0;
@@ -293,7 +300,7 @@ int32_t sosvo_unwrap_table(sosvo_ctx* ctx, const uint8_t* omni, const uint32_t* 
                 "image sizes out of range");
   SOSVO_REQUIRE(ctx, ((uintptr_t)table & 7) == 0 && ((uintptr_t)pano & 3) == 0, "table / pano alignment");
   if (nframes == 0) return SOSVO_OK;
-  SOSVO_LAUNCH(ctx, unwrap_lut_kernel, dim3(cdiv(rows * cols, kThreads), 2 * nframes), dim3(kThreads), 0,
+  SOSVO_LAUNCH(ctx, unwrap_lut_kernel, dim3((unsigned)(cdiv(rows * cols, kThreads) * 8 * cdiv(2 * nframes, 8))), dim3(kThreads), 0,
                ctx->stream, omni, reinterpret_cast<const uint2*>(table), nframes, H, W, rows * cols, pano);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
