@@ -1,0 +1,121 @@
+// Micro-benchmark: issue cost (cycles per wave-instruction per SIMD) of the integer VALU ops the median /
+// matching kernels are made of, at 1, 2 and 4 waves per SIMD.  Build: hipcc --offload-arch=gfx950 -O3 -o valu_rate valu_rate.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+
+#define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+
+template <int OP>
+__global__ __launch_bounds__(256) void k(uint32_t* out, int iters, uint32_t seed) {
+  uint32_t a[8], b = seed ^ threadIdx.x, c = seed * 3u + 1u;
+  for (int i = 0; i < 8; ++i) a[i] = seed + i * 977u + threadIdx.x;
+  unsigned long long bal = 0;
+  asm volatile("v_cmp_gt_u32 vcc, %0, %1" ::"v"(b), "v"(c) : "vcc");
+  unsigned long long bal2 = 0x123456789abcdefULL + seed;
+  double d[8] = {1, 2, 3, 4, 5, 6, 7, 8}, dd = 1.0000001;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#define STEP(i)                                                                                              \
+  if (OP == 0) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                   \
+  if (OP == 1) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b));                              \
+  if (OP == 2) asm volatile("v_alignbit_b32 %0, %0, %1, 11" : "+v"(a[i]) : "v"(b));                          \
+  if (OP == 3) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : );                      \
+  if (OP == 19) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "s"(bal2));           \
+  if (OP == 20) a[i] = (b > a[i]) ? (a[i] ^ c) : a[i] + 1;                                                    \
+  if (OP == 21) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(a[i]) : "v"(b), "v"(c));                      \
+  if (OP == 22) asm volatile("v_xad_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));                      \
+  if (OP == 23) asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));                      \
+  if (OP == 24) asm volatile("v_lshrrev_b32 %0, 11, %0" : "+v"(a[i]) : );                                    \
+  if (OP == 25) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                  \
+  if (OP == 26) asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b));                               \
+  if (OP == 27) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                  \
+  if (OP == 28) asm volatile("v_max3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));                     \
+  if (OP == 29) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                  \
+  if (OP == 30) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a[i]) : "v"(b));                              \
+  if (OP == 31) asm volatile("v_sad_u8 %0, %0, %1, %0" : "+v"(a[i]) : "v"(b));                               \
+  if (OP == 4) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                   \
+  if (OP == 5) asm volatile("v_lshrrev_b64 %0, %1, %2" : "=v"(bal) : "v"(a[i] & 63), "s"(bal2));             \
+  if (OP == 6) asm volatile("v_cmp_ne_u32 %0, %1, %2" : "=s"(bal) : "v"(a[i]), "v"(b));                      \
+  if (OP == 7) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                   \
+  if (OP == 8) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[i]) : "v"(b));                               \
+  if (OP == 9) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                \
+  if (OP == 10) asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(a[i]) : "v"(b));                          \
+  if (OP == 11) asm volatile("v_bfe_u32 %0, %0, %1, 11" : "+v"(a[i]) : "v"(b));                              \
+  if (OP == 12) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                  \
+  if (OP == 13) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[i]) : "v"(dd));                                 \
+  if (OP == 14) asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(d[i]) : "v"(dd));                             \
+  if (OP == 15) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d[i]) : "v"(dd));                                 \
+  if (OP == 16) asm volatile("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "=v"(a[i]) : "v"(b)); \
+  if (OP == 17) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(a[i]) : "v"(b));                           \
+  if (OP == 18) asm volatile("v_and_or_b32 %0, %0, %1, %0" : "+v"(a[i]) : "v"(b));
+      REP8(STEP)
+    }
+  }
+  uint32_t r = (uint32_t)bal;
+  for (int i = 0; i < 8; ++i) r ^= (uint32_t)d[i];
+  for (int i = 0; i < 8; ++i) r ^= a[i];
+  if (r == 0xDEADBEEF) out[threadIdx.x] = r + c;
+}
+
+template <int OP>
+void run(const char* name, uint32_t* out) {
+  const int iters = 20000;
+  for (int wps : {4}) {
+    const int blocks = 256 * wps;  // 4 waves per block -> wps waves per SIMD when one block lands per CU slot
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, 100, 7u);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, iters, 7u);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double instr_per_simd = (double)iters * 32 * wps;
+    printf("%-18s waves/SIMD %d: %.3f ms, %.2f ns per wave-instr per SIMD (= %.2f cyc at 2.4 GHz)\n", name, wps, ms,
+           ms * 1e6 / instr_per_simd, ms * 1e6 / instr_per_simd * 2.4);
+  }
+}
+
+int main() {
+  uint32_t* out;
+  hipMalloc(&out, 4096);
+  run<0>("v_and_b32", out);
+  run<1>("v_bcnt_u32_b32", out);
+  run<2>("v_alignbit_b32", out);
+  run<3>("v_cndmask_b32", out);
+  run<4>("v_xor_b32", out);
+  run<5>("v_lshrrev_b64", out);
+  run<6>("v_cmp_ne_u32 sgpr", out);
+  run<7>("v_add_f32", out);
+  run<8>("v_fma_f32", out);
+  run<9>("v_mul_lo_u32", out);
+  run<10>("v_mad_u32_u24", out);
+  run<11>("v_bfe_u32", out);
+  run<12>("v_add_u32", out);
+  run<13>("v_add_f64", out);
+  run<14>("v_fma_f64", out);
+  run<15>("v_mul_f64", out);
+  run<16>("v_mov_dpp wave_shr", out);
+  run<17>("v_lshl_or_b32", out);
+  run<18>("v_and_or_b32", out);
+  run<19>("v_cndmask e64 sgpr", out);
+  run<20>("c++ select", out);
+  run<21>("v_bfi_b32", out);
+  run<22>("v_xad_u32", out);
+  run<23>("v_or3_b32", out);
+  run<24>("v_lshrrev_b32", out);
+  run<25>("v_min_u32", out);
+  run<26>("v_pk_min_u16", out);
+  run<27>("v_sub_u32", out);
+  run<28>("v_max3_u32", out);
+  run<29>("v_mul_f32", out);
+  run<30>("v_mul_u32_u24", out);
+  run<31>("v_sad_u8", out);
+  return 0;
+}

@@ -229,53 +229,84 @@ __global__ __launch_bounds__(kThreads) void gft_select_kernel(const float* __res
     for (int i = tid; i < ns * bh; i += kThreads) {
       const int ry = i / ns, sidx = s0 + (i - ry * ns);
       const int y = by0 + ry;
+      const int xbase = sidx * kEigStripW - kEigHalo;  // column of bit 0
       unsigned long long w = fl[(size_t)y * strips + sidx];
+      {  // keep the bits whose column lies inside [bx0, bx1]
+        const int l_lo = max(0, bx0 - xbase), l_hi = min(63, bx1 - xbase);
+        w = l_hi >= l_lo ? (w >> l_lo << l_lo) & (~0ULL >> (63 - l_hi)) : 0ULL;
+      }
+      const int rowpix = y * cols + xbase;
       while (w) {
-        const int l = __ffsll((long long)w) - 1;
-        w &= w - 1ULL;
-        const int x = sidx * kEigStripW - kEigHalo + l;
-        if (x < bx0 || x > bx1) continue;
-        const int pix = y * cols + x;
-        if (!((mb[pix] >> m) & 1u)) continue;
-        const float c = e[pix];
-        const float v = c > thr ? c : 0.0f;
-        if (v == 0.0f) continue;
-        if (v < 0.0f) {
-          // negative response above a negative threshold (all-negative mask): the thresholded neighbours
-          // (zeros) matter, evaluate the dilation as written
-          float dil = v;
+        // four flagged pixels per round: their mask and response loads are issued together
+        int l[4];
+        bool ok[4];
+        uint32_t mbv[4];
+        float ev[4];
 #pragma unroll
-          for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-              const float q = e[pix + dy * cols + dx];
-              const float t = q > thr ? q : 0.0f;
-              dil = t > dil ? t : dil;
-            }
-          if (v != dil) continue;
+        for (int q = 0; q < 4; ++q) {
+          ok[q] = w != 0ULL;
+          l[q] = ok[q] ? __ffsll((long long)w) - 1 : (q ? l[q - 1] : 0);
+          w &= w - 1ULL;  // 0 stays 0
         }
-        const int slot = atomicAdd(&s_count, 1);
-        if (slot < kCandCap) keys[slot] = ((unsigned long long)sosvo_float_ordered(v) << 32) | (uint32_t)pix;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          mbv[q] = mb[rowpix + l[q]];
+          ev[q] = e[rowpix + l[q]];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (!ok[q] || !((mbv[q] >> m) & 1u)) continue;
+          const int pix = rowpix + l[q];
+          const float c = ev[q];
+          const float v = c > thr ? c : 0.0f;
+          if (v == 0.0f) continue;
+          if (v < 0.0f) {
+            // negative response above a negative threshold (all-negative mask): the thresholded neighbours
+            // (zeros) matter, evaluate the dilation as written
+            float dil = v;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+              for (int dx = -1; dx <= 1; ++dx) {
+                const float qv = e[pix + dy * cols + dx];
+                const float t = qv > thr ? qv : 0.0f;
+                dil = t > dil ? t : dil;
+              }
+            if (v != dil) continue;
+          }
+          const int slot = atomicAdd(&s_count, 1);
+          if (slot < kCandCap) keys[slot] = ((unsigned long long)sosvo_float_ordered(v) << 32) | (uint32_t)pix;
+        }
       }
     }
   }
   __syncthreads();
   const int total = s_count;
   const int n = min(total, kCandCap);
-  // ---- phase 2: rank sort (keys are unique) --------------------------------------------------------------
-  const int n2 = (n + 1) & ~1;
-  if (tid == 0 && n2 > n) keys[n] = 0ULL;  // pad: never greater than a real key
+  // ---- phase 2: bitonic sort, descending (keys are unique: value, then higher address first) ---------------
+  int N = 64;
+  while (N < n) N <<= 1;
+  for (int i = n + tid; i < N; i += kThreads) keys[i] = 0ULL;  // padding sorts last
   __syncthreads();
-  for (int i = tid; i < n; i += kThreads) {
-    const unsigned long long mine = keys[i];
-    int rank = 0;
-    const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(keys);
-#pragma unroll 8
-    for (int j = 0; j < n2 / 2; ++j) {
-      const ulonglong2 kk = k2[j];
-      rank += (kk.x > mine) + (kk.y > mine);
+  for (int k = 2; k <= N; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < N / 2; t += kThreads) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), ixj = i | j;
+        const unsigned long long a = keys[i], b = keys[ixj];
+        const bool desc = (i & k) == 0;
+        if ((a < b) == desc) {
+          keys[i] = b;
+          keys[ixj] = a;
+        }
+      }
+      __syncthreads();
     }
-    sorted[rank] = (uint32_t)mine;
+  }
+  // candidates leave as packed (y << 16 | x), in order
+  for (int i = tid; i < n; i += kThreads) {
+    const uint32_t pix = (uint32_t)keys[i];
+    const uint32_t y = pix / (uint32_t)cols;
+    sorted[i] = (y << 16) | (pix - y * (uint32_t)cols);
   }
   int stt = total > kCandCap ? 1 : 0;
   const int cx0 = bx0 / cell, cy0 = by0 / cell;
@@ -286,6 +317,10 @@ __global__ __launch_bounds__(kThreads) void gft_select_kernel(const float* __res
   for (int i = tid; i < (use_grid ? gw * gh * 2 : 0); i += kThreads) grid[i] = 0u;
   __syncthreads();
   // ---- phase 3: greedy minimum-distance pass, first wave ----------------------------------------------------
+  // 64 candidates per round.  Every lane tests its candidate against the points accepted in earlier rounds
+  // (cell grid: 9 cells x 2 slots, packed coordinates + 1).  The survivors are then taken in order: the first
+  // one alive is accepted (wave-uniform), its coordinates are broadcast (v_readlane) and every later survivor
+  // closer than minDistance dies -- exactly the sequential rule, in as many steps as points get accepted.
   if (tid < 64) {
     const float md2 = min_distance * min_distance;
     const int lane = tid;
@@ -300,9 +335,9 @@ __global__ __launch_bounds__(kThreads) void gft_select_kernel(const float* __res
     for (int k0 = 0; k0 < n && accepted < limit; k0 += 64) {
       const int kend = min(64, n - k0);
       const bool active = lane < kend;
-      const int pix = active ? (int)sorted[k0 + lane] : 0;  // one coalesced read per 64 candidates
-      const int y = pix / cols, x = pix - y * cols;
-      bool prior = false;  // conflict with a point accepted in an earlier batch
+      const uint32_t xy = active ? sorted[k0 + lane] : 0u;  // one coalesced read per 64 candidates
+      const int y = (int)(xy >> 16), x = (int)(xy & 0xFFFFu);
+      bool prior = false;  // conflict with a point accepted in an earlier round
       if (active && spaced) {
         if (use_grid) {
           const int xc = x / cell - cx0, yc = y / cell - cy0;
@@ -310,45 +345,36 @@ __global__ __launch_bounds__(kThreads) void gft_select_kernel(const float* __res
           for (int c9 = 0; c9 < 9; ++c9) {
             const int xx = xc + (c9 % 3) - 1, yy = yc + (c9 / 3) - 1;
             if (xx < 0 || xx >= gw || yy < 0 || yy >= gh) continue;
+            const uint2 q2 = *reinterpret_cast<const uint2*>(&grid[(yy * gw + xx) * 2]);
 #pragma unroll
             for (int slot = 0; slot < 2; ++slot) {
-              const uint32_t q = grid[(yy * gw + xx) * 2 + slot];
+              const uint32_t q = slot ? q2.y : q2.x;
               if (q) {
-                const int qp = (int)q - 1, qy = qp / cols, qx = qp - qy * cols;
-                const float dx = (float)(x - qx), dy = (float)(y - qy);
+                const float dx = (float)(x - (int)((q - 1u) & 0xFFFFu)), dy = (float)(y - (int)((q - 1u) >> 16));
                 prior = prior || (dx * dx + dy * dy < md2);
               }
             }
           }
         } else {
           for (int a = 0; a < accepted; ++a) {
-            const int qp = (int)acc_list[a], qy = qp / cols, qx = qp - qy * cols;
-            const float dx = (float)(x - qx), dy = (float)(y - qy);
+            const uint32_t q = acc_list[a];
+            const float dx = (float)(x - (int)(q & 0xFFFFu)), dy = (float)(y - (int)(q >> 16));
             prior = prior || (dx * dx + dy * dy < md2);
           }
         }
       }
-      // conflicts with earlier lanes of this batch
-      unsigned long long cm = 0ULL;
-      if (spaced) {
-        for (int j = 0; j < kend; ++j) {  // j is wave-uniform: v_readlane broadcasts through an SGPR
-          const int xj = __builtin_amdgcn_readlane(x, j), yj = __builtin_amdgcn_readlane(y, j);
-          const float dx = (float)(x - xj), dy = (float)(y - yj);
-          if (j < lane && (dx * dx + dy * dy < md2)) cm |= 1ULL << j;
-        }
-      }
-      const unsigned long long okmask = __ballot(active && !prior);
-      // replay of the sequential rule over the batch (wave-uniform)
+      unsigned long long alive = __ballot(active && !prior);
       unsigned long long acc = 0ULL;
       int room = limit - accepted;
-      const uint32_t cm_lo = (uint32_t)cm, cm_hi = (uint32_t)(cm >> 32);
-      for (unsigned long long todo = okmask; todo && room > 0; todo &= todo - 1ULL) {
-        const int j = __ffsll((long long)todo) - 1;
-        const unsigned long long cmj = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)cm_hi, j) << 32) |
-                                       (uint32_t)__builtin_amdgcn_readlane((int)cm_lo, j);
-        if ((cmj & acc) == 0ULL) {
-          acc |= 1ULL << j;
-          room--;
+      while (alive && room > 0) {
+        const int j = __ffsll((long long)alive) - 1;
+        alive &= alive - 1ULL;
+        acc |= 1ULL << j;
+        room--;
+        if (spaced) {
+          const int xj = __builtin_amdgcn_readlane(x, j), yj = __builtin_amdgcn_readlane(y, j);
+          const float dx = (float)(x - xj), dy = (float)(y - yj);
+          alive &= ~__ballot(dx * dx + dy * dy < md2);
         }
       }
       if ((acc >> lane) & 1ULL) {
@@ -358,9 +384,9 @@ __global__ __launch_bounds__(kThreads) void gft_select_kernel(const float* __res
         if (spaced) {
           if (use_grid) {
             uint32_t* c = &grid[((y / cell - cy0) * gw + (x / cell - cx0)) * 2];
-            if (atomicCAS(&c[0], 0u, (uint32_t)pix + 1u) != 0u) c[1] = (uint32_t)pix + 1u;
+            if (atomicCAS(&c[0], 0u, xy + 1u) != 0u) c[1] = xy + 1u;
           } else {
-            acc_list[pos] = (uint32_t)pix;
+            acc_list[pos] = xy;
           }
         }
       }
