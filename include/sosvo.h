@@ -243,6 +243,9 @@ int32_t sosvo_refine_abs_pose(sosvo_ctx* ctx, const double* f, const double* p, 
  * sosvo_triangulate_midpoint: OmniStereoModel.get_triangulated_point_from_direction_angles
  *   (camera_models.py:3323, use_midpoint_triangulation=True) -> get_triangulated_midpoint (:2420)
  *   -> triangulate_for_skew_rays (:2481).  F_top_host / F_bot_host: HOST pointers to 3 doubles.
+ * sosvo_triangulate2: pyopengv.triangulation_triangulate2(b1, b2, t12, R12) (pose_est_tools.py:359, :163):
+ *   OpenGV's closed-form midpoint, g = R12 b2, [[b1.b1, -b1.g], [b1.g, -g.g]] lambda = (t12.b1, t12.g),
+ *   X = (lambda0 b1 + t12 + lambda1 g) / 2 in frame 1.  b1, b2, X [n,3] device; t12 (3), R12 (9, row-major) HOST.
  * sosvo_range_filter: filter_panoramic_points_due_to_range (camera_models.py:3299) as called with
  *   homogeneous rows at pose_est_tools.py:372 (norm includes the trailing 1); limit <= 0 disables.
  * sosvo_rgbd_backproject: RGBDCamModel.get_XYZ (camera_models.py:835) + get_depth_Z (:781) at
@@ -253,6 +256,8 @@ int32_t sosvo_pano_to_bearing(sosvo_ctx* ctx, const double* uv, int32_t n, doubl
 int32_t sosvo_triangulate_midpoint(sosvo_ctx* ctx, const double* az_top, const double* el_top,
                                    const double* az_bot, const double* el_bot, int32_t n,
                                    const double* F_top_host, const double* F_bot_host, double* X);
+int32_t sosvo_triangulate2(sosvo_ctx* ctx, const double* b1, const double* b2, int32_t n, const double* t12_host,
+                           const double* R12_host, double* X);
 int32_t sosvo_range_filter(sosvo_ctx* ctx, const double* X, int32_t n, double min_range,
                            double max_range, uint8_t* ok);
 int32_t sosvo_rgbd_backproject(sosvo_ctx* ctx, const float* depth, int32_t rows, int32_t cols,

@@ -191,6 +191,16 @@ def triangulate_midpoint(az1, el1, az2, el2, F1, F2):
     return X
 
 
+def triangulate2(b1, b2, t12, R12):
+    b1 = _c(b1, np.float64).reshape(-1, 3)
+    b2 = _c(b2, np.float64).reshape(-1, 3)
+    t12 = _c(t12, np.float64).reshape(3)
+    R12 = _c(R12, np.float64).reshape(9)
+    X = np.empty_like(b1)
+    lib().orc_triangulate2(_p(b1), _p(b2), ctypes.c_int32(b1.shape[0]), _p(t12), _p(R12), _p(X))
+    return X
+
+
 def range_filter_homo(X, min_range, max_range):
     X = _c(X, np.float64).reshape(-1, 3)
     ok = np.empty(X.shape[0], dtype=np.uint8)

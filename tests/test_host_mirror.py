@@ -67,3 +67,75 @@ def test_annulus_masks_and_bucket_columns():
     assert pn.get_panorama_col_from_azimuth(0.0) == 1199
     assert pn.get_panorama_col_from_azimuth(np.pi) == 599
     assert pn.get_panorama_col_from_azimuth(2 * np.pi - 1e-9) in (0, 1)
+
+
+# ---- the per-frame API mirrors (camera_models / common_cv / pose_est_tools / pyopengv) ---------------------
+def test_filter_pixel_correspondences_matches_reference_gates():
+    from vo_single_camera_sos_amd.omnistereo.common_cv import filter_pixel_correspondences
+    m_top, m_bot = G["m_top"], G["m_bot"]
+    st = filter_pixel_correspondences(matched_points_top=m_top[:, :2], matched_points_bot=m_bot[:, :2],
+                                      min_rectified_disparity=1, max_horizontal_diff=2.5)
+    ff = filter_pixel_correspondences(matched_points_top=m_top[:, :2], matched_points_bot=m_bot[:, :2],
+                                      min_rectified_disparity=-1, max_horizontal_diff=1.25)
+    assert np.array_equal(st, G["gate_stereo"]) and np.array_equal(ff, G["gate_f2f"])
+    none = filter_pixel_correspondences(m_top[:, :2], m_bot[:, :2], -1, -1)
+    assert none.all() and none.shape == (m_top.shape[0],)
+
+
+def test_tracker_parameters_and_score_definition():
+    from vo_single_camera_sos_amd.omnistereo import pose_est_tools as pet
+    tr = object.__new__(pet.TrackerSE3)
+    assert pet.TrackerSE3.compute_num_of_iterations_RANSAC(tr, 3, 0.65) == int(G["ransac_iters_3_065"][0])
+    assert pet.TrackerSE3.compute_num_of_iterations_RANSAC(tr, 3, 0.90) == int(G["ransac_iters_3_090"][0])
+    t = pet.TrackerSE3(camera_model=None)
+    assert t.backprojection_score_threshold_3D_to_2D == G["thr_5deg"][0]
+    assert t.max_ransac_iterations_3D_to_2D == int(G["ransac_iters_3_065"][0]) and t.detection_method == "GFT"
+    T = np.vstack([G["score_T"], [0, 0, 0, 1]])
+    s = pet.get_selected_distances_to_model(T, np.arange(64), G["score_p"], G["score_f"], False)
+    assert np.allclose(s, G["score_expected"], rtol=0, atol=1e-15)
+    inl, outl = pet.select_inliers_within_distance(T, np.arange(64), G["thr_5deg"][0], G["score_p"], G["score_f"], False)
+    assert np.array_equal(inl, np.flatnonzero(G["score_expected"] < G["thr_5deg"][0])) and len(inl) + len(outl) == 64
+    assert pet.get_length_units_conversion_factor("mm", "m") == 0.001
+    assert pet.get_length_units_conversion_factor("m", "mm") == 1000.0 and pet.get_length_units_conversion_factor("m", "m") == 1.0
+
+
+def test_correspondence_containers():
+    from vo_single_camera_sos_amd.omnistereo.camera_models import (KeyPoint, KeyPointAndDescriptor, PanoramicCorrespondences,
+                                                                   MatchList, keypoints_to_array)
+    kl = [[KeyPoint(1.5, 2.0), KeyPoint(3.0, 4.0)], [], [KeyPoint(5.0, 6.5)]]
+    dl = [np.full((2, 32), 7, np.uint8), None, np.full((1, 32), 9, np.uint8)]
+    kd = KeyPointAndDescriptor(kl, dl, do_flattening=True)
+    assert len(kd.keypoints) == 3 and kd.descriptors.shape == (3, 32) and kd.pixel_coords.shape == (1, 3, 3)
+    assert np.array_equal(kd.pixel_coords[0, :, :2], [[1.5, 2.0], [3.0, 4.0], [5.0, 6.5]]) and np.all(kd.pixel_coords[0, :, 2] == 1)
+    assert kd.random_colors_RGB.shape == (3, 3) and kd.random_colors_RGB.dtype == np.uint8
+    pc = PanoramicCorrespondences(kl, dl, kl, dl, points_3D=np.arange(9.0).reshape(3, 3), do_flattening=True)
+    assert pc.m_top.shape == (3, 3) and np.all(pc.m_top[:, 2] == 1) and pc.desc_bot.shape == (3, 32)
+    assert pc.points_3D_coords_homo.shape == (3, 4) and np.all(pc.points_3D_coords_homo[:, 3] == 1)
+    empty = PanoramicCorrespondences([], [], [], [], points_3D=np.empty((0, 3)))
+    assert empty.m_top.shape == (0, 3) and empty.points_3D_coords_homo.shape == (0, 4)
+    assert keypoints_to_array([]).shape == (0, 2)
+    ml = MatchList([2, 0], [5, 1], [3.0, 8.0])
+    assert [m.queryIdx for m in ml] == [2, 0] and ml[1].trainIdx == 1 and ml[0].distance == 3.0 and len(ml) == 2
+
+
+def test_matcher_and_pyopengv_mirror_fail_loudly_without_gpu():
+    import pytest
+    import torch
+    from vo_single_camera_sos_amd import pyopengv
+    from vo_single_camera_sos_amd._lib import SosvoError
+    from vo_single_camera_sos_amd.omnistereo.camera_models import FeatureMatcher
+    with pytest.raises(NotImplementedError):
+        FeatureMatcher("ORB", "FLANN", 1)
+    fm = FeatureMatcher("GFT", "BF", 1, percentage_good_matches=0.5, num_of_features=77)
+    assert fm.percentage_good_matches == 0.5 and fm.num_of_features == 77 and fm.use_radius_match is False
+    with pytest.raises(NotImplementedError):
+        pyopengv.absolute_pose_ransac(np.zeros((8, 3)), np.zeros((8, 3)), "TWOPT", 0.01, 10)
+    if torch.cuda.is_available():
+        return
+    d = np.zeros((4, 32), np.uint8)
+    with pytest.raises(SosvoError):  # no CPU fallback behind the reference's API
+        fm.match(d, d)
+    with pytest.raises(SosvoError):
+        pyopengv.absolute_pose_ransac(np.eye(3).repeat(3, 0), np.ones((9, 3)), "KNEIP", 0.01, 10)
+    with pytest.raises(SosvoError):
+        pyopengv.triangulation_triangulate2(np.ones((2, 3)), np.ones((2, 3)), np.zeros(3), np.eye(3))

@@ -61,6 +61,7 @@ SIGNATURES = {
     "sosvo_sort_matches": (c_i32, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_p]),
     "sosvo_pano_to_bearing": (c_i32, [c_p, c_p, c_i32, c_f64, c_f64, c_f64, c_f64, c_p, c_p, c_p]),
     "sosvo_triangulate_midpoint": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_i32, c_p, c_p, c_p]),
+    "sosvo_triangulate2": (c_i32, [c_p, c_p, c_p, c_i32, c_p, c_p, c_p]),
     "sosvo_range_filter": (c_i32, [c_p, c_p, c_i32, c_f64, c_f64, c_p]),
     "sosvo_rgbd_backproject": (c_i32, [c_p, c_p, c_i32, c_i32, c_p, c_p, c_i32, c_f64, c_f64, c_f64, c_f64, c_f64,
                                        c_i32, c_p, c_p]),

@@ -51,6 +51,20 @@ __device__ __forceinline__ static void sv_triangulate(double az1, double el1, do
   }
 }
 
+// OpenGV triangulation::triangulate2 (closed-form midpoint in frame 1); 2x2 system by Cramer's rule.
+__device__ __forceinline__ static void sv_triangulate2(const double* f1, const double* f2, const double* t, const double* R,
+                                                        double* X) {
+  const double g[3] = {R[0] * f2[0] + R[1] * f2[1] + R[2] * f2[2], R[3] * f2[0] + R[4] * f2[1] + R[5] * f2[2],
+                       R[6] * f2[0] + R[7] * f2[1] + R[8] * f2[2]};
+  const double b0 = t[0] * f1[0] + t[1] * f1[1] + t[2] * f1[2], b1 = t[0] * g[0] + t[1] * g[1] + t[2] * g[2];
+  const double a00 = f1[0] * f1[0] + f1[1] * f1[1] + f1[2] * f1[2], a10 = f1[0] * g[0] + f1[1] * g[1] + f1[2] * g[2];
+  const double a01 = -a10, a11 = -(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+  const double det = a00 * a11 - a01 * a10;
+  const double l0 = (b0 * a11 - a01 * b1) / det, l1 = (a00 * b1 - a10 * b0) / det;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) X[k] = ((l0 * f1[k]) + (t[k] + l1 * g[k])) / 2.0;
+}
+
 __device__ __forceinline__ static bool sv_range_ok(const double* X, double min_range, double max_range) {
   const double nrm = sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2] + 1.0);
   bool good = true;

@@ -49,6 +49,22 @@ __global__ void triangulate_kernel(const double* __restrict__ az1, const double*
   X[3 * i + 2] = x[2];
 }
 
+struct Rt12 {
+  double t[3], R[9];
+};
+
+__global__ void triangulate2_kernel(const double* __restrict__ b1, const double* __restrict__ b2, int n, Rt12 rt,
+                                    double* __restrict__ X) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double f1[3] = {b1[3 * i], b1[3 * i + 1], b1[3 * i + 2]}, f2[3] = {b2[3 * i], b2[3 * i + 1], b2[3 * i + 2]};
+  double x[3];
+  sv_triangulate2(f1, f2, rt.t, rt.R, x);
+  X[3 * i] = x[0];
+  X[3 * i + 1] = x[1];
+  X[3 * i + 2] = x[2];
+}
+
 __global__ void range_filter_kernel(const double* __restrict__ X, int n, double min_range, double max_range,
                                     uint8_t* __restrict__ ok) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -257,6 +273,19 @@ int32_t sosvo_triangulate_midpoint(sosvo_ctx* ctx, const double* az_top, const d
   }
   SOSVO_LAUNCH(ctx,triangulate_kernel, dim3(cdiv(n, kThreads)), dim3(kThreads), 0, ctx->stream, az_top, el_top, az_bot,
                      el_bot, n, foci, X);
+  SOSVO_LAUNCH_CHECK(ctx);
+  return SOSVO_OK;
+}
+
+int32_t sosvo_triangulate2(sosvo_ctx* ctx, const double* b1, const double* b2, int32_t n, const double* t12_host,
+                           const double* R12_host, double* X) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, b1 && b2 && t12_host && R12_host && X && n >= 0, "bad arguments");
+  if (n == 0) return SOSVO_OK;
+  Rt12 rt;
+  for (int k = 0; k < 3; ++k) rt.t[k] = t12_host[k];
+  for (int k = 0; k < 9; ++k) rt.R[k] = R12_host[k];
+  SOSVO_LAUNCH(ctx, triangulate2_kernel, dim3(cdiv(n, kThreads)), dim3(kThreads), 0, ctx->stream, b1, b2, n, rt, X);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
 }

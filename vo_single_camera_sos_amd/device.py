@@ -401,6 +401,17 @@ class Context(object):
                    ctypes.cast(f1, c_p), ctypes.cast(f2, c_p), _ptr(X))
         return X
 
+    def triangulate2(self, b1, b2, t12, R12):
+        """b1, b2 [n,3] f64 unit bearings in frames 1 / 2, t12 (3), R12 (3x3) host -> X [n,3] in frame 1."""
+        n = b1.shape[0]
+        _check(b1, torch.float64, "b1", (n, 3))
+        _check(b2, torch.float64, "b2", (n, 3))
+        X = torch.empty((n, 3), dtype=torch.float64, device=b1.device)
+        t = (ctypes.c_double * 3)(*[float(v) for v in t12])
+        R = (ctypes.c_double * 9)(*[float(v) for row in R12 for v in row])
+        self._call(self._lib.sosvo_triangulate2, _ptr(b1), _ptr(b2), n, ctypes.cast(t, c_p), ctypes.cast(R, c_p), _ptr(X))
+        return X
+
     def range_filter(self, X, min_range, max_range):
         _check(X, torch.float64, "X", (None, 3))
         ok = torch.empty((X.shape[0],), dtype=torch.uint8, device=X.device)

@@ -1,0 +1,219 @@
+"""Host-side mirror of the hot-path types of omnistereo/camera_models.py: same names, arguments and return
+structure, the arithmetic behind them on the GPU through libsosvo's C ABI.
+
+    KeyPointAndDescriptor      camera_models.py:250-289
+    PanoramicCorrespondences   camera_models.py:291-362
+    FeatureMatcher             camera_models.py:364-446  (cv2.BFMatcher(NORM_HAMMING) -> sosvo_match_hamming +
+                                                          sosvo_sort_matches)
+
+cv2 is not a dependency here, so the two cv2 value types the reference passes around are small Python classes
+with the same attribute names: KeyPoint (.pt .size .angle .response .octave .class_id) and DMatch (.queryIdx
+.trainIdx .imgIdx .distance).  There is no CPU fallback: FeatureMatcher.match needs the GPU library."""
+import numpy as np
+
+
+class KeyPoint(object):
+    """cv2.KeyPoint's attribute set."""
+    __slots__ = ("pt", "size", "angle", "response", "octave", "class_id")
+
+    def __init__(self, x, y, size=31.0, angle=-1.0, response=0.0, octave=0, class_id=-1):
+        self.pt = (float(x), float(y))
+        self.size, self.angle, self.response = float(size), float(angle), float(response)
+        self.octave, self.class_id = int(octave), int(class_id)
+
+    def __repr__(self):
+        return "KeyPoint(%.1f, %.1f)" % self.pt
+
+
+class DMatch(object):
+    """cv2.DMatch's attribute set."""
+    __slots__ = ("queryIdx", "trainIdx", "imgIdx", "distance")
+
+    def __init__(self, queryIdx, trainIdx, distance, imgIdx=0):
+        self.queryIdx, self.trainIdx, self.imgIdx = int(queryIdx), int(trainIdx), int(imgIdx)
+        self.distance = float(distance)
+
+    def __repr__(self):
+        return "DMatch(q=%d, t=%d, d=%g)" % (self.queryIdx, self.trainIdx, self.distance)
+
+
+class MatchList(list):
+    """What FeatureMatcher.match returns: a list of DMatch (so reference-style loops work) that also carries
+    the same information as arrays (.query_idx, .train_idx, .distances) for vectorised callers."""
+
+    def __init__(self, query_idx, train_idx, distances):
+        self.query_idx = np.asarray(query_idx, dtype=np.int64)
+        self.train_idx = np.asarray(train_idx, dtype=np.int64)
+        self.distances = np.asarray(distances, dtype=np.float32)
+        list.__init__(self, [DMatch(q, t, d) for q, t, d in zip(self.query_idx, self.train_idx, self.distances)])
+
+
+def keypoints_to_array(kpts):
+    """cv2.KeyPoint_convert(kpts): [n,2] float32 of .pt."""
+    if len(kpts) == 0:
+        return np.empty((0, 2), dtype=np.float32)
+    return np.array([k.pt for k in kpts], dtype=np.float32)
+
+
+def _flatten(list_of_lists):
+    out = []
+    for item in list_of_lists:
+        if item is None:
+            continue
+        out.extend(item)
+    return out
+
+
+class KeyPointAndDescriptor(object):
+    """camera_models.py:250-289."""
+
+    def __init__(self, kpts_list, desc_list, coords_array=None, random_colors_RGB_list=[], do_flattening=False, **kwargs):
+        if do_flattening:
+            self.keypoints = _flatten(kpts_list)
+            self.descriptors = np.array(_flatten(desc_list))
+        else:
+            self.keypoints = kpts_list
+            self.descriptors = desc_list
+        n = len(self.keypoints)
+        if coords_array is None or len(coords_array) == 0:
+            self.pixel_coords = np.ones((1, n, 3))
+            if n:
+                self.pixel_coords[0, :, :2] = keypoints_to_array(self.keypoints)
+        else:
+            self.pixel_coords = coords_array
+        if random_colors_RGB_list is None or len(random_colors_RGB_list) < n:
+            self.random_colors_RGB = np.random.randint(low=0, high=256, size=(n, 3), dtype="uint8")
+        else:
+            self.random_colors_RGB = random_colors_RGB_list
+
+
+class PanoramicCorrespondences(object):
+    """camera_models.py:291-362: the per-frame container between frame set-up and tracking."""
+
+    def __init__(self, kpts_top_list, desc_top_list, kpts_bot_list, desc_bot_list, points_3D=None, m_top_array=None,
+                 m_bot_array=None, random_colors_RGB_list=[], do_flattening=False, **kwargs):
+        if do_flattening:
+            self.kpts_top, self.kpts_bot = _flatten(kpts_top_list), _flatten(kpts_bot_list)
+            self.desc_top, self.desc_bot = np.array(_flatten(desc_top_list)), np.array(_flatten(desc_bot_list))
+        else:
+            self.kpts_top, self.kpts_bot = kpts_top_list, kpts_bot_list
+            self.desc_top, self.desc_bot = desc_top_list, desc_bot_list
+        if points_3D is not None:
+            if len(points_3D) > 0:
+                if points_3D.shape[-1] == 3:
+                    self.points_3D_coords_homo = np.ones((len(points_3D), 4))
+                    self.points_3D_coords_homo[:, :3] = points_3D[:, :3]
+                else:
+                    self.points_3D_coords_homo = points_3D
+            else:
+                self.points_3D_coords_homo = np.empty((0, 4))
+        else:
+            self.points_3D_coords_homo = []
+        self.m_top = self._homogeneous_pixels(self.kpts_top, m_top_array)
+        self.m_bot = self._homogeneous_pixels(self.kpts_bot, m_bot_array)
+        n = max(len(self.kpts_top), len(self.kpts_bot))
+        if random_colors_RGB_list is None or len(random_colors_RGB_list) < n:
+            self.random_colors_RGB = np.random.randint(low=0, high=256, size=(n, 3), dtype="uint8")
+        else:
+            self.random_colors_RGB = random_colors_RGB_list
+
+    @staticmethod
+    def _homogeneous_pixels(kpts, given):
+        if given is not None and len(given) > 0:
+            return given
+        if len(kpts) > 0:
+            m = keypoints_to_array(kpts).astype(np.float64)
+            return np.hstack((m, np.ones_like(m[..., 0, np.newaxis])))
+        return np.empty((0, 3))
+
+
+class FeatureMatcher(object):
+    """camera_models.py:364-446.  Brute-force Hamming matching of 32-byte binary descriptors on the GPU.
+    Built: matcher_type "BF", k_best 1 (the trackers' setting, pose_est_tools.py:686) and 2, the "SIFT"
+    k_best == 2 ratio rule applied to whatever distances the descriptors give.  Not built (raises):
+    "FLANN", float (L2) descriptors, k_best > 2, radius match."""
+
+    def __init__(self, method, matcher_type, k_best, *args, **kwargs):
+        self.feature_detection_method = method
+        self.matcher_type = matcher_type
+        self.k_best = k_best
+        self.FLANN_INDEX_KDTREE = 1
+        self.FLANN_INDEX_LSH = 6
+        self.MIN_MATCH_COUNT = 10
+        self.percentage_good_matches = kwargs.get("percentage_good_matches", 1.0)
+        self.num_of_features = kwargs.get("num_of_features", 100)
+        self.use_radius_match = kwargs.get("use_radius_match", False)
+        if str(matcher_type).upper() != "BF":
+            raise NotImplementedError("matcher_type %r: only the brute-force matcher is built" % matcher_type)
+        self._ctx = kwargs.get("context", None)
+
+    def _context(self):
+        if self._ctx is None:
+            from ..runtime import default_context
+            self._ctx = default_context()
+        return self._ctx
+
+    @staticmethod
+    def _device_desc(ctx, d, name):
+        import torch
+        if isinstance(d, torch.Tensor):
+            t = d
+        else:
+            a = np.asarray(d)
+            if a.dtype != np.uint8:
+                raise NotImplementedError("%s: dtype %s -- only uint8 (binary, Hamming) descriptors are built" % (name, a.dtype))
+            t = torch.from_numpy(np.ascontiguousarray(a))
+        if t.dim() != 2 or t.shape[1] != 32:
+            raise ValueError("%s: expected [n, 32] uint8 descriptors, got %s" % (name, tuple(t.shape)))
+        n = t.shape[0]
+        buf = torch.zeros((1, max(n, 1), 32), dtype=torch.uint8, device=ctx.device)
+        if n:
+            buf[0, :n] = t.to(ctx.device)
+        return buf, n
+
+    def match_arrays(self, query_descriptors, train_descriptors):
+        """-> (query_idx, train_idx, distance) numpy arrays in the order of match()."""
+        import torch
+        if self.use_radius_match:
+            raise NotImplementedError("radius match (camera_models.py:412-415) is not built")
+        if self.k_best > 2:
+            raise NotImplementedError("k_best > 2 is not built")
+        ctx = self._context()
+        dq, nq = self._device_desc(ctx, query_descriptors, "query_descriptors")
+        dt, nt = self._device_desc(ctx, train_descriptors, "train_descriptors")
+        if nq == 0 or nt == 0:
+            return (np.empty(0, np.int64),) * 2 + (np.empty(0, np.float32),)
+        from .._lib import KEY_SHIFT, KEY_IDX_MASK, KEY_NONE
+        dev = ctx.device
+        nq_t = torch.tensor([nq], dtype=torch.int32, device=dev)
+        nt_t = torch.tensor([nt], dtype=torch.int32, device=dev)
+        k = 2 if self.k_best == 2 else 1
+        keys = ctx.match_hamming(dq, dt, nq_t, nt_t, k=k)  # [1, nq, k]
+        ratio_rule = k == 2 and str(self.feature_detection_method).upper() == "SIFT"
+        if k == 1 or ratio_rule:
+            # sorted(matches, key=distance) of one match per query (:442-444); for the ratio rule the filter
+            # below keeps the sorted order of the survivors, which is the sorted order of the filtered list
+            best = keys[:, :, :1].contiguous()
+            order = ctx.sort_matches(best, nq_t)
+            kh = keys[0, :nq].cpu().numpy().astype(np.int64)
+            oh = order[0, :nq].cpu().numpy().astype(np.int64)
+            q = oh
+            t = kh[oh, 0] & KEY_IDX_MASK
+            d = (kh[oh, 0] >> KEY_SHIFT).astype(np.float32)
+            if ratio_rule:
+                second = kh[oh, 1]
+                keep = (second != KEY_NONE) & (d < (second >> KEY_SHIFT).astype(np.float32) * 0.75)
+                q, t, d = q[keep], t[keep], d[keep]
+            return q, t, d
+        # k_best == 2: the k-lists are flattened [q0 best, q0 second, q1 best, ...] and sorted by distance (:439)
+        flat = keys.reshape(1, 2 * nq, 1)
+        n2 = torch.tensor([2 * nq], dtype=torch.int32, device=dev)
+        order = ctx.sort_matches(flat, n2)
+        kh = flat[0, :, 0].cpu().numpy().astype(np.int64)
+        oh = order[0, :2 * nq].cpu().numpy().astype(np.int64)
+        oh = oh[kh[oh] != KEY_NONE]  # a train set of one descriptor gives k-lists of length 1
+        return oh // 2, kh[oh] & KEY_IDX_MASK, (kh[oh] >> KEY_SHIFT).astype(np.float32)
+
+    def match(self, query_descriptors, train_descriptors, max_descriptor_distance_radius=-1):
+        """-> MatchList (a list of DMatch), ascending by distance, ties in query order."""
+        return MatchList(*self.match_arrays(query_descriptors, train_descriptors))

@@ -108,6 +108,26 @@ class GUM(object):
                                                                                           elevation=elevation))
 
     # ---- masks (camera_models.py:1546-1569; discs are x^2 + y^2 <= r^2) ----
+    # ---- per-frame API (camera_models.py:1610-1797, :1544-1580) on the GPU ----
+    def set_omni_image(self, img, pano_width_in_pixels=1200, generate_panorama=False, idx=-1, view=False, apply_mask=True,
+                       mask_RGB=None):
+        self.current_omni_img = img
+        if self.panorama is None:
+            from .panorama import Panorama
+            self.panorama = Panorama(self, width=pano_width_in_pixels)
+        if generate_panorama:
+            self.panorama.set_panoramic_image(img)
+
+    def detect_sparse_features_on_panorama(self, feature_detection_method="ORB", num_of_features=50, median_win_size=0,
+                                           show=True):
+        """-> (list of keypoint lists, list of descriptor arrays), one entry per azimuthal mask.  The image stages
+        of both mirrors run in one batched pass of the rig's device front end (results cached per omni image)."""
+        rig = getattr(self, "rig", None)
+        if rig is None:
+            raise RuntimeError("detect_sparse_features_on_panorama: the model must belong to a GUMStereo rig")
+        kp_lists, desc_lists = rig._detect_both(feature_detection_method, num_of_features, median_win_size)
+        return kp_lists[self.view_index], desc_lists[self.view_index]
+
     @staticmethod
     def _disc(shape, center, radius):
         yy, xx = np.mgrid[0:shape[0], 0:shape[1]]
@@ -137,6 +157,151 @@ class GUMStereo(object):
         self.construct_new_mask = True
         self.feature_matcher_for_static_stereo = None
         self.feature_matcher_for_motion = None
+        top_model.rig, top_model.view_index = self, 0
+        bottom_model.rig, bottom_model.view_index = self, 1
+        # pose of the bottom model wrt the top one (camera_models.py:2811-2813)
+        self.T_bot_wrt_top = top_model.T_C_wrt_model.dot(bottom_model.T_model_wrt_C)
+        self._dev_model = None
+        self._front_ends = {}
+        self._omni_serial = 0
+        self._detect_cache = (None, None)
+
+    # ---- per-frame API on the GPU -------------------------------------------------------------------------
+    def _context(self):
+        from ..runtime import default_context
+        return default_context()
+
+    def _device_model(self):
+        """Model constants in HBM (unwrap maps, annulus masks, azimuthal bucket masks): built once."""
+        if self._dev_model is None:
+            from ..frontend import DeviceImageModel
+            shape = self.current_omni_img.shape[:2]
+            bits = None
+            if all(len(m.panorama.azimuthal_masks) > 0 for m in (self.top_model, self.bot_model)):
+                bits = np.stack([m.panorama.mask_bits() for m in (self.top_model, self.bot_model)])
+            elif not any(len(m.panorama.azimuthal_masks) > 0 for m in (self.top_model, self.bot_model)):
+                rows, cols = self.top_model.panorama.rows, self.top_model.panorama.cols
+                bits = np.ones((2, rows, cols), dtype=np.uint32)  # no buckets: one mask covering the panorama
+            self._dev_model = DeviceImageModel(self._context(), self, shape, mask_bits=bits)
+        return self._dev_model
+
+    def _front_end(self, method, num_of_features, median_win_size):
+        key = (str(method).upper(), int(num_of_features), int(median_win_size))
+        if key not in self._front_ends:
+            from ..frontend import ImageFrontEnd
+            cap = int(min(4096, max(64, -(-int(num_of_features * (1.25 if key[0] == "ORB" else 1.0)) // 64) * 64)))
+            self._front_ends[key] = ImageFrontEnd(self._context(), self._device_model(), 1, detection_method=key[0],
+                                                  num_of_features=key[1], kp_cap=cap, median_win_size=key[2])
+        return self._front_ends[key]
+
+    def set_current_omni_image(self, img, pano_width_in_pixels=1200, generate_panoramas=False, idx=-1, view=False,
+                               apply_mask=True, mask_RGB=None):
+        """camera_models.py:3107-3120.  The annulus masks are part of the unwrap table (K1), so the masked omni
+        images are never materialised; with generate_panoramas the two panoramas come back to the host."""
+        self.current_omni_img = img
+        self._omni_serial += 1
+        for m in (self.top_model, self.bot_model):
+            m.set_omni_image(img, pano_width_in_pixels=pano_width_in_pixels, generate_panorama=False)
+        if generate_panoramas:
+            import torch
+            ctx, dm = self._context(), self._device_model()
+            if getattr(dm, "unwrap_table", None) is None:
+                dm.unwrap_table = ctx.unwrap_prepare(dm.omni_masks if apply_mask else None, dm.map_x, dm.map_y, (dm.H, dm.W))
+            omni = torch.from_numpy(np.ascontiguousarray(img)[None]).to(ctx.device)
+            pano = ctx.unwrap_table(omni, dm.unwrap_table)
+            ctx.synchronize()
+            host = pano.cpu().numpy()
+            self.top_model.panorama.panoramic_img = host[0, 0]
+            self.bot_model.panorama.panoramic_img = host[1, 0]
+            self.top_model.panorama.omni_img = self.bot_model.panorama.omni_img = img
+
+    def _detect_both(self, method, num_of_features, median_win_size):
+        token = (self._omni_serial, str(method).upper(), int(num_of_features), int(median_win_size))
+        if self._detect_cache[0] == token:
+            return self._detect_cache[1]
+        from .camera_models import KeyPoint
+        fe = self._front_end(method, num_of_features, median_win_size)
+        fe.load_frames(np.ascontiguousarray(self.current_omni_img)[None])
+        fe.run()
+        fe.ctx.synchronize()
+        nm = fe.model.nmask
+        kp, n, desc = fe.kp.cpu().numpy(), fe.n.cpu().numpy(), fe.desc.cpu().numpy()
+        kp_lists, desc_lists = [[], []], [[], []]
+        for view in range(2):
+            for m in range(nm):
+                p = view * nm + m
+                cnt = int(n[p])
+                kp_lists[view].append([KeyPoint(x, y, size=1.0) for x, y in kp[p, :cnt]])
+                desc_lists[view].append(np.ascontiguousarray(desc[p, :cnt]))
+        self._detect_cache = (token, (kp_lists, desc_lists))
+        return self._detect_cache[1]
+
+    def match_features_panoramic_top_bottom(self, keypts_list_top, desc_list_top, keypts_list_bot, desc_list_bot,
+                                            min_rectified_disparity=1, max_horizontal_diff=1, show_matches=False,
+                                            win_name="Matches"):
+        """camera_models.py:3027-3101: per bucket, match bottom (query) against top (train), keep the first
+        percentage_good_matches of the sorted matches, concatenate, gate the pixel pairs."""
+        from .camera_models import keypoints_to_array
+        from .common_cv import filter_pixel_correspondences
+        fm = self.feature_matcher_for_static_stereo
+        sel_top, sel_bot, dsel_top, dsel_bot = [], [], [], []
+        for top_k, top_d, bot_k, bot_d in zip(keypts_list_top, desc_list_top, keypts_list_bot, desc_list_bot):
+            if len(top_k) == 0 or len(bot_k) == 0:
+                continue
+            q, t, _ = fm.match_arrays(bot_d, top_d)
+            good = int(fm.percentage_good_matches * len(q))
+            if good > 0:
+                sel_top.append(np.array(top_k, dtype=object)[t[:good]])
+                sel_bot.append(np.array(bot_k, dtype=object)[q[:good]])
+                dsel_top.append(np.asarray(top_d)[t[:good]])
+                dsel_bot.append(np.asarray(bot_d)[q[:good]])
+        if not sel_top:
+            e = np.empty((0,), dtype=object)
+            return (np.empty((0, 3)), e, np.empty((0, 32), np.uint8)), (np.empty((0, 3)), e, np.empty((0, 32), np.uint8)), \
+                np.empty((0, 3), np.uint8)
+        k_top, k_bot = np.concatenate(sel_top), np.concatenate(sel_bot)
+        d_top, d_bot = np.concatenate(dsel_top), np.concatenate(dsel_bot)
+        p_top = keypoints_to_array(k_top).astype(np.float64)
+        p_bot = keypoints_to_array(k_bot).astype(np.float64)
+        ok = filter_pixel_correspondences(matched_points_top=p_top, matched_points_bot=p_bot,
+                                          min_rectified_disparity=min_rectified_disparity,
+                                          max_horizontal_diff=max_horizontal_diff)
+        colors = np.random.randint(low=0, high=256, size=(int(ok.sum()), 3), dtype="uint8")
+        m_top = np.hstack((p_top[ok], np.ones((int(ok.sum()), 1))))
+        m_bot = np.hstack((p_bot[ok], np.ones((int(ok.sum()), 1))))
+        return (m_top, k_top[ok], d_top[ok]), (m_bot, k_bot[ok], d_bot[ok]), colors
+
+    def get_triangulated_point_from_direction_angles(self, dir_angs_top, dir_angs_bot, use_midpoint_triangulation=True):
+        """camera_models.py:3323-3364 -> [1, m, 4] homogeneous points wrt [C] (midpoint of the common
+        perpendicular of the two rays; the only method the VO path uses)."""
+        import torch
+        if not use_midpoint_triangulation:
+            raise NotImplementedError("only the midpoint triangulation (the VO default) is built")
+        ctx = self._context()
+        az1, el1 = [np.asarray(a, dtype=np.float64).reshape(-1) for a in dir_angs_top]
+        az2, el2 = [np.asarray(a, dtype=np.float64).reshape(-1) for a in dir_angs_bot]
+        out = np.ones((1, az1.shape[0], 4))
+        if az1.shape[0]:
+            t = [torch.from_numpy(np.ascontiguousarray(a)).to(ctx.device) for a in (az1, el1, az2, el2)]
+            X = ctx.triangulate_midpoint(t[0], t[1], t[2], t[3], self.top_model.F[:3, 0], self.bot_model.F[:3, 0])
+            ctx.synchronize()
+            out[0, :, :3] = X.cpu().numpy()
+        return out
+
+    def filter_panoramic_points_due_to_range(self, xyz_points_wrt_C, min_3D_range=0, max_3D_range=0):
+        """camera_models.py:3299-3321 -> bool [m].  As the reference, the norm runs over ALL columns of the rows it
+        is given: the VO path passes homogeneous rows (pose_est_tools.py:372), so the trailing 1 is included."""
+        import torch
+        ctx = self._context()
+        pts = np.asarray(xyz_points_wrt_C, dtype=np.float64)
+        if pts.shape[-1] != 4:
+            raise NotImplementedError("the GPU range filter takes the homogeneous [m,4] rows the VO path passes")
+        pts = pts.reshape(-1, 4)
+        if pts.shape[0] == 0:
+            return np.zeros((0,), dtype=bool)
+        ok = ctx.range_filter(torch.from_numpy(np.ascontiguousarray(pts[:, :3])).to(ctx.device), min_3D_range, max_3D_range)
+        ctx.synchronize()
+        return ok.cpu().numpy().astype(bool)
 
     def get_baseline(self):
         return self.top_model.F[2, 0] - self.bot_model.F[2, 0]
