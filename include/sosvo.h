@@ -321,6 +321,48 @@ int32_t sosvo_f2f_assemble(sosvo_ctx* ctx, const sosvo_rig* rig_host, const floa
                            int32_t npairs, int32_t corr_cap, double* f, double* p, int32_t* cam,
                            int32_t* corr_q, int32_t* corr_t, int32_t* n, int32_t* n_topview);
 
+/* ---- the whole hot path for a batch of frame pairs (the throughput entry point) ----------------
+ * One call = for B independent pairs (frames 2i = reference / keyframe, 2i+1 = current):
+ *   OmniStereoModel.set_current_omni_image + StereoPanoramicFrame.__init__ for both frames
+ *   (omnistereo/camera_models.py:3107-3120, pose_est_tools.py:271-402: unwrap both mirrors, medianBlur, gray,
+ *   goodFeaturesToTrack per azimuthal mask, ORB descriptors, per-bucket top/bottom matching, gates, bearings,
+ *   midpoint triangulation, range filter), then TrackerStereoSE3.track_frame (pose_est_tools.py:736-847:
+ *   frame-to-frame matching per view, |du| gate, stacking, non-central RANSAC, LM on the inliers).
+ * It sequences the stage functions above on the context's stream; nothing is allocated and the host is never
+ * synchronised.  Detector: GFT (the reference default, pose_est_tools.py:684).
+ *   omni         [2B, H, W, 3] u8 BGR (device)
+ *   unwrap_table from sosvo_unwrap_prepare (model constant), mask_bits [2, rows, cols] u32 (set 0 = top mirror,
+ *                set 1 = bottom mirror), pattern [512, 2] i8 (descriptor test points)
+ *   workspace    caller-owned device memory, 256-byte aligned, >= sosvo_frame_pair_batch_workspace(cfg) bytes;
+ *                contents on entry are irrelevant, intermediates (panoramas, keypoints, correspondences, ...) are
+ *                left in it
+ *   results      [B, 16] f64 (device): refined pose T = [R | t] row-major 3x4 (model units), n_inliers,
+ *                n_correspondences, status (0 ok, 1 too few correspondences), best RANSAC iteration        */
+typedef struct sosvo_batch_cfg {
+  int32_t n_pairs;
+  int32_t H, W;            /* omni frame */
+  int32_t rows, cols;      /* panorama (both mirrors) */
+  int32_t nmask;           /* azimuthal masks per mirror */
+  int32_t kp_cap;          /* keypoint capacity per (frame, mirror, mask) */
+  int32_t frame_cap;       /* stereo correspondences kept per frame (<= 16384) */
+  int32_t median_ksize;    /* 11 (pose_est_tools.py:296) */
+  int32_t max_corners;     /* per mask: FeatureMatcher.num_of_features (pose_est_tools.py:862) */
+  int32_t edge;            /* ORB border, 31 */
+  int32_t ransac_max_iter;
+  int32_t ransac_adaptive; /* 1 = OpenGV's adaptive stop, 0 = exactly ransac_max_iter hypotheses */
+  int32_t lm_max_iter;
+  double quality;          /* 0.01 */
+  double min_distance;     /* 5 */
+  double ransac_threshold; /* 1 - cos(5 deg) (pose_est_tools.py:675-676) */
+  uint64_t seed;           /* pair i samples with seed + i */
+  float cos_a, sin_a;      /* descriptor orientation given to the GFT keypoints */
+} sosvo_batch_cfg;
+
+size_t sosvo_frame_pair_batch_workspace(const sosvo_batch_cfg* cfg);
+int32_t sosvo_frame_pair_batch(sosvo_ctx* ctx, const sosvo_rig* rig_host, const sosvo_batch_cfg* cfg_host,
+                               const uint8_t* omni, const uint32_t* unwrap_table, const uint32_t* mask_bits,
+                               const int8_t* pattern, void* workspace, size_t workspace_bytes, double* results);
+
 #ifdef __cplusplus
 }
 #endif

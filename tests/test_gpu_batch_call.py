@@ -1,0 +1,69 @@
+"""GPU: sosvo_frame_pair_batch (ONE C-ABI call for the whole hot path over B pairs, include/sosvo.h) returns
+exactly what the stage-by-stage sequence (ImageFrontEnd + FramePairPipeline, itself parity-tested against the
+oracle in test_gpu_endtoend.py) returns on the same frames: records bit-identical, including a black frame;
+argument errors are reported, not executed."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from vo_single_camera_sos_amd import _lib, synthetic
+from vo_single_camera_sos_amd.frontend import DeviceImageModel, ImageFrontEnd
+from vo_single_camera_sos_amd.omnistereo.gum import synthetic_gums
+from vo_single_camera_sos_amd.omnistereo.panorama import Panorama
+from vo_single_camera_sos_amd.pipeline import FramePairBatch, FramePairPipeline, RigConfig
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(ctx, B, width=1200):
+    gs = synthetic_gums()
+    for m in (gs.top_model, gs.bot_model):
+        m.panorama = Panorama(m, width=width)
+    gs.make_annulus_masks((480, 640))
+    pano = gs.top_model.panorama
+    geo = (pano.cols, pano.rows, pano.pixel_size, pano.cyl_height_max)
+    rig = RigConfig(pano_top=geo, pano_bot=geo, F_top=gs.top_model.F[:3, 0], F_bot=gs.bot_model.F[:3, 0],
+                    min_range=500.0, max_range=7000.0)
+    model = DeviceImageModel(ctx, gs, (480, 640))
+    omni, _ = synthetic.make_frame_pairs(gs, B, seed=4242)
+    return model, rig, omni
+
+
+def test_one_call_equals_stage_sequence(ctx):
+    B, nfeat, cap = 4, 300, 320
+    model, rig, omni = _setup(ctx, B)
+    omni[3] = 0  # pair 1: black current frame
+    fe = ImageFrontEnd(ctx, model, 2 * B, num_of_features=nfeat, kp_cap=cap)
+    pipe = FramePairPipeline(ctx, rig, B, frame_cap=1024, max_iter=300, seed=11, front_end=fe)
+    fe.load_frames(omni)
+    pipe.step()
+    want = pipe.results().cpu().numpy()
+    batch = FramePairBatch(ctx, model, rig, B, num_of_features=nfeat, kp_cap=cap, frame_cap=1024, max_iter=300, seed=11)
+    batch.workspace.fill_(0xA5)  # contents on entry are irrelevant
+    batch.load_frames(omni)
+    got = batch.step()
+    ctx.synchronize()
+    got = got.cpu().numpy()
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    assert got[1, 14] == 1 and got[1, 13] == 0 and (got[[0, 2, 3], 14] == 0).all()
+    # a second step on the dirty workspace gives the same records (no state carried between steps)
+    got2 = batch.step()
+    ctx.synchronize()
+    assert np.array_equal(got2.cpu().numpy().view(np.uint64), want.view(np.uint64))
+
+
+def test_argument_errors(ctx):
+    model, rig, omni = _setup(ctx, 1)
+    batch = FramePairBatch(ctx, model, rig, 1, num_of_features=100, frame_cap=512, max_iter=50)
+    small = torch.empty((batch.workspace.numel() // 2,), dtype=torch.uint8, device=ctx.device)
+    with pytest.raises(_lib.SosvoError):
+        ctx.frame_pair_batch(batch.rig, batch.cfg, batch.omni, model.unwrap_table, model.mask_bits, model.pattern, small)
+    bad = _lib.BatchCfg()
+    ctypes.memmove(ctypes.addressof(bad), ctypes.addressof(batch.cfg), ctypes.sizeof(bad))
+    bad.frame_cap = 1 << 20
+    assert ctx.frame_pair_batch_workspace(bad) > 0
+    with pytest.raises(_lib.SosvoError):
+        ctx.frame_pair_batch(batch.rig, bad, batch.omni, model.unwrap_table, model.mask_bits, model.pattern,
+                             batch.workspace)

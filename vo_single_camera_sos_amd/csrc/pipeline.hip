@@ -1,0 +1,188 @@
+// sosvo_frame_pair_batch -- the whole hot path for B independent frame pairs behind ONE C-ABI call:
+// the order of operations of OmniStereoModel.set_current_omni_image + StereoPanoramicFrame.__init__
+// (omnistereo/camera_models.py:3107-3120, pose_est_tools.py:271-402) for both frames of every pair, then
+// TrackerStereoSE3.track_frame (pose_est_tools.py:736-847) per pair.  It only sequences the stage entry points
+// of this library on the context's stream (no host synchronisation, no allocation: every intermediate lives in
+// the caller's workspace), so its results are those of calling the stages one by one.
+#include "common.h"
+
+namespace {
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  template <typename T>
+  T* take(size_t count) {
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += (count * sizeof(T) + 255) & ~(size_t)255;
+    return p;
+  }
+};
+
+struct Buffers {
+  uint8_t *pano, *gray, *desc, *d_top, *d_bot, *mask;
+  float *kp, *m_top, *m_bot;
+  int32_t *n, *status, *s_order, *M, *n_cand, *ref_frame, *cur_frame, *o_top, *o_bot, *cam, *cq, *ct, *cn, *cn_top, *idx,
+      *n_inl, *info, *lm_iters;
+  uint32_t *s_keys, *k_top, *k_bot;
+  double *X, *b_top, *b_bot, *f, *p, *T_ransac, *T, *cam_off, *cam_rot, *lm_cost;
+  size_t bytes;
+};
+
+Buffers carve(const sosvo_batch_cfg& c, void* ws) {
+  Carver cv{reinterpret_cast<char*>(ws)};
+  Buffers b;
+  const size_t B = c.n_pairs, F = 2 * B, NI = 2 * F, P = NI * c.nmask, cap = c.kp_cap, Fc = c.frame_cap, Cc = 2 * Fc;
+  const size_t npx = (size_t)c.rows * c.cols;
+  b.pano = cv.take<uint8_t>(NI * npx * 3);
+  b.gray = cv.take<uint8_t>(NI * npx);
+  b.kp = cv.take<float>(P * cap * 2);
+  b.n = cv.take<int32_t>(P);
+  b.status = cv.take<int32_t>(P);
+  b.desc = cv.take<uint8_t>(P * cap * 32);
+  b.s_keys = cv.take<uint32_t>(P / 2 * cap);
+  b.s_order = cv.take<int32_t>(P / 2 * cap);
+  b.m_top = cv.take<float>(F * Fc * 2);
+  b.m_bot = cv.take<float>(F * Fc * 2);
+  b.d_top = cv.take<uint8_t>(F * Fc * 32);
+  b.d_bot = cv.take<uint8_t>(F * Fc * 32);
+  b.X = cv.take<double>(F * Fc * 3);
+  b.b_top = cv.take<double>(F * Fc * 3);
+  b.b_bot = cv.take<double>(F * Fc * 3);
+  b.M = cv.take<int32_t>(F);
+  b.n_cand = cv.take<int32_t>(F);
+  b.ref_frame = cv.take<int32_t>(B);
+  b.cur_frame = cv.take<int32_t>(B);
+  b.k_top = cv.take<uint32_t>(B * Fc);
+  b.k_bot = cv.take<uint32_t>(B * Fc);
+  b.o_top = cv.take<int32_t>(B * Fc);
+  b.o_bot = cv.take<int32_t>(B * Fc);
+  b.f = cv.take<double>(B * Cc * 3);
+  b.p = cv.take<double>(B * Cc * 3);
+  b.cam = cv.take<int32_t>(B * Cc);
+  b.cq = cv.take<int32_t>(B * Cc);
+  b.ct = cv.take<int32_t>(B * Cc);
+  b.cn = cv.take<int32_t>(B);
+  b.cn_top = cv.take<int32_t>(B);
+  b.T_ransac = cv.take<double>(B * 12);
+  b.mask = cv.take<uint8_t>(B * Cc);
+  b.idx = cv.take<int32_t>(B * Cc);
+  b.n_inl = cv.take<int32_t>(B);
+  b.info = cv.take<int32_t>(B * 4);
+  b.T = cv.take<double>(B * 12);
+  b.cam_off = cv.take<double>(2 * 3);
+  b.cam_rot = cv.take<double>(2 * 9);
+  b.lm_cost = cv.take<double>(B);
+  b.lm_iters = cv.take<int32_t>(B);
+  b.bytes = cv.off;
+  return b;
+}
+
+struct Foci {
+  double top[3], bot[3];
+};
+
+// pair i tracks frame 2i + 1 against frame 2i; the two mirrors' foci are the non-central rig (identity rotations)
+__global__ void batch_setup_kernel(int npairs, Foci foci, int32_t* __restrict__ ref_frame, int32_t* __restrict__ cur_frame,
+                                   double* __restrict__ cam_off, double* __restrict__ cam_rot) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < npairs) {
+    ref_frame[i] = 2 * i;
+    cur_frame[i] = 2 * i + 1;
+  }
+  if (i < 3) {
+    cam_off[i] = foci.top[i];
+    cam_off[3 + i] = foci.bot[i];
+  }
+  if (i < 18) cam_rot[i] = (i % 9) % 4 == 0 ? 1.0 : 0.0;
+}
+
+// [B,16]: refined 3x4 pose, n_inliers, n_correspondences, status, RANSAC best iteration
+__global__ void batch_results_kernel(int npairs, const double* __restrict__ T, const int32_t* __restrict__ n_inl,
+                                     const int32_t* __restrict__ n_corr, const int32_t* __restrict__ info,
+                                     double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npairs) return;
+  for (int k = 0; k < 12; ++k) out[16 * i + k] = T[12 * i + k];
+  out[16 * i + 12] = (double)n_inl[i];
+  out[16 * i + 13] = (double)n_corr[i];
+  out[16 * i + 14] = (double)info[4 * i + 2];
+  out[16 * i + 15] = (double)info[4 * i + 0];
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t sosvo_frame_pair_batch_workspace(const sosvo_batch_cfg* cfg) {
+  if (!cfg || cfg->n_pairs <= 0 || cfg->rows <= 0 || cfg->cols <= 0 || cfg->nmask <= 0 || cfg->kp_cap <= 0 ||
+      cfg->frame_cap <= 0)
+    return 0;
+  return carve(*cfg, nullptr).bytes;
+}
+
+int32_t sosvo_frame_pair_batch(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo_batch_cfg* cfg, const uint8_t* omni,
+                               const uint32_t* unwrap_table, const uint32_t* mask_bits, const int8_t* pattern,
+                               void* workspace, size_t workspace_bytes, double* results) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, rig && cfg && omni && unwrap_table && mask_bits && pattern && workspace && results, "null pointer");
+  SOSVO_REQUIRE(ctx, cfg->n_pairs > 0 && cfg->n_pairs <= 8192, "n_pairs out of range (1..8192)");
+  SOSVO_REQUIRE(ctx, cfg->nmask >= 1 && cfg->nmask <= 32 && cfg->kp_cap > 0 && cfg->kp_cap <= 4096, "nmask / kp_cap out of range");
+  SOSVO_REQUIRE(ctx, cfg->frame_cap > 0 && cfg->frame_cap <= 16384, "frame_cap out of range (max 16384)");
+  SOSVO_REQUIRE(ctx, ((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
+  const Buffers b = carve(*cfg, workspace);
+  SOSVO_REQUIRE(ctx, workspace_bytes >= b.bytes, "workspace too small (see sosvo_frame_pair_batch_workspace)");
+  const int B = cfg->n_pairs, F = 2 * B, NI = 2 * F, NM = cfg->nmask, cap = cfg->kp_cap, Fc = cfg->frame_cap, Cc = 2 * Fc;
+  const int h = F * NM;  // problems of one view: (frame, mask); the top view's come first (view-major images)
+  int32_t rc;
+#define STAGE(call)              \
+  do {                           \
+    rc = (call);                 \
+    if (rc != SOSVO_OK) return rc; \
+  } while (0)
+
+  Foci foci;
+  for (int k = 0; k < 3; ++k) {
+    foci.top[k] = rig->F_top[k];
+    foci.bot[k] = rig->F_bot[k];
+  }
+  SOSVO_LAUNCH(ctx, batch_setup_kernel, dim3(cdiv(B > 18 ? B : 18, 256)), dim3(256), 0, ctx->stream, B, foci, b.ref_frame,
+               b.cur_frame, b.cam_off, b.cam_rot);
+  SOSVO_LAUNCH_CHECK(ctx);
+  // image front end: K1, K2 + K3, K4, K6 over all 2 * F panoramas
+  STAGE(sosvo_unwrap_table(ctx, omni, unwrap_table, F, cfg->H, cfg->W, cfg->rows, cfg->cols, b.pano));
+  STAGE(sosvo_median_gray(ctx, b.pano, NI, cfg->rows, cfg->cols, cfg->median_ksize, b.gray));
+  STAGE(sosvo_detect_gft(ctx, b.gray, mask_bits, NI, F, cfg->rows, cfg->cols, NM, cfg->quality, cfg->min_distance,
+                         cfg->max_corners, cap, b.kp, b.n, b.status));
+  STAGE(sosvo_describe_orb(ctx, b.gray, NI, cfg->rows, cfg->cols, NM, cap, b.kp, b.n, cfg->cos_a, cfg->sin_a, pattern,
+                           cfg->edge, b.desc));
+  // static stereo per frame: query = bottom view, train = top view, bucket by bucket
+  const float *kp_top = b.kp, *kp_bot = b.kp + (size_t)h * cap * 2;
+  const uint8_t *desc_top = b.desc, *desc_bot = b.desc + (size_t)h * cap * 32;
+  const int32_t *n_top = b.n, *n_bot = b.n + h;
+  STAGE(sosvo_match_hamming(ctx, desc_bot, desc_top, n_bot, n_top, nullptr, nullptr, h, cap, cap, 1, b.s_keys));
+  STAGE(sosvo_sort_matches(ctx, b.s_keys, n_bot, nullptr, h, cap, b.s_order));
+  STAGE(sosvo_stereo_assemble(ctx, rig, kp_top, kp_bot, desc_top, desc_bot, n_top, n_bot, b.s_keys, b.s_order, F, NM, cap,
+                              Fc, b.m_top, b.m_bot, b.d_top, b.d_bot, b.X, b.b_top, b.b_bot, b.M, b.n_cand));
+  // frame-to-frame per pair and view: query = current frame, train = reference frame
+  STAGE(sosvo_match_hamming(ctx, b.d_top, b.d_top, b.M, b.M, b.cur_frame, b.ref_frame, B, Fc, Fc, 1, b.k_top));
+  STAGE(sosvo_sort_matches(ctx, b.k_top, b.M, b.cur_frame, B, Fc, b.o_top));
+  STAGE(sosvo_match_hamming(ctx, b.d_bot, b.d_bot, b.M, b.M, b.cur_frame, b.ref_frame, B, Fc, Fc, 1, b.k_bot));
+  STAGE(sosvo_sort_matches(ctx, b.k_bot, b.M, b.cur_frame, B, Fc, b.o_bot));
+  STAGE(sosvo_f2f_assemble(ctx, rig, b.m_top, b.m_bot, b.X, b.b_top, b.b_bot, b.M, Fc, b.ref_frame, b.cur_frame, b.k_top,
+                           b.o_top, b.k_bot, b.o_bot, B, Cc, b.f, b.p, b.cam, b.cq, b.ct, b.cn, b.cn_top));
+  // 3D-2D absolute pose: RANSAC, then LM on the inliers
+  STAGE(sosvo_ransac_abs_pose(ctx, b.f, b.p, b.cam, b.cam_off, b.cam_rot, 2, SOSVO_FLAG_CAM_ROT_IDENTITY, b.cn, B, Cc,
+                              cfg->ransac_threshold, cfg->ransac_max_iter, cfg->ransac_adaptive, cfg->seed, b.T_ransac,
+                              b.mask, b.idx, b.n_inl, b.info, nullptr));
+  SOSVO_HIP(ctx, hipMemcpyAsync(b.T, b.T_ransac, sizeof(double) * 12 * B, hipMemcpyDeviceToDevice, ctx->stream));
+  STAGE(sosvo_refine_abs_pose(ctx, b.f, b.p, b.cam, b.cam_off, b.cam_rot, 2, b.cn, B, Cc, b.idx, b.n_inl, cfg->lm_max_iter,
+                              b.T, b.lm_cost, b.lm_iters));
+  SOSVO_LAUNCH(ctx, batch_results_kernel, dim3(cdiv(B, 256)), dim3(256), 0, ctx->stream, B, b.T, b.n_inl, b.cn, b.info,
+               results);
+  SOSVO_LAUNCH_CHECK(ctx);
+#undef STAGE
+  return SOSVO_OK;
+}
+
+}  // extern "C"

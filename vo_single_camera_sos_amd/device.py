@@ -472,6 +472,27 @@ class Context(object):
                    _ptr(out["X"]), _ptr(out["b_top"]), _ptr(out["b_bot"]), _ptr(out["M"]), _ptr(out["n_cand"]))
         return out
 
+    # ---- whole hot path ------------------------------------------------------------------
+    def frame_pair_batch_workspace(self, cfg):
+        return int(self._lib.sosvo_frame_pair_batch_workspace(ctypes.cast(ctypes.pointer(cfg), c_p)))
+
+    def frame_pair_batch(self, rig, cfg, omni, unwrap_table, mask_bits, pattern, workspace, results=None):
+        """omni [2B,H,W,3] u8, unwrap_table [2,rows,cols,2] u32, mask_bits [2,rows,cols] u32, pattern [512,2] i8,
+        workspace u8 [>= frame_pair_batch_workspace(cfg)] -> results [B,16] f64 (see include/sosvo.h)."""
+        B = int(cfg.n_pairs)
+        _check(omni, torch.uint8, "omni", (2 * B, cfg.H, cfg.W, 3))
+        _check(unwrap_table, torch.uint32, "unwrap_table", (2, cfg.rows, cfg.cols, 2))
+        _check(mask_bits, torch.uint32, "mask_bits", (2, cfg.rows, cfg.cols))
+        _check(pattern, torch.int8, "pattern", (512, 2))
+        _check(workspace, torch.uint8, "workspace", ndim=1)
+        if results is None:
+            results = torch.empty((B, 16), dtype=torch.float64, device=omni.device)
+        _check(results, torch.float64, "results", (B, 16))
+        self._call(self._lib.sosvo_frame_pair_batch, ctypes.cast(ctypes.pointer(rig), c_p),
+                   ctypes.cast(ctypes.pointer(cfg), c_p), _ptr(omni), _ptr(unwrap_table), _ptr(mask_bits), _ptr(pattern),
+                   _ptr(workspace), int(workspace.numel()), _ptr(results))
+        return results
+
     def f2f_assemble(self, rig, frames, ref_frame, cur_frame, keys_top, order_top, keys_bot, order_bot, corr_cap,
                      out=None):
         """frames = dict from stereo_assemble; ref_frame / cur_frame [NP] i32; keys_* [NP, frame_cap, 1] u32,

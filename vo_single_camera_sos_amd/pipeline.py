@@ -130,3 +130,47 @@ class FramePairPipeline(object):
         out[:, 14] = self.ransac["info"][:, 2].to(torch.float64)
         out[:, 15] = self.ransac["info"][:, 0].to(torch.float64)
         return out
+
+
+class FramePairBatch(object):
+    """The same hot path behind ONE C-ABI call per step (sosvo_frame_pair_batch): what a non-Python host would
+    bind.  `model` is a DeviceImageModel (model constants in HBM); the workspace is allocated once."""
+
+    def __init__(self, ctx, model, rig, n_pairs, num_of_features=1000, kp_cap=None, frame_cap=2048, median_win_size=11,
+                 quality=0.01, min_distance=5.0, edge=31, thr=None, max_iter=2000, adaptive=False, seed=0, lm_iter=30):
+        from . import _lib, orb_pattern
+        self.ctx, self.model, self.rig_cfg, self.rig = ctx, model, rig, rig.as_struct()
+        self.B = int(n_pairs)
+        if kp_cap is None:
+            kp_cap = int(min(1024, max(64, -(-int(num_of_features) // 64) * 64)))
+        cos_a, sin_a = orb_pattern.angle_cos_sin(orb_pattern.GFT_KEYPOINT_ANGLE)
+        c = _lib.BatchCfg()
+        c.n_pairs, c.H, c.W, c.rows, c.cols, c.nmask = self.B, model.H, model.W, model.rows, model.cols, model.nmask
+        c.kp_cap, c.frame_cap, c.median_ksize, c.max_corners, c.edge = int(kp_cap), int(frame_cap), int(median_win_size), \
+            int(num_of_features), int(edge)
+        c.ransac_max_iter, c.ransac_adaptive, c.lm_max_iter = int(max_iter), 1 if adaptive else 0, int(lm_iter)
+        c.quality, c.min_distance = float(quality), float(min_distance)
+        c.ransac_threshold = float(1.0 - np.cos(np.deg2rad(5.0))) if thr is None else float(thr)
+        c.seed, c.cos_a, c.sin_a = int(seed), float(cos_a), float(sin_a)
+        self.cfg = c
+        if getattr(model, "unwrap_table", None) is None:  # once per model
+            model.unwrap_table = ctx.unwrap_prepare(model.omni_masks, model.map_x, model.map_y, (model.H, model.W))
+        nbytes = ctx.frame_pair_batch_workspace(c)
+        if nbytes <= 0:
+            raise ValueError("bad batch configuration")
+        self.workspace = torch.empty((nbytes,), dtype=torch.uint8, device=ctx.device)
+        self.omni = torch.zeros((2 * self.B, model.H, model.W, 3), dtype=torch.uint8, device=ctx.device)
+        self.out = torch.zeros((self.B, 16), dtype=torch.float64, device=ctx.device)
+
+    def load_frames(self, omni):
+        t = torch.from_numpy(np.ascontiguousarray(omni)) if isinstance(omni, np.ndarray) else omni
+        self.omni.copy_(t.to(self.ctx.device))
+
+    def step(self):
+        """-> results [B,16] f64 (asynchronous)."""
+        m = self.model
+        return self.ctx.frame_pair_batch(self.rig, self.cfg, self.omni, m.unwrap_table, m.mask_bits, m.pattern, self.workspace,
+                                         results=self.out)
+
+    def results(self):
+        return self.out
