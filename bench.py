@@ -32,12 +32,34 @@ def b_alg_c2(H, W, kpts):
     return 2 * H * W * 3 + 4 * kpts * 12 + 2 * kpts + 96
 
 
+def pmc_traffic(kernel, pairs_per_launch, pmc_csv=None):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 --pmc summary of this same command
+    (profiles/*/*_pmc_hbm_per_kernel.csv, written by scripts/summarize_pmc.py from separate FETCH_SIZE and
+    WRITE_SIZE passes; 2 * FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950), rescaled to this
+    run's batch.  (None, None) when no summary names the kernel: PMC passes cannot share a run with the timing."""
+    import csv
+    import glob
+    label = kernel.strip("()").split("<")[0]
+    paths = [pmc_csv] if pmc_csv else sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*pmc_hbm_per_kernel.csv")))
+    for path in reversed(paths):
+        if not os.path.exists(path):
+            continue
+        with open(path) as fh:
+            for row in csv.DictReader(fh):
+                if row.get("label") == label and int(row.get("pairs_per_launch") or 0) > 0:
+                    scale = pairs_per_launch / float(row["pairs_per_launch"])
+                    return float(row["hbm_bytes_per_launch"]) * scale, os.path.relpath(path, ROOT)
+    return None, None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs-per-gpu", type=int, default=64, help="B: frame pairs per GPU per step (C4: 512/8)")
+    ap.add_argument("--pairs-per-gpu", type=int, default=256,
+                    help="B: independent frame pairs per GPU per step (weak scaling: fixed per GPU; C4's 512 pairs "
+                         "over 8 GPUs is --pairs-per-gpu 64)")
     ap.add_argument("--detector", default="GFT", choices=["GFT", "ORB"],
                     help="GFT: the reference's default detector (pose_est_tools.py:684), always with ORB descriptors; "
                          "ORB: FAST/Harris pyramid detector (finds few corners on an 11x11-median-blurred panorama)")
@@ -50,6 +72,7 @@ def parse():
     ap.add_argument("--iters", type=int, default=2000, help="RANSAC iterations, fixed (C2: 2000)")
     ap.add_argument("--cpu-pairs", type=int, default=32, help="frame pairs timed on the host for cpu_baseline")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--pmc-csv", default=None, help="per-kernel PMC summary for roofline.traffic (default: newest in profiles/)")
     ap.add_argument("--seed", type=int, default=1234)
     return ap.parse_args()
 
@@ -72,17 +95,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    n_gpus = world if world > 1 else 1
-    if args.gpus != n_gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d; using %d" % (args.gpus, world, n_gpus), file=sys.stderr)
-
     from vo_single_camera_sos_amd import synthetic
     from vo_single_camera_sos_amd.device import Context
     from vo_single_camera_sos_amd.frontend import DeviceImageModel, ImageFrontEnd
@@ -102,13 +114,26 @@ def main():
     rig_kw = dict(pano_top=geo, pano_bot=geo, F_top=gs.top_model.F[:3, 0], F_bot=gs.bot_model.F[:3, 0],
                   min_range=500.0, max_range=7000.0, stereo_min_disp=1.0, stereo_max_hdiff=2.5,
                   f2f_max_hdiff=0.125 * 0.5 * pano.cols, pct_good_matches=1.0)
+    # frames are rendered on the host (forked workers) BEFORE this process touches the GPU
+    workers = max(1, min(16, (os.cpu_count() or 1) // max(1, world)))
+    omni, poses = synthetic.make_frame_pairs(gs, B, seed=args.seed + 100000 * rank, workers=workers)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    n_gpus = world if world > 1 else 1
+    if args.gpus != n_gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d; using %d" % (args.gpus, world, n_gpus), file=sys.stderr)
+
     ctx = Context(local_rank)
     model = DeviceImageModel(ctx, gs, (H, W))
     fe = ImageFrontEnd(ctx, model, 2 * B, detection_method=args.detector, num_of_features=args.features_per_mask,
-                       kp_cap=512)
+                       kp_cap=512, keep_panoramas=False)  # K1 fused into the median kernel
     pipe = FramePairPipeline(ctx, RigConfig(**rig_kw), B, frame_cap=2048, max_iter=args.iters, adaptive=False,
                              seed=args.seed, front_end=fe)
-    omni, poses = synthetic.make_frame_pairs(gs, B, seed=args.seed + 100000 * rank)
     fe.load_frames(omni)
     gathered = torch.empty((n_gpus * B, 16), dtype=torch.float64, device=ctx.device) if dist else None
 
@@ -153,6 +178,7 @@ def main():
         b_alg = b_alg_c2(H, W, kpts)
         b_alg_launch = b_alg * B  # one launch of the dominant kernel covers the whole batch of B pairs
         achieved = b_alg_launch / dom_avg_s / 1e9
+        traffic, traffic_src = pmc_traffic(dom[0], B, args.pmc_csv)
         ok = rec[:, 14] == 0
         rot_err = []
         for i in range(B):
@@ -180,7 +206,7 @@ def main():
                        "inliers_per_pair_mean": float(rec[:, 12].mean()), "tracked_ok": int(ok.sum()),
                        "rotation_error_deg_median": float(np.median(rot_err))},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": dom_avg_s * 1e3, "launches": dom[1][0],
                          "algorithmic_bytes_per_pair": b_alg, "algorithmic_bytes_per_launch": b_alg_launch,
                          "note": "no contraction anywhere (no MFMA); the dominant kernel is VALU-bound integer/bit work, "

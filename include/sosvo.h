@@ -108,6 +108,13 @@ int32_t sosvo_unwrap_table(sosvo_ctx* ctx, const uint8_t* omni, const uint32_t* 
  *   img [nimg, rows, cols, 3] u8 -> gray [nimg, rows, cols] u8.  ksize in {0, 1, 3, 5, 11}.       */
 int32_t sosvo_median_gray(sosvo_ctx* ctx, const uint8_t* img, int32_t nimg, int32_t rows,
                           int32_t cols, int32_t ksize, uint8_t* gray);
+/* K1 + K2 + K3 in one kernel for the batched path (identical results to sosvo_unwrap_table followed by
+ * sosvo_median_gray on its output): every lane unwraps its source pixel from the table on the fly, so the
+ * colour panoramas (camera_models.py:2991-2996 -> :1711 -> :1714) are never written to HBM.
+ *   omni [nframes, H, W, 3] u8, table from sosvo_unwrap_prepare -> gray [2 * nframes, rows, cols] u8
+ *   (view-major).  ksize in {3, 5, 11}.                                                            */
+int32_t sosvo_unwrap_median_gray(sosvo_ctx* ctx, const uint8_t* omni, const uint32_t* table, int32_t nframes,
+                                 int32_t H, int32_t W, int32_t rows, int32_t cols, int32_t ksize, uint8_t* gray);
 
 /* ---- K4: goodFeaturesToTrack per azimuthal mask (a4, the reference's default detector) ---------
  * Replaces cv2.goodFeaturesToTrack(image, maxCorners, qualityLevel, minDistance, mask, useHarris=False)

@@ -130,3 +130,44 @@ def test_get_panoramic_image_mirror_method(ctx, rig):
     mx, my = pn.float32_maps()
     assert np.array_equal(out, oracle.unwrap(omni, None, mx, my))
     assert np.array_equal(pn.panoramic_img, out)
+
+
+@pytest.mark.parametrize("pshape,k", [((40, 72), 11), ((41, 71), 5), ((13, 130), 3), ((1, 5), 11)])
+def test_fused_unwrap_median_gray_equals_oracle_chain(ctx, pshape, k):
+    """sosvo_unwrap_median_gray (K1 inside the median kernel, no colour panorama in HBM) against
+    oracle.unwrap -> oracle.median_gray; taps on the first/last bytes of a frame included."""
+    rng = np.random.default_rng(pshape[1] + k)
+    omni = rng.integers(0, 256, (3, 37, 53, 3), dtype=np.uint8)
+    mx = rng.uniform(-6, 59, (2,) + pshape).astype(np.float32)
+    my = rng.uniform(-6, 43, (2,) + pshape).astype(np.float32)
+    mx[0, 0, :5] = [np.nan, 52.0, 51.99, -0.5, 0.0]
+    my[0, 0, :5] = [3.0, 36.0, 35.99, 0.0, 0.0]  # last source pixel, a tap row starting before the frame, first pixel
+    masks = (rng.random((2, 37, 53)) < 0.7).astype(np.uint8) * 255
+    masks[:, 36, 52] = masks[:, 0, 0] = 255
+    t_omni, t_masks, t_mx, t_my = _to(ctx.device, omni, masks, mx, my)
+    for tm, hm in ((t_masks, masks), (None, [None, None])):
+        table = ctx.unwrap_prepare(tm, t_mx, t_my, (37, 53))
+        gray = ctx.unwrap_median_gray(t_omni, table, k)
+        chain = ctx.median_gray(ctx.unwrap_table(t_omni, table), k)
+        ctx.synchronize()
+        assert torch.equal(gray.view_as(chain), chain)
+        gray = gray.cpu().numpy().reshape(2, 3, *pshape)
+        for v in range(2):
+            for f in range(3):
+                assert np.array_equal(gray[v, f], oracle.median_gray(oracle.unwrap(omni[f], hm[v], mx[v], my[v]), k))
+
+
+def test_fused_front_end_c2(ctx, rig):
+    """C2 geometry: the fused front end (keep_panoramas=False) produces the gray images of the unfused one."""
+    from vo_single_camera_sos_amd.frontend import DeviceImageModel, ImageFrontEnd
+    rng = np.random.default_rng(8)
+    omni = np.stack([_textured(rng, (480, 640, 3)) for _ in range(2)])
+    model = DeviceImageModel(ctx, rig, (480, 640))
+    a = ImageFrontEnd(ctx, model, 2, num_of_features=50)
+    b = ImageFrontEnd(ctx, model, 2, num_of_features=50, keep_panoramas=False)
+    for fe in (a, b):
+        fe.load_frames(omni)
+        fe.run()
+    ctx.synchronize()
+    assert b.pano is None and torch.equal(a.gray, b.gray) and torch.equal(a.kp, b.kp) and torch.equal(a.desc, b.desc)
+    assert int(a.n.sum()) > 100

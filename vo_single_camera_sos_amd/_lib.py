@@ -49,6 +49,7 @@ SIGNATURES = {
     "sosvo_unwrap_prepare": (c_i32, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p]),
     "sosvo_unwrap_table": (c_i32, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]),
     "sosvo_median_gray": (c_i32, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p]),
+    "sosvo_unwrap_median_gray": (c_i32, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]),
     "sosvo_detect_gft": (c_i32, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_f64, c_f64, c_i32, c_i32, c_p,
                                  c_p, c_p]),
     "sosvo_describe_orb": (c_i32, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_f32, c_f32, c_p, c_i32,

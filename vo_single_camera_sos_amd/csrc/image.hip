@@ -91,9 +91,47 @@ __global__ __launch_bounds__(kThreads) void unwrap_table_kernel(const uint8_t* _
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 typedef unsigned long long __attribute__((aligned(1))) u64_unaligned;
 
+// The bilinear taps of one panorama pixel from its table entry: the two taps of a source row are adjacent
+// pixels = 6 consecutive bytes, fetched with ONE unaligned 8-byte load per row.  The load is unconditional and
+// branch-free (so it can be issued a whole row ahead of its use): the address is clamped into the frame, and
+// unwrap_blend() undoes the clamp (only where a tap row starts before the frame or ends within its last 8 bytes).
+__device__ __forceinline__ int unwrap_tap_offset(uint2 e, int r, int W) {
+  const int ix = (int)(int16_t)(e.x & 0xFFFFu), iy = (int)(int16_t)(e.x >> 16);
+  return 3 * ((iy + r) * W + ix);  // byte offset of tap (ix, iy + r) inside the frame; H * W * 3 < 2^31
+}
+__device__ __forceinline__ void unwrap_gather(const uint8_t* __restrict__ src, int frame_bytes, int W, uint2 e,
+                                              unsigned long long v[2]) {
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int off = unwrap_tap_offset(e, r, W);
+    v[r] = *reinterpret_cast<const u64_unaligned*>(src + min(max(off, 0), frame_bytes - 8));
+  }
+}
+
+// 1/32-px fixed-point blend of the gathered taps -> B | G << 8 | R << 16
+__device__ __forceinline__ uint32_t unwrap_blend(int frame_bytes, int W, uint2 e, const unsigned long long vin[2]) {
+  const uint32_t valid = e.y >> 10;
+  const int fx = (int)(e.y & 31u), fy = (int)((e.y >> 5) & 31u);
+  int acc0 = 0, acc1 = 0, acc2 = 0;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    unsigned long long v = vin[r];
+    const int off = unwrap_tap_offset(e, r, W);
+    const int delta = off - min(max(off, 0), frame_bytes - 8);  // bytes by which the load was moved (rarely != 0)
+    if (delta > 0) v >>= 8 * delta;
+    if (delta < 0) v <<= 8 * -delta;
+    const int wy = r ? fy : 32 - fy;
+    const int wl = ((valid >> (2 * r)) & 1u) ? (32 - fx) * wy : 0;  // tap (ix, iy + r)
+    const int wr = ((valid >> (2 * r)) & 2u) ? fx * wy : 0;         // tap (ix + 1, iy + r)
+    acc0 += wl * (int)(v & 0xFFu) + wr * (int)((v >> 24) & 0xFFu);
+    acc1 += wl * (int)((v >> 8) & 0xFFu) + wr * (int)((v >> 32) & 0xFFu);
+    acc2 += wl * (int)((v >> 16) & 0xFFu) + wr * (int)((v >> 40) & 0xFFu);
+  }
+  return (uint32_t)((acc0 + 512) >> 10) | ((uint32_t)((acc1 + 512) >> 10) << 8) | ((uint32_t)((acc2 + 512) >> 10) << 16);
+}
+
 // One panorama pixel per lane (neighbouring lanes = neighbouring pixels, so a wave's taps fall on a short arc
-// of the omni image: few cache lines per load instruction).  The two taps of a source row are adjacent pixels
-// = 6 consecutive bytes: ONE unaligned 8-byte load per row.  The 768 output bytes of a workgroup are staged
+// of the omni image: few cache lines per load instruction).  The 768 output bytes of a workgroup are staged
 // in LDS and leave as 192 aligned dwords.
 __global__ __launch_bounds__(kThreads) void unwrap_lut_kernel(const uint8_t* __restrict__ omni,
                                                               const uint2* __restrict__ table, int nframes, int H, int W,
@@ -111,57 +149,27 @@ __global__ __launch_bounds__(kThreads) void unwrap_lut_kernel(const uint8_t* __r
   const int pix = blk * kThreads + tid;
   const int view = img / nframes, frame = img - view * nframes;
   const uint8_t* src = omni + (size_t)frame * H * W * 3;
-  const size_t npx_src = (size_t)H * W;
-  int acc0 = 0, acc1 = 0, acc2 = 0;
+  uint32_t bgr = 0u;
   if (pix < npix) {
     const uint2 e = table[(size_t)view * npix + pix];
-    const uint32_t valid = e.y >> 10;
-    if (valid) {
-      const int ix = (int)(int16_t)(e.x & 0xFFFFu), iy = (int)(int16_t)(e.x >> 16);
-      const int fx = (int)(e.y & 31u), fy = (int)((e.y >> 5) & 31u);
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const uint32_t vr = (valid >> (2 * r)) & 3u;  // bit 0: tap (ix, iy + r), bit 1: tap (ix + 1, iy + r)
-        if (!vr) continue;
-        const int wy = r ? fy : 32 - fy;
-        const long long o = (long long)(iy + r) * W + ix;  // may be -1 when only the right tap is inside
-        unsigned long long v = 0ULL;
-        if (o >= 0 && (size_t)o + 3 <= npx_src) {  // 8 bytes from 3 * o stay inside the frame
-          v = *reinterpret_cast<const u64_unaligned*>(src + 3 * o);
-        } else {
-          if (vr & 1u) v |= (unsigned long long)src[3 * o] | ((unsigned long long)src[3 * o + 1] << 8) | ((unsigned long long)src[3 * o + 2] << 16);
-          if (vr & 2u) v |= ((unsigned long long)src[3 * o + 3] << 24) | ((unsigned long long)src[3 * o + 4] << 32) | ((unsigned long long)src[3 * o + 5] << 40);
-        }
-        if (vr & 1u) {
-          const int w = (32 - fx) * wy;
-          acc0 += w * (int)(v & 0xFFu);
-          acc1 += w * (int)((v >> 8) & 0xFFu);
-          acc2 += w * (int)((v >> 16) & 0xFFu);
-        }
-        if (vr & 2u) {
-          const int w = fx * wy;
-          acc0 += w * (int)((v >> 24) & 0xFFu);
-          acc1 += w * (int)((v >> 32) & 0xFFu);
-          acc2 += w * (int)((v >> 40) & 0xFFu);
-        }
-      }
-    }
+    unsigned long long v[2];
+    unwrap_gather(src, H * W * 3, W, e, v);
+    bgr = unwrap_blend(H * W * 3, W, e, v);
   }
-  const uint32_t b0 = (uint32_t)((acc0 + 512) >> 10), b1 = (uint32_t)((acc1 + 512) >> 10), b2 = (uint32_t)((acc2 + 512) >> 10);
   const size_t out0 = ((size_t)img * npix + (size_t)blk * kThreads) * 3;  // first output byte of this workgroup
   const int nvalid = min(kThreads, npix - blk * kThreads);
   if ((out0 & 3) == 0 && nvalid == kThreads) {
     uint8_t* sb = reinterpret_cast<uint8_t*>(stage);
-    sb[3 * tid + 0] = (uint8_t)b0;
-    sb[3 * tid + 1] = (uint8_t)b1;
-    sb[3 * tid + 2] = (uint8_t)b2;
+    sb[3 * tid + 0] = (uint8_t)bgr;
+    sb[3 * tid + 1] = (uint8_t)(bgr >> 8);
+    sb[3 * tid + 2] = (uint8_t)(bgr >> 16);
     __syncthreads();
     if (tid < kThreads * 3 / 4) reinterpret_cast<uint32_t*>(pano + out0)[tid] = stage[tid];
   } else if (pix < npix) {
     uint8_t* out = pano + out0 + 3 * tid;
-    out[0] = (uint8_t)b0;
-    out[1] = (uint8_t)b1;
-    out[2] = (uint8_t)b2;
+    out[0] = (uint8_t)bgr;
+    out[1] = (uint8_t)(bgr >> 8);
+    out[2] = (uint8_t)(bgr >> 16);
   }
 }
 
@@ -176,20 +184,41 @@ __global__ __launch_bounds__(kThreads) void gray_kernel(const uint8_t* __restric
   gray[i] = bgr2gray(img[3 * i], img[3 * i + 1], img[3 * i + 2]);
 }
 
-// ---- K2 + K3 ----------------------------------------------------------------------------------------
-// K x K median per channel (replicated border) followed by BGR->gray.  K odd, 3 <= K <= 15.
-template <int K>
-__global__ __launch_bounds__(kThreads) void median_gray_kernel(const uint8_t* __restrict__ img, int nimg, int rows,
-                                                               int cols, int strips, uint8_t* __restrict__ gray) {
+// 64-bit wave ballot of "byte `byte` of x has its top bit set", as ONE SDWA compare (all lanes must be active).
+__device__ __forceinline__ unsigned long long ballot_byte_sign(uint32_t x, int byte, uint32_t vzero) {
+  unsigned long long bal;
+  if (byte == 0) asm("v_cmp_lt_i16_sdwa %0, sext(%1), %2 src0_sel:BYTE_0 src1_sel:DWORD" : "=s"(bal) : "v"(x), "v"(vzero));
+  else if (byte == 1) asm("v_cmp_lt_i16_sdwa %0, sext(%1), %2 src0_sel:BYTE_1 src1_sel:DWORD" : "=s"(bal) : "v"(x), "v"(vzero));
+  else asm("v_cmp_lt_i16_sdwa %0, sext(%1), %2 src0_sel:BYTE_2 src1_sel:DWORD" : "=s"(bal) : "v"(x), "v"(vzero));
+  return bal;
+}
+// c & ~(w ^ m): the candidates whose window bit equals the chosen bit (m = all-ones / zero), one v_bitop3
+__device__ __forceinline__ uint32_t keep_equal(uint32_t c, uint32_t m, uint32_t w) {
+  uint32_t r;
+  asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x90" : "=v"(r) : "v"(c), "v"(m), "v"(w));
+  return r;
+}
+
+// ---- K2 + K3 (optionally with K1 in front) --------------------------------------------------------------
+// K x K median per channel (replicated border) followed by BGR->gray.  K odd, 3 <= K <= 11.
+// FUSED = false: img is the BGR panorama batch [nimg, rows, cols, 3].
+// FUSED = true : img is the omni batch [nframes, H, W, 3] and every lane unwraps its source pixel from the table
+//                on the fly (same integer arithmetic as unwrap_lut_kernel), so the colour panoramas never touch
+//                HBM: the per-row gather hides under the other waves' VALU work.
+// Window registers: per (channel, bit-plane) the K * K window bits sit at the TOP of NW words (newest row in
+// the top K bits of the last word); a row step is NW v_alignbit ops fed by the lane's slice of the ballot.
+// The G = 32 * NW - K * K low bits of word 0 are stale and excluded by the initial candidate mask.
+template <int K, bool FUSED>
+__global__ __launch_bounds__(kThreads) void median_gray_kernel(const uint8_t* __restrict__ img,
+                                                               const uint2* __restrict__ table, int nframes, int H, int W,
+                                                               int nimg, int rows, int cols, int strips,
+                                                               uint8_t* __restrict__ gray) {
   constexpr int R = K / 2;
-  constexpr int NB = K * K;               // window bits per bit-plane, rows packed back to back (oldest row first)
+  constexpr int NB = K * K;
   constexpr int NW = (NB + 31) / 32;      // words per bit-plane: 4 for 11 x 11
-  constexpr int POS = (K - 1) * K - 32 * (NW - 1);  // where the newest row goes inside the last word
-  static_assert(POS >= 0 && POS + K <= 32, "newest row must not straddle words");
+  constexpr int G = 32 * NW - NB;         // stale low bits of word 0
   constexpr int OUTW = 64 - 2 * R;        // output columns per wave
-  constexpr uint32_t FIELD = (1u << K) - 1u;
-  constexpr uint32_t LASTMASK = (NB - 32 * (NW - 1)) == 32 ? 0xFFFFFFFFu : ((1u << (NB - 32 * (NW - 1))) - 1u);
-  constexpr int HALF = NB / 2 + 1;        // rank of the median, 1-based
+  constexpr uint32_t ABOVE = NB - (NB / 2 + 1);  // window elements ranked above the median
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * kThreads + threadIdx.x) >> 6;
   if (wave >= nimg * strips) return;  // wave-uniform
@@ -198,9 +227,34 @@ __global__ __launch_bounds__(kThreads) void median_gray_kernel(const uint8_t* __
   const int x_src = clampi(x0 - R + lane, 0, cols - 1);
   const int x_out = x0 + lane;
   const bool out_ok = lane < OUTW && x_out < cols;
-  const uint8_t* src = img + (size_t)im * rows * cols * 3;
   uint8_t* dst = gray + (size_t)im * rows * cols;
 
+  // ---- source pixel of (row, x_src) as B | G << 8 | R << 16, fetched one row ahead of its use
+  const int view = FUSED ? im / nframes : 0, frame = FUSED ? im - view * nframes : 0;
+  const uint8_t* src = FUSED ? img + (size_t)frame * H * W * 3 : img + (size_t)im * rows * cols * 3;
+  const uint2* tab = FUSED ? table + (size_t)view * rows * cols + x_src : nullptr;
+  const int frame_bytes = H * W * 3;
+  const bool last_image = im == nimg - 1;
+  uint2 e_cur = make_uint2(0u, 0u), e_nxt = make_uint2(0u, 0u);
+  unsigned long long taps[2] = {0ULL, 0ULL};
+  uint32_t raw = 0u;
+  auto row_of = [&](int r) { return clampi(r, 0, rows - 1); };
+  auto load_raw = [&](int r) -> uint32_t {
+    const int rr = row_of(r);
+    const uint8_t* px = src + ((size_t)rr * cols + x_src) * 3;
+    if (!(last_image && rr == rows - 1 && x_src == cols - 1)) return *reinterpret_cast<const u32_unaligned*>(px);
+    return (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16);  // the buffer's last 3 bytes
+  };
+  if (FUSED) {
+    e_cur = tab[(size_t)row_of(-R) * cols];
+    e_nxt = tab[(size_t)row_of(-R + 1) * cols];
+    unwrap_gather(src, frame_bytes, W, e_cur, taps);
+  } else {
+    raw = load_raw(-R);
+  }
+
+  uint32_t vzero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));  // SDWA compares take no constant operand
   uint32_t Wp[3][8][NW];
 #pragma unroll
   for (int c = 0; c < 3; ++c)
@@ -210,20 +264,27 @@ __global__ __launch_bounds__(kThreads) void median_gray_kernel(const uint8_t* __
       for (int j = 0; j < NW; ++j) Wp[c][b][j] = 0u;
 
   for (int r_src = -R; r_src < rows + R; ++r_src) {
-    const int rr = clampi(r_src, 0, rows - 1);
-    const uint8_t* px = src + ((size_t)rr * cols + x_src) * 3;
-    const uint32_t pix[3] = {px[0], px[1], px[2]};
-    // shift the window up by one row and append the new row's 8 bit-plane fields
+    uint32_t pix;
+    if (FUSED) {
+      pix = unwrap_blend(frame_bytes, W, e_cur, taps);
+      e_cur = e_nxt;
+      unwrap_gather(src, frame_bytes, W, e_cur, taps);   // row r_src + 1
+      e_nxt = tab[(size_t)row_of(r_src + 2) * cols];  // row r_src + 2
+    } else {
+      pix = raw;
+      raw = load_raw(r_src + 1);
+    }
+    // shift the window up by one row and append the new row's 24 bit-plane slices
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int b = 7; b >= 0; --b) {
+      const uint32_t sh = pix << (7 - b);  // bit b of every channel now sits in the sign position of its byte
 #pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        const unsigned long long bal = __ballot((pix[c] >> b) & 1u);
-        const uint32_t field = (uint32_t)(bal >> lane) & FIELD;
-        // drop the oldest row (K bits) of the NB-bit window, append the new one at the top
+      for (int c = 0; c < 3; ++c) {
+        const unsigned long long bal = ballot_byte_sign(sh, c, vzero);
+        const uint32_t x = (uint32_t)(bal >> lane);  // only its low K bits survive the funnel shift
 #pragma unroll
         for (int j = 0; j + 1 < NW; ++j) Wp[c][b][j] = __funnelshift_r(Wp[c][b][j], Wp[c][b][j + 1], K);
-        Wp[c][b][NW - 1] = (Wp[c][b][NW - 1] >> K) | (field << POS);
+        Wp[c][b][NW - 1] = __funnelshift_r(Wp[c][b][NW - 1], x, K);
       }
     }
     const int r_out = r_src - R;
@@ -231,32 +292,48 @@ __global__ __launch_bounds__(kThreads) void median_gray_kernel(const uint8_t* __
     int med[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
+      // radix select from the MSB down.  `above` = candidates ranked above the wanted element; the candidates
+      // whose current bit is 1 rank above those whose bit is 0.
       uint32_t C[NW];
 #pragma unroll
       for (int j = 0; j < NW; ++j) C[j] = 0xFFFFFFFFu;
-      C[NW - 1] = LASTMASK;
-      int k = HALF, cntC = NB, res = 0;
+      C[0] = G ? ~((1u << G) - 1u) : 0xFFFFFFFFu;
+      uint32_t above = ABOVE, res = 0u;
 #pragma unroll
       for (int b = 7; b >= 0; --b) {
-        uint32_t t[NW];
-        int n1 = 0;
+        uint32_t n1 = 0;
 #pragma unroll
-        for (int j = 0; j < NW; ++j) {
-          t[j] = C[j] & Wp[c][b][j];
-          n1 += __popc(t[j]);
-        }
-        const int nz = cntC - n1;           // candidates whose bit b is 0
-        const bool take0 = k <= nz;          // the k-th smallest is among them
-        res |= take0 ? 0 : (1 << b);
-        k = take0 ? k : k - nz;
-        cntC = take0 ? nz : n1;
+        for (int j = 0; j < NW; ++j) n1 += __popc(C[j] & Wp[c][b][j]);
+        const uint32_t d = above - n1;
+        const uint32_t ones = (uint32_t)((int32_t)d >> 31);  // all-ones: the wanted element has bit b set
+        above = min(above, d);                                // (unsigned) d wraps above `above` exactly then
+        res |= ones & (1u << b);
 #pragma unroll
-        for (int j = 0; j < NW; ++j) C[j] = take0 ? (C[j] ^ t[j]) : t[j];
+        for (int j = 0; j < NW; ++j) C[j] = b == 7 ? (C[j] & ~(Wp[c][b][j] ^ ones)) : keep_equal(C[j], ones, Wp[c][b][j]);
       }
-      med[c] = res;
+      med[c] = (int)res;
     }
     if (out_ok) dst[(size_t)r_out * cols + x_out] = bgr2gray(med[0], med[1], med[2]);
   }
+}
+
+// launches the K-templated strip kernel; FUSED takes the omni batch + unwrap table instead of panoramas
+template <bool FUSED>
+int32_t launch_median(sosvo_ctx* ctx, const uint8_t* img, const uint2* table, int nframes, int H, int W, int nimg,
+                             int rows, int cols, int ksize, uint8_t* gray) {
+  const int outw = 64 - 2 * (ksize / 2);
+  const int strips = cdiv(cols, outw);
+  const int waves = nimg * strips;
+  dim3 grid(cdiv(waves, kThreads / 64)), block(kThreads);
+  // (named aliases so that the profile labels tell the two forms apart)
+  constexpr auto k11 = median_gray_kernel<11, FUSED>;
+  constexpr auto k5 = median_gray_kernel<5, FUSED>;
+  constexpr auto k3 = median_gray_kernel<3, FUSED>;
+  SosvoProfScope prof(ctx, FUSED ? "unwrap_median_gray_kernel" : "median_gray_kernel");
+  hipLaunchKernelGGL(ksize == 11 ? k11 : (ksize == 5 ? k5 : k3), grid, block, 0, ctx->stream, img, table, nframes, H, W, nimg,
+                     rows, cols, strips, gray);
+  SOSVO_LAUNCH_CHECK(ctx);
+  return SOSVO_OK;
 }
 
 }  // namespace
@@ -318,20 +395,24 @@ int32_t sosvo_median_gray(sosvo_ctx* ctx, const uint8_t* img, int32_t nimg, int3
     const size_t n = (size_t)nimg * rows * cols;
     SOSVO_LAUNCH(ctx, gray_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream, img, n,
                  gray);
-  } else {
-    const int outw = 64 - 2 * (ksize / 2);
-    const int strips = cdiv(cols, outw);
-    const int waves = nimg * strips;
-    dim3 grid(cdiv(waves, kThreads / 64)), block(kThreads);
-    if (ksize == 11)
-      SOSVO_LAUNCH(ctx, median_gray_kernel<11>, grid, block, 0, ctx->stream, img, nimg, rows, cols, strips, gray);
-    else if (ksize == 5)
-      SOSVO_LAUNCH(ctx, median_gray_kernel<5>, grid, block, 0, ctx->stream, img, nimg, rows, cols, strips, gray);
-    else
-      SOSVO_LAUNCH(ctx, median_gray_kernel<3>, grid, block, 0, ctx->stream, img, nimg, rows, cols, strips, gray);
+    SOSVO_LAUNCH_CHECK(ctx);
+    return SOSVO_OK;
   }
-  SOSVO_LAUNCH_CHECK(ctx);
-  return SOSVO_OK;
+  return launch_median<false>(ctx, img, nullptr, 0, 0, 0, nimg, rows, cols, ksize, gray);
+}
+
+int32_t sosvo_unwrap_median_gray(sosvo_ctx* ctx, const uint8_t* omni, const uint32_t* table, int32_t nframes, int32_t H,
+                                 int32_t W, int32_t rows, int32_t cols, int32_t ksize, uint8_t* gray) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, omni && table && gray, "null pointer");
+  SOSVO_REQUIRE(ctx, nframes >= 0 && nframes <= 32767, "nframes out of range");
+  SOSVO_REQUIRE(ctx, H > 0 && W > 0 && H <= 16384 && W <= 16384 && rows > 0 && cols > 0 && rows * (int64_t)cols < (1 << 28),
+                "image sizes out of range");
+  SOSVO_REQUIRE(ctx, ((uintptr_t)table & 7) == 0, "table must be 8-byte aligned");
+  SOSVO_REQUIRE(ctx, ksize == 3 || ksize == 5 || ksize == 11, "ksize must be 3, 5 or 11");
+  if (nframes == 0) return SOSVO_OK;
+  return launch_median<true>(ctx, omni, reinterpret_cast<const uint2*>(table), nframes, H, W, 2 * nframes, rows, cols, ksize,
+                             gray);
 }
 
 }  // extern "C"

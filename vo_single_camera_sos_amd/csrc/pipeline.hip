@@ -34,7 +34,8 @@ Buffers carve(const sosvo_batch_cfg& c, void* ws) {
   Buffers b;
   const size_t B = c.n_pairs, F = 2 * B, NI = 2 * F, P = NI * c.nmask, cap = c.kp_cap, Fc = c.frame_cap, Cc = 2 * Fc;
   const size_t npx = (size_t)c.rows * c.cols;
-  b.pano = cv.take<uint8_t>(NI * npx * 3);
+  const bool fused = c.median_ksize == 3 || c.median_ksize == 5 || c.median_ksize == 11;  // K1 inside the median kernel
+  b.pano = fused ? nullptr : cv.take<uint8_t>(NI * npx * 3);
   b.gray = cv.take<uint8_t>(NI * npx);
   b.kp = cv.take<float>(P * cap * 2);
   b.n = cv.take<int32_t>(P);
@@ -150,8 +151,13 @@ int32_t sosvo_frame_pair_batch(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo
                b.cur_frame, b.cam_off, b.cam_rot);
   SOSVO_LAUNCH_CHECK(ctx);
   // image front end: K1, K2 + K3, K4, K6 over all 2 * F panoramas
-  STAGE(sosvo_unwrap_table(ctx, omni, unwrap_table, F, cfg->H, cfg->W, cfg->rows, cfg->cols, b.pano));
-  STAGE(sosvo_median_gray(ctx, b.pano, NI, cfg->rows, cfg->cols, cfg->median_ksize, b.gray));
+  if (cfg->median_ksize == 3 || cfg->median_ksize == 5 || cfg->median_ksize == 11) {
+    STAGE(sosvo_unwrap_median_gray(ctx, omni, unwrap_table, F, cfg->H, cfg->W, cfg->rows, cfg->cols, cfg->median_ksize,
+                                   b.gray));
+  } else {
+    STAGE(sosvo_unwrap_table(ctx, omni, unwrap_table, F, cfg->H, cfg->W, cfg->rows, cfg->cols, b.pano));
+    STAGE(sosvo_median_gray(ctx, b.pano, NI, cfg->rows, cfg->cols, cfg->median_ksize, b.gray));
+  }
   STAGE(sosvo_detect_gft(ctx, b.gray, mask_bits, NI, F, cfg->rows, cfg->cols, NM, cfg->quality, cfg->min_distance,
                          cfg->max_corners, cap, b.kp, b.n, b.status));
   STAGE(sosvo_describe_orb(ctx, b.gray, NI, cfg->rows, cfg->cols, NM, cap, b.kp, b.n, cfg->cos_a, cfg->sin_a, pattern,

@@ -169,6 +169,19 @@ class Context(object):
         self._call(self._lib.sosvo_median_gray, _ptr(img), nimg, rows, cols, int(ksize), _ptr(gray))
         return gray
 
+    def unwrap_median_gray(self, omni, table, ksize, gray=None):
+        """K1 + K2 + K3 fused: omni [F,H,W,3] u8, table from unwrap_prepare -> gray [2F,rows,cols] u8 (view-major);
+        the colour panoramas are never materialised.  Same result as unwrap_table + median_gray."""
+        _check(omni, torch.uint8, "omni", (None, None, None, 3))
+        F, H, W = omni.shape[0], omni.shape[1], omni.shape[2]
+        _check(table, torch.uint32, "table", (2, None, None, 2))
+        rows, cols = table.shape[1], table.shape[2]
+        if gray is None:
+            gray = torch.empty((2 * F, rows, cols), dtype=torch.uint8, device=omni.device)
+        _check(gray, torch.uint8, "gray", (2 * F, rows, cols))
+        self._call(self._lib.sosvo_unwrap_median_gray, _ptr(omni), _ptr(table), F, H, W, rows, cols, int(ksize), _ptr(gray))
+        return gray
+
     # ---- K4 / K6 -----------------------------------------------------------------------
     def detect_gft(self, gray, mask_bits, images_per_maskset, nmask, cap, quality=0.01, min_distance=5.0,
                    max_corners=1000, kp=None, n=None, status=None):

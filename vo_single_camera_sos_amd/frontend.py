@@ -50,8 +50,10 @@ class DeviceImageModel(object):
 
 class ImageFrontEnd(object):
     def __init__(self, ctx, model, nframes, detection_method="GFT", num_of_features=1000, kp_cap=None,
-                 median_win_size=11, quality=0.01, min_distance=5.0, edge=31):
-        """num_of_features: per azimuthal mask (FeatureMatcher.num_of_features, pose_est_tools.py:862)."""
+                 median_win_size=11, quality=0.01, min_distance=5.0, edge=31, keep_panoramas=True):
+        """num_of_features: per azimuthal mask (FeatureMatcher.num_of_features, pose_est_tools.py:862).
+        keep_panoramas=False: K1 is fused into the median kernel and the colour panoramas are not materialised
+        (nothing downstream of K3 reads them); identical gray images."""
         if detection_method.upper() not in ("GFT", "ORB"):
             raise NotImplementedError("detection method %r: GFT (the reference default, pose_est_tools.py:684) and "
                                       "ORB are built" % detection_method)
@@ -68,7 +70,8 @@ class ImageFrontEnd(object):
         dev, m = ctx.device, model
         NI, P = 2 * self.F, 2 * self.F * m.nmask
         self.omni = torch.zeros((self.F, m.H, m.W, 3), dtype=torch.uint8, device=dev)
-        self.pano = torch.zeros((2, self.F, m.rows, m.cols, 3), dtype=torch.uint8, device=dev)
+        self.keep_panoramas = bool(keep_panoramas) or self.median_win_size not in (3, 5, 11)
+        self.pano = torch.zeros((2, self.F, m.rows, m.cols, 3), dtype=torch.uint8, device=dev) if self.keep_panoramas else None
         self.gray = torch.zeros((NI, m.rows, m.cols), dtype=torch.uint8, device=dev)
         self.kp = torch.zeros((P, self.kp_cap, 2), dtype=torch.float32, device=dev)
         self.n = torch.zeros((P,), dtype=torch.int32, device=dev)
@@ -90,8 +93,11 @@ class ImageFrontEnd(object):
         c, m = self.ctx, self.model
         if getattr(m, "unwrap_table", None) is None:  # once per model
             m.unwrap_table = c.unwrap_prepare(m.omni_masks, m.map_x, m.map_y, (m.H, m.W))
-        c.unwrap_table(self.omni, m.unwrap_table, pano=self.pano)                                 # K1 (a1 + a2)
-        c.median_gray(self.pano.view(2 * self.F, m.rows, m.cols, 3), self.median_win_size, gray=self.gray)  # K2 + K3
+        if self.keep_panoramas:
+            c.unwrap_table(self.omni, m.unwrap_table, pano=self.pano)                                 # K1 (a1 + a2)
+            c.median_gray(self.pano.view(2 * self.F, m.rows, m.cols, 3), self.median_win_size, gray=self.gray)  # K2 + K3
+        else:
+            c.unwrap_median_gray(self.omni, m.unwrap_table, self.median_win_size, gray=self.gray)    # K1 + K2 + K3
         if self.method == "ORB":
             c.detect_orb(self.gray, m.mask_pyr, self.F, m.nmask, self.num_of_features, self.kp_cap, kp4=self.kp4,
                          resp=self.resp, n=self.n)                                                # K5

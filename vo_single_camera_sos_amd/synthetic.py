@@ -96,17 +96,43 @@ def random_step(rng, max_t=100.0, max_deg=5.0):
     return R, t
 
 
-def make_frame_pairs(gums, n_pairs, seed=1234, noise_sigma=2.0):
+def _render_pair(args):
+    gums, seed, i, noise_sigma = args
+    rng = np.random.default_rng(seed + i)
+    room = Room(seed=seed + i)
+    R, t = random_step(rng)
+    ref = render_omni(gums, room, np.eye(3), np.zeros(3), noise_sigma, rng)
+    cur = render_omni(gums, room, R, t, noise_sigma, rng)
+    return ref, cur, (R, t)
+
+
+_POOL_GUMS = None
+
+
+def _render_pair_pooled(args):
+    return _render_pair((_POOL_GUMS,) + args)
+
+
+def make_frame_pairs(gums, n_pairs, seed=1234, noise_sigma=2.0, workers=1):
     """-> (omni [2*n_pairs, H, W, 3] u8, poses list of (R, t)): pair i = frames 2i (reference, identity pose)
-    and 2i+1 (current, pose (R, t) in the reference frame); one room per pair."""
+    and 2i+1 (current, pose (R, t) in the reference frame); one room per pair.  workers > 1 renders the pairs in
+    forked worker processes (same frames; call it BEFORE the process touches the GPU)."""
+    global _POOL_GUMS
     W, H = gums.top_model.image_size
+    if gums.top_model.mask is None:
+        gums.make_annulus_masks((H, W))
     omni = np.zeros((2 * n_pairs, H, W, 3), dtype=np.uint8)
     poses = []
-    for i in range(n_pairs):
-        rng = np.random.default_rng(seed + i)
-        room = Room(seed=seed + i)
-        R, t = random_step(rng)
-        omni[2 * i] = render_omni(gums, room, np.eye(3), np.zeros(3), noise_sigma, rng)
-        omni[2 * i + 1] = render_omni(gums, room, R, t, noise_sigma, rng)
-        poses.append((R, t))
+    jobs = [(seed, i, noise_sigma) for i in range(n_pairs)]
+    if workers > 1 and n_pairs > 1:
+        import multiprocessing
+        _POOL_GUMS = gums
+        with multiprocessing.get_context("fork").Pool(min(int(workers), n_pairs)) as pool:
+            results = pool.map(_render_pair_pooled, jobs, chunksize=max(1, n_pairs // (4 * int(workers))))
+        _POOL_GUMS = None
+    else:
+        results = [_render_pair((gums,) + j) for j in jobs]
+    for i, (ref, cur, pose) in enumerate(results):
+        omni[2 * i], omni[2 * i + 1] = ref, cur
+        poses.append(pose)
     return omni, poses
