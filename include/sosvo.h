@@ -128,8 +128,10 @@ int32_t sosvo_unwrap_median_gray(sosvo_ctx* ctx, const uint8_t* omni, const uint
  * image border, descending sort (ties: higher address first), greedy min-distance on a cell grid,
  * stop at max_corners (<= 0: no limit) or at the output capacity `cap`.
  *   kp [nimg*nmask, cap, 2] f32 (x, y) in acceptance order, n [nimg*nmask] i32,
- *   status [nimg*nmask] i32 (optional): bit 0 = more than 4096 candidates (result then depends on
- *   which were kept), bit 1 = mask too large for the on-chip grid and more than 1024 corners wanted. */
+ *   status [nimg*nmask] i32 (optional): bit 0 = more candidates than the selection keeps (4096; 16384 when
+ *   cap > 1024: the large-mask variant for whole-image detection, e.g. the RGB-D frames) -- the result then
+ *   depends on which were kept; bit 1 = mask too large for the on-chip grid (3584 / 15872 cells of
+ *   minDistance^2 pixels) and more than 1024 corners wanted. */
 int32_t sosvo_detect_gft(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* mask_bits, int32_t nimg,
                          int32_t images_per_maskset, int32_t rows, int32_t cols, int32_t nmask,
                          double quality, double min_distance, int32_t max_corners, int32_t cap,
@@ -327,6 +329,38 @@ int32_t sosvo_f2f_assemble(sosvo_ctx* ctx, const sosvo_rig* rig_host, const floa
                            const int32_t* order_top, const uint32_t* keys_bot, const int32_t* order_bot,
                            int32_t npairs, int32_t corr_cap, double* f, double* p, int32_t* cam,
                            int32_t* corr_q, int32_t* corr_t, int32_t* n, int32_t* n_topview);
+
+/* ---- RGB-D (perspective camera) variant: a12 + a15 glue ----------------------------------------
+ * Constants of one RGB-D camera (HOST struct): RGBDCamModel (omnistereo/camera_models.py:756-779) and the
+ * RGBDFrame ranges (pose_est_tools.py:428-430, in the depth map's units).                           */
+typedef struct sosvo_rgbd_cam {
+  double fx, fy, cx, cy;
+  double focal_length_m;   /* only used when depth is radial (depth_is_Z == 0, camera_models.py:781-799) */
+  int32_t depth_is_Z;      /* 1: the depth map holds Z values */
+  int32_t reserved;
+  double min_range;        /* keep min_range <= |Z| <= max_range; <= 0 disables (pose_est_tools.py:570-592) */
+  double max_range;
+} sosvo_rgbd_cam;
+
+/* sosvo_rgbd_assemble: RGBDFrame.establish_keypoints after detection (pose_est_tools.py:609-623) for nframes
+ * frames: depth at the keypoints' integer pixels -> XYZ (get_XYZ), keypoints with zero depth (NaN) or out of
+ * range dropped, bearings = normalised XYZ, survivors written in keypoint order.
+ *   kp [nframes, cap, 2] f32, desc [nframes, cap, 32] u8, n [nframes] i32, depth [nframes, rows, cols] f32
+ *   -> m [nframes, out_cap, 2] f32, d [nframes, out_cap, 32] u8, X, b [nframes, out_cap, 3] f64, M [nframes] i32
+ * sosvo_f2f_assemble_central: TrackerRGBDSE3.track_frame steps 1-2 (pose_est_tools.py:896-913) for npairs pairs:
+ *   keys / order [npairs, frame_cap] from sosvo_match_hamming (query = current frame's d, train = reference
+ *   frame's d, k = 1) + sosvo_sort_matches; the first pct_good_matches * nq matches (:225), |du| <= max_hdiff
+ *   (<= 0 disables, :245-247) -> f (bearings of the current frame), p (points of the reference frame)
+ *   [npairs, corr_cap, 3] f64, corr_q / corr_t [npairs, corr_cap] i32 (indices into the frames), n [npairs].
+ *   Feed f, p, n to sosvo_ransac_abs_pose / sosvo_refine_abs_pose with cam = NULL (central, :915, :937).   */
+int32_t sosvo_rgbd_assemble(sosvo_ctx* ctx, const sosvo_rgbd_cam* cam_host, const float* kp, const uint8_t* desc,
+                            const int32_t* n, const float* depth, int32_t nframes, int32_t rows, int32_t cols,
+                            int32_t cap, int32_t out_cap, float* m, uint8_t* d, double* X, double* b, int32_t* M);
+int32_t sosvo_f2f_assemble_central(sosvo_ctx* ctx, double pct_good_matches, double max_hdiff, const float* m,
+                                   const double* X, const double* b, const int32_t* M, int32_t frame_cap,
+                                   const int32_t* ref_frame, const int32_t* cur_frame, const uint32_t* keys,
+                                   const int32_t* order, int32_t npairs, int32_t corr_cap, double* f, double* p,
+                                   int32_t* corr_q, int32_t* corr_t, int32_t* n);
 
 /* ---- the whole hot path for a batch of frame pairs (the throughput entry point) ----------------
  * One call = for B independent pairs (frames 2i = reference / keyframe, 2i+1 = current):

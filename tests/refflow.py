@@ -151,3 +151,49 @@ def track_pair(rig, ref, cur, thr, max_iter, seed, adaptive=False, lm_iter=30):
         T, _, _ = oracle.refine_abs_pose(c["f"], c["p"], r["T"], idx=idx, cam=c["cam"], cam_off=cam_off,
                                          cam_rot=cam_rot, max_lm_iter=lm_iter)
     return dict(corr=c, ransac=r, T=T)
+
+
+# ---- RGB-D (perspective) variant ---------------------------------------------------------------------------
+class RGBDParams(object):
+    """Host constants of the RGB-D path: RGBDCamModel (camera_models.py:756-779), RGBDFrame ranges
+    (pose_est_tools.py:428-430) and the tracker's |du| gate (:958)."""
+
+    def __init__(self, fx, fy, cx, cy, focal_length_m=1e-3, depth_is_Z=True, min_range=0.8, max_range=7.0,
+                 f2f_max_hdiff=-1.0, pct_good_matches=1.0):
+        self.intr = np.array([fx, fy, cx, cy, focal_length_m], dtype=np.float64)
+        self.depth_is_Z, self.min_range, self.max_range = depth_is_Z, min_range, max_range
+        self.f2f_max_hdiff, self.pct_good_matches = f2f_max_hdiff, pct_good_matches
+
+
+def rgbd_frame(cam, bgr, depth, max_corners, pattern, cos_a, sin_a, median_ksize=0, quality=0.01, min_distance=5.0,
+               edge=31, mask=None):
+    """RGBDFrame.establish_keypoints (pose_est_tools.py:600-623) with the GFT detector (:544) and ORB descriptors
+    (:553) on the oracle -> dict(m [M,2] f32, d [M,32] u8, X [M,3], b [M,3])."""
+    gray = oracle.median_gray(bgr, median_ksize)                                     # :528, :531
+    mb = np.ones(gray.shape, np.uint32) if mask is None else (np.asarray(mask) != 0).astype(np.uint32)
+    kp, _ = oracle.gft_select(oracle.min_eigen(gray), mb, 0, quality, min_distance, max_corners)   # :544
+    d, kept = oracle.orb_describe(oracle.gauss7(gray), kp, cos_a, sin_a, pattern, edge)            # :553
+    kp = kp[kept]
+    u, v = kp[:, 0].astype(np.uint64).astype(np.int32), kp[:, 1].astype(np.uint64).astype(np.int32)  # :611
+    xyz, b = oracle.rgbd_backproject(depth, u, v, cam.intr, cam.depth_is_Z)          # camera_models.py:835-860
+    Z = xyz[:, 2]
+    valid = ~np.isnan(Z)                                                             # :613
+    az = np.abs(np.nan_to_num(Z))                                                    # :583-584 on the Z row
+    if cam.min_range > 0:
+        valid &= az >= cam.min_range
+    if cam.max_range > 0:
+        valid &= az <= cam.max_range
+    return dict(m=kp[valid], d=d[valid], X=xyz[valid], b=b[valid], n_kp=len(kp))
+
+
+def track_pair_rgbd(cam, ref, cur, thr, max_iter, seed, adaptive=False, lm_iter=30):
+    """TrackerRGBDSE3.track_frame (pose_est_tools.py:896-954) on the oracle: frame-to-frame matches, central
+    RANSAC (:915), LM on the inliers (:937)."""
+    t, q = f2f_view(cam, ref["m"], ref["d"], cur["m"], cur["d"])
+    f, p = cur["b"][q], ref["X"][t]
+    r = oracle.ransac_abs_pose(f, p, thr, max_iter, seed=seed, adaptive=adaptive)
+    idx = np.nonzero(r["mask"])[0].astype(np.int32)
+    T = r["T"]
+    if r["status"] == 0:
+        T, _, _ = oracle.refine_abs_pose(f, p, r["T"], idx=idx, max_lm_iter=lm_iter)
+    return dict(corr=dict(f=f, p=p, q=q, t=t), ransac=r, T=T)

@@ -72,6 +72,9 @@ SIGNATURES = {
                                       c_i32, c_i32, c_u64, c_p, c_p, c_p, c_p, c_p, c_p]),
     "sosvo_refine_abs_pose": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_p, c_i32, c_i32, c_p, c_p, c_i32,
                                       c_p, c_p, c_p]),
+    "sosvo_rgbd_assemble": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p, c_p]),
+    "sosvo_f2f_assemble_central": (c_i32, [c_p, c_f64, c_f64, c_p, c_p, c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_i32, c_i32,
+                                           c_p, c_p, c_p, c_p, c_p]),
     "sosvo_frame_pair_batch_workspace": (ctypes.c_size_t, [c_p]),
     "sosvo_frame_pair_batch": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
 }
@@ -85,6 +88,12 @@ class Rig(ctypes.Structure):
                 ("min_range", c_f64), ("max_range", c_f64), ("stereo_min_disp", c_f64),
                 ("stereo_max_hdiff", c_f64), ("f2f_max_hdiff", c_f64), ("pct_good_matches", c_f64)]
 
+
+
+class RgbdCam(ctypes.Structure):
+    """Mirror of `struct sosvo_rgbd_cam` (include/sosvo.h)."""
+    _fields_ = [("fx", c_f64), ("fy", c_f64), ("cx", c_f64), ("cy", c_f64), ("focal_length_m", c_f64),
+                ("depth_is_Z", c_i32), ("reserved", c_i32), ("min_range", c_f64), ("max_range", c_f64)]
 
 
 class BatchCfg(ctypes.Structure):

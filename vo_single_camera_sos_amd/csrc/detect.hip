@@ -20,7 +20,8 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kCandCap = 4096;   // candidates kept per (image, mask)
+constexpr int kCandCap = 4096;       // candidates kept per (image, mask): 32 KB of LDS sort keys
+constexpr int kCandCapLarge = 16384; // large-mask variant (whole-image detection, cap > 1024): 128 KB of the 160 KB LDS
 constexpr int kMaxMasks = 32;
 
 __device__ __forceinline__ int refl101(int i, int n) {
@@ -189,8 +190,7 @@ __global__ __launch_bounds__(kThreads) void mask_bbox_kernel(const uint32_t* __r
 // candidate against the grid of already accepted points (9 cells x 2 slots) and against the earlier lanes
 // of its batch (64 shuffles -> a 64-bit conflict mask); a short scalar pass over the batch then replays the
 // sequential acceptance rule exactly (accept iff no conflict with anything accepted before).
-constexpr int kSelGridCells = (kCandCap * 8 - 1024 * 4) / 8;  // 2 slots (u32) per cell, 1024 u32 left for the list
-
+template <int CAND>
 __global__ __launch_bounds__(kThreads) void gft_select_kernel(const float* __restrict__ eig,
                                                               const unsigned long long* __restrict__ flags, int strips,
                                                               const uint32_t* __restrict__ mask_bits,
@@ -199,7 +199,8 @@ __global__ __launch_bounds__(kThreads) void gft_select_kernel(const float* __res
                                                               float min_distance, int cell, int max_corners, int cap,
                                                               uint32_t* __restrict__ sorted_g, float* __restrict__ kp,
                                                               int32_t* __restrict__ n_out, int32_t* __restrict__ status) {
-  __shared__ unsigned long long lds_u64[kCandCap];
+  constexpr int kSelGridCells = (CAND * 8 - 1024 * 4) / 8;  // 2 slots (u32) per cell, 1024 u32 left for the list
+  __shared__ unsigned long long lds_u64[CAND];
   __shared__ int s_count, s_accepted;
   unsigned long long* keys = lds_u64;
   uint32_t* grid = reinterpret_cast<uint32_t*>(lds_u64);  // phase 3: 2 slots per cell, pixel index + 1 (0 = empty)
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(kThreads) void gft_select_kernel(const float* __res
   const int img = p / nmask, m = p - img * nmask;
   const uint32_t* st = mstat + (size_t)p * 5;                                                              // [0]: max
   const uint32_t* sb = mstat + ((size_t)(img / images_per_maskset) * images_per_maskset * nmask + m) * 5;  // bbox
-  uint32_t* sorted = sorted_g + (size_t)p * kCandCap;
+  uint32_t* sorted = sorted_g + (size_t)p * CAND;
   if (tid == 0) {
     s_count = 0;
     s_accepted = 0;
@@ -275,14 +276,14 @@ __global__ __launch_bounds__(kThreads) void gft_select_kernel(const float* __res
             if (v != dil) continue;
           }
           const int slot = atomicAdd(&s_count, 1);
-          if (slot < kCandCap) keys[slot] = ((unsigned long long)sosvo_float_ordered(v) << 32) | (uint32_t)pix;
+          if (slot < CAND) keys[slot] = ((unsigned long long)sosvo_float_ordered(v) << 32) | (uint32_t)pix;
         }
       }
     }
   }
   __syncthreads();
   const int total = s_count;
-  const int n = min(total, kCandCap);
+  const int n = min(total, CAND);
   // ---- phase 2: bitonic sort, descending (keys are unique: value, then higher address first) ---------------
   int N = 64;
   while (N < n) N <<= 1;
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(kThreads) void gft_select_kernel(const float* __res
     const uint32_t y = pix / (uint32_t)cols;
     sorted[i] = (y << 16) | (pix - y * (uint32_t)cols);
   }
-  int stt = total > kCandCap ? 1 : 0;
+  int stt = total > CAND ? 1 : 0;
   const int cx0 = bx0 / cell, cy0 = by0 / cell;
   const int gw = bw > 0 ? bx1 / cell - cx0 + 1 : 0, gh = bh > 0 ? by1 / cell - cy0 + 1 : 0;
   const bool use_grid = gw * gh <= kSelGridCells;
@@ -583,7 +584,8 @@ int32_t sosvo_detect_gft(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* ma
   const size_t o_eig = carve(sizeof(float) * (size_t)nimg * rows * cols);
   const size_t o_flags = carve(sizeof(unsigned long long) * (size_t)nimg * rows * strips);
   const size_t o_stat = carve(sizeof(uint32_t) * P * 5);
-  const size_t o_sorted = carve(sizeof(uint32_t) * P * kCandCap);
+  const bool large = cap > 1024;  // whole-image masks (RGB-D frames): 16384 candidates, 15872 grid cells
+  const size_t o_sorted = carve(sizeof(uint32_t) * P * (large ? kCandCapLarge : kCandCap));
   int32_t rc = sosvo_ws_reserve(ctx, off);
   if (rc != SOSVO_OK) return rc;
   char* ws = (char*)ctx->ws;
@@ -602,9 +604,12 @@ int32_t sosvo_detect_gft(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* ma
                images_per_maskset, rows, cols, nmask, strips, nchunks, chunk_rows, eig, flags, mstat);
   SOSVO_LAUNCH_CHECK(ctx);
   const int cell = min_distance >= 1 ? (int)lrint(min_distance) : 1;
-  SOSVO_LAUNCH(ctx, gft_select_kernel, dim3((unsigned)P), dim3(kThreads), 0, ctx->stream, eig, flags, strips, mask_bits,
-               mstat, images_per_maskset, nmask, rows, cols, quality, (float)min_distance, cell, max_corners, cap, sorted_g, kp, n,
-               status);
+  {
+    SOSVO_PROFILE(ctx, "gft_select_kernel");
+    hipLaunchKernelGGL(large ? gft_select_kernel<kCandCapLarge> : gft_select_kernel<kCandCap>, dim3((unsigned)P),
+                       dim3(kThreads), 0, ctx->stream, eig, flags, strips, mask_bits, mstat, images_per_maskset, nmask, rows,
+                       cols, quality, (float)min_distance, cell, max_corners, cap, sorted_g, kp, n, status);
+  }
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
 }

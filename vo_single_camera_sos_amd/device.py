@@ -485,6 +485,63 @@ class Context(object):
                    _ptr(out["X"]), _ptr(out["b_top"]), _ptr(out["b_bot"]), _ptr(out["M"]), _ptr(out["n_cand"]))
         return out
 
+    # ---- RGB-D variant ---------------------------------------------------------------------
+    def rgbd_assemble(self, cam, kp, desc, n, depth, out_cap, out=None):
+        """RGBDFrame.establish_keypoints after detection, batched.  cam: _lib.RgbdCam; kp [F,cap,2] f32,
+        desc [F,cap,32] u8, n [F] i32, depth [F,rows,cols] f32 -> dict(m [F,out_cap,2] f32, d [F,out_cap,32] u8,
+        X, b [F,out_cap,3] f64, M [F] i32)."""
+        _check(kp, torch.float32, "kp", (None, None, 2))
+        F, cap = kp.shape[0], kp.shape[1]
+        _check(desc, torch.uint8, "desc", (F, cap, 32))
+        _check(n, torch.int32, "n", (F,))
+        _check(depth, torch.float32, "depth", (F, None, None))
+        rows, cols = depth.shape[1], depth.shape[2]
+        dev = kp.device
+        if out is None:
+            out = dict(m=torch.zeros((F, out_cap, 2), dtype=torch.float32, device=dev),
+                       d=torch.zeros((F, out_cap, 32), dtype=torch.uint8, device=dev),
+                       X=torch.zeros((F, out_cap, 3), dtype=torch.float64, device=dev),
+                       b=torch.zeros((F, out_cap, 3), dtype=torch.float64, device=dev),
+                       M=torch.zeros((F,), dtype=torch.int32, device=dev))
+        _check(out["m"], torch.float32, "m", (F, out_cap, 2))
+        _check(out["d"], torch.uint8, "d", (F, out_cap, 32))
+        _check(out["X"], torch.float64, "X", (F, out_cap, 3))
+        _check(out["b"], torch.float64, "b", (F, out_cap, 3))
+        _check(out["M"], torch.int32, "M", (F,))
+        self._call(self._lib.sosvo_rgbd_assemble, ctypes.cast(ctypes.pointer(cam), c_p), _ptr(kp), _ptr(desc), _ptr(n),
+                   _ptr(depth), F, rows, cols, cap, int(out_cap), _ptr(out["m"]), _ptr(out["d"]), _ptr(out["X"]),
+                   _ptr(out["b"]), _ptr(out["M"]))
+        return out
+
+    def f2f_assemble_central(self, frames, ref_frame, cur_frame, keys, order, corr_cap, pct_good_matches=1.0,
+                             max_hdiff=-1.0, out=None):
+        """TrackerRGBDSE3.track_frame steps 1-2, batched.  frames: dict from rgbd_assemble; ref_frame / cur_frame
+        [NP] i32; keys [NP, frame_cap, 1] u32, order [NP, frame_cap] i32 -> dict(f, p [NP,corr_cap,3] f64,
+        q, t [NP,corr_cap] i32, n [NP] i32)."""
+        NP = ref_frame.shape[0]
+        frame_cap = frames["m"].shape[1]
+        _check(ref_frame, torch.int32, "ref_frame", (NP,))
+        _check(cur_frame, torch.int32, "cur_frame", (NP,))
+        _check(keys, torch.uint32, "keys", (NP, frame_cap, 1))
+        _check(order, torch.int32, "order", (NP, frame_cap))
+        dev = ref_frame.device
+        if out is None:
+            out = dict(f=torch.zeros((NP, corr_cap, 3), dtype=torch.float64, device=dev),
+                       p=torch.zeros((NP, corr_cap, 3), dtype=torch.float64, device=dev),
+                       q=torch.zeros((NP, corr_cap), dtype=torch.int32, device=dev),
+                       t=torch.zeros((NP, corr_cap), dtype=torch.int32, device=dev),
+                       n=torch.zeros((NP,), dtype=torch.int32, device=dev))
+        _check(out["f"], torch.float64, "f", (NP, corr_cap, 3))
+        _check(out["p"], torch.float64, "p", (NP, corr_cap, 3))
+        _check(out["q"], torch.int32, "q", (NP, corr_cap))
+        _check(out["t"], torch.int32, "t", (NP, corr_cap))
+        _check(out["n"], torch.int32, "n", (NP,))
+        self._call(self._lib.sosvo_f2f_assemble_central, float(pct_good_matches), float(max_hdiff), _ptr(frames["m"]),
+                   _ptr(frames["X"]), _ptr(frames["b"]), _ptr(frames["M"]), frame_cap, _ptr(ref_frame), _ptr(cur_frame),
+                   _ptr(keys), _ptr(order), NP, int(corr_cap), _ptr(out["f"]), _ptr(out["p"]), _ptr(out["q"]),
+                   _ptr(out["t"]), _ptr(out["n"]))
+        return out
+
     # ---- whole hot path ------------------------------------------------------------------
     def frame_pair_batch_workspace(self, cfg):
         return int(self._lib.sosvo_frame_pair_batch_workspace(ctypes.cast(ctypes.pointer(cfg), c_p)))

@@ -174,3 +174,118 @@ class FramePairBatch(object):
 
     def results(self):
         return self.out
+
+
+class RGBDCamConfig(object):
+    """What the RGB-D hot path needs to know about the camera (host numbers): RGBDCamModel
+    (omnistereo/camera_models.py:756-779), the RGBDFrame ranges (pose_est_tools.py:428-430, depth units) and
+    TrackerRGBDSE3.bootstrap_tracker's |du| gate (pose_est_tools.py:956-958: 0.5 * 2 * center_x)."""
+
+    def __init__(self, fx=525.0, fy=525.0, center_x=319.5, center_y=239.5, focal_length_m=1.0 / 1000.0, depth_is_Z=True,
+                 min_range=0.8, max_range=7.0, f2f_max_hdiff=None, pct_good_matches=1.0):
+        self.fx, self.fy, self.center_x, self.center_y = float(fx), float(fy), float(center_x), float(center_y)
+        self.focal_length_m, self.depth_is_Z = float(focal_length_m), bool(depth_is_Z)
+        self.min_range, self.max_range = float(min_range), float(max_range)
+        self.f2f_max_hdiff = 0.5 * (2.0 * self.center_x) if f2f_max_hdiff is None else float(f2f_max_hdiff)
+        self.pct_good_matches = float(pct_good_matches)
+
+    def as_struct(self):
+        from . import _lib
+        c = _lib.RgbdCam()
+        c.fx, c.fy, c.cx, c.cy, c.focal_length_m = self.fx, self.fy, self.center_x, self.center_y, self.focal_length_m
+        c.depth_is_Z, c.reserved, c.min_range, c.max_range = 1 if self.depth_is_Z else 0, 0, self.min_range, self.max_range
+        return c
+
+
+class RGBDPairPipeline(object):
+    """The RGB-D (perspective) counterpart of ImageFrontEnd + FramePairPipeline (BASELINE config 5): for B
+    independent pairs of (BGR image, depth map) frames, RGBDFrame.establish_keypoints (pose_est_tools.py:600-623:
+    [median,] gray, goodFeaturesToTrack on the whole image, ORB descriptors, depth back-projection, range filter)
+    and TrackerRGBDSE3.track_frame (:896-954: frame-to-frame matching, |du| gate, central RANSAC, LM).
+    Pair i tracks frame 2i+1 against frame 2i.  Everything stays in HBM; one step = 10 asynchronous C-ABI calls."""
+
+    def __init__(self, ctx, cam, n_pairs, image_shape=(480, 640), num_of_features=1000, kp_cap=None, frame_cap=None,
+                 median_win_size=0, quality=0.01, min_distance=5.0, edge=31, thr=None, max_iter=2000, adaptive=False,
+                 seed=0, lm_iter=30, mask=None):
+        from . import orb_pattern
+        assert isinstance(ctx, Context)
+        self.ctx, self.cam_cfg, self.cam = ctx, cam, cam.as_struct()
+        self.B, self.F = int(n_pairs), 2 * int(n_pairs)
+        self.rows, self.cols = int(image_shape[0]), int(image_shape[1])
+        self.num_of_features, self.median_win_size = int(num_of_features), int(median_win_size)
+        self.quality, self.min_distance, self.edge = float(quality), float(min_distance), int(edge)
+        # > 1024 selects the detector's large-mask variant (whole-image masks), see sosvo_detect_gft
+        self.kp_cap = int(kp_cap) if kp_cap else int(min(4096, max(1088, -(-self.num_of_features // 64) * 64)))
+        self.frame_cap = int(frame_cap) if frame_cap else self.kp_cap
+        self.thr = float(1.0 - np.cos(np.deg2rad(5.0))) if thr is None else float(thr)
+        self.max_iter, self.adaptive, self.seed, self.lm_iter = int(max_iter), bool(adaptive), int(seed), int(lm_iter)
+        dev, F, B = ctx.device, self.F, self.B
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
+        self.bgr = z((F, self.rows, self.cols, 3), torch.uint8)
+        self.depth = z((F, self.rows, self.cols), torch.float32)
+        self.gray = z((F, self.rows, self.cols), torch.uint8)
+        mb = np.ones((1, self.rows, self.cols), np.uint32) if mask is None else \
+            (np.asarray(mask) != 0).astype(np.uint32).reshape(1, self.rows, self.cols)
+        self.mask_bits = torch.from_numpy(mb).to(dev)       # one mask (bit 0): RGBDFrame.mask or the whole image
+        self.pattern = torch.from_numpy(orb_pattern.orb_pattern()).to(dev)
+        self.cos_a, self.sin_a = orb_pattern.angle_cos_sin(orb_pattern.GFT_KEYPOINT_ANGLE)
+        self.kp, self.n = z((F, self.kp_cap, 2), torch.float32), z((F,), torch.int32)
+        self.status, self.desc = z((F,), torch.int32), z((F, self.kp_cap, 32), torch.uint8)
+        Fc = self.frame_cap
+        self.frames = dict(m=z((F, Fc, 2), torch.float32), d=z((F, Fc, 32), torch.uint8), X=z((F, Fc, 3), torch.float64),
+                           b=z((F, Fc, 3), torch.float64), M=z((F,), torch.int32))
+        self.ref_frame = torch.arange(0, F, 2, dtype=torch.int32, device=dev)
+        self.cur_frame = torch.arange(1, F, 2, dtype=torch.int32, device=dev)
+        self.keys, self.order = z((B, Fc, 1), torch.uint32), z((B, Fc), torch.int32)
+        self.corr = dict(f=z((B, Fc, 3), torch.float64), p=z((B, Fc, 3), torch.float64), q=z((B, Fc), torch.int32),
+                         t=z((B, Fc), torch.int32), n=z((B,), torch.int32))
+        self.ransac = dict(T=z((B, 3, 4), torch.float64), mask=z((B, Fc), torch.uint8), idx=z((B, Fc), torch.int32),
+                           n_inliers=z((B,), torch.int32), info=z((B, 4), torch.int32))
+        self.T = z((B, 3, 4), torch.float64)
+        self.lm_cost, self.lm_iters = z((B,), torch.float64), z((B,), torch.int32)
+
+    def load_frames(self, bgr, depth):
+        """bgr [2B,rows,cols,3] u8, depth [2B,rows,cols] f32 (the camera's depth units, 0 = no reading)."""
+        dev = self.ctx.device
+        self.bgr.copy_((torch.from_numpy(np.ascontiguousarray(bgr)) if isinstance(bgr, np.ndarray) else bgr).to(dev))
+        self.depth.copy_((torch.from_numpy(np.ascontiguousarray(depth, dtype=np.float32))
+                          if isinstance(depth, np.ndarray) else depth).to(dev))
+
+    def detect(self):
+        c = self.ctx
+        c.median_gray(self.bgr, self.median_win_size, gray=self.gray)                              # :528, :531
+        c.detect_gft(self.gray, self.mask_bits, self.F, 1, self.kp_cap, quality=self.quality,
+                     min_distance=self.min_distance, max_corners=self.num_of_features, kp=self.kp, n=self.n,
+                     status=self.status)                                                            # :544
+        c.describe_orb(self.gray, self.kp, self.n, 1, self.pattern, self.cos_a, self.sin_a, edge=self.edge,
+                       desc=self.desc)                                                              # :553
+        c.rgbd_assemble(self.cam, self.kp, self.desc, self.n, self.depth, self.frame_cap, out=self.frames)  # :609-623
+
+    def track(self):
+        c, fr, cfg = self.ctx, self.frames, self.cam_cfg
+        c.match_hamming(fr["d"], fr["d"], fr["M"], fr["M"], k=1, keys=self.keys, q_slot=self.cur_frame,
+                        t_slot=self.ref_frame)
+        c.sort_matches(self.keys, fr["M"], order=self.order, q_slot=self.cur_frame)
+        c.f2f_assemble_central(fr, self.ref_frame, self.cur_frame, self.keys, self.order, self.frame_cap,
+                               pct_good_matches=cfg.pct_good_matches, max_hdiff=cfg.f2f_max_hdiff, out=self.corr)
+        co = self.corr
+        c.ransac_abs_pose(co["f"], co["p"], co["n"], self.thr, self.max_iter, seed=self.seed, adaptive=self.adaptive,
+                          out=self.ransac)                                                          # :915 (central)
+        self.T.copy_(self.ransac["T"])
+        c.refine_abs_pose(co["f"], co["p"], co["n"], self.T, idx=self.ransac["idx"], m=self.ransac["n_inliers"],
+                          max_lm_iter=self.lm_iter, cost=self.lm_cost, iters=self.lm_iters)          # :937
+
+    def step(self):
+        self.detect()
+        self.track()
+        return self.T
+
+    def results(self):
+        """[B,16] f64 rows as FramePairPipeline.results()."""
+        out = torch.empty((self.B, 16), dtype=torch.float64, device=self.ctx.device)
+        out[:, :12] = self.T.reshape(self.B, 12)
+        out[:, 12] = self.ransac["n_inliers"].to(torch.float64)
+        out[:, 13] = self.corr["n"].to(torch.float64)
+        out[:, 14] = self.ransac["info"][:, 2].to(torch.float64)
+        out[:, 15] = self.ransac["info"][:, 0].to(torch.float64)
+        return out
