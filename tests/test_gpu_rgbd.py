@@ -17,21 +17,8 @@ FX = FY = 554.256258
 CX, CY = 319.5, 239.5
 
 
-def _render_rgbd(room, R, t, rng, depth_is_Z=True, holes=0.05):
-    """Pinhole view of the textured room: BGR u8 [480,640,3], depth f32 [480,640] in metres (0 = no reading)."""
-    v, u = np.mgrid[0:480, 0:640]
-    d = np.stack([(u - CX) / FX, (v - CY) / FY, np.ones_like(u, dtype=np.float64)], axis=-1).reshape(-1, 3)
-    # camera looks along +Y of the room (optical axis z -> world y, image x -> world x, image y -> world -z)
-    C = np.array([[1.0, 0, 0], [0, 0, 1.0], [0, -1.0, 0]])
-    dirs = d @ (R @ C).T
-    P, tt = room.cast(t, dirs)
-    bgr = room.colour(P).reshape(480, 640, 3)
-    bgr = np.clip(bgr.astype(np.float64) + rng.normal(0, 2.0, bgr.shape), 0, 255).astype(np.uint8)
-    Z = (tt * 1e-3).reshape(480, 640)                       # ray parameter with d_z = 1 IS the Z depth [m]
-    depth = Z if depth_is_Z else Z * np.linalg.norm(d, axis=1).reshape(480, 640)
-    depth = np.round(depth * 1000.0) / 1000.0               # 1 mm quantisation of a u16 depth PNG
-    depth[rng.random((480, 640)) < holes] = 0.0
-    return bgr, depth.astype(np.float32)
+def _render_rgbd(room, R, t, rng, depth_is_Z=True):
+    return synthetic.render_rgbd(room, R, t, rng, FX, FY, CX, CY, depth_is_Z=depth_is_Z)
 
 
 @pytest.mark.parametrize("depth_is_Z,thr_deg", [(True, 5.0), (False, 0.5)])

@@ -1,0 +1,75 @@
+"""GPU, BASELINE config 1 (plumbing): the demo entry points run end to end on small synthetic sequences written to
+disk -- demo_vo_sos.main_sos_vo (GUMS JSON -> driver_VO -> run_VO on a worker thread -> TrackerStereoSE3) and
+demo_vo_rgbd.main_rgbd_vo (RGBDCamModel -> TrackerRGBDSE3) -- and leave the reference's result files
+(pose_est_tools.py:1376-1383, :1611-1621): one "idx tx ty tz qx qy qz qw" line per frame in metres, the associated
+ground truth, keyframe ids, the message log.  The estimated trajectory follows the planted one."""
+import os
+
+import numpy as np
+import pytest
+
+from vo_single_camera_sos_amd import synthetic
+from vo_single_camera_sos_amd.omnistereo import transformations as tr
+from vo_single_camera_sos_amd.omnistereo.gum import synthetic_gums
+from vo_single_camera_sos_amd.omnistereo.panorama import Panorama
+
+pytestmark = pytest.mark.gpu
+
+
+def _read_tum(fn):
+    rows = np.loadtxt(fn, ndmin=2)
+    return rows[:, 0].astype(int), [tr.transform44_from_TUM_entry(list(r), has_timestamp=True) for r in rows]
+
+
+def _check_files(results, n):
+    for name in ("estimated_frame_poses_TUM.txt", "gt_associated_frame_poses_TUM.txt", "keyframe_ids.txt",
+                 "printed_messages.log"):
+        assert os.path.exists(os.path.join(results, name)), name
+    idx, est = _read_tum(os.path.join(results, "estimated_frame_poses_TUM.txt"))
+    idx_gt, gt = _read_tum(os.path.join(results, "gt_associated_frame_poses_TUM.txt"))
+    assert list(idx) == list(range(n)) and list(idx_gt) == list(range(n))
+    kf = [int(x) for x in open(os.path.join(results, "keyframe_ids.txt")).read().split()]
+    assert kf[0] == 0 and kf == sorted(kf) and len(kf) >= 2
+    log = open(os.path.join(results, "printed_messages.log")).read()
+    assert "DONE with F[%d]" % (n - 1) in log and "VO done with %d keyframes" % len(kf) in log
+    assert np.allclose(est[0], np.identity(4)) and np.allclose(gt[0], np.identity(4), atol=1e-9)
+    return est, gt, kf
+
+
+def test_demo_vo_sos_end_to_end(ctx, tmp_path):
+    import demo_vo_sos
+    gs = synthetic_gums()
+    for m in (gs.top_model, gs.bot_model):
+        m.panorama = Panorama(m, width=1200)
+    gs.make_annulus_masks((480, 640))
+    n = 6
+    seq = str(tmp_path / "seq_sos")
+    synthetic.write_sos_sequence(seq, gs, n_frames=n, seed=21, max_t=40.0, max_deg=2.0)
+    out = demo_vo_sos.main_sos_vo([seq, "--calibrated_gums_file", os.path.join(seq, "gums-calibrated.json")])
+    assert out["tracked"] == n - 1 and len(out["poses"]) == n
+    est, gt, kf = _check_files(os.path.join(seq, "results-omni"), n)
+    assert out["keyframe_ids"] == kf
+    for i in range(1, n):
+        E = tr.rpe(gt[i], est[i])
+        assert tr.rpe_rotation_metric(E) < np.deg2rad(3.0), (i, np.degrees(tr.rpe_rotation_metric(E)))
+        assert tr.rpe_translation_metric(E) < 0.05 * (i + 1), (i, tr.rpe_translation_metric(E))  # drift accumulates over keyframes
+    # inline (no worker thread) run over a sub-range gives the time-stamped pose file name (:1683-1687)
+    out2 = demo_vo_sos.main_sos_vo([seq, "--calibrated_gums_file", os.path.join(seq, "gums-calibrated.json"),
+                                    "--use_multithreads_for_VO", "false", "--first_image_index", "1", "--last_image_index", "4"])
+    assert [p[0] for p in out2["poses"]] == [1, 2, 3]
+    assert any(f.startswith("estimated_frame_poses_TUM-") for f in os.listdir(os.path.join(seq, "results-omni")))
+
+
+def test_demo_vo_rgbd_end_to_end(ctx, tmp_path):
+    import demo_vo_rgbd
+    n = 5
+    seq = str(tmp_path / "seq_rgbd")
+    synthetic.write_rgbd_sequence(seq, n_frames=n, seed=33, max_t=40.0, max_deg=2.0, depth_is_Z=False)
+    out = demo_vo_rgbd.main_rgbd_vo([seq, "--is_synthetic", "true"])
+    assert out["tracked"] == n - 1
+    est, gt, kf = _check_files(os.path.join(seq, "results-rgbd"), n)
+    # 5-degree RANSAC threshold + narrow field of view: rotation and sideways translation trade off (see
+    # test_gpu_rgbd.py); the trajectory stays within a few degrees / decimetres of the planted one
+    for i in range(1, n):
+        E = tr.rpe(gt[i], est[i])
+        assert tr.rpe_rotation_metric(E) < np.deg2rad(12.0) and tr.rpe_translation_metric(E) < 0.8, (i, E)

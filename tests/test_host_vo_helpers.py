@@ -1,0 +1,100 @@
+"""CPU: the host helpers of the VO loop against tests/golden/transforms.npz, captured
+from the reference's omnistereo.transformations / common_tools by tests/golden/make_transform_fixtures.py; the
+sequence readers; the rig JSON round trip.  No GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from vo_single_camera_sos_amd.omnistereo import common_cv, common_tools as ct, transformations as tr
+from vo_single_camera_sos_amd.omnistereo.gum import gums_from_dict, gums_to_dict, synthetic_gums
+from vo_single_camera_sos_amd.omnistereo.panorama import Panorama
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "transforms.npz"))
+TOL = dict(rtol=0, atol=1e-14)
+
+
+def test_quaternions_and_matrices_match_reference():
+    assert np.allclose(np.stack([tr.quaternion_from_matrix(m, isprecise=False) for m in G["T"]]), G["quat"], **TOL)
+    assert np.allclose(np.stack([tr.quaternion_from_matrix(m) for m in G["T_noisy"]]), G["quat_noisy"], **TOL)
+    assert np.array_equal(np.stack([tr.quaternion_matrix(q) for q in G["quat"]]), G["quat_matrix"])
+    assert np.array_equal(np.stack([tr.translation_from_matrix(m) for m in G["T"]]), G["trans"])
+    assert np.array_equal(np.stack([tr.inverse_matrix(m) for m in G["T"]]), G["inv"])
+    n = len(G["T"])
+    cat = np.stack([tr.concatenate_matrices(G["T"][i], G["T"][(i + 1) % n], G["T"][(i + 2) % n]) for i in range(n)])
+    assert np.array_equal(cat, G["concat3"])
+    assert np.array_equal(np.array([tr.rpe_rotation_metric(m) for m in G["T_noisy"]]), G["rpe_rot"])
+    assert np.array_equal(np.array([tr.rpe_translation_metric(m) for m in G["T_noisy"]]), G["rpe_trans"])
+    assert (G["quat"][:, 0] >= 0).all() and np.allclose(np.linalg.norm(G["quat"], axis=1), 1.0)
+
+
+def test_doctest_values_of_the_reference_module():
+    # transformations.py doctests: quaternion_from_matrix(identity) = [1, 0, 0, 0]; diag(1, -1, -1, 1) -> [0, 1, 0, 0]
+    assert np.allclose(tr.quaternion_from_matrix(np.identity(4), True), [1, 0, 0, 0])
+    q = tr.quaternion_from_matrix(np.diag([1.0, -1.0, -1.0, 1.0]))
+    assert np.allclose(q, [0, 1, 0, 0]) or np.allclose(q, [0, -1, 0, 0])
+    R = tr.rotation_matrix(0.123, [1, 2, 3])
+    assert np.allclose(tr.quaternion_from_matrix(R, True), [0.9981095, 0.0164262, 0.0328524, 0.0492786])
+    assert np.allclose(tr.quaternion_matrix([0.99810947, 0.06146124, 0, 0]), tr.rotation_matrix(0.123, [1, 0, 0]))
+    assert np.allclose(tr.rotation_matrix(np.pi / 2, [0, 0, 1], [1, 0, 0]).dot([0, 0, 0, 1]), [1, -1, 0, 1])
+
+
+def test_tum_entries_and_pose_file_reader(tmp_path):
+    rows = G["tum_rows"]
+    assert np.array_equal(np.stack([tr.transform44_from_TUM_entry(list(r), has_timestamp=True) for r in rows]), G["from_tum"])
+    got = np.stack([tr.transform44_from_TUM_entry(list(r[1:]), 1000.0, has_timestamp=False) for r in rows])
+    assert np.array_equal(got, G["from_tum_scaled"])
+    fn = str(tmp_path / "gt_TUM.txt")
+    with open(fn, "w") as fh:
+        fh.write("# timestamp tx ty tz qx qy qz qw\n")
+        for r in rows:
+            fh.write(" ".join(repr(float(v)) for v in r) + "\n")
+    for zero_up in (0, 1):
+        p7, mats = ct.get_poses_from_file(fn, "m", "mm", [], "tum", bool(zero_up))
+        assert np.allclose(np.array(p7), G["file_poses7_%d" % zero_up], rtol=0, atol=1e-12)
+        assert np.allclose(np.stack(mats), G["file_mats_%d" % zero_up], rtol=0, atol=1e-12)
+    assert np.allclose(ct.get_poses_from_file(fn, zero_up_wrt_origin=True)[1][0], np.identity(4), atol=1e-15)
+    with pytest.raises(NotImplementedError):
+        ct.get_poses_from_file(fn, pose_format="povray")
+    units = [ct.get_length_units_conversion_factor(a, b) for a, b in (("mm", "m"), ("m", "mm"), ("cm", "m"), ("m", "m"))]
+    assert np.array_equal(units, G["units_mm_m"])
+    out = str(tmp_path / "out.txt")
+    ct.save_as_tum_poses_to_file(out, [[1.0, 2.0, 3.0, 0.0, 0.0, 0.0, 1.0]], "mm", "tum", "m")
+    assert open(out).read() == "0 0.001000000 0.002000000 0.003000000 0.000000000 0.000000000 0.000000000 1.000000000\n"
+
+
+def test_sequence_readers(tmp_path):
+    rng = np.random.default_rng(3)
+    d = tmp_path / "omni"
+    d.mkdir()
+    imgs = {}
+    for i in (10, 2, 1):  # written out of order: the listing must come back sorted
+        imgs[i] = rng.integers(0, 256, (12, 17, 3), dtype=np.uint8)
+        common_cv.imwrite(str(d / ("image-%04d.png" % i)), imgs[i])
+    (d / "notes.txt").write_text("x")
+    names = common_cv.get_images(str(d / "image-*.png"), return_names_only=True)
+    assert [os.path.basename(n) for n in names] == ["image-0001.png", "image-0002.png", "image-0010.png"]
+    assert common_cv.get_images(str(d / "image-*.png"), indices_list=[2, 0], return_names_only=True) == [names[2], names[0]]
+    got = common_cv.get_images(str(d / "image-*.png"))
+    assert np.array_equal(got[0], imgs[1]) and np.array_equal(got[2], imgs[10])   # BGR round trip
+    assert common_cv.imread(str(d / "missing.png")) is None
+    from PIL import Image
+    depth = rng.integers(0, 9000, (12, 17)).astype(np.uint16)
+    Image.fromarray(depth).save(str(tmp_path / "d.png"))
+    f = common_cv.get_depthmap_float32_from_png(str(tmp_path / "d.png"), 1.0 / 1000.0)
+    assert f.dtype == np.float32 and np.array_equal(f, np.float32((1.0 / 1000.0) * depth))
+
+
+def test_rig_json_round_trip():
+    gs = synthetic_gums()
+    for m in (gs.top_model, gs.bot_model):
+        m.panorama = Panorama(m, width=1200)
+    back = gums_from_dict(gums_to_dict(gs))
+    for a, b in ((gs.top_model, back.top_model), (gs.bot_model, back.bot_model)):
+        assert a.precalib_params.__dict__ == b.precalib_params.__dict__
+        assert np.array_equal(a.F, b.F) and a.image_size == b.image_size and a.z_axis == b.z_axis
+        for x, y in zip(a.panorama.float32_maps(), b.panorama.float32_maps()):
+            assert np.array_equal(x, y, equal_nan=True)
+    assert back.units == gs.units and back.top_model.panorama.cols == 1200
+    with pytest.raises(ValueError):
+        gums_from_dict({"format": "pickle"})

@@ -217,3 +217,71 @@ class FeatureMatcher(object):
     def match(self, query_descriptors, train_descriptors, max_descriptor_distance_radius=-1):
         """-> MatchList (a list of DMatch), ascending by distance, ties in query order."""
         return MatchList(*self.match_arrays(query_descriptors, train_descriptors))
+
+
+class RGBDCamModel(object):
+    """camera_models.py:756-860: the pinhole RGB-D camera (intrinsics, depth convention, units).  get_XYZ /
+    get_depth_Z keep the reference's numpy arithmetic (they pin the GPU path's sosvo_rgbd_backproject /
+    sosvo_rgbd_assemble); per-frame feature extraction runs on the GPU through RGBDFrame."""
+
+    def __init__(self, **kwargs):
+        self.fx = kwargs.get("fx", 525.0)
+        self.fy = kwargs.get("fy", 525.0)
+        self.center_x = kwargs.get("center_x", 319.5)
+        self.center_y = kwargs.get("center_y", 239.5)
+        self.focal_length_m = kwargs.get("focal_length_m", 1.0 / 1000.0)
+        self.depth_is_Z = kwargs.get("depth_is_Z", True)
+        self.units = kwargs.get("units", "m")
+        self.scaling_factor = kwargs.get("scaling_factor", 1. / 1000.0)  # depth PNG counts -> units (:772)
+        self.do_undistortion = kwargs.get("do_undistortion", False)
+        self.K = np.array([[self.fx, 0, self.center_x], [0, self.fy, self.center_y], [0, 0, 1]])
+        self.image_size = kwargs.get("image_size", None)
+        self.T_model_wrt_C = np.identity(4)
+        self.T_C_wrt_model = np.identity(4)
+        self.T_Cest_wrt_Rgt = None
+        self.feature_matcher_for_motion = None
+
+    def get_depth_Z(self, depth, uv_coords=None, verbose=False):
+        """camera_models.py:781-799: radial depth -> Z (identity when the map already holds Z)."""
+        if not self.depth_is_Z:
+            if uv_coords is None:
+                uv_coords = np.transpose(np.indices(depth.shape[::-1]), (0, 2, 1))
+            focal_length = self.focal_length_m
+            x_i = (focal_length / self.fx) * (uv_coords[0] - self.center_x)
+            y_i = (focal_length / self.fy) * (uv_coords[1] - self.center_y)
+            z_i = np.ones_like(x_i) * focal_length
+            d_to_img_plane = np.linalg.norm(np.dstack([x_i, y_i, z_i]), axis=-1)
+            depth = focal_length * depth / d_to_img_plane
+        return depth
+
+    def get_XYZ(self, depth, u_coords=None, v_coords=None):
+        """camera_models.py:835-860: XYZ at the given integer pixels ([1, n, 3]) or for the whole map; zero depth -> NaN."""
+        depth = self.get_depth_Z(depth=depth, uv_coords=None)
+        Z = np.where(depth != 0, depth, np.nan)
+        if u_coords is None or v_coords is None:
+            uv_coords = np.transpose(np.indices(depth.shape[::-1]), (0, 2, 1))
+            u_coords, v_coords = uv_coords[0], uv_coords[1]
+        else:
+            u_coords, v_coords = u_coords.ravel(), v_coords.ravel()
+            Z = Z[v_coords, u_coords]
+        X = (u_coords - self.center_x) * Z / self.fx
+        Y = (v_coords - self.center_y) * Z / self.fy
+        return np.dstack((X, Y, Z))
+
+    # ---- device side ---------------------------------------------------------------------------------------
+    def _context(self):
+        from ..runtime import default_context
+        return default_context()
+
+    def _front_end(self, shape, num_of_features, median_win_size, min_range, max_range, mask):
+        """One-frame RGBDFrontEnd per (image shape, detector budget, filter) -- buffers are reused across frames."""
+        from ..pipeline import RGBDCamConfig, RGBDFrontEnd
+        key = (tuple(shape), int(num_of_features), int(median_win_size), float(min_range), float(max_range),
+               None if mask is None else id(mask))
+        cache = self.__dict__.setdefault("_front_ends", {})
+        if key not in cache:
+            cfg = RGBDCamConfig(self.fx, self.fy, self.center_x, self.center_y, self.focal_length_m, self.depth_is_Z,
+                                min_range, max_range)
+            cache[key] = RGBDFrontEnd(self._context(), cfg, 1, image_shape=shape, num_of_features=num_of_features,
+                                      median_win_size=median_win_size, mask=mask)
+        return cache[key]

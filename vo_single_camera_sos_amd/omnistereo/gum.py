@@ -157,6 +157,7 @@ class GUMStereo(object):
         self.construct_new_mask = True
         self.feature_matcher_for_static_stereo = None
         self.feature_matcher_for_motion = None
+        self.T_Cest_wrt_Rgt = None  # hand-eye transformation to a ground-truth rig frame (camera_models.py:2826)
         top_model.rig, top_model.view_index = self, 0
         bottom_model.rig, bottom_model.view_index = self, 1
         # pose of the bottom model wrt the top one (camera_models.py:2811-2813)
@@ -335,3 +336,54 @@ def synthetic_gums(scale=1.0, units="mm"):
               (0.0, 0.0, 50.0), -0.3487218912619687, 0.26202807633801434, 50 * scale, 101 * scale, image_size=size,
               units=units)
     return GUMStereo(top, bot, units=units)
+
+
+# ---- calibrated-model files --------------------------------------------------------------------------------
+# The reference stores a calibrated rig as a pickle of live Python objects (common_tools.py:131,
+# demo_vo_sos.py:119).  Here a rig is a small JSON document of the calibrated numbers:
+# per mirror the GUM parameters (gum.py:77-116), focus, elevation limits, image radii and centre; plus units
+# and the panorama width.
+_PARAM_FIELDS = ("xi1", "xi2", "xi3", "k1", "k2", "k3", "gamma1", "gamma2", "alpha_c", "u_center", "v_center",
+                 "use_distortion")
+
+
+def gums_to_dict(gums):
+    def mirror(m):
+        d = {k: getattr(m.precalib_params, k) for k in _PARAM_FIELDS}
+        d.update(z_axis=m.z_axis, F=[float(v) for v in m.F[:3, 0]], lowest_elevation_angle=m.lowest_elevation_angle,
+                 highest_elevation_angle=m.highest_elevation_angle, inner_img_radius=float(m.inner_img_radius),
+                 outer_img_radius=float(m.outer_img_radius), center_point=[float(v) for v in m.center_point],
+                 image_size=[int(v) for v in m.image_size])
+        return d
+    width = gums.top_model.panorama.cols if gums.top_model.panorama is not None else 1200
+    return dict(format="sosvo-gums-1", units=gums.units, panorama_width=int(width), top=mirror(gums.top_model),
+                bottom=mirror(gums.bot_model))
+
+
+def gums_from_dict(d, with_panoramas=True):
+    from .panorama import Panorama
+    if d.get("format") != "sosvo-gums-1":
+        raise ValueError("not a sosvo GUMS description (format %r)" % d.get("format"))
+
+    def mirror(m):
+        params = GUMParams(**{k: m[k] for k in _PARAM_FIELDS})
+        return GUM(params, m["z_axis"], m["F"], m["lowest_elevation_angle"], m["highest_elevation_angle"],
+                   m["inner_img_radius"], m["outer_img_radius"], center_point=m["center_point"],
+                   image_size=tuple(m["image_size"]), units=d["units"])
+    gums = GUMStereo(mirror(d["top"]), mirror(d["bottom"]), units=d["units"])
+    if with_panoramas:
+        for m in (gums.top_model, gums.bot_model):
+            m.panorama = Panorama(m, width=int(d.get("panorama_width", 1200)))
+    return gums
+
+
+def save_gums_json(gums, filename):
+    import json
+    with open(filename, "w") as f:
+        json.dump(gums_to_dict(gums), f, indent=1)
+
+
+def load_gums_json(filename, with_panoramas=True):
+    import json
+    with open(filename) as f:
+        return gums_from_dict(json.load(f), with_panoramas=with_panoramas)

@@ -9,22 +9,27 @@ on the GPU through libsosvo (FeatureMatcher, pyopengv mirror, the rig's device f
 
 The batched throughput path (vo_single_camera_sos_amd.pipeline.FramePairPipeline) runs the same sequence for many
 frame pairs at once without host round trips; this module is the drop-in for code written against the
-reference's per-frame API.  Out of scope here: run_VO, keyframe policy, TUM writer,
-visualisation, the live-camera driver."""
+reference's per-frame API.
+
+    RGBDFrame / TrackerRGBDSE3                                          pose_est_tools.py:404-623, :880-958
+    StereoPanoramicKeyFrame / RGBDKeyFrame                              pose_est_tools.py:625-641
+    run_VO / driver_VO (frame loop, keyframe policy, TUM pose files)    pose_est_tools.py:1264-1741
+
+Not built: visualisation (vispy / matplotlib windows), the live-camera driver (run_VO_live)."""
+import os
+import threading
+import time
+from warnings import warn
+
 from math import log10, sqrt
 
 import numpy as np
 
 from .. import pyopengv
-from .camera_models import FeatureMatcher, PanoramicCorrespondences, keypoints_to_array
+from . import transformations as tr
+from .camera_models import FeatureMatcher, KeyPoint, KeyPointAndDescriptor, PanoramicCorrespondences, keypoints_to_array
 from .common_cv import filter_pixel_correspondences
-
-
-def get_length_units_conversion_factor(input_units, output_units):
-    """common_tools.py:580-597"""
-    table = {("cm", "mm"): 10.0, ("cm", "m"): 0.01, ("mm", "cm"): 0.1, ("mm", "m"): 0.001, ("m", "mm"): 1000.0,
-             ("m", "cm"): 100.0}
-    return table.get((input_units, output_units), 1.0)
+from .common_tools import copy_only_attributes, get_length_units_conversion_factor, make_sure_path_exists
 
 
 def normalized(v):
@@ -296,3 +301,359 @@ class TrackerStereoSE3(TrackerSE3):
             self.xyz_homo_points_wrt_C_inliers = np.hstack((p_all[inliers] * current_frame.conversion_factor_length_to_m,
                                                             np.ones((len(inliers), 1))))
         return True, "tracking used %d inlier point correspondences" % (self.num_tracked_correspondences)
+
+
+class StereoPanoramicKeyFrame(StereoPanoramicFrame):
+    """pose_est_tools.py:625-632: a frame promoted to keyframe (a blind copy of its attributes)."""
+
+    def __init__(self, frame, **kwargs):
+        copy_only_attributes(objfrom=frame, objto=self)
+        self.children_ids = []
+
+
+class RGBDFrame(object):
+    """pose_est_tools.py:404-623: one RGB-D frame = keypoints with valid depth, their descriptors, 3-D points and
+    bearings.  Detection + description + back-projection run on the GPU (RGBDFrontEnd, one frame)."""
+
+    def __init__(self, rgbd_camera_model, frame_id, **kwargs):
+        self.rgbd_camera_model = rgbd_camera_model
+        self.frame_id = frame_id
+        self.parent_id = kwargs.get("parent_id", -1)
+        self.T_frame_wrt_tracking_ref_frame = kwargs.get("T_wrt_ref", np.identity(4))
+        self.conversion_factor_length_to_m = get_length_units_conversion_factor(rgbd_camera_model.units, "m")
+        self.total_time = 0.
+        self.median_win_size = 0
+        self.min_range = 0.8
+        self.max_range = 7.
+        self.mask = kwargs.get("mask", None)
+        self.rgb_img = kwargs.get("rgb_img", None)
+        self.depth_map = kwargs.get("depth_map", None)
+        self.num_valid_keypoints = 0
+        self.keypoints_and_descriptors = None
+        self.bearing_vectors = None
+        self.keypoints_3D_points = None
+        self.current_depth = None
+        if (self.rgb_img is not None) and (self.depth_map is not None):
+            self.establish_keypoints(rgb=self.rgb_img, depth=self.depth_map)
+
+    def filter_3D_points_due_to_range(self, xyz_points_wrt_C, min_3D_range=0, max_3D_range=0.):
+        """pose_est_tools.py:570-592 (numpy, as there)."""
+        valid = np.ones(shape=(xyz_points_wrt_C.shape), dtype="bool")
+        if min_3D_range > 0 or max_3D_range > 0:
+            nrm = np.nan_to_num(np.linalg.norm(xyz_points_wrt_C, axis=0, keepdims=True), copy=True)
+            if min_3D_range > 0:
+                valid = np.logical_and(valid, nrm >= min_3D_range)
+            if max_3D_range > 0:
+                valid = np.logical_and(valid, nrm <= max_3D_range)
+        return valid
+
+    def establish_keypoints(self, rgb, depth):
+        """pose_est_tools.py:600-623.  `rgb` is handed to the detector as it is (the gray conversion weights the
+        first channel as blue, like cv2.COLOR_BGR2GRAY applied to whatever the caller passes, :531)."""
+        fm = self.rgbd_camera_model.feature_matcher_for_motion
+        method = "GFT" if fm is None else str(fm.feature_detection_method).upper()
+        if method != "GFT":
+            raise NotImplementedError("RGB-D detection method %r: GFT (the trackers' default, pose_est_tools.py:684) is built"
+                                      % method)
+        nfeat = 50 if fm is None else fm.num_of_features
+        self.current_depth = depth
+        fe = self.rgbd_camera_model._front_end(np.asarray(rgb).shape[:2], nfeat, self.median_win_size, self.min_range,
+                                               self.max_range, self.mask)
+        fe.load_frames(np.ascontiguousarray(rgb)[None], np.ascontiguousarray(depth, dtype=np.float32)[None])
+        fe.run()
+        fe.ctx.synchronize()
+        M = int(fe.frames["M"][0])
+        m = fe.frames["m"][0, :M].cpu().numpy()
+        self.keypoints_3D_points = fe.frames["X"][0, :M].cpu().numpy()
+        self.bearing_vectors = fe.frames["b"][0, :M].cpu().numpy()
+        kpts = [KeyPoint(x, y, size=31.0) for x, y in m]
+        self.keypoints_and_descriptors = KeyPointAndDescriptor(kpts_list=kpts, desc_list=fe.frames["d"][0, :M].cpu().numpy(),
+                                                               coords_array=m.astype(np.float64), do_flattening=False)
+        self.num_valid_keypoints = M
+
+
+class RGBDKeyFrame(RGBDFrame):
+    """pose_est_tools.py:634-641"""
+
+    def __init__(self, frame, **kwargs):
+        copy_only_attributes(objfrom=frame, objto=self)
+        self.children_ids = []
+
+
+class TrackerRGBDSE3(TrackerSE3):
+    """pose_est_tools.py:880-958: central 3D-2D tracking of RGB-D frames."""
+
+    def __init__(self, camera_model, show_3D_points=False, **kwargs):
+        TrackerSE3.__init__(self, camera_model, show_3D_points, **kwargs)
+        self.number_of_cams = 1
+        self.T_C_wrt_S_init = np.identity(4)
+        self.T_C_curr_frame_wrt_S_est = kwargs.get("T_C_wrt_S_init", self.T_C_wrt_S_init)
+        self.bootstrap_tracker()
+
+    def bootstrap_tracker(self):
+        """pose_est_tools.py:956-958"""
+        self.camera_model.feature_matcher_for_motion = FeatureMatcher(
+            method=self.detection_method, matcher_type=self.matching_type, k_best=self.k_best_matches,
+            percentage_good_matches=self.percentage_good_matches, num_of_features=self.num_features_detection_for_motion,
+            use_radius_match=self.use_descriptor_radius_match_for_motion)
+        self.max_horizontal_diff_f2f_matches = self.max_horizontal_search_ratio * (self.camera_model.center_x * 2.)
+
+    def track_frame(self, reference_frame, current_frame):
+        """pose_est_tools.py:896-954 -> (ok, message)."""
+        self.num_tracked_correspondences = 0
+        self.inlier_tracked_correspondences_ratio = 0.
+        ref, cur = reference_frame.keypoints_and_descriptors, current_frame.keypoints_and_descriptors
+        (t_idx, _, _), (q_idx, _, _), _ = match_features_frame_to_frame(
+            cam_model=self.camera_model, train_kpts=ref.keypoints, train_desc=ref.descriptors, query_kpts=cur.keypoints,
+            query_desc=cur.descriptors, random_colors_RGB=ref.random_colors_RGB,
+            keypts_as_points_train=ref.pixel_coords, keypts_as_points_query=cur.pixel_coords,
+            max_horizontal_diff=self.max_horizontal_diff_f2f_matches, max_descriptor_distance_radius=-1)
+        t_idx, q_idx = np.asarray(t_idx, dtype=np.int64), np.asarray(q_idx, dtype=np.int64)
+        num_initial_matches = len(t_idx)
+        if num_initial_matches < 2 * self.n_points_for_RANSAC_model * self.number_of_cams:
+            return False, "Cannot track on only %d point correspondences" % (num_initial_matches)
+        b = current_frame.bearing_vectors[q_idx]
+        p = reference_frame.keypoints_3D_points[t_idx]
+        T_ransac, inliers = pyopengv.absolute_pose_ransac(b[..., :3], p[..., :3], self.pose_est_algorithm,
+                                                          self.backprojection_score_threshold_3D_to_2D,
+                                                          self.max_ransac_iterations_3D_to_2D)
+        self.num_tracked_correspondences = len(inliers)
+        self.inlier_tracked_correspondences_ratio = float(self.num_tracked_correspondences) / float(num_initial_matches)
+        T_nl = pyopengv.absolute_pose_optimize_nonlinear(b[inliers], p[inliers], T_ransac[:3, 3], T_ransac[:3, :3])
+        T_homo = np.identity(4)
+        T_homo[:3] = T_nl
+        T_homo[:3, 3] = T_nl[:3, 3] * current_frame.conversion_factor_length_to_m
+        current_frame.T_frame_wrt_tracking_ref_frame = T_homo
+        T_key = self.T_Ckey_wrt_S_est_list[-1] if self.T_Ckey_wrt_S_est_list else np.identity(4)
+        self.T_C_curr_frame_wrt_S_est = tr.concatenate_matrices(T_key, T_homo)
+        if self.show_3D_points:
+            self.xyz_homo_points_wrt_C_inliers = np.hstack((p[inliers] * current_frame.conversion_factor_length_to_m,
+                                                            np.ones((len(inliers), 1))))
+        return True, "tracking used %d inlier point correspondences" % (self.num_tracked_correspondences)
+
+
+def _is_rgbd_model(camera_model):
+    from .camera_models import RGBDCamModel
+    return isinstance(camera_model, RGBDCamModel)
+
+
+def run_VO(visualizer_3D_VO, camera_model, gt_poses_filename=None, est_poses_filename="estimated_frame_poses_TUM.txt",
+           img_filename_template=None, depth_filename_template=None, img_indices=(), results_path="~/temp", thread_name=""):
+    """pose_est_tools.py:1264-1678 without the 3-D visualisation (visualizer_3D_VO must be None): the frame loop,
+    the keyframe policy (translation 0.01-0.20 m or rotation 1-10 degrees wrt the keyframe, enough tracked
+    correspondences and keypoints), pose chaining through the keyframes, and the result files
+        estimated_frame_poses_TUM.txt, gt_associated_frame_poses_TUM.txt  "idx tx ty tz qx qy qz qw" [m]
+        keyframe_ids.txt, printed_messages.log
+    -> dict(poses=[(idx, T 4x4)], keyframe_ids=[...], tracked=number of tracked frames, message=summary)."""
+    from .common_cv import get_depthmap_float32_from_png, get_images, imread
+    from .common_tools import get_poses_from_file
+    if visualizer_3D_VO is not None:
+        raise NotImplementedError("3-D visualisation is not built: pass visualizer_3D_VO=None")
+    prefix = thread_name + ": " if len(thread_name) > 0 else ""
+    rgbd = _is_rgbd_model(camera_model)
+    trackerClass, KeyFrameClass = (TrackerRGBDSE3, RGBDKeyFrame) if rgbd else (TrackerStereoSE3, StereoPanoramicKeyFrame)
+    results_path = os.path.realpath(os.path.expanduser(results_path))
+    make_sure_path_exists(results_path)
+    log = open(os.path.join(results_path, "printed_messages.log"), "w")
+
+    def say(msg):
+        print(msg)
+        print(msg, file=log)
+
+    pose_output_file_units = "m"
+    zero_up_gt_wrt_origin = True
+    # indoor thresholds (pose_est_tools.py:1308-1313)
+    pos_thr, pos_max = 0.01, 0.20
+    ang_thr, ang_max = np.deg2rad(1.0), np.deg2rad(10.0)
+    thr_tracked, thr_keypoints = 0.10, 0.10
+
+    image_names = get_images(img_filename_template, indices_list=img_indices, return_names_only=True)
+    depth_names = get_images(depth_filename_template, indices_list=img_indices, return_names_only=True) if rgbd else None
+    if img_indices is None or len(img_indices) == 0:
+        img_indices = list(range(len(image_names)))
+    tracker = trackerClass(camera_model=camera_model, show_3D_points=False, results_path=results_path)
+    if gt_poses_filename is None or not os.path.exists(gt_poses_filename):
+        n_gt = max(len(img_indices), img_indices[-1] + 1)
+        gt_list = n_gt * [np.identity(4)]
+    else:
+        _, gt_list = get_poses_from_file(poses_filename=gt_poses_filename, input_units="m",
+                                         output_working_units=pose_output_file_units, indices=[], pose_format="tum",
+                                         zero_up_wrt_origin=zero_up_gt_wrt_origin)
+    T_Rgt_wrt_S = None
+    if gt_poses_filename is not None and os.path.exists(gt_poses_filename) and getattr(camera_model, "T_Cest_wrt_Rgt", None) is not None:
+        # fixed hand-eye transformation between the estimated camera frame and the ground-truth rig frame (:1362-1367)
+        k_units = get_length_units_conversion_factor(camera_model.units, pose_output_file_units)
+        T_Cest_wrt_Rgt = np.array(camera_model.T_Cest_wrt_Rgt, dtype=np.float64, copy=True)
+        T_Cest_wrt_Rgt[:3, 3] = k_units * T_Cest_wrt_Rgt[:3, 3]
+        T_Rgt_wrt_S = tr.concatenate_matrices(tracker.T_C_wrt_S_init, tr.inverse_matrix(T_Cest_wrt_Rgt))
+        T_S_wrt_Rgt = tr.inverse_matrix(T_Rgt_wrt_S)
+    est_path = os.path.join(results_path, est_poses_filename)
+    est_file = open(est_path, "w")
+    gt_file = open(est_path.replace("estimated", "gt_associated"), "w")
+    kf_path = os.path.join(results_path, "keyframe_ids.txt")
+    kf_file = open(kf_path, "w")
+
+    reference_frame, current_frame = None, None
+    create_keyframe = True
+    current_keyframe_id = img_indices[0]
+    number_of_keyframes = 0
+    tracked_wrt_keyframe = 0
+    tracked_prev_avg = 0.
+    inlier_ratio_cma = tracker.inlier_tracked_correspondences_ratio
+    acc = dict(read=0., setup=0., track=0., vo=0., corr=0., ratio=0.)
+    poses_out, keyframe_ids = [], []
+    n_done = 0
+    for img_index_number, idx in enumerate(img_indices):
+        t_frame = time.process_time()
+        t0 = time.process_time()
+        if rgbd:
+            # the reference converts BGR -> RGB (:1430) and then treats the array as BGR (:531): reproduced as is
+            img = np.ascontiguousarray(imread(image_names[img_index_number])[..., ::-1])
+            depth_map = get_depthmap_float32_from_png(depth_names[img_index_number], camera_model.scaling_factor)
+        else:
+            img = imread(image_names[img_index_number])
+        if img_index_number > 0:
+            acc["read"] += time.process_time() - t0
+        t0 = time.process_time()
+        if rgbd:
+            current_frame = RGBDFrame(rgbd_camera_model=camera_model, frame_id=idx, rgb_img=img, depth_map=depth_map,
+                                      parent_id=current_keyframe_id)
+        else:
+            camera_model.set_current_omni_image(img, generate_panoramas=False, view=False, apply_mask=True, mask_RGB=(0, 0, 0))
+            current_frame = StereoPanoramicFrame(stereo_camera_model=camera_model, frame_id=idx, parent_id=current_keyframe_id)
+        if img_index_number > 0:
+            acc["setup"] += time.process_time() - t0
+        T_gt = gt_list[idx] if idx < len(gt_list) else np.full((4, 4), np.nan)
+        if T_Rgt_wrt_S is not None:
+            T_gt = tr.concatenate_matrices(T_Rgt_wrt_S, T_gt, T_S_wrt_Rgt)   # :1472
+        if img_index_number > 0:
+            t0 = time.process_time()
+            ok, msg = tracker.track_frame(reference_frame=reference_frame, current_frame=current_frame)
+            if not ok:
+                print(msg, file=log)
+                warn("%sWarning failed: %s" % (prefix, msg))
+                break
+            reference_frame.children_ids.append(current_frame.frame_id)
+            tracked_wrt_keyframe += 1
+            acc["track"] += time.process_time() - t0
+            # keyframe policy (:1516-1550)
+            dist = tr.rpe_translation_metric(current_frame.T_frame_wrt_tracking_ref_frame)
+            ang = tr.rpe_rotation_metric(current_frame.T_frame_wrt_tracking_ref_frame)
+            n_tracked = tracker.num_tracked_correspondences / float(tracker.number_of_cams)
+            acc["corr"] += n_tracked
+            M_K, M_F = reference_frame.num_valid_keypoints, current_frame.num_valid_keypoints
+            if (pos_thr < dist < pos_max) or (ang_thr < ang < ang_max):
+                if n_tracked > thr_tracked * tracked_prev_avg and M_F > thr_keypoints * M_K:
+                    reason = ""
+                    if pos_thr < dist < pos_max:
+                        if ang < ang_max:
+                            reason += "translation %.2f < %.4f < %.2f [m]" % (pos_thr, dist, pos_max)
+                            create_keyframe = True
+                    elif ang_thr < ang:
+                        if dist < pos_max < ang_max:   # as written in the reference (:1534)
+                            reason += " rotation: %.2f > %.2f [radians]" % (ang, ang_thr)
+                            create_keyframe = True
+                    if create_keyframe:
+                        say("%sFrame [%d] as Keyframe due to %s... with %d tracked keypoint correspondences after tracking "
+                            "%d frames" % (prefix, idx, reason, n_tracked, tracked_wrt_keyframe))
+                    else:
+                        say("%sFrame [%d] as failed to create Keyframe due to some CRAZYNESS" % (prefix, idx))
+                else:
+                    say("%sFrame [%d] as Keyframe...doesn't satisfy %d > %.2f * %.2f and %d > %.2f * %.2f"
+                        % (prefix, idx, n_tracked, thr_tracked, tracked_prev_avg, M_F, thr_keypoints, M_K))
+            tracked_prev_avg = (n_tracked + (float(tracked_wrt_keyframe) - 1.) * tracked_prev_avg) / float(tracked_wrt_keyframe)
+            acc["ratio"] += tracker.inlier_tracked_correspondences_ratio
+            inlier_ratio_cma = (tracker.inlier_tracked_correspondences_ratio + float(img_index_number - 1) * inlier_ratio_cma) \
+                / float(img_index_number)
+        if create_keyframe:
+            tracked_wrt_keyframe = 0
+            tracked_prev_avg = 0.
+            reference_frame = KeyFrameClass(frame=current_frame)
+            current_keyframe_id = reference_frame.frame_id
+            print(current_keyframe_id, file=kf_file)
+            keyframe_ids.append(current_keyframe_id)
+            if len(tracker.T_Ckey_wrt_S_est_list) > 0:
+                T_key = tr.concatenate_matrices(tracker.T_Ckey_wrt_S_est_list[-1], reference_frame.T_frame_wrt_tracking_ref_frame)
+            else:
+                T_key = tracker.T_C_curr_frame_wrt_S_est
+            tracker.T_Ckey_wrt_S_est_list.append(T_key)
+            create_keyframe = False
+            number_of_keyframes += 1
+        # TUM lines: idx tx ty tz qx qy qz qw (:1611-1621)
+        q = tr.quaternion_from_matrix(matrix=tracker.T_C_curr_frame_wrt_S_est, isprecise=False)
+        t = tr.translation_from_matrix(matrix=tracker.T_C_curr_frame_wrt_S_est)
+        print(idx, t[0], t[1], t[2], q[1], q[2], q[3], q[0], sep=" ", end="\n", file=est_file)
+        if np.any(np.isnan(T_gt)):
+            qg, tg = 4 * [np.nan], 3 * [np.nan]
+        else:
+            qg, tg = tr.quaternion_from_matrix(matrix=T_gt, isprecise=False), tr.translation_from_matrix(matrix=T_gt)
+        print(idx, tg[0], tg[1], tg[2], qg[1], qg[2], qg[3], qg[0], sep=" ", end="\n", file=gt_file)
+        poses_out.append((idx, np.array(tracker.T_C_curr_frame_wrt_S_est, copy=True)))
+        if img_index_number > 0:
+            acc["vo"] += time.process_time() - t_frame
+        n_done = img_index_number
+        say("%sDONE with F[%d] (Parent K[%d]). C.M.Avg. RANSAC inlier ratio = %.3f"
+            % (prefix, current_frame.frame_id, current_frame.parent_id, inlier_ratio_cma))
+    d = float(max(n_done, 1))
+    summary = "\n".join([
+        "%sVO done with %d keyframes" % (prefix, number_of_keyframes),
+        "Image Read Avg Time: {time:.8f} seconds".format(time=acc["read"] / d),
+        "Frame Setup Avg Time: {time:.8f} seconds".format(time=acc["setup"] / d),
+        "Frame Tracking Avg Time: {time:.8f} seconds".format(time=acc["track"] / d),
+        "Overall Frame VO Avg Time: {time:.8f} seconds".format(time=acc["vo"] / d),
+        "Total Number of tracked correspondences: {corrs}".format(corrs=int(acc["corr"])),
+        "Average Number of tracked correspondences: {corrs}".format(corrs=int(int(acc["corr"]) / d)),
+        "Average tracked correspondences RANSAC inlier ratio: {ratio:.8f}".format(ratio=acc["ratio"] / d),
+        "Estimated poses in TUM format SAVED as " + est_path,
+        "Keyframes (indices) SAVED as " + kf_path])
+    say(summary)
+    for f in (est_file, gt_file, kf_file, log):
+        f.close()
+    return dict(poses=poses_out, keyframe_ids=keyframe_ids, tracked=n_done, message=summary)
+
+
+def driver_VO(camera_model, scene_path, scene_path_vo_results, scene_img_filename_template, depth_filename_template,
+              num_scene_images, visualize_VO=False, use_multithreads_for_VO=True, step_for_scene_images=1, first_image_index=0,
+              last_image_index=-1, thread_name=""):
+    """pose_est_tools.py:1680-1741: frame index list, ground truth file discovery (gt_TUM.txt unless the scene is a
+    static one), run_VO on a worker thread (as the reference does next to its GUI loop) or inline."""
+    if visualize_VO:
+        raise NotImplementedError("3-D visualisation is not built: visualize_VO must be False")
+    if use_multithreads_for_VO:
+        est_poses_filename = "estimated_frame_poses_TUM.txt"
+    else:
+        from datetime import datetime
+        now = datetime.now()
+        est_poses_filename = "estimated_frame_poses_TUM-%d-%d-%d-%d-%d-%d.txt" % (now.year, now.month, now.day, now.hour,
+                                                                                   now.minute, now.second)
+    gt_poses_filename = None
+    low = scene_path.lower()
+    rig_is_static = "static" in low or "GCT" in scene_path.upper() or "CCNY" in scene_path.upper() or "park" in low \
+        or "grand" in low
+    if not rig_is_static:
+        gt_poses_filename = os.path.join(scene_path, "gt_TUM.txt")
+    last_image_index = min(last_image_index, num_scene_images) if last_image_index > 0 else num_scene_images
+    vo_frame_indices = list(range(first_image_index, last_image_index, step_for_scene_images))
+    kwargs = dict(visualizer_3D_VO=None, camera_model=camera_model, gt_poses_filename=gt_poses_filename,
+                  est_poses_filename=est_poses_filename, img_filename_template=scene_img_filename_template,
+                  depth_filename_template=depth_filename_template, img_indices=vo_frame_indices,
+                  results_path=scene_path_vo_results, thread_name=thread_name)
+    result = {}
+    if use_multithreads_for_VO:
+        # one libsosvo context per host thread (INTEGRATION.md section 6): the worker creates its own
+        failure = []
+
+        def work():
+            try:
+                result.update(run_VO(**kwargs))
+            except BaseException as e:  # noqa: B902 -- handed to the calling thread
+                failure.append(e)
+        th = threading.Thread(target=work)
+        th.start()
+        th.join()
+        if failure:
+            raise failure[0]
+    else:
+        result.update(run_VO(**kwargs))
+    print("%s Done with VO for %s!" % (thread_name, scene_path))
+    return result

@@ -197,29 +197,24 @@ class RGBDCamConfig(object):
         return c
 
 
-class RGBDPairPipeline(object):
-    """The RGB-D (perspective) counterpart of ImageFrontEnd + FramePairPipeline (BASELINE config 5): for B
-    independent pairs of (BGR image, depth map) frames, RGBDFrame.establish_keypoints (pose_est_tools.py:600-623:
-    [median,] gray, goodFeaturesToTrack on the whole image, ORB descriptors, depth back-projection, range filter)
-    and TrackerRGBDSE3.track_frame (:896-954: frame-to-frame matching, |du| gate, central RANSAC, LM).
-    Pair i tracks frame 2i+1 against frame 2i.  Everything stays in HBM; one step = 10 asynchronous C-ABI calls."""
+class RGBDFrontEnd(object):
+    """RGBDFrame.establish_keypoints (pose_est_tools.py:600-623) for F frames at once: [median,] gray,
+    goodFeaturesToTrack on the whole image (or RGBDFrame.mask), ORB descriptors, depth back-projection, NaN / range
+    filter, bearings.  All buffers in HBM; four asynchronous C-ABI calls."""
 
-    def __init__(self, ctx, cam, n_pairs, image_shape=(480, 640), num_of_features=1000, kp_cap=None, frame_cap=None,
-                 median_win_size=0, quality=0.01, min_distance=5.0, edge=31, thr=None, max_iter=2000, adaptive=False,
-                 seed=0, lm_iter=30, mask=None):
+    def __init__(self, ctx, cam, nframes, image_shape=(480, 640), num_of_features=1000, kp_cap=None, frame_cap=None,
+                 median_win_size=0, quality=0.01, min_distance=5.0, edge=31, mask=None):
         from . import orb_pattern
         assert isinstance(ctx, Context)
         self.ctx, self.cam_cfg, self.cam = ctx, cam, cam.as_struct()
-        self.B, self.F = int(n_pairs), 2 * int(n_pairs)
+        self.F = int(nframes)
         self.rows, self.cols = int(image_shape[0]), int(image_shape[1])
         self.num_of_features, self.median_win_size = int(num_of_features), int(median_win_size)
         self.quality, self.min_distance, self.edge = float(quality), float(min_distance), int(edge)
         # > 1024 selects the detector's large-mask variant (whole-image masks), see sosvo_detect_gft
         self.kp_cap = int(kp_cap) if kp_cap else int(min(4096, max(1088, -(-self.num_of_features // 64) * 64)))
         self.frame_cap = int(frame_cap) if frame_cap else self.kp_cap
-        self.thr = float(1.0 - np.cos(np.deg2rad(5.0))) if thr is None else float(thr)
-        self.max_iter, self.adaptive, self.seed, self.lm_iter = int(max_iter), bool(adaptive), int(seed), int(lm_iter)
-        dev, F, B = ctx.device, self.F, self.B
+        dev, F = ctx.device, self.F
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
         self.bgr = z((F, self.rows, self.cols, 3), torch.uint8)
         self.depth = z((F, self.rows, self.cols), torch.float32)
@@ -234,6 +229,44 @@ class RGBDPairPipeline(object):
         Fc = self.frame_cap
         self.frames = dict(m=z((F, Fc, 2), torch.float32), d=z((F, Fc, 32), torch.uint8), X=z((F, Fc, 3), torch.float64),
                            b=z((F, Fc, 3), torch.float64), M=z((F,), torch.int32))
+
+    def load_frames(self, bgr, depth):
+        """bgr [F,rows,cols,3] u8, depth [F,rows,cols] f32 (the camera's depth units, 0 = no reading)."""
+        dev = self.ctx.device
+        self.bgr.copy_((torch.from_numpy(np.ascontiguousarray(bgr)) if isinstance(bgr, np.ndarray) else bgr).to(dev))
+        self.depth.copy_((torch.from_numpy(np.ascontiguousarray(depth, dtype=np.float32))
+                          if isinstance(depth, np.ndarray) else depth).to(dev))
+
+    def run(self):
+        c = self.ctx
+        c.median_gray(self.bgr, self.median_win_size, gray=self.gray)                              # :528, :531
+        c.detect_gft(self.gray, self.mask_bits, self.F, 1, self.kp_cap, quality=self.quality,
+                     min_distance=self.min_distance, max_corners=self.num_of_features, kp=self.kp, n=self.n,
+                     status=self.status)                                                            # :544
+        c.describe_orb(self.gray, self.kp, self.n, 1, self.pattern, self.cos_a, self.sin_a, edge=self.edge,
+                       desc=self.desc)                                                              # :553
+        c.rgbd_assemble(self.cam, self.kp, self.desc, self.n, self.depth, self.frame_cap, out=self.frames)  # :609-623
+
+
+class RGBDPairPipeline(object):
+    """The RGB-D (perspective) counterpart of ImageFrontEnd + FramePairPipeline (BASELINE config 5): for B
+    independent pairs of (BGR image, depth map) frames, RGBDFrontEnd and then TrackerRGBDSE3.track_frame
+    (pose_est_tools.py:896-954: frame-to-frame matching, |du| gate, central RANSAC, LM).
+    Pair i tracks frame 2i+1 against frame 2i.  Everything stays in HBM; one step = 10 asynchronous C-ABI calls."""
+
+    def __init__(self, ctx, cam, n_pairs, image_shape=(480, 640), num_of_features=1000, kp_cap=None, frame_cap=None,
+                 median_win_size=0, quality=0.01, min_distance=5.0, edge=31, thr=None, max_iter=2000, adaptive=False,
+                 seed=0, lm_iter=30, mask=None):
+        self.ctx, self.cam_cfg = ctx, cam
+        self.B, self.F = int(n_pairs), 2 * int(n_pairs)
+        fe = RGBDFrontEnd(ctx, cam, self.F, image_shape, num_of_features, kp_cap, frame_cap, median_win_size, quality,
+                          min_distance, edge, mask)
+        self.front_end, self.frames, self.kp_cap, self.frame_cap = fe, fe.frames, fe.kp_cap, fe.frame_cap
+        self.n, self.status, self.kp, self.desc, self.gray = fe.n, fe.status, fe.kp, fe.desc, fe.gray
+        self.thr = float(1.0 - np.cos(np.deg2rad(5.0))) if thr is None else float(thr)
+        self.max_iter, self.adaptive, self.seed, self.lm_iter = int(max_iter), bool(adaptive), int(seed), int(lm_iter)
+        dev, F, B, Fc = ctx.device, self.F, self.B, self.frame_cap
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
         self.ref_frame = torch.arange(0, F, 2, dtype=torch.int32, device=dev)
         self.cur_frame = torch.arange(1, F, 2, dtype=torch.int32, device=dev)
         self.keys, self.order = z((B, Fc, 1), torch.uint32), z((B, Fc), torch.int32)
@@ -245,21 +278,10 @@ class RGBDPairPipeline(object):
         self.lm_cost, self.lm_iters = z((B,), torch.float64), z((B,), torch.int32)
 
     def load_frames(self, bgr, depth):
-        """bgr [2B,rows,cols,3] u8, depth [2B,rows,cols] f32 (the camera's depth units, 0 = no reading)."""
-        dev = self.ctx.device
-        self.bgr.copy_((torch.from_numpy(np.ascontiguousarray(bgr)) if isinstance(bgr, np.ndarray) else bgr).to(dev))
-        self.depth.copy_((torch.from_numpy(np.ascontiguousarray(depth, dtype=np.float32))
-                          if isinstance(depth, np.ndarray) else depth).to(dev))
+        self.front_end.load_frames(bgr, depth)
 
     def detect(self):
-        c = self.ctx
-        c.median_gray(self.bgr, self.median_win_size, gray=self.gray)                              # :528, :531
-        c.detect_gft(self.gray, self.mask_bits, self.F, 1, self.kp_cap, quality=self.quality,
-                     min_distance=self.min_distance, max_corners=self.num_of_features, kp=self.kp, n=self.n,
-                     status=self.status)                                                            # :544
-        c.describe_orb(self.gray, self.kp, self.n, 1, self.pattern, self.cos_a, self.sin_a, edge=self.edge,
-                       desc=self.desc)                                                              # :553
-        c.rgbd_assemble(self.cam, self.kp, self.desc, self.n, self.depth, self.frame_cap, out=self.frames)  # :609-623
+        self.front_end.run()
 
     def track(self):
         c, fr, cfg = self.ctx, self.frames, self.cam_cfg

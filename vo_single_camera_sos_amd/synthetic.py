@@ -136,3 +136,81 @@ def make_frame_pairs(gums, n_pairs, seed=1234, noise_sigma=2.0, workers=1):
         omni[2 * i], omni[2 * i + 1] = ref, cur
         poses.append(pose)
     return omni, poses
+
+
+# ---- perspective RGB-D frames and on-disk sequences (for the demo CLIs / VO-loop tests) ---------------------
+RGBD_AXES = np.array([[1.0, 0, 0], [0, 0, 1.0], [0, -1.0, 0]])  # camera (x right, y down, z forward) in the rig frame
+
+
+def render_rgbd(room, R, t, rng, fx=554.256258, fy=554.256258, cx=319.5, cy=239.5, shape=(480, 640), depth_is_Z=True,
+                holes=0.05, noise_sigma=2.0):
+    """Pinhole view of the textured room from the rig pose X_world = R x + t (mm): BGR u8 [rows,cols,3] and depth
+    f32 [rows,cols] in metres quantised to 1 mm (0 = no reading); radial distance when depth_is_Z is False."""
+    v, u = np.mgrid[0:shape[0], 0:shape[1]]
+    d = np.stack([(u - cx) / fx, (v - cy) / fy, np.ones(shape)], axis=-1).reshape(-1, 3)
+    P, tt = room.cast(np.asarray(t, dtype=np.float64), d @ (R @ RGBD_AXES).T)
+    bgr = room.colour(P).reshape(shape + (3,))
+    bgr = np.clip(bgr.astype(np.float64) + rng.normal(0, noise_sigma, bgr.shape), 0, 255).astype(np.uint8)
+    Z = (tt * 1e-3).reshape(shape)  # the ray parameter with d_z = 1 is the Z depth
+    depth = Z if depth_is_Z else Z * np.linalg.norm(d, axis=1).reshape(shape)
+    depth = np.round(depth * 1000.0) / 1000.0
+    depth[rng.random(shape) < holes] = 0.0
+    return bgr, depth.astype(np.float32)
+
+
+def trajectory(n_frames, seed=0, max_t=40.0, max_deg=2.0):
+    """n rig poses (R, t [mm]) in the world: identity first, then a random walk of small SE(3) steps."""
+    rng = np.random.default_rng(seed)
+    R, t = np.eye(3), np.zeros(3)
+    poses = [(R, t)]
+    for _ in range(n_frames - 1):
+        dR, dt = random_step(rng, max_t=max_t, max_deg=max_deg)
+        R, t = R @ dR, R @ dt + t
+        poses.append((R, t))
+    return poses
+
+
+def _write_gt_tum(filename, poses):
+    from .omnistereo.transformations import quaternion_from_matrix
+    with open(filename, "w") as f:
+        f.write("# index tx ty tz qx qy qz qw   [m]\n")
+        for i, (R, t) in enumerate(poses):
+            T = np.eye(4)
+            T[:3, :3] = R
+            q = quaternion_from_matrix(T)
+            f.write("%d %.9f %.9f %.9f %.9f %.9f %.9f %.9f\n" % (i, t[0] * 1e-3, t[1] * 1e-3, t[2] * 1e-3, q[1], q[2], q[3], q[0]))
+
+
+def write_sos_sequence(path, gums, n_frames=6, seed=0, max_t=40.0, max_deg=2.0):
+    """<path>/omni/image-%04d.png + gt_TUM.txt, <path>/gums-calibrated.json: what demo_vo_sos.py reads."""
+    import os
+    from .omnistereo.common_cv import imwrite
+    from .omnistereo.gum import save_gums_json
+    os.makedirs(os.path.join(path, "omni"), exist_ok=True)
+    room = Room(seed=seed)
+    poses = trajectory(n_frames, seed, max_t, max_deg)
+    rng = np.random.default_rng(seed + 1)
+    for i, (R, t) in enumerate(poses):
+        imwrite(os.path.join(path, "omni", "image-%04d.png" % i), render_omni(gums, room, R, t, 2.0, rng))
+    _write_gt_tum(os.path.join(path, "omni", "gt_TUM.txt"), poses)
+    save_gums_json(gums, os.path.join(path, "gums-calibrated.json"))
+    return poses
+
+
+def write_rgbd_sequence(path, n_frames=6, seed=0, max_t=40.0, max_deg=2.0, depth_is_Z=False):
+    """<path>/rgbd/rgb/%04d.png, <path>/rgbd/depth/%04d.png (16-bit, mm) + gt_TUM.txt: what demo_vo_rgbd.py reads
+    (its synthetic setting stores RADIAL depth, demo_vo_rgbd.py:68)."""
+    import os
+    from PIL import Image
+    from .omnistereo.common_cv import imwrite
+    for sub in ("rgb", "depth"):
+        os.makedirs(os.path.join(path, "rgbd", sub), exist_ok=True)
+    room = Room(seed=seed, half_x=(1800.0, 2600.0), half_y=(2500.0, 3500.0), cells=(150.0, 40.0))
+    poses = trajectory(n_frames, seed, max_t, max_deg)
+    rng = np.random.default_rng(seed + 1)
+    for i, (R, t) in enumerate(poses):
+        bgr, depth = render_rgbd(room, R, t, rng, depth_is_Z=depth_is_Z)
+        imwrite(os.path.join(path, "rgbd", "rgb", "%04d.png" % i), bgr)
+        Image.fromarray(np.round(depth * 1000.0).astype(np.uint16)).save(os.path.join(path, "rgbd", "depth", "%04d.png" % i))
+    _write_gt_tum(os.path.join(path, "rgbd", "gt_TUM.txt"), poses)
+    return poses
