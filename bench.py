@@ -71,6 +71,9 @@ def parse():
                          "1440 -> 1440 x 146 gives the ~2000 keypoints per view BASELINE's metric is quoted on")
     ap.add_argument("--iters", type=int, default=2000, help="RANSAC iterations, fixed (C2: 2000)")
     ap.add_argument("--cpu-pairs", type=int, default=32, help="frame pairs timed on the host for cpu_baseline")
+    ap.add_argument("--render-workers", type=int, default=0,
+                    help="host processes rendering the synthetic frames (0 = auto; use 1 under rocprofv3, whose preloaded "
+                         "tool initialises the GPU before this program forks)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--pmc-csv", default=None, help="per-kernel PMC summary for roofline.traffic (default: newest in profiles/)")
     ap.add_argument("--seed", type=int, default=1234)
@@ -115,7 +118,7 @@ def main():
                   min_range=500.0, max_range=7000.0, stereo_min_disp=1.0, stereo_max_hdiff=2.5,
                   f2f_max_hdiff=0.125 * 0.5 * pano.cols, pct_good_matches=1.0)
     # frames are rendered on the host (forked workers) BEFORE this process touches the GPU
-    workers = max(1, min(16, (os.cpu_count() or 1) // max(1, world)))
+    workers = args.render_workers if args.render_workers > 0 else max(1, min(16, (os.cpu_count() or 1) // max(1, world)))
     omni, poses = synthetic.make_frame_pairs(gs, B, seed=args.seed + 100000 * rank, workers=workers)
     dist = None
     if world > 1:

@@ -1,0 +1,21 @@
+#!/bin/bash
+# rocprofv3 passes over the bench command (run on the GPU box from the repo root):
+#   scripts/profile_bench.sh <tag>      e.g. r1m  -> gpurun_out/prof_<tag>/, pmc_<tag>_fetch/, pmc_<tag>_write/
+# 1. --kernel-trace --stats (per-kernel durations), 2./3. --pmc FETCH_SIZE / WRITE_SIZE in their own passes (they do
+# not fit one pass on gfx950, and PMC passes must not be combined with API tracing).  The program itself follows
+# `--` (no env/bash hop: the profiler's preloaded tool initialises the GPU first).  --render-workers 1: no fork
+# under the profiler.  Then: python scripts/summarize_pmc.py ... > profiles/roundN/<tag>_pmc_hbm_per_kernel.csv
+set -e -o pipefail
+TAG=${1:-run}
+ARGS="--steps 10 --warmup 2 --no-cpu --render-workers 1"
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$TAG --output-format csv -- python3 bench.py $ARGS > gpurun_out/prof_${TAG}_bench.log 2>&1
+echo "stats pass done"
+rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_${TAG}_fetch --output-format csv -- python3 bench.py $ARGS > gpurun_out/pmc_${TAG}_fetch.log 2>&1
+echo "fetch pass done"
+rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_${TAG}_write --output-format csv -- python3 bench.py $ARGS > gpurun_out/pmc_${TAG}_write.log 2>&1
+echo "write pass done"
+python3 scripts/summarize_pmc.py gpurun_out/pmc_${TAG}_fetch gpurun_out/pmc_${TAG}_write 256 > gpurun_out/${TAG}_pmc_hbm_per_kernel.csv
+find gpurun_out/prof_$TAG -name "*kernel_stats.csv" -exec cp {} gpurun_out/${TAG}_kernel_stats.csv \;
+grep -h '^{"metric"' gpurun_out/prof_${TAG}_bench.log > gpurun_out/${TAG}_bench_under_rocprof.json || true
