@@ -71,6 +71,9 @@ def parse():
                          "1440 -> 1440 x 146 gives the ~2000 keypoints per view BASELINE's metric is quoted on")
     ap.add_argument("--iters", type=int, default=2000, help="RANSAC iterations, fixed (C2: 2000)")
     ap.add_argument("--cpu-pairs", type=int, default=32, help="frame pairs timed on the host for cpu_baseline")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams per GPU the batch is split over (the median launches take turns, the latency-bound "
+                         "stages of the other parts overlap them); 1 = one stream")
     ap.add_argument("--render-workers", type=int, default=0,
                     help="host processes rendering the synthetic frames (0 = auto; use 1 under rocprofv3, whose preloaded "
                          "tool initialises the GPU before this program forks)")
@@ -99,12 +102,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     from vo_single_camera_sos_amd import synthetic
-    from vo_single_camera_sos_amd.device import Context
-    from vo_single_camera_sos_amd.frontend import DeviceImageModel, ImageFrontEnd
     from vo_single_camera_sos_amd.omnistereo.gum import synthetic_gums
     from vo_single_camera_sos_amd.omnistereo.panorama import Panorama
     from vo_single_camera_sos_amd.parallel import gather_records, max_over_ranks
-    from vo_single_camera_sos_amd.pipeline import FramePairPipeline, RigConfig
+    from vo_single_camera_sos_amd.pipeline import OverlappedFramePairs, RigConfig
 
     B = args.pairs_per_gpu
     H, W = 480, 640
@@ -131,20 +132,20 @@ def main():
     if args.gpus != n_gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d; using %d" % (args.gpus, world, n_gpus), file=sys.stderr)
 
-    ctx = Context(local_rank)
-    model = DeviceImageModel(ctx, gs, (H, W))
-    fe = ImageFrontEnd(ctx, model, 2 * B, detection_method=args.detector, num_of_features=args.features_per_mask,
-                       kp_cap=512, keep_panoramas=False)  # K1 fused into the median kernel
-    pipe = FramePairPipeline(ctx, RigConfig(**rig_kw), B, frame_cap=2048, max_iter=args.iters, adaptive=False,
-                             seed=args.seed, front_end=fe)
-    fe.load_frames(omni)
-    gathered = torch.empty((n_gpus * B, 16), dtype=torch.float64, device=ctx.device) if dist else None
+    torch.cuda.set_device(local_rank)
+    eng = OverlappedFramePairs(local_rank, gs, (H, W), RigConfig(**rig_kw), B, n_streams=args.streams,
+                               num_of_features=args.features_per_mask, kp_cap=512, frame_cap=2048, max_iter=args.iters,
+                               adaptive=False, seed=args.seed, detection_method=args.detector)
+    model, dev = eng.model, eng.device
+    eng.load_frames(omni)
+    gathered = torch.empty((n_gpus * B, 16), dtype=torch.float64, device=dev) if dist else None
 
     def step():
-        pipe.step()
-        rec = pipe.results()
+        eng.step()
+        rec = eng.results()
         if dist:
             gather_records(rec, out=gathered)  # 16 doubles per pair: latency-bound, one flat RCCL all-gather
+        eng.consumed()
         return rec
 
     for _ in range(args.warmup):
@@ -153,7 +154,7 @@ def main():
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
-    ctx.profile_enable(True)
+    eng.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         rec = step()
@@ -162,14 +163,15 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    prof = ctx.profile_read()
-    ctx.profile_enable(False)
-    elapsed = max_over_ranks(elapsed, ctx.device)
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+    elapsed = max_over_ranks(elapsed, dev)
 
     if rank == 0:
         rec = rec.cpu().numpy()
-        n_kp = fe.n.cpu().numpy().reshape(2, 2 * B, model.nmask).sum(-1)  # [view, frame]
-        M = pipe.frames["M"].cpu().numpy()
+        n_kp = np.concatenate([p.fe.n.cpu().numpy().reshape(2, -1, model.nmask).sum(-1) for p in eng.parts], axis=1)  # [view, frame]
+        M = np.concatenate([p.pipe.frames["M"].cpu().numpy() for p in eng.parts])
+        cap_hit = any(int(p.fe.n.max().item()) >= p.fe.kp_cap for p in eng.parts)
         per_kernel = {}
         for name, ms in prof:
             s = per_kernel.setdefault(name, [0, 0.0])
@@ -177,11 +179,12 @@ def main():
             s[1] += ms
         dom = max(per_kernel.items(), key=lambda kv: kv[1][1])
         dom_avg_s = dom[1][1] / dom[1][0] / 1e3
+        dom_pairs = B / float(eng.S)  # one launch of the dominant kernel covers one stream's share of the batch
         kpts = int(round(float(n_kp.mean())))
         b_alg = b_alg_c2(H, W, kpts)
-        b_alg_launch = b_alg * B  # one launch of the dominant kernel covers the whole batch of B pairs
+        b_alg_launch = b_alg * dom_pairs
         achieved = b_alg_launch / dom_avg_s / 1e9
-        traffic, traffic_src = pmc_traffic(dom[0], B, args.pmc_csv)
+        traffic, traffic_src = pmc_traffic(dom[0], dom_pairs, args.pmc_csv)
         ok = rec[:, 14] == 0
         rot_err = []
         for i in range(B):
@@ -201,9 +204,9 @@ def main():
                                    "non-central P3P RANSAC %d iterations fixed, LM"
                                    % (pano.cols, pano.rows, args.detector, args.features_per_mask, model.nmask,
                                       2 * model.nmask, args.iters),
-                       "keypoint_capacity_hit": bool(int(fe.n.max().item()) >= fe.kp_cap),
+                       "keypoint_capacity_hit": bool(cap_hit),
                        "pairs_per_gpu": B, "global_pairs_per_step": n_gpus * B,
-                       "parallelism": "pairs sharded over ranks, dp%d" % n_gpus,
+                       "parallelism": "pairs sharded over ranks, dp%d; %d HIP streams per GPU" % (n_gpus, eng.S),
                        "keypoints_per_view_mean": float(n_kp.mean()), "stereo_points_per_frame_mean": float(M.mean()),
                        "correspondences_per_pair_mean": float(rec[:, 13].mean()),
                        "inliers_per_pair_mean": float(rec[:, 12].mean()), "tracked_ok": int(ok.sum()),
@@ -214,6 +217,7 @@ def main():
                          "algorithmic_bytes_per_pair": b_alg, "algorithmic_bytes_per_launch": b_alg_launch,
                          "note": "no contraction anywhere (no MFMA); the dominant kernel is VALU-bound integer/bit work, "
                                  "so the HBM fraction is small by construction (SURVEY 8d)"},
+            "streams": eng.S,
             "kernels_ms_per_step": {k: v[1] / args.steps for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])},
             "kernel_ms_per_step_total": sum(v[1] for v in per_kernel.values()) / args.steps,
         }
@@ -223,9 +227,9 @@ def main():
             ca, sa = orb_pattern.angle_cos_sin(-1.0)
             im = refflow.ImageModel(model.map_x.cpu().numpy(), model.map_y.cpu().numpy(), model.omni_masks.cpu().numpy(),
                                     model.mask_bits_host, model.nmask, args.features_per_mask, model.pattern_host, ca, sa,
-                                    method=args.detector, kp_cap=fe.kp_cap)
+                                    method=args.detector, kp_cap=eng.parts[0].fe.kp_cap)
             n_cpu = min(args.cpu_pairs, B)
-            v, dt = cpu_baseline(omni, im, rig_kw, pipe.thr, args.iters, args.seed, n_cpu)
+            v, dt = cpu_baseline(omni, im, rig_kw, eng.thr, args.iters, args.seed, n_cpu)
             out["cpu_baseline"] = {"value": v, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
                                    "sample": "%d of the same frame pairs through the C oracle (oracle/*.c) driven by "
                                              "tests/refflow.py, %.1f s" % (n_cpu, dt)}
@@ -233,7 +237,7 @@ def main():
     if dist:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    eng.close()
 
 
 if __name__ == "__main__":

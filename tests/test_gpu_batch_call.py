@@ -67,3 +67,33 @@ def test_argument_errors(ctx):
     with pytest.raises(_lib.SosvoError):
         ctx.frame_pair_batch(batch.rig, bad, batch.omni, model.unwrap_table, model.mask_bits, model.pattern,
                              batch.workspace)
+
+
+@pytest.mark.parametrize("n_streams", [1, 3])
+def test_overlapped_streams_equal_single_pipeline(ctx, n_streams):
+    """OverlappedFramePairs (the batch split over HIP streams, medians taking turns) returns the records of one
+    FramePairPipeline over all pairs, bit for bit, step after step."""
+    from vo_single_camera_sos_amd.pipeline import OverlappedFramePairs
+    B, nfeat = 5, 200
+    model, rig, omni = _setup(ctx, B)
+    fe = ImageFrontEnd(ctx, model, 2 * B, num_of_features=nfeat, kp_cap=256)
+    pipe = FramePairPipeline(ctx, rig, B, frame_cap=1024, max_iter=200, seed=3, front_end=fe)
+    fe.load_frames(omni)
+    pipe.step()
+    want = pipe.results().cpu().numpy()
+    ctx.synchronize()
+    gs = synthetic_gums()
+    for m in (gs.top_model, gs.bot_model):
+        m.panorama = Panorama(m, width=1200)
+    gs.make_annulus_masks((480, 640))
+    eng = OverlappedFramePairs(0, gs, (480, 640), rig, B, n_streams=n_streams, num_of_features=nfeat, kp_cap=256,
+                               frame_cap=1024, max_iter=200, seed=3)
+    assert eng.S == n_streams and [p.hi - p.lo for p in eng.parts] == ([5] if n_streams == 1 else [2, 2, 1])
+    eng.load_frames(omni)
+    for _ in range(3):
+        eng.step()
+        got = eng.results().clone()
+        eng.consumed()
+        torch.cuda.synchronize()
+        assert np.array_equal(got.cpu().numpy().view(np.uint64), want.view(np.uint64))
+    eng.close()

@@ -16,6 +16,9 @@
 // compare-and-count.
 #include "common.h"
 
+#include <type_traits>
+#include <utility>
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -192,11 +195,38 @@ __device__ __forceinline__ unsigned long long ballot_byte_sign(uint32_t x, int b
   else asm("v_cmp_lt_i16_sdwa %0, sext(%1), %2 src0_sel:BYTE_2 src1_sel:DWORD" : "=s"(bal) : "v"(x), "v"(vzero));
   return bal;
 }
+// popcount(x) + acc as ONE v_bcnt (kept as a chain: the compiler otherwise splits it into four independent
+// popcounts plus an add3 to shorten the dependency chain, one more issue slot per bit in an issue-bound kernel)
+__device__ __forceinline__ uint32_t popc_add(uint32_t x, uint32_t acc) {
+  uint32_t r;
+  asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+  return r;
+}
 // c & ~(w ^ m): the candidates whose window bit equals the chosen bit (m = all-ones / zero), one v_bitop3
 __device__ __forceinline__ uint32_t keep_equal(uint32_t c, uint32_t m, uint32_t w) {
   uint32_t r;
   asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x90" : "=v"(r) : "v"(c), "v"(m), "v"(w));
   return r;
+}
+
+// Writes the K-bit row slice `x` (bits above K are ignored) into ring slot `slot` of one bit-plane's window:
+// slot s occupies bits [K * s, K * s + K) of the NW-word register; a slot that straddles two words takes a
+// second shift + v_bfi.  `slot` is a compile-time constant after unrolling: masks and shifts become literals.
+template <int K, int NW>
+__device__ __forceinline__ void ring_insert(uint32_t (&Wp)[NW], uint32_t x, int slot) {
+  const int bit = K * slot, w = bit >> 5, pos = bit & 31;
+  const uint32_t field = (1u << K) - 1u;
+  const uint32_t m0 = field << pos;
+  Wp[w] = (Wp[w] & ~m0) | ((x << pos) & m0);
+  if (pos + K > 32) {
+    const uint32_t m1 = field >> (32 - pos);
+    Wp[w + 1] = (Wp[w + 1] & ~m1) | ((x >> (32 - pos)) & m1);
+  }
+}
+
+template <typename F, int... I>
+__device__ __forceinline__ void for_each_slot(F& f, int r_base, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}, r_base + I), ...);
 }
 
 // ---- K2 + K3 (optionally with K1 in front) --------------------------------------------------------------
@@ -205,9 +235,10 @@ __device__ __forceinline__ uint32_t keep_equal(uint32_t c, uint32_t m, uint32_t 
 // FUSED = true : img is the omni batch [nframes, H, W, 3] and every lane unwraps its source pixel from the table
 //                on the fly (same integer arithmetic as unwrap_lut_kernel), so the colour panoramas never touch
 //                HBM: the per-row gather hides under the other waves' VALU work.
-// Window registers: per (channel, bit-plane) the K * K window bits sit at the TOP of NW words (newest row in
-// the top K bits of the last word); a row step is NW v_alignbit ops fed by the lane's slice of the ballot.
-// The G = 32 * NW - K * K low bits of word 0 are stale and excluded by the initial candidate mask.
+// Window registers: per (channel, bit-plane) the K * K window bits are a RING of K row slots of K bits in NW words
+// (the median does not care about the order of the window's elements): a row step overwrites the oldest slot with
+// the lane's slice of the ballot -- one shift + one v_bfi with literal mask -- instead of shifting the whole
+// register; the row loop is unrolled K times so that the slot number is a compile-time constant.
 template <int K, bool FUSED>
 __global__ __launch_bounds__(kThreads) void median_gray_kernel(const uint8_t* __restrict__ img,
                                                                const uint2* __restrict__ table, int nframes, int H, int W,
@@ -216,7 +247,7 @@ __global__ __launch_bounds__(kThreads) void median_gray_kernel(const uint8_t* __
   constexpr int R = K / 2;
   constexpr int NB = K * K;
   constexpr int NW = (NB + 31) / 32;      // words per bit-plane: 4 for 11 x 11
-  constexpr int G = 32 * NW - NB;         // stale low bits of word 0
+  constexpr uint32_t LASTMASK = (NB & 31) ? ((1u << (NB & 31)) - 1u) : 0xFFFFFFFFu;  // window bits of the last word
   constexpr int OUTW = 64 - 2 * R;        // output columns per wave
   constexpr uint32_t ABOVE = NB - (NB / 2 + 1);  // window elements ranked above the median
   const int lane = threadIdx.x & 63;
@@ -263,7 +294,10 @@ __global__ __launch_bounds__(kThreads) void median_gray_kernel(const uint8_t* __
 #pragma unroll
       for (int j = 0; j < NW; ++j) Wp[c][b][j] = 0u;
 
-  for (int r_src = -R; r_src < rows + R; ++r_src) {
+  // one source row: ring slot = compile-time constant (the row loop below is unrolled K times by a fold)
+  auto row_step = [&](auto slot_tag, const int r_src) __attribute__((always_inline)) {
+    constexpr int slot = decltype(slot_tag)::value;
+    if (r_src >= rows + R) return;  // uniform (the tail of the last group)
     uint32_t pix;
     if (FUSED) {
       pix = unwrap_blend(frame_bytes, W, e_cur, taps);
@@ -274,21 +308,16 @@ __global__ __launch_bounds__(kThreads) void median_gray_kernel(const uint8_t* __
       pix = raw;
       raw = load_raw(r_src + 1);
     }
-    // shift the window up by one row and append the new row's 24 bit-plane slices
+    // overwrite the oldest row slot with the new row's 24 bit-plane slices
 #pragma unroll
     for (int b = 7; b >= 0; --b) {
       const uint32_t sh = pix << (7 - b);  // bit b of every channel now sits in the sign position of its byte
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const unsigned long long bal = ballot_byte_sign(sh, c, vzero);
-        const uint32_t x = (uint32_t)(bal >> lane);  // only its low K bits survive the funnel shift
-#pragma unroll
-        for (int j = 0; j + 1 < NW; ++j) Wp[c][b][j] = __funnelshift_r(Wp[c][b][j], Wp[c][b][j + 1], K);
-        Wp[c][b][NW - 1] = __funnelshift_r(Wp[c][b][NW - 1], x, K);
-      }
+      for (int c = 0; c < 3; ++c)
+        ring_insert<K, NW>(Wp[c][b], (uint32_t)(ballot_byte_sign(sh, c, vzero) >> lane), slot);
     }
     const int r_out = r_src - R;
-    if (r_out < 0) continue;  // window not complete yet (uniform)
+    if (r_out < 0) return;  // window not complete yet (uniform)
     int med[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -297,13 +326,13 @@ __global__ __launch_bounds__(kThreads) void median_gray_kernel(const uint8_t* __
       uint32_t C[NW];
 #pragma unroll
       for (int j = 0; j < NW; ++j) C[j] = 0xFFFFFFFFu;
-      C[0] = G ? ~((1u << G) - 1u) : 0xFFFFFFFFu;
+      C[NW - 1] = LASTMASK;
       uint32_t above = ABOVE, res = 0u;
 #pragma unroll
       for (int b = 7; b >= 0; --b) {
         uint32_t n1 = 0;
 #pragma unroll
-        for (int j = 0; j < NW; ++j) n1 += __popc(C[j] & Wp[c][b][j]);
+        for (int j = 0; j < NW; ++j) n1 = popc_add(C[j] & Wp[c][b][j], n1);
         const uint32_t d = above - n1;
         const uint32_t ones = (uint32_t)((int32_t)d >> 31);  // all-ones: the wanted element has bit b set
         above = min(above, d);                                // (unsigned) d wraps above `above` exactly then
@@ -314,7 +343,8 @@ __global__ __launch_bounds__(kThreads) void median_gray_kernel(const uint8_t* __
       med[c] = (int)res;
     }
     if (out_ok) dst[(size_t)r_out * cols + x_out] = bgr2gray(med[0], med[1], med[2]);
-  }
+  };
+  for (int r_base = -R; r_base < rows + R; r_base += K) for_each_slot(row_step, r_base, std::make_integer_sequence<int, K>{});
 }
 
 // launches the K-templated strip kernel; FUSED takes the omni batch + unwrap table instead of panoramas

@@ -90,6 +90,11 @@ class ImageFrontEnd(object):
         self.omni.copy_(t.to(self.ctx.device))
 
     def run(self):
+        self.run_images()
+        self.run_features()
+
+    def run_images(self):
+        """K1 + K2 + K3: omni frames -> median-blurred gray panoramas (the VALU-bound half of the front end)."""
         c, m = self.ctx, self.model
         if getattr(m, "unwrap_table", None) is None:  # once per model
             m.unwrap_table = c.unwrap_prepare(m.omni_masks, m.map_x, m.map_y, (m.H, m.W))
@@ -98,6 +103,10 @@ class ImageFrontEnd(object):
             c.median_gray(self.pano.view(2 * self.F, m.rows, m.cols, 3), self.median_win_size, gray=self.gray)  # K2 + K3
         else:
             c.unwrap_median_gray(self.omni, m.unwrap_table, self.median_win_size, gray=self.gray)    # K1 + K2 + K3
+
+    def run_features(self):
+        """K4 / K5 + K6: keypoints and descriptors per azimuthal mask on the gray panoramas."""
+        c, m = self.ctx, self.model
         if self.method == "ORB":
             c.detect_orb(self.gray, m.mask_pyr, self.F, m.nmask, self.num_of_features, self.kp_cap, kp4=self.kp4,
                          resp=self.resp, n=self.n)                                                # K5

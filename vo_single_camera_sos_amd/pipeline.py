@@ -120,16 +120,120 @@ class FramePairPipeline(object):
         self.track()
         return self.T
 
-    def results(self):
+    def results(self, out=None):
         """[B,16] f64 rows: 3x4 refined pose, n_inliers, n_correspondences, status, RANSAC best iteration
         (the per-pair record gathered over ranks in the multi-GPU configuration)."""
-        out = torch.empty((self.B, 16), dtype=torch.float64, device=self.ctx.device)
+        if out is None:
+            out = torch.empty((self.B, 16), dtype=torch.float64, device=self.ctx.device)
         out[:, :12] = self.T.reshape(self.B, 12)
         out[:, 12] = self.ransac["n_inliers"].to(torch.float64)
         out[:, 13] = self.corr["n"].to(torch.float64)
         out[:, 14] = self.ransac["info"][:, 2].to(torch.float64)
         out[:, 15] = self.ransac["info"][:, 0].to(torch.float64)
         return out
+
+
+class OverlappedFramePairs(object):
+    """The hot path for B pairs split over S HIP streams (one libsosvo context, front end and pipeline per
+    stream, model constants shared).  The path alternates between a VALU-bound stage (K1-K3, the median) and
+    latency-bound ones (corner selection, descriptors, matching of small problems, RANSAC bookkeeping, LM) that
+    leave most of the chip's issue slots idle; a token (HIP event) passed from stream to stream serialises the
+    median launches, so that while one part of the batch is in its median the other parts' latency-bound
+    kernels fill the gaps.  Results are those of one FramePairPipeline over all B pairs, bit for bit (pair i
+    samples with seed + i)."""
+
+    class _Part(object):
+        pass
+
+    def __init__(self, device, gums, omni_shape, rig, n_pairs, n_streams=2, num_of_features=1000, kp_cap=512,
+                 frame_cap=2048, max_iter=2000, adaptive=False, seed=0, detection_method="GFT", lm_iter=30, thr=None,
+                 serialize_medians=True):
+        from .frontend import DeviceImageModel, ImageFrontEnd
+        from .parallel import shard_range
+        self.main = Context(device)                       # model constants + result collection: torch's current stream
+        self.device = self.main.device
+        self.model = DeviceImageModel(self.main, gums, omni_shape)
+        m = self.model
+        m.unwrap_table = self.main.unwrap_prepare(m.omni_masks, m.map_x, m.map_y, (m.H, m.W))
+        self.B, self.S = int(n_pairs), max(1, min(int(n_streams), int(n_pairs)))
+        self.out = torch.zeros((self.B, 16), dtype=torch.float64, device=self.device)
+        self.main.synchronize()
+        self.parts = []
+        for s in range(self.S):
+            lo, hi = shard_range(self.B, s, self.S)
+            p = self._Part()
+            p.lo, p.hi = lo, hi
+            p.stream = torch.cuda.Stream(self.device)
+            with torch.cuda.stream(p.stream):
+                p.ctx = Context(self.device.index, p.stream)
+                p.fe = ImageFrontEnd(p.ctx, m, 2 * (hi - lo), detection_method=detection_method,
+                                     num_of_features=num_of_features, kp_cap=kp_cap, keep_panoramas=False)
+                p.pipe = FramePairPipeline(p.ctx, rig, hi - lo, frame_cap=frame_cap, max_iter=max_iter, adaptive=adaptive,
+                                           seed=seed + lo, front_end=p.fe, lm_iter=lm_iter, thr=thr)
+            p.median_done = torch.cuda.Event()
+            p.done = torch.cuda.Event()
+            self.parts.append(p)
+        self.thr = self.parts[0].pipe.thr
+        self.use_token = bool(serialize_medians)
+        self._token = None       # the last median launch
+        self._consumed = None    # self.out has been read by its consumer (see results())
+        torch.cuda.synchronize(self.device)
+
+    def contexts(self):
+        return [p.ctx for p in self.parts]
+
+    def load_frames(self, omni):
+        """omni [2B,H,W,3] u8 (numpy or torch): pair i = frames 2i (reference) and 2i+1 (current)."""
+        for p in self.parts:
+            with torch.cuda.stream(p.stream):
+                p.fe.load_frames(omni[2 * p.lo:2 * p.hi])
+        torch.cuda.synchronize(self.device)
+
+    def step(self):
+        """One pass of the whole hot path over all B pairs (asynchronous)."""
+        for p in self.parts:
+            with torch.cuda.stream(p.stream):
+                if self._token is not None and self.use_token:
+                    p.stream.wait_event(self._token)      # medians take turns
+                p.fe.run_images()
+                p.median_done.record(p.stream)
+                self._token = p.median_done
+                p.fe.run_features()
+                p.pipe.stereo()
+                p.pipe.track()
+                if self._consumed is not None:
+                    p.stream.wait_event(self._consumed)   # the previous step's records have been read
+                p.pipe.results(out=self.out[p.lo:p.hi])
+                p.done.record(p.stream)
+
+    def results(self):
+        """[B,16] f64 records of the last step, valid on torch's current stream (which is made to wait for every
+        part).  Call consumed() after enqueuing whatever reads them, before the next step()."""
+        cur = torch.cuda.current_stream(self.device)
+        for p in self.parts:
+            cur.wait_event(p.done)
+        return self.out
+
+    def consumed(self):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._consumed = ev
+
+    def profile_enable(self, on=True):
+        for p in self.parts:
+            p.ctx.profile_enable(on)
+
+    def profile_read(self):
+        out = []
+        for p in self.parts:
+            out.extend(p.ctx.profile_read())
+        return out
+
+    def close(self):
+        torch.cuda.synchronize(self.device)
+        for p in self.parts:
+            p.ctx.close()
+        self.main.close()
 
 
 class FramePairBatch(object):
