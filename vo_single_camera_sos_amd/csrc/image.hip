@@ -62,11 +62,23 @@ __global__ __launch_bounds__(kThreads) void unwrap_kernel(const uint8_t* __restr
 }
 
 // ---- K1, table-driven form -----------------------------------------------------------------------------
-// The float maps, the 1/32-px rounding, the border test and the annulus mask depend only on the model, so
-// they are folded once into a packed table: word0 = (iy << 16) | (ix & 0xFFFF) (int16 each), word1 =
-// fx | fy << 5 | valid << 10 (4 bits: tap t in-bounds and unmasked).  The per-frame kernel then does no
-// float work and no mask loads: one 8-byte table load and four 4-byte tap loads per pixel, four pixels per
-// lane so that the 12 output bytes leave as three aligned dwords.
+// The float maps, the 1/32-px rounding, the border test and the annulus mask depend only on the model, so they
+// are folded once into a table of one 8-byte entry per panorama pixel.  Two entry formats (bit 31 of .y tells):
+//   fast  (.y bit 31 = 0): everything the per-frame kernels need, ready to use --
+//         .x = off0 | w11 << 22     off0 = byte offset of tap (ix, iy) in the frame (< 2^22), the taps of the
+//         .y = w00 | w01 << 11 | w10 << 21    next row are at off0 + 3 W; w.. = the four bilinear weights in 1/1024
+//                                    (0 for a tap outside the image or masked out: w00 <= 1024, the others <= 992)
+//         Both 8-byte row loads at off0 and off0 + 3 W lie inside the frame.  A pixel without valid taps is the
+//         all-zero entry.
+//   edge  (.y bit 31 = 1): a tap row starts before the frame or ends within its last 8 bytes (or the frame is
+//         larger than 4 MB): .x = (iy << 16) | (ix & 0xFFFF) (int16 each), .y = fx | fy << 5 | valid << 10 | 1 << 31
+//         (valid: 4 bits, tap t in-bounds and unmasked); the kernels clamp the loads and shift the bytes back.
+// The per-frame kernels then do no float work, no mask loads, no bounds tests: one 8-byte table load, two
+// unaligned 8-byte tap loads (the two taps of a source row are adjacent pixels = 6 consecutive bytes) and 12
+// multiply-adds per pixel.
+constexpr uint32_t kTabEdge = 0x80000000u;
+constexpr uint32_t kTabOffMask = 0x3FFFFFu;
+
 __global__ __launch_bounds__(kThreads) void unwrap_table_kernel(const uint8_t* __restrict__ masks,
                                                                 const float* __restrict__ map_x,
                                                                 const float* __restrict__ map_y, int H, int W, int npix,
@@ -85,8 +97,18 @@ __global__ __launch_bounds__(kThreads) void unwrap_table_kernel(const uint8_t* _
       const int x = ix + (t & 1), y = iy + (t >> 1);
       if (x >= 0 && x < W && y >= 0 && y < H && (!msk || msk[(size_t)y * W + x])) valid |= 1u << t;
     }
-    e.x = ((uint32_t)(iy & 0xFFFF) << 16) | (uint32_t)(ix & 0xFFFF);
-    e.y = (uint32_t)fx | ((uint32_t)fy << 5) | (valid << 10);
+    if (valid) {
+      const long long off0 = 3LL * ((long long)iy * W + ix), off1 = off0 + 3LL * W, fb = 3LL * H * W;
+      if (off0 >= 0 && off1 + 8 <= fb && off0 <= (long long)kTabOffMask) {
+        const uint32_t w00 = (valid & 1u) ? (uint32_t)((32 - fx) * (32 - fy)) : 0u, w01 = (valid & 2u) ? (uint32_t)(fx * (32 - fy)) : 0u;
+        const uint32_t w10 = (valid & 4u) ? (uint32_t)((32 - fx) * fy) : 0u, w11 = (valid & 8u) ? (uint32_t)(fx * fy) : 0u;
+        e.x = (uint32_t)off0 | (w11 << 22);
+        e.y = w00 | (w01 << 11) | (w10 << 21);
+      } else {
+        e.x = ((uint32_t)(iy & 0xFFFF) << 16) | (uint32_t)(ix & 0xFFFF);
+        e.y = (uint32_t)fx | ((uint32_t)fy << 5) | (valid << 10) | kTabEdge;
+      }
+    }
   }
   table[(size_t)view * npix + pix] = e;
 }
@@ -94,43 +116,54 @@ __global__ __launch_bounds__(kThreads) void unwrap_table_kernel(const uint8_t* _
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 typedef unsigned long long __attribute__((aligned(1))) u64_unaligned;
 
-// The bilinear taps of one panorama pixel from its table entry: the two taps of a source row are adjacent
-// pixels = 6 consecutive bytes, fetched with ONE unaligned 8-byte load per row.  The load is unconditional and
-// branch-free (so it can be issued a whole row ahead of its use): the address is clamped into the frame, and
-// unwrap_blend() undoes the clamp (only where a tap row starts before the frame or ends within its last 8 bytes).
-__device__ __forceinline__ int unwrap_tap_offset(uint2 e, int r, int W) {
+// Tap loads of one table entry, unconditional and branch-free so that they can be issued a whole row ahead of
+// their use: a fast entry loads at off0 and off0 + 3 W; an edge entry loads at the clamped offsets (the blend
+// shifts the bytes back).  `row_bytes` = 3 W.
+__device__ __forceinline__ int edge_tap_offset(uint2 e, int r, int W) {
   const int ix = (int)(int16_t)(e.x & 0xFFFFu), iy = (int)(int16_t)(e.x >> 16);
   return 3 * ((iy + r) * W + ix);  // byte offset of tap (ix, iy + r) inside the frame; H * W * 3 < 2^31
 }
 __device__ __forceinline__ void unwrap_gather(const uint8_t* __restrict__ src, int frame_bytes, int W, uint2 e,
                                               unsigned long long v[2]) {
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int off = unwrap_tap_offset(e, r, W);
-    v[r] = *reinterpret_cast<const u64_unaligned*>(src + min(max(off, 0), frame_bytes - 8));
+  uint32_t o0 = e.x & kTabOffMask, o1 = o0 + 3u * (uint32_t)W;
+  const bool edge = (e.y & kTabEdge) != 0u;
+  if (__ballot(edge) != 0ULL) {  // wave-uniform branch, rarely taken: some lane has frame-edge taps
+    if (edge) {
+      o0 = (uint32_t)min(max(edge_tap_offset(e, 0, W), 0), frame_bytes - 8);
+      o1 = (uint32_t)min(max(edge_tap_offset(e, 1, W), 0), frame_bytes - 8);
+    }
   }
+  v[0] = *reinterpret_cast<const u64_unaligned*>(src + o0);
+  v[1] = *reinterpret_cast<const u64_unaligned*>(src + o1);
 }
 
 // 1/32-px fixed-point blend of the gathered taps -> B | G << 8 | R << 16
 __device__ __forceinline__ uint32_t unwrap_blend(int frame_bytes, int W, uint2 e, const unsigned long long vin[2]) {
-  const uint32_t valid = e.y >> 10;
-  const int fx = (int)(e.y & 31u), fy = (int)((e.y >> 5) & 31u);
-  int acc0 = 0, acc1 = 0, acc2 = 0;
+  unsigned long long v0 = vin[0], v1 = vin[1];
+  uint32_t w00 = e.y & 0x7FFu, w01 = (e.y >> 11) & 0x3FFu, w10 = (e.y >> 21) & 0x3FFu, w11 = e.x >> 22;
+  const bool edge = (e.y & kTabEdge) != 0u;
+  if (__ballot(edge) != 0ULL && edge) {  // wave-uniform skip; rare: undo the clamp of the loads, weights from (fx, fy, valid)
+    const uint32_t valid = (e.y >> 10) & 15u;
+    const uint32_t fx = e.y & 31u, fy = (e.y >> 5) & 31u;
+    w00 = (valid & 1u) ? (32u - fx) * (32u - fy) : 0u;
+    w01 = (valid & 2u) ? fx * (32u - fy) : 0u;
+    w10 = (valid & 4u) ? (32u - fx) * fy : 0u;
+    w11 = (valid & 8u) ? fx * fy : 0u;
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    unsigned long long v = vin[r];
-    const int off = unwrap_tap_offset(e, r, W);
-    const int delta = off - min(max(off, 0), frame_bytes - 8);  // bytes by which the load was moved (rarely != 0)
-    if (delta > 0) v >>= 8 * delta;
-    if (delta < 0) v <<= 8 * -delta;
-    const int wy = r ? fy : 32 - fy;
-    const int wl = ((valid >> (2 * r)) & 1u) ? (32 - fx) * wy : 0;  // tap (ix, iy + r)
-    const int wr = ((valid >> (2 * r)) & 2u) ? fx * wy : 0;         // tap (ix + 1, iy + r)
-    acc0 += wl * (int)(v & 0xFFu) + wr * (int)((v >> 24) & 0xFFu);
-    acc1 += wl * (int)((v >> 8) & 0xFFu) + wr * (int)((v >> 32) & 0xFFu);
-    acc2 += wl * (int)((v >> 16) & 0xFFu) + wr * (int)((v >> 40) & 0xFFu);
+    for (int r = 0; r < 2; ++r) {
+      unsigned long long& v = r ? v1 : v0;
+      const int off = edge_tap_offset(e, r, W);
+      const int delta = off - min(max(off, 0), frame_bytes - 8);  // bytes by which the load was moved
+      if (delta > 0) v >>= 8 * delta;
+      if (delta < 0) v <<= 8 * -delta;
+    }
   }
-  return (uint32_t)((acc0 + 512) >> 10) | ((uint32_t)((acc1 + 512) >> 10) << 8) | ((uint32_t)((acc2 + 512) >> 10) << 16);
+  const uint32_t a0 = (uint32_t)v0, a1 = (uint32_t)(v0 >> 32), b0 = (uint32_t)v1, b1 = (uint32_t)(v1 >> 32);
+  // bytes: a0 = [B G R | B'] a1 = [G' R' . .] of row 0 (left tap, right tap), b0 / b1 the same of row 1
+  const uint32_t acc0 = w00 * (a0 & 0xFFu) + w01 * (a0 >> 24) + w10 * (b0 & 0xFFu) + w11 * (b0 >> 24);
+  const uint32_t acc1 = w00 * ((a0 >> 8) & 0xFFu) + w01 * (a1 & 0xFFu) + w10 * ((b0 >> 8) & 0xFFu) + w11 * (b1 & 0xFFu);
+  const uint32_t acc2 = w00 * ((a0 >> 16) & 0xFFu) + w01 * ((a1 >> 8) & 0xFFu) + w10 * ((b0 >> 16) & 0xFFu) + w11 * ((b1 >> 8) & 0xFFu);
+  return ((acc0 + 512u) >> 10) | (((acc1 + 512u) >> 10) << 8) | (((acc2 + 512u) >> 10) << 16);
 }
 
 // One panorama pixel per lane (neighbouring lanes = neighbouring pixels, so a wave's taps fall on a short arc
