@@ -17,6 +17,8 @@
 // Everything is integer work or float32 with a pinned evaluation order -> bit-exact against the oracle.
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -31,6 +33,16 @@ __device__ __forceinline__ int refl101(int i, int n) {
 }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// Value of the neighbouring lane through the DPP operand path (wave_shr:1 / wave_shl:1): a VALU move the compiler
+// folds into the consuming add/max where it can, instead of a ds_bpermute through the LDS crossbar -- the rolling
+// kernels issue 6-10 lane exchanges per row and the LDS pipe, shared by the four SIMDs of a CU, was their limit.
+// Lane 0 / 63 receive 0 (they are halo lanes).  Only valid where "neighbouring lane" = "neighbouring column",
+// i.e. not in the strips that touch the image border (mirrored columns): those keep the bpermute form.
+__device__ __forceinline__ int lane_from_left(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, true); }
+__device__ __forceinline__ int lane_from_right(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xF, 0xF, true); }
+__device__ __forceinline__ float lane_from_left(float v) { return __int_as_float(lane_from_left(__float_as_int(v))); }
+__device__ __forceinline__ float lane_from_right(float v) { return __int_as_float(lane_from_right(__float_as_int(v))); }
 
 // ---- K4a: min-eigenvalue map, rolling over rows ---------------------------------------------------------
 // One wave owns a 64-column strip (3 halo columns each side, 58 output columns) of one image and walks down a
@@ -65,7 +77,7 @@ __global__ __launch_bounds__(kThreads) void min_eigen_kernel(const uint8_t* __re
                                                              unsigned long long* __restrict__ flags,
                                                              uint32_t* __restrict__ mstat) {
   const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * kThreads + threadIdx.x) >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * kThreads + threadIdx.x) >> 6));  // in an SGPR: per-image bases become scalar
   if (wave >= nimg * strips * nchunks) return;  // wave-uniform
   const int img = wave / (strips * nchunks);
   const int rem = wave - img * strips * nchunks;
@@ -87,39 +99,52 @@ __global__ __launch_bounds__(kThreads) void min_eigen_kernel(const uint8_t* __re
   uint32_t* mstat_img = mstat + (size_t)img * nmask * 5;
   const float scale = (float)(1.0 / 3060.0);
 
-  int hd0 = 0, hd1 = 0, hd2 = 0, hs0 = 0, hs1 = 0, hs2 = 0;                     // gray rows t-2, t-1, t
-  float pxx0 = 0.f, pxx1 = 0.f, pxx2 = 0.f, pxy0 = 0.f, pxy1 = 0.f, pxy2 = 0.f;  // h-sums of P rows v-2, v-1, v
-  float pyy0 = 0.f, pyy1 = 0.f, pyy2 = 0.f;
-  float hm0 = 0.f, hm1 = 0.f, hm2 = 0.f, ec1 = 0.f, ec2 = 0.f;                   // e rows y-2, y-1, y
+  // Three-deep register rings indexed by (row mod 3): the row loop is unrolled three times by a fold so that the
+  // slot numbers are compile-time constants (no register shuffling); slot P holds the newest row of a phase-P step.
+  int hd[3] = {0, 0, 0}, hs[3] = {0, 0, 0};                                          // gray rows t-2, t-1, t
+  float pxx[3] = {0.f, 0.f, 0.f}, pxy[3] = {0.f, 0.f, 0.f}, pyy[3] = {0.f, 0.f, 0.f};  // h-sums of P rows v-2, v-1, v
+  float hm[3] = {0.f, 0.f, 0.f}, ec[3] = {0.f, 0.f, 0.f};                            // e rows y-2, y-1, y
   uint32_t cur_bits = 0u, cur_max = 0u;
+  const int t_first = e_lo - 2, t_last = e_hi + 2;
 
-  for (int t = e_lo - 2; t <= e_hi + 2; ++t) {
+  // interior strips: the columns x-1 / x+1 of every lane that matters live in lanes -1 / +1
+  const bool edge_strip = xb < 1 || xb + 64 > cols - 1;  // wave-uniform
+  auto step = [&](auto phase_tag, auto edge_tag, const int t) __attribute__((always_inline)) {
+    constexpr int P = decltype(phase_tag)::value;
+    constexpr bool EDGE = decltype(edge_tag)::value;
+    auto left = [&](auto v) { return EDGE ? __shfl(v, ll) : lane_from_left(v); };
+    auto right = [&](auto v) { return EDGE ? __shfl(v, lr) : lane_from_right(v); };
+    constexpr int i0 = (P + 1) % 3, i1 = (P + 2) % 3, i2 = P;  // slots of rows t-2, t-1, t
+    if (t > t_last) return;  // uniform
     {
-      const int c = (int)g[(size_t)refl101(t, rows) * cols + xs];
-      const int l = __shfl(c, ll), r = __shfl(c, lr);
-      hd0 = hd1; hd1 = hd2; hd2 = r - l;
-      hs0 = hs1; hs1 = hs2; hs2 = (l + 2 * c) + r;
+      const uint32_t row_off = (uint32_t)(refl101(t, rows) * cols);  // uniform; rows * cols < 2^28
+      const int c = (int)g[row_off + (uint32_t)xs];
+      const int l = left(c), r = right(c);
+      hd[i2] = r - l;
+      hs[i2] = (l + 2 * c) + r;
     }
     const int v = t - 1;
-    if (v < e_lo - 1) continue;  // uniform
+    if (v < e_lo - 1) return;  // uniform
     {
-      const int dxi = (hd0 + 2 * hd1) + hd2, dyi = hs2 - hs0;
+      const int dxi = (hd[i0] + 2 * hd[i1]) + hd[i2], dyi = hs[i2] - hs[i0];
       const float dx = (float)dxi * scale, dy = (float)dyi * scale;
       const float xx = dx * dx, yy = dy * dy;
       float xy = dx * dy;
       if (v < 0 || v >= rows) xy = -xy;  // mirrored row: dy came out negated
-      pxx0 = pxx1; pxx1 = pxx2; pxx2 = (__shfl(xx, ll) + xx) + __shfl(xx, lr);
-      pxy0 = pxy1; pxy1 = pxy2; pxy2 = (__shfl(xy, ll) + xy) + __shfl(xy, lr);
-      pyy0 = pyy1; pyy1 = pyy2; pyy2 = (__shfl(yy, ll) + yy) + __shfl(yy, lr);
+      pxx[i2] = (left(xx) + xx) + right(xx);
+      pxy[i2] = (left(xy) + xy) + right(xy);
+      pyy[i2] = (left(yy) + yy) + right(yy);
     }
     const int y = v - 1;
-    if (y < e_lo) continue;  // uniform
+    if (y < e_lo) return;  // uniform
     {
-      const float a = ((pxx0 + pxx1) + pxx2) * 0.5f, b = (pxy0 + pxy1) + pxy2, c = ((pyy0 + pyy1) + pyy2) * 0.5f;
+      const float a = ((pxx[i0] + pxx[i1]) + pxx[i2]) * 0.5f, b = (pxy[i0] + pxy[i1]) + pxy[i2];
+      const float c = ((pyy[i0] + pyy[i1]) + pyy[i2]) * 0.5f;
       const float e = (a + c) - sqrtf(((a - c) * (a - c)) + (b * b));
       if (y >= ys && y < ye && out_lane) {
-        eo[(size_t)y * cols + xc] = e;
-        const uint32_t bits = mb[(size_t)y * cols + xc] & mask_all;
+        const uint32_t o = (uint32_t)(y * cols) + (uint32_t)xc;
+        eo[o] = e;
+        const uint32_t bits = mb[o] & mask_all;
         if (bits != cur_bits) {
           eig_flush(mstat_img, cur_bits, cur_max);
           cur_bits = bits;
@@ -127,18 +152,26 @@ __global__ __launch_bounds__(kThreads) void min_eigen_kernel(const uint8_t* __re
         }
         cur_max = max(cur_max, sosvo_float_ordered(e));
       }
-      const float el = __shfl(e, ll), er = __shfl(e, lr);
-      hm0 = hm1; hm1 = hm2; hm2 = fmaxf(fmaxf(el, e), er);
-      ec1 = ec2; ec2 = e;
+      const float el = left(e), er = right(e);
+      hm[i2] = fmaxf(fmaxf(el, e), er);
+      ec[i2] = e;
     }
     const int f = y - 1;
-    if (f < f_lo || f > f_hi) continue;  // uniform
+    if (f < f_lo || f > f_hi) return;  // uniform
     {
-      const bool is_max = out_lane && xc >= 1 && xc <= cols - 2 && ec1 == fmaxf(fmaxf(hm0, hm1), hm2);
+      const bool is_max = out_lane && xc >= 1 && xc <= cols - 2 && ec[i1] == fmaxf(fmaxf(hm[i0], hm[i1]), hm[i2]);
       const unsigned long long bal = __ballot(is_max);
-      if (lane == 0) fo[(size_t)f * strips + strip] = bal;
+      if (lane == 0) fo[(uint32_t)(f * strips + strip)] = bal;
     }
-  }
+  };
+  auto run = [&](auto edge_tag) __attribute__((always_inline)) {
+    for (int t = t_first; t <= t_last; t += 3) {
+      step(std::integral_constant<int, 0>{}, edge_tag, t);
+      step(std::integral_constant<int, 1>{}, edge_tag, t + 1);
+      step(std::integral_constant<int, 2>{}, edge_tag, t + 2);
+    }
+  };
+  if (edge_strip) run(std::true_type{}); else run(std::false_type{});
   // per-mask maxima: one set of atomics per wave when all its output lanes saw a single mask word
   const unsigned long long act = __ballot(out_lane && cur_bits != 0u);
   if (act) {
@@ -410,7 +443,7 @@ __global__ __launch_bounds__(kThreads) void gauss7_kernel(const uint8_t* __restr
                                                           int strips, int nchunks, int chunk_rows,
                                                           uint8_t* __restrict__ out) {
   const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * kThreads + threadIdx.x) >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * kThreads + threadIdx.x) >> 6));  // in an SGPR: per-image bases become scalar
   if (wave >= nimg * strips * nchunks) return;  // wave-uniform
   const int img = wave / (strips * nchunks);
   const int rem = wave - img * strips * nchunks;
@@ -425,17 +458,43 @@ __global__ __launch_bounds__(kThreads) void gauss7_kernel(const uint8_t* __restr
   const int ys = chunk * chunk_rows, ye = min(rows, ys + chunk_rows);
   const uint8_t* g = gray + (size_t)img * rows * cols;
   uint8_t* o = out + (size_t)img * rows * cols;
-  uint32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, h6 = 0;
-  for (int t = ys - 3; t <= ye + 2; ++t) {
-    const int c = (int)g[(size_t)refl101(t, rows) * cols + xs];
-    const uint32_t s = 18u * (uint32_t)(__shfl(c, src[0]) + __shfl(c, src[6])) + 34u * (uint32_t)(__shfl(c, src[1]) + __shfl(c, src[5])) +
-                       49u * (uint32_t)(__shfl(c, src[2]) + __shfl(c, src[4])) + 54u * (uint32_t)c;
-    h0 = h1; h1 = h2; h2 = h3; h3 = h4; h4 = h5; h5 = h6; h6 = s;
+  // seven-deep ring of horizontal sums indexed by (row mod 7): the row loop is unrolled seven times by a fold
+  uint32_t h[7] = {0, 0, 0, 0, 0, 0, 0};
+  const bool edge_strip = xb < 3 || xb + 64 > cols - 3;  // wave-uniform: some lane's x-3 .. x+3 are mirrored columns
+  const int t_first = ys - 3, t_last = ye + 2;
+  auto step = [&](auto phase_tag, auto edge_tag, const int t) __attribute__((always_inline)) {
+    constexpr int P = decltype(phase_tag)::value;
+    constexpr bool EDGE = decltype(edge_tag)::value;
+    if (t > t_last) return;  // uniform
+    const int c = (int)g[(uint32_t)(refl101(t, rows) * cols) + (uint32_t)xs];
+    int l1, l2, l3, r1, r2, r3;
+    if (EDGE) {
+      l3 = __shfl(c, src[0]); l2 = __shfl(c, src[1]); l1 = __shfl(c, src[2]);
+      r1 = __shfl(c, src[4]); r2 = __shfl(c, src[5]); r3 = __shfl(c, src[6]);
+    } else {
+      l1 = lane_from_left(c); l2 = lane_from_left(l1); l3 = lane_from_left(l2);
+      r1 = lane_from_right(c); r2 = lane_from_right(r1); r3 = lane_from_right(r2);
+    }
+    h[P] = 18u * (uint32_t)(l3 + r3) + 34u * (uint32_t)(l2 + r2) + 49u * (uint32_t)(l1 + r1) + 54u * (uint32_t)c;
     const int y = t - 3;
-    if (y < ys) continue;  // uniform
-    const uint32_t vsum = 18u * (h0 + h6) + 34u * (h1 + h5) + 49u * (h2 + h4) + 54u * h3;
-    if (out_lane) o[(size_t)y * cols + xc] = (uint8_t)((vsum + 32768u) >> 16);
-  }
+    if (y < ys) return;  // uniform
+    // rows y-3 .. y+3 = t-6 .. t live in slots P+1 .. P+7 (mod 7)
+    const uint32_t vsum = 18u * (h[(P + 1) % 7] + h[P]) + 34u * (h[(P + 2) % 7] + h[(P + 6) % 7]) +
+                          49u * (h[(P + 3) % 7] + h[(P + 5) % 7]) + 54u * h[(P + 4) % 7];
+    if (out_lane) o[(uint32_t)(y * cols) + (uint32_t)xc] = (uint8_t)((vsum + 32768u) >> 16);
+  };
+  auto run = [&](auto edge_tag) __attribute__((always_inline)) {
+    for (int t = t_first; t <= t_last; t += 7) {
+      step(std::integral_constant<int, 0>{}, edge_tag, t);
+      step(std::integral_constant<int, 1>{}, edge_tag, t + 1);
+      step(std::integral_constant<int, 2>{}, edge_tag, t + 2);
+      step(std::integral_constant<int, 3>{}, edge_tag, t + 3);
+      step(std::integral_constant<int, 4>{}, edge_tag, t + 4);
+      step(std::integral_constant<int, 5>{}, edge_tag, t + 5);
+      step(std::integral_constant<int, 6>{}, edge_tag, t + 6);
+    }
+  };
+  if (edge_strip) run(std::true_type{}); else run(std::false_type{});
 }
 
 // ---- K6b: border rule + descriptors ---------------------------------------------------------------------

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(kThreads) void median_gray_kernel(const uint8_t* __
   constexpr int OUTW = 64 - 2 * R;        // output columns per wave
   constexpr uint32_t ABOVE = NB - (NB / 2 + 1);  // window elements ranked above the median
   const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * kThreads + threadIdx.x) >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * kThreads + threadIdx.x) >> 6));  // in an SGPR: per-image bases become scalar
   if (wave >= nimg * strips) return;  // wave-uniform
   const int im = wave / strips, strip = wave - im * strips;
   const int x0 = strip * OUTW;
