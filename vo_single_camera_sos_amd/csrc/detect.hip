@@ -23,6 +23,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kCandCap = 4096;       // candidates kept per (image, mask): 32 KB of LDS sort keys
+constexpr int kCandCapSmall = 2048;   // first pass of the two-pass selection: 16 KB of LDS keys, 1536 grid cells
 constexpr int kCandCapLarge = 16384; // large-mask variant (whole-image detection, cap > 1024): 128 KB of the 160 KB LDS
 constexpr int kMaxMasks = 32;
 
@@ -230,9 +231,15 @@ __global__ __launch_bounds__(kThreads) void gft_select_kernel(const float* __res
                                                               const uint32_t* __restrict__ mstat, int images_per_maskset,
                                                               int nmask, int rows, int cols, double quality,
                                                               float min_distance, int cell, int max_corners, int cap,
-                                                              uint32_t* __restrict__ sorted_g, float* __restrict__ kp,
-                                                              int32_t* __restrict__ n_out, int32_t* __restrict__ status) {
+                                                              uint32_t* __restrict__ sorted_g, int sorted_stride,
+                                                              float* __restrict__ kp, int32_t* __restrict__ n_out,
+                                                              int32_t* __restrict__ status, int32_t* __restrict__ redo,
+                                                              int redo_pass) {
+  // Two-pass scheme (redo != nullptr): pass 0 runs the small variant (half the LDS: twice the workgroups per CU of
+  // this latency-bound kernel) and hands the few problems that do not fit it -- more candidates than CAND, or a
+  // mask bounding box larger than its cell grid -- to pass 1, which runs the full-size variant on those only.
   constexpr int kSelGridCells = (CAND * 8 - 1024 * 4) / 8;  // 2 slots (u32) per cell, 1024 u32 left for the list
+  if (redo && redo_pass == 1 && redo[blockIdx.x] == 0) return;  // uniform
   __shared__ unsigned long long lds_u64[CAND];
   __shared__ int s_count, s_accepted;
   unsigned long long* keys = lds_u64;
@@ -242,7 +249,7 @@ __global__ __launch_bounds__(kThreads) void gft_select_kernel(const float* __res
   const int img = p / nmask, m = p - img * nmask;
   const uint32_t* st = mstat + (size_t)p * 5;                                                              // [0]: max
   const uint32_t* sb = mstat + ((size_t)(img / images_per_maskset) * images_per_maskset * nmask + m) * 5;  // bbox
-  uint32_t* sorted = sorted_g + (size_t)p * CAND;
+  uint32_t* sorted = sorted_g + (size_t)p * sorted_stride;
   if (tid == 0) {
     s_count = 0;
     s_accepted = 0;
@@ -316,6 +323,13 @@ __global__ __launch_bounds__(kThreads) void gft_select_kernel(const float* __res
   }
   __syncthreads();
   const int total = s_count;
+  if (redo && redo_pass == 0) {  // uniform decision of the whole workgroup
+    const int cx0_ = bx0 / cell, cy0_ = by0 / cell;
+    const int gw_ = bw > 0 ? bx1 / cell - cx0_ + 1 : 0, gh_ = bh > 0 ? by1 / cell - cy0_ + 1 : 0;
+    const bool fits = total <= CAND && gw_ * gh_ <= kSelGridCells;
+    if (tid == 0) redo[p] = fits ? 0 : 1;
+    if (!fits) return;
+  }
   const int n = min(total, CAND);
   // ---- phase 2: bitonic sort, descending (keys are unique: value, then higher address first) ---------------
   int N = 64;
@@ -644,7 +658,9 @@ int32_t sosvo_detect_gft(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* ma
   const size_t o_flags = carve(sizeof(unsigned long long) * (size_t)nimg * rows * strips);
   const size_t o_stat = carve(sizeof(uint32_t) * P * 5);
   const bool large = cap > 1024;  // whole-image masks (RGB-D frames): 16384 candidates, 15872 grid cells
-  const size_t o_sorted = carve(sizeof(uint32_t) * P * (large ? kCandCapLarge : kCandCap));
+  const int sorted_stride = large ? kCandCapLarge : kCandCap;
+  const size_t o_sorted = carve(sizeof(uint32_t) * P * sorted_stride);
+  const size_t o_redo = carve(sizeof(int32_t) * P);
   int32_t rc = sosvo_ws_reserve(ctx, off);
   if (rc != SOSVO_OK) return rc;
   char* ws = (char*)ctx->ws;
@@ -663,11 +679,20 @@ int32_t sosvo_detect_gft(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* ma
                images_per_maskset, rows, cols, nmask, strips, nchunks, chunk_rows, eig, flags, mstat);
   SOSVO_LAUNCH_CHECK(ctx);
   const int cell = min_distance >= 1 ? (int)lrint(min_distance) : 1;
-  {
+  int32_t* redo = (int32_t*)(ws + o_redo);
+  if (large) {
     SOSVO_PROFILE(ctx, "gft_select_kernel");
-    hipLaunchKernelGGL(large ? gft_select_kernel<kCandCapLarge> : gft_select_kernel<kCandCap>, dim3((unsigned)P),
-                       dim3(kThreads), 0, ctx->stream, eig, flags, strips, mask_bits, mstat, images_per_maskset, nmask, rows,
-                       cols, quality, (float)min_distance, cell, max_corners, cap, sorted_g, kp, n, status);
+    hipLaunchKernelGGL(gft_select_kernel<kCandCapLarge>, dim3((unsigned)P), dim3(kThreads), 0, ctx->stream, eig, flags, strips,
+                       mask_bits, mstat, images_per_maskset, nmask, rows, cols, quality, (float)min_distance, cell, max_corners,
+                       cap, sorted_g, sorted_stride, kp, n, status, nullptr, 0);
+  } else {
+    SOSVO_PROFILE(ctx, "gft_select_kernel");
+    hipLaunchKernelGGL(gft_select_kernel<kCandCapSmall>, dim3((unsigned)P), dim3(kThreads), 0, ctx->stream, eig, flags, strips,
+                       mask_bits, mstat, images_per_maskset, nmask, rows, cols, quality, (float)min_distance, cell, max_corners,
+                       cap, sorted_g, sorted_stride, kp, n, status, redo, 0);
+    hipLaunchKernelGGL(gft_select_kernel<kCandCap>, dim3((unsigned)P), dim3(kThreads), 0, ctx->stream, eig, flags, strips,
+                       mask_bits, mstat, images_per_maskset, nmask, rows, cols, quality, (float)min_distance, cell, max_corners,
+                       cap, sorted_g, sorted_stride, kp, n, status, redo, 1);
   }
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
