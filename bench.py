@@ -74,6 +74,8 @@ def parse():
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams per GPU the batch is split over (the median launches take turns, the latency-bound "
                          "stages of the other parts overlap them); 1 = one stream")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the flow on one GPU)")
     ap.add_argument("--render-workers", type=int, default=0,
                     help="host processes rendering the synthetic frames (0 = auto; use 1 under rocprofv3, whose preloaded "
                          "tool initialises the GPU before this program forks)")
@@ -125,9 +127,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local_rank = local_rank % max(1, torch.cuda.device_count())  # (rehearsals with more ranks than GPUs)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":  # RCCL on ROCm
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.dist_backend, rank=rank, world_size=world)
     n_gpus = world if world > 1 else 1
     if args.gpus != n_gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d; using %d" % (args.gpus, world, n_gpus), file=sys.stderr)

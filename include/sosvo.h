@@ -191,6 +191,17 @@ int32_t sosvo_match_hamming(sosvo_ctx* ctx, const uint8_t* q_desc, const uint8_t
                             const int32_t* t_slot, int32_t nprob, int32_t q_stride,
                             int32_t t_stride, int32_t k, uint32_t* keys);
 
+/* Radius match: cv2.BFMatcher.radiusMatch(query, train, maxDistance) as called from FeatureMatcher.match when
+ * use_radius_match is set (omnistereo/camera_models.py:412-415).  For each query row i < nq[qs] ALL train rows j
+ * with hamming(q_i, t_j) <= max_distance, as packed keys in ascending order (distance, then train index):
+ *   keys[(p*q_stride + i)*cap + r], r < min(counts, cap); the rest SOSVO_KEY_NONE
+ *   counts[p*q_stride + i] = number of train rows within the radius (when it exceeds cap, the cap smallest
+ *   keys are the ones kept).  cap <= 512.  Blocks / slots as in sosvo_match_hamming.                      */
+int32_t sosvo_match_radius(sosvo_ctx* ctx, const uint8_t* q_desc, const uint8_t* t_desc, const int32_t* nq,
+                           const int32_t* nt, const int32_t* q_slot, const int32_t* t_slot, int32_t nprob,
+                           int32_t q_stride, int32_t t_stride, int32_t max_distance, int32_t cap,
+                           uint32_t* keys, int32_t* counts);
+
 /* Stable sort of each problem's 1-NN matches by distance, the `sorted(matches,
  * key=distance)` of omnistereo/camera_models.py:444.  Input keys as written by
  * sosvo_match_hamming with k = 1.  Output, for rank r < nq[qs]:

@@ -55,6 +55,17 @@ def match_hamming(q, t, k=1):
     return keys
 
 
+def match_radius(q, t, max_distance, cap):
+    """q [nq,32] u8, t [nt,32] u8 -> (keys [nq,cap] u32 ascending, KEY_NONE padded; counts [nq] i32)."""
+    q = _c(q, np.uint8).reshape(-1, 32)
+    t = _c(t, np.uint8).reshape(-1, 32)
+    keys = np.empty((q.shape[0], cap), dtype=np.uint32)
+    counts = np.empty((q.shape[0],), dtype=np.int32)
+    lib().orc_match_radius(_p(q), _p(t), ctypes.c_int32(q.shape[0]), ctypes.c_int32(t.shape[0]),
+                           ctypes.c_int32(int(max_distance)), ctypes.c_int32(cap), _p(keys), _p(counts))
+    return keys, counts
+
+
 def sort_matches(keys):
     """keys [nq] or [nq,1] u32 -> order [nq] i32, stable by distance."""
     keys = _c(keys, np.uint32).reshape(-1)

@@ -12,6 +12,7 @@
  *   omnistereo/camera_models.py:402   BFMatcher(normType=NORM_HAMMING), crossCheck off
  *   omnistereo/camera_models.py:442   matcher.match(query, train)       -> 1-NN
  *   omnistereo/camera_models.py:420   matcher.knnMatch(query, train, k) -> k-NN
+ *   omnistereo/camera_models.py:413   matcher.radiusMatch(query, train, maxDistance) -> all within the radius
  *   omnistereo/camera_models.py:444   sorted(matches, key=distance)     -> stable sort
  * Parity status: UNPINNED against OpenCV binaries (the reference ships no tests or golden
  * vectors for this path); pinned by hand-computable known-answer
@@ -91,4 +92,29 @@ void orc_sort_matches(const uint32_t* keys, int32_t nq, int32_t* order) {
   merge_sort(order, tmp, dist, 0, nq);
   free(dist);
   free(tmp);
+}
+
+/* radiusMatch (camera_models.py:413): for each query row ALL train rows with distance <= max_distance
+ * ("not farther than", inclusive), as keys (distance << 20 | train index) in ascending key order = ascending
+ * distance, lowest train index first among equals (OpenCV's per-query std::sort leaves the order of equal
+ * distances unspecified; this is the deterministic choice).  At most cap keys per query are written
+ * (keys[i*cap + r]), counts[i] = number found (may exceed cap: the smallest cap keys are the ones kept). */
+static int cmp_u32(const void* a, const void* b) {
+  const uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b;
+  return x < y ? -1 : (x > y ? 1 : 0);
+}
+void orc_match_radius(const uint8_t* q, const uint8_t* t, int32_t nq, int32_t nt, int32_t max_distance,
+                      int32_t cap, uint32_t* keys, int32_t* counts) {
+  uint32_t* all = (uint32_t*)malloc((size_t)(nt > 0 ? nt : 1) * sizeof(uint32_t));
+  for (int i = 0; i < nq; ++i) {
+    int m = 0;
+    for (int j = 0; j < nt; ++j) {
+      int d = hamming32(q + 32 * (size_t)i, t + 32 * (size_t)j);
+      if (d <= max_distance) all[m++] = (((uint32_t)d) << KEY_SHIFT) | (uint32_t)j;
+    }
+    qsort(all, (size_t)m, sizeof(uint32_t), cmp_u32);
+    counts[i] = m;
+    for (int r = 0; r < cap; ++r) keys[(size_t)i * cap + r] = r < m ? all[r] : KEY_NONE;
+  }
+  free(all);
 }

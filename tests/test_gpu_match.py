@@ -106,3 +106,30 @@ def test_properties_at_full_size(ctx):
     assert np.all(keys >> 20 == 0)
     inv = np.stack([np.argsort(perm[p]) for p in range(P)])
     assert np.array_equal((keys & 0xFFFFF).astype(np.int64), inv)
+
+
+def test_radius_match_ragged_batch_with_slots_and_truncation(ctx):
+    """sosvo_match_radius against the oracle: ragged problems sharing descriptor blocks through slots, an empty
+    train set, a radius that matches everything (cap smallest keys kept), duplicates (train order breaks ties)."""
+    rng = np.random.default_rng(21)
+    S = 96
+    blocks = rng.integers(0, 256, (4, S, 32), dtype=np.uint8)
+    blocks[1, 5] = blocks[0, 3]
+    blocks[1, 70] = blocks[0, 3]
+    n = np.array([96, 80, 17, 0], dtype=np.int32)
+    q_slot = np.array([0, 1, 2, 0, 3], dtype=np.int32)
+    t_slot = np.array([1, 0, 1, 3, 0], dtype=np.int32)
+    dev = ctx.device
+    tb, tn = torch.from_numpy(blocks).to(dev), torch.from_numpy(n).to(dev)
+    for radius, cap in ((110, 32), (256, 8), (0, 4)):
+        keys, counts = ctx.match_radius(tb, tb, tn, tn, radius, cap, q_slot=torch.from_numpy(q_slot).to(dev),
+                                        t_slot=torch.from_numpy(t_slot).to(dev))
+        ctx.synchronize()
+        keys, counts = keys.cpu().numpy(), counts.cpu().numpy()
+        for p in range(5):
+            nq, nt = n[q_slot[p]], n[t_slot[p]]
+            wk, wc = oracle.match_radius(blocks[q_slot[p], :nq], blocks[t_slot[p], :nt], radius, cap)
+            assert np.array_equal(counts[p, :nq], wc), (radius, p)
+            assert np.array_equal(keys[p, :nq], wk), (radius, p)
+    with pytest.raises(Exception):
+        ctx.match_radius(tb, tb, tn, tn, 10, 513)

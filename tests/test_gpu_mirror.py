@@ -59,8 +59,17 @@ def test_feature_matcher_two_best_flattened_and_ratio_rule(ctx):
     # one train descriptor: k-lists of length 1
     ms = FeatureMatcher("ORB", "BF", 2, context=ctx).match(q[:9], t[:1])
     assert len(ms) == 9 and all(m.trainIdx == 0 for m in ms)
-    with pytest.raises(NotImplementedError):
-        FeatureMatcher("ORB", "BF", 1, use_radius_match=True, context=ctx).match(q, t, 40)
+    # radius match (camera_models.py:412-415): all train rows within the radius per query, flattened in query order,
+    # then sorted by distance (stable)
+    keys, counts = oracle.match_radius(q, t, 112, 512)
+    fq = np.repeat(np.arange(220), counts)
+    fk = keys[np.arange(512)[None, :] < counts[:, None]].astype(np.int64)
+    o = np.argsort(fk >> 20, kind="stable")
+    ms = FeatureMatcher("ORB", "BF", 1, use_radius_match=True, context=ctx).match(q, t, 112)
+    assert counts.sum() > 50 and len(ms) == counts.sum()
+    assert [m.queryIdx for m in ms] == list(fq[o]) and [m.trainIdx for m in ms] == list((fk & 0xFFFFF)[o])
+    assert [m.distance for m in ms] == [float(v) for v in (fk >> 20)[o]]
+    assert len(FeatureMatcher("ORB", "BF", 1, use_radius_match=True, context=ctx).match(q, t, -1)) == 0
 
 
 def test_pyopengv_mirror_against_oracle(ctx):

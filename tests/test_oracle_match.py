@@ -57,3 +57,24 @@ def test_sort_is_stable_by_distance():
     assert order.tolist() == [3, 7, 1, 4, 5, 0, 2, 6]
     assert order.tolist() == sorted(range(8), key=lambda i: dist[i])
     assert oracle.sort_matches(np.zeros(0, np.uint32)).shape == (0,)
+
+
+def test_radius_match_against_numpy_and_truncation():
+    rng = np.random.default_rng(9)
+    q = rng.integers(0, 256, (23, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (150, 32), dtype=np.uint8)
+    t[7] = t[90] = q[3]                       # two exact matches of query 3: train order breaks the tie
+    d = np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=-1).sum(-1)
+    r = 118
+    keys, counts = oracle.match_radius(q, t, r, 64)
+    assert np.array_equal(counts, (d <= r).sum(1))              # inclusive radius
+    for i in range(23):
+        want = sorted((int(d[i, j]) << 20) | j for j in range(150) if d[i, j] <= r)
+        assert keys[i, : min(len(want), 64)].tolist() == want[:64]
+        assert (keys[i, len(want):] == oracle.KEY_NONE).all()
+    assert keys[3, :2].tolist() == [7, 90]
+    k2, c2 = oracle.match_radius(q, t, 256, 5)                  # everything matches: the 5 smallest keys are kept
+    assert (c2 == 150).all()
+    assert k2[0].tolist() == sorted((int(d[0, j]) << 20) | j for j in range(150))[:5]
+    k0, c0 = oracle.match_radius(q, t[:0], 10, 4)
+    assert (c0 == 0).all() and (k0 == oracle.KEY_NONE).all()

@@ -59,6 +59,7 @@ SIGNATURES = {
     "sosvo_detect_orb": (c_i32, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p]),
     "sosvo_describe_orb_levels": (c_i32, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p, c_p]),
     "sosvo_match_hamming": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p]),
+    "sosvo_match_radius": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p]),
     "sosvo_sort_matches": (c_i32, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_p]),
     "sosvo_pano_to_bearing": (c_i32, [c_p, c_p, c_i32, c_f64, c_f64, c_f64, c_f64, c_p, c_p, c_p]),
     "sosvo_triangulate_midpoint": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_i32, c_p, c_p, c_p]),

@@ -132,6 +132,93 @@ __global__ __launch_bounds__(kThreads) void sort_matches_kernel(const uint32_t* 
   if (i < n) order[(size_t)p * q_stride + rank] = i;
 }
 
+// ---- radius match ------------------------------------------------------------------------------------------
+// cv2.BFMatcher.radiusMatch (omnistereo/camera_models.py:413, FeatureMatcher.use_radius_match): for every query
+// ALL train descriptors within max_distance.  One wave per query: the query sits in 8 VGPRs of every lane, lane l
+// tests train rows l, l + 64, ...; hits are appended to the query's LDS list in train order through a ballot
+// prefix, and the list (at most `cap` keys) leaves sorted by a rank sort on the packed key (distance, then train
+// index).  When more than cap rows match, the cap smallest keys are kept by replacing the list's current maximum.
+constexpr int kRadiusCapMax = 512;
+
+__global__ __launch_bounds__(kThreads) void match_radius_kernel(
+    const uint4* __restrict__ q_desc, const uint4* __restrict__ t_desc, const int32_t* __restrict__ nq,
+    const int32_t* __restrict__ nt, const int32_t* __restrict__ q_slot, const int32_t* __restrict__ t_slot,
+    int q_stride, int t_stride, uint32_t max_distance, int cap, uint32_t* __restrict__ keys,
+    int32_t* __restrict__ counts) {
+  __shared__ uint32_t lists[kThreads / 64][kRadiusCapMax];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int p = blockIdx.x;
+  const int qs = q_slot ? q_slot[p] : p, ts = t_slot ? t_slot[p] : p;
+  const int nqp = min(nq[qs], q_stride), ntp = min(nt[ts], t_stride);
+  const int i = blockIdx.y * (kThreads / 64) + wid;  // wave-uniform
+  if (i >= nqp) return;
+  uint32_t* list = lists[wid];
+  const uint4 qa = q_desc[((size_t)qs * q_stride + i) * 2], qb = q_desc[((size_t)qs * q_stride + i) * 2 + 1];
+  const uint4* tb = t_desc + (size_t)ts * t_stride * 2;
+  int total = 0, kept = 0;  // wave-uniform
+  for (int j0 = 0; j0 < ntp; j0 += 64) {
+    const int j = j0 + lane;
+    bool hit = false;
+    uint32_t key = SOSVO_KEY_NONE;
+    if (j < ntp) {
+      const uint32_t d = hamming256(qa, qb, tb[2 * (size_t)j], tb[2 * (size_t)j + 1]);
+      hit = d <= max_distance;
+      key = (d << SOSVO_KEY_SHIFT) | (uint32_t)j;
+    }
+    unsigned long long bal = __ballot(hit);
+    if (!bal) continue;
+    const int nh = __popcll(bal);
+    total += nh;
+    if (kept + nh <= cap) {
+      if (hit) list[kept + __popcll(bal & ((1ULL << lane) - 1ULL))] = key;
+      kept += nh;
+    } else {  // overflow: one hit at a time, each replaces the list's maximum if smaller (rare)
+      while (bal) {
+        const int src = __ffsll((long long)bal) - 1;
+        bal &= bal - 1ULL;
+        const uint32_t k1 = (uint32_t)__shfl((int)key, src);
+        if (kept < cap) {
+          if (lane == 0) list[kept] = k1;
+          kept++;
+        } else {
+          uint32_t mx = 0u;
+          int mi = 0;
+          for (int e = lane; e < cap; e += 64) {
+            const uint32_t v = list[e];
+            if (v > mx) {
+              mx = v;
+              mi = e;
+            }
+          }
+          for (int s = 32; s > 0; s >>= 1) {
+            const uint32_t ov = (uint32_t)__shfl_down((int)mx, s);
+            const int oi = __shfl_down(mi, s);
+            if (ov > mx) {
+              mx = ov;
+              mi = oi;
+            }
+          }
+          mx = (uint32_t)__shfl((int)mx, 0);
+          mi = __shfl(mi, 0);
+          if (lane == 0 && k1 < mx) list[mi] = k1;
+        }
+      }
+    }
+  }
+  // rank sort of the kept keys (unique: the train index is part of the key), KEY_NONE padding
+  uint32_t* out = keys + ((size_t)p * q_stride + i) * cap;
+  for (int e = lane; e < cap; e += 64) {
+    if (e >= kept) out[e] = SOSVO_KEY_NONE;
+  }
+  for (int e = lane; e < kept; e += 64) {
+    const uint32_t v = list[e];
+    int rank = 0;
+    for (int o = 0; o < kept; ++o) rank += list[o] < v ? 1 : 0;
+    out[rank] = v;
+  }
+  if (lane == 0) counts[(size_t)p * q_stride + i] = total;
+}
+
 }  // namespace
 
 extern "C" {
@@ -197,6 +284,26 @@ int32_t sosvo_sort_matches(sosvo_ctx* ctx, const uint32_t* keys, const int32_t* 
   const size_t lds = (size_t)((q_stride + 3) & ~3) * sizeof(uint32_t);
   dim3 grid(nprob, cdiv(q_stride, kThreads)), block(kThreads);
   SOSVO_LAUNCH(ctx,sort_matches_kernel, grid, block, lds, ctx->stream, keys, nq, q_slot, q_stride, order);
+  SOSVO_LAUNCH_CHECK(ctx);
+  return SOSVO_OK;
+}
+
+int32_t sosvo_match_radius(sosvo_ctx* ctx, const uint8_t* q_desc, const uint8_t* t_desc, const int32_t* nq,
+                           const int32_t* nt, const int32_t* q_slot, const int32_t* t_slot, int32_t nprob,
+                           int32_t q_stride, int32_t t_stride, int32_t max_distance, int32_t cap, uint32_t* keys,
+                           int32_t* counts) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, q_desc && t_desc && nq && nt && keys && counts, "null pointer");
+  SOSVO_REQUIRE(ctx, nprob >= 0 && nprob <= 65535, "nprob out of range");
+  SOSVO_REQUIRE(ctx, q_stride > 0 && q_stride <= (1 << SOSVO_KEY_SHIFT) && t_stride > 0 && t_stride <= (1 << SOSVO_KEY_SHIFT),
+                "strides out of range");
+  SOSVO_REQUIRE(ctx, cap > 0 && cap <= kRadiusCapMax, "cap out of range (1..512)");
+  SOSVO_REQUIRE(ctx, max_distance >= 0, "max_distance must be >= 0");
+  SOSVO_REQUIRE(ctx, (((uintptr_t)q_desc | (uintptr_t)t_desc) & 15) == 0, "descriptors must be 16-byte aligned");
+  if (nprob == 0) return SOSVO_OK;
+  SOSVO_LAUNCH(ctx, match_radius_kernel, dim3(nprob, cdiv(q_stride, kThreads / 64)), dim3(kThreads), 0, ctx->stream,
+               reinterpret_cast<const uint4*>(q_desc), reinterpret_cast<const uint4*>(t_desc), nq, nt, q_slot, t_slot,
+               q_stride, t_stride, (uint32_t)max_distance, cap, keys, counts);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
 }

@@ -305,6 +305,31 @@ class Context(object):
                    _ptr(t_slot), P, Sq, St, int(k), _ptr(keys))
         return keys
 
+    def match_radius(self, q_desc, t_desc, nq, nt, max_distance, cap, q_slot=None, t_slot=None):
+        """radiusMatch: q_desc [Bq, Sq, 32] u8, t_desc [Bt, St, 32] u8 -> (keys [P, Sq, cap] u32 ascending,
+        KEY_NONE padded; counts [P, Sq] i32 = matches within max_distance, may exceed cap)."""
+        _check(q_desc, torch.uint8, "q_desc", (None, None, _lib.DESC_BYTES))
+        _check(t_desc, torch.uint8, "t_desc", (None, None, _lib.DESC_BYTES))
+        Bq, Sq = q_desc.shape[0], q_desc.shape[1]
+        Bt, St = t_desc.shape[0], t_desc.shape[1]
+        _check(nq, torch.int32, "nq", (Bq,))
+        _check(nt, torch.int32, "nt", (Bt,))
+        if (q_slot is None) != (t_slot is None):
+            raise SosvoError("q_slot and t_slot go together")
+        if q_slot is not None:
+            P = q_slot.shape[0]
+            _check(q_slot, torch.int32, "q_slot", (P,))
+            _check(t_slot, torch.int32, "t_slot", (P,))
+        else:
+            if Bq != Bt:
+                raise SosvoError("q_desc and t_desc must have the same number of blocks without slots")
+            P = Bq
+        keys = torch.empty((P, Sq, int(cap)), dtype=torch.uint32, device=q_desc.device)
+        counts = torch.zeros((P, Sq), dtype=torch.int32, device=q_desc.device)
+        self._call(self._lib.sosvo_match_radius, _ptr(q_desc), _ptr(t_desc), _ptr(nq), _ptr(nt), _ptr(q_slot), _ptr(t_slot),
+                   P, Sq, St, int(max_distance), int(cap), _ptr(keys), _ptr(counts))
+        return keys, counts
+
     def sort_matches(self, keys, nq, order=None, q_slot=None):
         """keys [P, Sq, 1] u32 (1-NN), nq i32 (per block) -> order [P, Sq] i32 (query index by rank)."""
         _check(keys, torch.uint32, "keys", (None, None, 1))

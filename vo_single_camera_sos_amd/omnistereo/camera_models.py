@@ -130,8 +130,9 @@ class PanoramicCorrespondences(object):
 class FeatureMatcher(object):
     """camera_models.py:364-446.  Brute-force Hamming matching of 32-byte binary descriptors on the GPU.
     Built: matcher_type "BF", k_best 1 (the trackers' setting, pose_est_tools.py:686) and 2, the "SIFT"
-    k_best == 2 ratio rule applied to whatever distances the descriptors give.  Not built (raises):
-    "FLANN", float (L2) descriptors, k_best > 2, radius match."""
+    k_best == 2 ratio rule applied to whatever distances the descriptors give, radius match
+    (use_radius_match, at most 512 matches per query).  Not built (raises): "FLANN", float (L2) descriptors,
+    k_best > 2."""
 
     def __init__(self, method, matcher_type, k_best, *args, **kwargs):
         self.feature_detection_method = method
@@ -171,11 +172,11 @@ class FeatureMatcher(object):
             buf[0, :n] = t.to(ctx.device)
         return buf, n
 
-    def match_arrays(self, query_descriptors, train_descriptors):
+    def match_arrays(self, query_descriptors, train_descriptors, max_descriptor_distance_radius=-1):
         """-> (query_idx, train_idx, distance) numpy arrays in the order of match()."""
         import torch
         if self.use_radius_match:
-            raise NotImplementedError("radius match (camera_models.py:412-415) is not built")
+            return self._radius_arrays(query_descriptors, train_descriptors, max_descriptor_distance_radius)
         if self.k_best > 2:
             raise NotImplementedError("k_best > 2 is not built")
         ctx = self._context()
@@ -214,9 +215,34 @@ class FeatureMatcher(object):
         oh = oh[kh[oh] != KEY_NONE]  # a train set of one descriptor gives k-lists of length 1
         return oh // 2, kh[oh] & KEY_IDX_MASK, (kh[oh] >> KEY_SHIFT).astype(np.float32)
 
+    RADIUS_CAP = 512
+
+    def _radius_arrays(self, query_descriptors, train_descriptors, radius):
+        """camera_models.py:412-415: radiusMatch, the per-query lists flattened in query order, then sorted by
+        distance (stable, :444).  Within one query, equal distances come in train order."""
+        import torch
+        from .._lib import KEY_SHIFT, KEY_IDX_MASK
+        ctx = self._context()
+        dq, nq = self._device_desc(ctx, query_descriptors, "query_descriptors")
+        dt, nt = self._device_desc(ctx, train_descriptors, "train_descriptors")
+        if nq == 0 or nt == 0 or radius < 0:
+            return (np.empty(0, np.int64),) * 2 + (np.empty(0, np.float32),)
+        dev = ctx.device
+        nq_t = torch.tensor([nq], dtype=torch.int32, device=dev)
+        nt_t = torch.tensor([nt], dtype=torch.int32, device=dev)
+        keys, counts = ctx.match_radius(dq, dt, nq_t, nt_t, int(np.floor(radius)), self.RADIUS_CAP)
+        ctx.synchronize()
+        k = keys[0, :nq].cpu().numpy().astype(np.int64)
+        c = np.minimum(counts[0, :nq].cpu().numpy(), self.RADIUS_CAP)
+        q = np.repeat(np.arange(nq, dtype=np.int64), c)
+        flat = k[np.arange(self.RADIUS_CAP)[None, :] < c[:, None]]
+        d = flat >> KEY_SHIFT
+        order = np.argsort(d, kind="stable")
+        return q[order], (flat & KEY_IDX_MASK)[order], d[order].astype(np.float32)
+
     def match(self, query_descriptors, train_descriptors, max_descriptor_distance_radius=-1):
         """-> MatchList (a list of DMatch), ascending by distance, ties in query order."""
-        return MatchList(*self.match_arrays(query_descriptors, train_descriptors))
+        return MatchList(*self.match_arrays(query_descriptors, train_descriptors, max_descriptor_distance_radius))
 
 
 class RGBDCamModel(object):
