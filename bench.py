@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs-per-gpu", type=int, default=256,
+    ap.add_argument("--pairs-per-gpu", type=int, default=512,
                     help="B: independent frame pairs per GPU per step (weak scaling: fixed per GPU; C4's 512 pairs "
                          "over 8 GPUs is --pairs-per-gpu 64)")
     ap.add_argument("--detector", default="GFT", choices=["GFT", "ORB"],

@@ -7,6 +7,7 @@
 # under the profiler.  Then: python scripts/summarize_pmc.py ... > profiles/roundN/<tag>_pmc_hbm_per_kernel.csv
 set -e -o pipefail
 TAG=${1:-run}
+PAIRS_PER_LAUNCH=${2:-256}   # pairs one kernel launch covers = pairs-per-gpu / streams (bench defaults: 512 / 2)
 ARGS="--steps 10 --warmup 2 --no-cpu --render-workers 1"
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
@@ -16,6 +17,6 @@ rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_${TAG}_fetch --output-format csv --
 echo "fetch pass done"
 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_${TAG}_write --output-format csv -- python3 bench.py $ARGS > gpurun_out/pmc_${TAG}_write.log 2>&1
 echo "write pass done"
-python3 scripts/summarize_pmc.py gpurun_out/pmc_${TAG}_fetch gpurun_out/pmc_${TAG}_write 256 > gpurun_out/${TAG}_pmc_hbm_per_kernel.csv
+python3 scripts/summarize_pmc.py gpurun_out/pmc_${TAG}_fetch gpurun_out/pmc_${TAG}_write $PAIRS_PER_LAUNCH > gpurun_out/${TAG}_pmc_hbm_per_kernel.csv
 find gpurun_out/prof_$TAG -name "*kernel_stats.csv" -exec cp {} gpurun_out/${TAG}_kernel_stats.csv \;
 grep -h '^{"metric"' gpurun_out/prof_${TAG}_bench.log > gpurun_out/${TAG}_bench_under_rocprof.json || true
