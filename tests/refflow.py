@@ -197,3 +197,18 @@ def track_pair_rgbd(cam, ref, cur, thr, max_iter, seed, adaptive=False, lm_iter=
     if r["status"] == 0:
         T, _, _ = oracle.refine_abs_pose(f, p, r["T"], idx=idx, max_lm_iter=lm_iter)
     return dict(corr=dict(f=f, p=p, q=q, t=t), ransac=r, T=T)
+
+
+def pairs_worker(job):
+    """One host process of the all-cores CPU baseline (bench.py): the whole reference flow on the oracle for a
+    chunk of frame pairs.  job = (rig_kw, im_kw, omni [2n,H,W,3], thr, iters, seed0) -> seconds spent."""
+    import time
+    rig_kw, im_kw, omni, thr, iters, seed0 = job
+    rp = RigParams(**rig_kw)
+    im = ImageModel(**im_kw)
+    t0 = time.perf_counter()
+    for i in range(omni.shape[0] // 2):
+        ref = frame_from_image(rp, im, omni[2 * i])
+        cur = frame_from_image(rp, im, omni[2 * i + 1])
+        track_pair(rp, ref, cur, thr, iters, seed=seed0 + i)
+    return time.perf_counter() - t0
