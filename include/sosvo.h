@@ -174,6 +174,18 @@ int32_t sosvo_describe_orb_levels(sosvo_ctx* ctx, const uint8_t* gray, int32_t n
                                   int32_t cols, int32_t nmask, int32_t cap, float* kp4, int32_t* n,
                                   const int8_t* pattern, uint8_t* desc, float* kp_xy);
 
+/* ---- FAST as a detector of its own (a4, feature_detection_method "FAST") -------------------------------
+ * Replaces cv2.FastFeatureDetector_create() + setNonmaxSuppression(True) + .detect(image, mask)
+ * (omnistereo/camera_models.py:1664-1666, :1755; pose_est_tools.py:506-508) for all azimuthal masks of all
+ * images: FAST-9/16 with `threshold` (OpenCV default 10) on the whole image, 3x3 non-maximum suppression on the
+ * corner score, keypoints where the mask bit is set, in raster order (rows, then x).  The descriptors then come
+ * from sosvo_describe_orb with the fixed angle -1 degree, as for GFT keypoints (camera_models.py:1765).
+ *   kp [nimg*nmask, cap, 2] f32 (x, y), n [nimg*nmask] i32, status (optional): 1 = more than cap corners (the
+ *   first cap in raster order are kept).                                                                      */
+int32_t sosvo_detect_fast(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* mask_bits, int32_t nimg,
+                          int32_t images_per_maskset, int32_t rows, int32_t cols, int32_t nmask,
+                          int32_t threshold, int32_t cap, float* kp, int32_t* n, int32_t* status);
+
 /* ---- K7: brute-force Hamming matching ------------------------------------------------
  * Replaces cv2.BFMatcher(NORM_HAMMING).match / .knnMatch as called from
  * omnistereo/camera_models.py:442 and :420 (FeatureMatcher.match, :404-446).

@@ -78,6 +78,22 @@ class ImageModel(object):
         self.method, self.kp_cap = method.upper(), kp_cap
 
 
+def fast_keypoints(gray, mask_bits, which, thr=10):
+    """cv2.FastFeatureDetector_create() (threshold 10, NMS, TYPE_9_16).detect(gray, mask): corner score > 0, strictly
+    greater than the 8 neighbours, mask set; raster order -> [n,2] float32 (x, y)."""
+    s = oracle.fast_score_map(gray, thr).astype(np.int32)
+    keep = s > 0
+    pad = np.pad(s, 1)
+    for dy in (0, 1, 2):
+        for dx in (0, 1, 2):
+            if dy == 1 and dx == 1:
+                continue
+            keep &= pad[dy:dy + s.shape[0], dx:dx + s.shape[1]] < s
+    keep &= ((mask_bits >> which) & 1).astype(bool)
+    ys, xs = np.nonzero(keep)
+    return np.stack([xs, ys], axis=1).astype(np.float32)
+
+
 def detect_view(im, omni, view):
     """set_current_omni_image (camera_models.py:3107) + detect_sparse_features_on_panorama with GFT
     (camera_models.py:1708-1797) for one mirror: lists over azimuthal masks of keypoints / descriptors."""
@@ -90,9 +106,16 @@ def detect_view(im, omni, view):
             kps.append(np.ascontiguousarray(kp4[kept][:, :2]))
             descs.append(d)
         return kps, descs, pano, gray
-    eig = oracle.min_eigen(gray)
     blurred = oracle.gauss7(gray)
     kps, descs = [], []
+    if im.method == "FAST":                                                           # :1664-1666, :1755, :1765
+        for m in range(im.nmask):
+            kp = fast_keypoints(gray, im.mask_bits[view], m)[: im.kp_cap]
+            d, kept = oracle.orb_describe(blurred, kp, im.cos_a, im.sin_a, im.pattern, im.edge)
+            kps.append(kp[kept])
+            descs.append(d)
+        return kps, descs, pano, gray
+    eig = oracle.min_eigen(gray)
     for m in range(im.nmask):                                                         # :1730
         kp, _ = oracle.gft_select(eig, im.mask_bits[view], m, im.quality, im.min_distance, im.max_corners)  # :1739
         d, kept = oracle.orb_describe(blurred, kp, im.cos_a, im.sin_a, im.pattern, im.edge)                 # :1765

@@ -104,3 +104,30 @@ def test_describe_orb_matches_oracle(ctx, angle):
         assert np.array_equal(desc[p, : len(kept)], wd), p
         kept_total += len(kept)
     assert kept_total > 100
+
+
+def test_fast_detector_raster_order_masks_and_cap(ctx):
+    """sosvo_detect_fast against the oracle's FAST score map + numpy NMS / mask / raster order; overlapping masks, an
+    empty mask, a cap smaller than the corner count (first `cap` in raster order, status 1)."""
+    import refflow
+    rng = np.random.default_rng(77)
+    rows, cols = 61, 203
+    imgs = np.stack([np.clip(rng.normal(120, 40, (rows, cols)), 0, 255).astype(np.uint8) for _ in range(3)])
+    imgs[2] = 90                                                     # flat image: no corners
+    masks = np.zeros((1, rows, cols), np.uint32)
+    masks[0, :, :120] |= 1
+    masks[0, 10:50, 100:] |= 2                                       # overlaps mask 0 on columns 100..119
+    masks[0, :, :] |= 8                                              # mask 3 = everything (mask 2 stays empty)
+    dev = ctx.device
+    t_img, t_mask = torch.from_numpy(imgs).to(dev), torch.from_numpy(masks).to(dev)
+    for cap in (2048, 40):
+        kp, n, status = ctx.detect_fast(t_img, t_mask, 3, 4, cap)
+        ctx.synchronize()
+        kp, n, status = kp.cpu().numpy(), n.cpu().numpy(), status.cpu().numpy()
+        for i in range(3):
+            for m in range(4):
+                want = refflow.fast_keypoints(imgs[i], masks[0], m)
+                p = i * 4 + m
+                assert n[p] == min(len(want), cap) and status[p] == (1 if len(want) > cap else 0), (cap, i, m, n[p], len(want))
+                assert np.array_equal(kp[p, : n[p]], want[:cap]), (cap, i, m)
+        assert n[0] >= min(cap, 100) and n[2] == 0 and n[8:].sum() == 0

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kThreads) void mask_level_kernel(uint32_t* __restri
 }
 
 // ---- FAST-9/16 score map over the whole pyramid ------------------------------------------------------------
-__device__ __forceinline__ int fast_score(const uint8_t* __restrict__ im, int w, int y, int x) {
+__device__ __forceinline__ int fast_score(const uint8_t* __restrict__ im, int w, int y, int x, int thr = kFastThr) {
   const int v = im[(size_t)y * w + x];
   int d[16];
   const int rx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
@@ -126,7 +126,7 @@ __device__ __forceinline__ int fast_score(const uint8_t* __restrict__ im, int w,
     }
     best = max(best, max(mn_b, mn_d));
   }
-  return best > kFastThr ? best - 1 : 0;
+  return best > thr ? best - 1 : 0;
 }
 
 __global__ __launch_bounds__(kThreads) void fast_score_kernel(const uint8_t* __restrict__ pyr, Pyr P,
@@ -145,6 +145,92 @@ __global__ __launch_bounds__(kThreads) void fast_score_kernel(const uint8_t* __r
   if (P.quota[l] > 0 && h > 2 * kEdge && w > 2 * kEdge && y >= 3 && y < h - 3 && x >= 3 && x < w - 3)
     s = fast_score(pyr + (size_t)img * P.total + P.off[l], w, y, x);
   score[(size_t)img * P.total + i] = (uint8_t)s;
+}
+
+// ---- FAST as a detector of its own (feature_detection_method "FAST") ------------------------------------------
+// cv2.FastFeatureDetector_create() + setNonmaxSuppression(True) + detect(image, mask) (omnistereo/camera_models.py:
+// 1664-1666, :1755; pose_est_tools.py:506-508): FAST-9/16 with threshold 10 on the whole image (3-px border), 3x3
+// non-maximum suppression on the corner score (strictly greater than the 8 neighbours), keypoints kept where the
+// mask is set, in raster order.  Three launches: score map, NMS flags (one u64 per 64 pixels of a row), and one
+// WAVE per (image, mask) that walks the rows and compacts the flagged, masked pixels in order.
+__global__ __launch_bounds__(kThreads) void fast_image_score_kernel(const uint8_t* __restrict__ gray, int rows, int cols,
+                                                                    int thr, uint8_t* __restrict__ score) {
+  const int i = blockIdx.x * kThreads + threadIdx.x, img = blockIdx.y;
+  if (i >= rows * cols) return;
+  const int y = i / cols, x = i - y * cols;
+  int s = 0;
+  if (y >= 3 && y < rows - 3 && x >= 3 && x < cols - 3) s = fast_score(gray + (size_t)img * rows * cols, cols, y, x, thr);
+  score[(size_t)img * rows * cols + i] = (uint8_t)s;
+}
+
+__global__ __launch_bounds__(kThreads) void fast_nms_flags_kernel(const uint8_t* __restrict__ score, int rows, int cols,
+                                                                  int words, unsigned long long* __restrict__ flags) {
+  // one wave per (row, 64-pixel word): grid.x covers rows * words waves, grid.y = image
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * kThreads + threadIdx.x) >> 6));
+  if (wv >= rows * words) return;
+  const int y = wv / words, w = wv - y * words, x = 64 * w + lane, img = blockIdx.y;
+  const uint8_t* sc = score + (size_t)img * rows * cols;
+  bool keep = false;
+  if (x < cols) {
+    const int s = sc[(size_t)y * cols + x];
+    if (s > 0) {  // score > 0 implies the 3-px border, so all 8 neighbours exist
+      keep = true;
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx)
+          if ((dy || dx) && sc[(size_t)(y + dy) * cols + x + dx] >= s) keep = false;
+    }
+  }
+  const unsigned long long bal = __ballot(keep);
+  if (lane == 0) flags[((size_t)img * rows + y) * words + w] = bal;
+}
+
+__global__ __launch_bounds__(64) void fast_collect_kernel(const unsigned long long* __restrict__ flags,
+                                                          const uint32_t* __restrict__ mask_bits, int images_per_maskset,
+                                                          int nmask, int rows, int cols, int words, int cap,
+                                                          float* __restrict__ kp, int32_t* __restrict__ n_out,
+                                                          int32_t* __restrict__ status) {
+  const int lane = threadIdx.x, p = blockIdx.x;
+  const int img = p / nmask, m = p - img * nmask;
+  const uint32_t* mb = mask_bits + (size_t)(img / images_per_maskset) * rows * cols;
+  const unsigned long long* fl = flags + (size_t)img * rows * words;
+  int total = 0;  // wave-uniform
+  for (int y = 3; y < rows - 3; ++y) {
+    for (int w0 = 0; w0 < words; w0 += 64) {
+      const int w = w0 + lane;
+      unsigned long long f = w < words ? fl[(size_t)y * words + w] : 0ULL;
+      // keep the flagged pixels whose mask bit is set (flags are sparse: a handful of bits per word)
+      unsigned long long kept = 0ULL;
+      while (f) {
+        const int b = __ffsll((long long)f) - 1;
+        f &= f - 1ULL;
+        if ((mb[(size_t)y * cols + 64 * w + b] >> m) & 1u) kept |= 1ULL << b;
+      }
+      int c = __popcll(kept), pre = c;  // inclusive prefix over the lanes (= words, in raster order)
+#pragma unroll
+      for (int s = 1; s < 64; s <<= 1) {
+        const int o = __shfl_up(pre, s);
+        if (lane >= s) pre += o;
+      }
+      int pos = total + pre - c;
+      while (kept) {
+        const int b = __ffsll((long long)kept) - 1;
+        kept &= kept - 1ULL;
+        if (pos < cap) {
+          kp[((size_t)p * cap + pos) * 2] = (float)(64 * w + b);
+          kp[((size_t)p * cap + pos) * 2 + 1] = (float)y;
+        }
+        pos++;
+      }
+      total += __shfl(pre, 63);
+    }
+  }
+  if (lane == 0) {
+    n_out[p] = min(total, cap);
+    if (status) status[p] = total > cap ? 1 : 0;
+  }
 }
 
 // ---- selection ------------------------------------------------------------------------------------------
@@ -557,6 +643,35 @@ int32_t sosvo_describe_orb_levels(sosvo_ctx* ctx, const uint8_t* gray, int32_t n
   }
   SOSVO_LAUNCH(ctx, orb_describe_levels_kernel, dim3((unsigned)((size_t)nimg * nmask)), dim3(kThreads),
                (size_t)cap * 4 * sizeof(float), ctx->stream, blur, P, rows, cols, nmask, cap, kp4, n, pattern, desc, kp_xy);
+  SOSVO_LAUNCH_CHECK(ctx);
+  return SOSVO_OK;
+}
+
+int32_t sosvo_detect_fast(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* mask_bits, int32_t nimg,
+                          int32_t images_per_maskset, int32_t rows, int32_t cols, int32_t nmask, int32_t threshold,
+                          int32_t cap, float* kp, int32_t* n, int32_t* status) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, gray && mask_bits && kp && n, "null pointer");
+  SOSVO_REQUIRE(ctx, nimg >= 0 && nimg <= 65535 && images_per_maskset > 0, "nimg out of range");
+  SOSVO_REQUIRE(ctx, rows >= 7 && cols >= 7 && rows * (int64_t)cols < (1 << 28), "image sizes out of range");
+  SOSVO_REQUIRE(ctx, nmask >= 1 && nmask <= 32, "nmask out of range (1..32)");
+  SOSVO_REQUIRE(ctx, cap > 0 && cap <= 16384 && threshold >= 0 && threshold <= 254, "bad detector parameters");
+  if (nimg == 0) return SOSVO_OK;
+  const int words = cdiv(cols, 64);
+  const size_t score_bytes = ((size_t)nimg * rows * cols + 255) & ~(size_t)255;
+  const size_t flag_bytes = sizeof(unsigned long long) * (size_t)nimg * rows * words;
+  int32_t rc = sosvo_ws_reserve(ctx, score_bytes + flag_bytes);
+  if (rc != SOSVO_OK) return rc;
+  uint8_t* score = (uint8_t*)ctx->ws;
+  unsigned long long* flags = (unsigned long long*)((char*)ctx->ws + score_bytes);
+  SOSVO_LAUNCH(ctx, fast_image_score_kernel, dim3(cdiv(rows * cols, kThreads), nimg), dim3(kThreads), 0, ctx->stream, gray, rows,
+               cols, threshold, score);
+  SOSVO_LAUNCH_CHECK(ctx);
+  SOSVO_LAUNCH(ctx, fast_nms_flags_kernel, dim3(cdiv(rows * words, kThreads / 64), nimg), dim3(kThreads), 0, ctx->stream, score,
+               rows, cols, words, flags);
+  SOSVO_LAUNCH_CHECK(ctx);
+  SOSVO_LAUNCH(ctx, fast_collect_kernel, dim3((unsigned)((size_t)nimg * nmask)), dim3(64), 0, ctx->stream, flags, mask_bits,
+               images_per_maskset, nmask, rows, cols, words, cap, kp, n, status);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
 }

@@ -182,6 +182,28 @@ class Context(object):
         self._call(self._lib.sosvo_unwrap_median_gray, _ptr(omni), _ptr(table), F, H, W, rows, cols, int(ksize), _ptr(gray))
         return gray
 
+    def detect_fast(self, gray, mask_bits, images_per_maskset, nmask, cap, threshold=10, kp=None, n=None, status=None):
+        """FAST-9/16 + NMS per azimuthal mask, raster order: gray [NI,rows,cols] u8, mask_bits [nsets,rows,cols] u32
+        -> kp [NI*nmask, cap, 2] f32, n [NI*nmask] i32, status [NI*nmask] i32."""
+        _check(gray, torch.uint8, "gray", ndim=3)
+        NI, rows, cols = gray.shape
+        _check(mask_bits, torch.uint32, "mask_bits", (None, rows, cols))
+        if mask_bits.shape[0] * images_per_maskset < NI:
+            raise SosvoError("mask_bits has too few sets for %d images" % NI)
+        P, dev = NI * nmask, gray.device
+        if kp is None:
+            kp = torch.zeros((P, cap, 2), dtype=torch.float32, device=dev)
+        if n is None:
+            n = torch.zeros((P,), dtype=torch.int32, device=dev)
+        if status is None:
+            status = torch.zeros((P,), dtype=torch.int32, device=dev)
+        _check(kp, torch.float32, "kp", (P, cap, 2))
+        _check(n, torch.int32, "n", (P,))
+        _check(status, torch.int32, "status", (P,))
+        self._call(self._lib.sosvo_detect_fast, _ptr(gray), _ptr(mask_bits), NI, int(images_per_maskset), rows, cols,
+                   int(nmask), int(threshold), int(cap), _ptr(kp), _ptr(n), _ptr(status))
+        return kp, n, status
+
     # ---- K4 / K6 -----------------------------------------------------------------------
     def detect_gft(self, gray, mask_bits, images_per_maskset, nmask, cap, quality=0.01, min_distance=5.0,
                    max_corners=1000, kp=None, n=None, status=None):

@@ -54,15 +54,17 @@ class ImageFrontEnd(object):
         """num_of_features: per azimuthal mask (FeatureMatcher.num_of_features, pose_est_tools.py:862).
         keep_panoramas=False: K1 is fused into the median kernel and the colour panoramas are not materialised
         (nothing downstream of K3 reads them); identical gray images."""
-        if detection_method.upper() not in ("GFT", "ORB"):
-            raise NotImplementedError("detection method %r: GFT (the reference default, pose_est_tools.py:684) and "
-                                      "ORB are built" % detection_method)
+        if detection_method.upper() not in ("GFT", "ORB", "FAST"):
+            raise NotImplementedError("detection method %r: GFT (the reference default, pose_est_tools.py:684), ORB "
+                                      "and FAST are built" % detection_method)
         self.ctx, self.model, self.F = ctx, model, int(nframes)
         self.method = detection_method.upper()
         self.num_of_features, self.median_win_size = int(num_of_features), int(median_win_size)
         self.quality, self.min_distance, self.edge = float(quality), float(min_distance), int(edge)
         if kp_cap:
             self.kp_cap = int(kp_cap)
+        elif self.method == "FAST":  # every corner is kept (num_of_features only names the ORB descriptor object)
+            self.kp_cap = 2048
         elif self.method == "ORB":  # retainBest keeps ties beyond the quota: leave head room
             self.kp_cap = int(min(2048, max(64, -(-int(self.num_of_features * 1.25) // 64) * 64)))
         else:
@@ -111,6 +113,12 @@ class ImageFrontEnd(object):
             c.detect_orb(self.gray, m.mask_pyr, self.F, m.nmask, self.num_of_features, self.kp_cap, kp4=self.kp4,
                          resp=self.resp, n=self.n)                                                # K5
             c.describe_orb_levels(self.gray, self.kp4, self.n, m.nmask, m.pattern, desc=self.desc, kp_xy=self.kp)  # K6'
+            return
+        if self.method == "FAST":
+            c.detect_fast(self.gray, m.mask_bits, self.F, m.nmask, self.kp_cap, threshold=10, kp=self.kp, n=self.n,
+                          status=self.status)                                                     # FAST + NMS
+            c.describe_orb(self.gray, self.kp, self.n, m.nmask, m.pattern, self.cos_a, self.sin_a, edge=self.edge,
+                           desc=self.desc)                                                        # K6
             return
         c.detect_gft(self.gray, m.mask_bits, self.F, m.nmask, self.kp_cap, quality=self.quality,
                      min_distance=self.min_distance, max_corners=self.num_of_features, kp=self.kp, n=self.n,
