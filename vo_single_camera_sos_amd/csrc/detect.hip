@@ -588,6 +588,13 @@ __global__ __launch_bounds__(kThreads) void orb_describe_kernel(const uint8_t* _
         if (it < nit && ld_lane && r < PR) reg[it] = *reinterpret_cast<const u32_unaligned*>(base + (size_t)r * cols);
       }
     };
+    // this lane's eight patch offsets (tests lane, 64 + lane, 128 + lane, 192 + lane) never change: registers
+    int pa[4], pb[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      pa[r] = poff[2 * (64 * r + lane)];
+      pb[r] = poff[2 * (64 * r + lane) + 1];
+    }
     int j = wid;
     if (j < m) issue(j);
     for (; j < m; j += kThreads / 64) {
@@ -598,12 +605,13 @@ __global__ __launch_bounds__(kThreads) void orb_describe_kernel(const uint8_t* _
       }
       if (j + kThreads / 64 < m) issue(j + kThreads / 64);  // next keypoint's rows fly while this one is tested
       unsigned long long* d = reinterpret_cast<unsigned long long*>(desc + ((size_t)p * cap + j) * 32);
+      unsigned long long mine = 0ULL;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int t = 64 * r + lane;
-        const unsigned long long bal = __ballot(patch[poff[2 * t]] < patch[poff[2 * t + 1]]);
-        if (lane == 0) d[r] = bal;
+        const unsigned long long bal = __ballot(patch[pa[r]] < patch[pb[r]]);
+        if (lane == r) mine = bal;
       }
+      if (lane < 4) d[lane] = mine;  // one 32-byte store
     }
     return;
   }
