@@ -117,9 +117,14 @@ __global__ __launch_bounds__(kThreads) void min_eigen_kernel(const uint8_t* __re
     auto right = [&](auto v) { return EDGE ? __shfl(v, lr) : lane_from_right(v); };
     constexpr int i0 = (P + 1) % 3, i1 = (P + 2) % 3, i2 = P;  // slots of rows t-2, t-1, t
     if (t > t_last) return;  // uniform
+    // the mask word of the e row this step finishes (y = t - 2) is requested first: its latency hides under the
+    // Sobel / box-sum arithmetic below
+    const int y_pre = t - 2;
+    const bool y_out = y_pre >= ys && y_pre < ye && y_pre >= e_lo && out_lane;
+    const uint32_t o_pre = (uint32_t)(max(y_pre, 0) * cols) + (uint32_t)xc;
+    const uint32_t mb_pre = y_out ? mb[o_pre] : 0u;
     {
-      const uint32_t row_off = (uint32_t)(refl101(t, rows) * cols);  // uniform; rows * cols < 2^28
-      const int c = (int)g[row_off + (uint32_t)xs];
+      const int c = (int)g[(uint32_t)(refl101(t, rows) * cols) + (uint32_t)xs];  // rows * cols < 2^28
       const int l = left(c), r = right(c);
       hd[i2] = r - l;
       hs[i2] = (l + 2 * c) + r;
@@ -142,10 +147,9 @@ __global__ __launch_bounds__(kThreads) void min_eigen_kernel(const uint8_t* __re
       const float a = ((pxx[i0] + pxx[i1]) + pxx[i2]) * 0.5f, b = (pxy[i0] + pxy[i1]) + pxy[i2];
       const float c = ((pyy[i0] + pyy[i1]) + pyy[i2]) * 0.5f;
       const float e = (a + c) - sqrtf(((a - c) * (a - c)) + (b * b));
-      if (y >= ys && y < ye && out_lane) {
-        const uint32_t o = (uint32_t)(y * cols) + (uint32_t)xc;
-        eo[o] = e;
-        const uint32_t bits = mb[o] & mask_all;
+      if (y_out) {
+        eo[o_pre] = e;
+        const uint32_t bits = mb_pre & mask_all;
         if (bits != cur_bits) {
           eig_flush(mstat_img, cur_bits, cur_max);
           cur_bits = bits;
@@ -476,11 +480,13 @@ __global__ __launch_bounds__(kThreads) void gauss7_kernel(const uint8_t* __restr
   uint32_t h[7] = {0, 0, 0, 0, 0, 0, 0};
   const bool edge_strip = xb < 3 || xb + 64 > cols - 3;  // wave-uniform: some lane's x-3 .. x+3 are mirrored columns
   const int t_first = ys - 3, t_last = ye + 2;
+  int c_next = (int)g[(uint32_t)(refl101(t_first, rows) * cols) + (uint32_t)xs];
   auto step = [&](auto phase_tag, auto edge_tag, const int t) __attribute__((always_inline)) {
     constexpr int P = decltype(phase_tag)::value;
     constexpr bool EDGE = decltype(edge_tag)::value;
     if (t > t_last) return;  // uniform
-    const int c = (int)g[(uint32_t)(refl101(t, rows) * cols) + (uint32_t)xs];
+    const int c = c_next;  // gray row t, requested one step ago; row t + 1 is requested now
+    c_next = (int)g[(uint32_t)(refl101(min(t + 1, t_last), rows) * cols) + (uint32_t)xs];
     int l1, l2, l3, r1, r2, r3;
     if (EDGE) {
       l3 = __shfl(c, src[0]); l2 = __shfl(c, src[1]); l1 = __shfl(c, src[2]);
