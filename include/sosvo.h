@@ -243,6 +243,10 @@ int32_t sosvo_sort_matches(sosvo_ctx* ctx, const uint32_t* keys, const int32_t* 
  * hyp_counts: optional [nprob,max_iter] i32, receives each hypothesis' inlier count (-1: the
  * minimal solve failed); NULL to keep them in the context workspace.                         */
 #define SOSVO_FLAG_CAM_ROT_IDENTITY 1
+/* central problems (cam == NULL): hypotheses from EPnP on 6-point samples, as OpenGV's absolute_pose_ransac does for
+ * algorithm "EPNP" (the RGB-D tracker's choice, pose_est_tools.py:697, :915), instead of Kneip P3P + a 4th point;
+ * the adaptive stop then uses w^6. */
+#define SOSVO_FLAG_EPNP 2
 int32_t sosvo_ransac_abs_pose(sosvo_ctx* ctx, const double* f, const double* p, const int32_t* cam,
                               const double* cam_off, const double* cam_rot, int32_t ncam, int32_t flags,
                               const int32_t* n, int32_t nprob, int32_t stride, double thr,

@@ -100,8 +100,9 @@ def score_points(f, p, T, cam=None, cam_off=None, cam_rot=None):
 
 
 def ransac_abs_pose(f, p, thr, max_iter, seed=0, adaptive=False, cam=None, cam_off=None, cam_rot=None,
-                    want_counts=False):
-    """-> dict(T [3,4], mask [n] bool, n_inliers, best_iter, iters_used, status[, counts])."""
+                    want_counts=False, epnp=False):
+    """-> dict(T [3,4], mask [n] bool, n_inliers, best_iter, iters_used, status[, counts]).  epnp: central problems
+    only, hypotheses from EPnP on 6-point samples instead of Kneip P3P + a 4th point."""
     f = _c(f, np.float64).reshape(-1, 3)
     p = _c(p, np.float64).reshape(-1, 3)
     n = f.shape[0]
@@ -116,13 +117,32 @@ def ransac_abs_pose(f, p, thr, max_iter, seed=0, adaptive=False, cam=None, cam_o
     L.orc_ransac_abs_pose.restype = ctypes.c_int32
     st = L.orc_ransac_abs_pose(_p(f), _p(p), _pn(cam), _pn(cam_off), _pn(cam_rot), ctypes.c_int32(n),
                                ctypes.c_int32(ncam), ctypes.c_double(thr), ctypes.c_int32(max_iter),
-                               ctypes.c_int32(1 if adaptive else 0), ctypes.c_uint64(seed), _p(T), _p(mask),
+                               ctypes.c_int32((1 if adaptive else 0) | (2 if epnp else 0)), ctypes.c_uint64(seed), _p(T), _p(mask),
                                ctypes.byref(n_inl), ctypes.byref(best_it), ctypes.byref(used), _pn(counts))
     out = dict(T=T, mask=mask[:n].astype(bool), n_inliers=n_inl.value, best_iter=best_it.value,
                iters_used=used.value, status=st)
     if want_counts:
         out["counts"] = counts[:max_iter]
     return out
+
+
+def epnp(f, p):
+    """EPnP on 5..8 correspondences -> T [3,4] (pose of the camera in the world) or None."""
+    f = _c(f, np.float64).reshape(-1, 3)
+    p = _c(p, np.float64).reshape(-1, 3)
+    T = np.zeros((3, 4), dtype=np.float64)
+    L = lib()
+    L.orc_epnp_solve.restype = ctypes.c_int32
+    ok = L.orc_epnp_solve(_p(f), _p(p), ctypes.c_int32(f.shape[0]), _p(T))
+    return T if ok else None
+
+
+def sample_distinct(n, k, seed, it):
+    s = np.zeros(k, dtype=np.int32)
+    L = lib()
+    L.orc_sample_distinct_once.restype = ctypes.c_int32
+    ok = L.orc_sample_distinct_once(ctypes.c_int32(n), ctypes.c_int32(k), ctypes.c_uint64(seed), ctypes.c_int32(it), _p(s))
+    return s if ok else None
 
 
 def hypothesis_once(f, p, seed, it, cam=None, cam_off=None, cam_rot=None):

@@ -38,6 +38,7 @@
 #include <string.h>
 
 #include "ransac_core.h"
+#include "epnp_core.h"
 
 /* ---- scoring of all points under one pose --------------------------------------------- */
 void orc_score_points(const double* f, const double* p, const int32_t* cam, const double* cam_off,
@@ -64,6 +65,10 @@ int32_t orc_ransac_abs_pose(const double* f, const double* p, const int32_t* cam
                             int32_t* counts_out /* [max_iter] or NULL */) {
   const double zero3[3] = {0, 0, 0};
   const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  /* `adaptive` bit 1 selects the EPnP hypothesis generator (central problems only): 6-point samples solved by
+   * orc_epnp, as OpenGV's AbsolutePoseSacProblem does for algorithm EPNP (pose_est_tools.py:697, :915). */
+  const int use_epnp = ((adaptive >> 1) & 1) && !cam;
+  adaptive &= 1;
   if (!cam) {
     ncam = 1;
     cam_off = zero3;
@@ -92,7 +97,22 @@ int32_t orc_ransac_abs_pose(const double* f, const double* p, const int32_t* cam
     if (adaptive && iterations > 0 && !orc_ransac_continue(base, iterations)) break;
     used = it + 1;
     double R[9], t[3];
-    int ok = orc_hypothesis(f, p, cam, cam_off, cam_rot, n, perm, cstart, ccount, seed, (uint64_t)it, R, t);
+    int ok;
+    if (use_epnp) {
+      int32_t s6[6];
+      double f6[18], p6[18];
+      ok = orc_sample_distinct(n, 6, seed, (uint64_t)it, s6);
+      if (ok) {
+        for (int k = 0; k < 6; ++k)
+          for (int c = 0; c < 3; ++c) {
+            f6[3 * k + c] = f[3 * s6[k] + c];
+            p6[3 * k + c] = p[3 * s6[k] + c];
+          }
+        ok = orc_epnp(f6, p6, 6, R, t);
+      }
+    } else {
+      ok = orc_hypothesis(f, p, cam, cam_off, cam_rot, n, perm, cstart, ccount, seed, (uint64_t)it, R, t);
+    }
     if (counts_out) counts_out[it] = -1;
     if (!ok) continue; /* failed solve: skipped, does not count as an iteration */
     int cnt = 0;
@@ -106,7 +126,7 @@ int32_t orc_ransac_abs_pose(const double* f, const double* p, const int32_t* cam
       best_it = it;
       memcpy(best_R, R, sizeof(R));
       memcpy(best_t, t, sizeof(t));
-      base = orc_adaptive_base(cnt, n);
+      base = use_epnp ? orc_adaptive_base6(cnt, n) : orc_adaptive_base(cnt, n);
     }
     iterations++;
   }
@@ -287,4 +307,16 @@ int32_t orc_refine_abs_pose(const double* f, const double* p, const int32_t* cam
   if (final_cost) *final_cost = cost;
   if (lm_iters) *lm_iters = it_done;
   return 0;
+}
+
+/* EPnP on n (5..8) correspondences (unit tests): T_out = [R | t], pose of the camera in the world. */
+int32_t orc_epnp_solve(const double* f, const double* p, int32_t n, double* T_out) {
+  double R[9], t[3];
+  const int ok = orc_epnp(f, p, n, R, t);
+  if (ok) orc_Rt_to_T(R, t, T_out);
+  return ok;
+}
+
+int32_t orc_sample_distinct_once(int32_t n, int32_t k, uint64_t seed, int32_t it, int32_t* s) {
+  return orc_sample_distinct(n, k, seed, (uint64_t)it, s);
 }

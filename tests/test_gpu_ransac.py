@@ -36,7 +36,7 @@ def _to(dev, *arrs):
     return [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in arrs]
 
 
-def _run_batch(ctx, problems, S, noncentral, max_iter, seed, adaptive=False, ident=True, thr=synth.THR_5DEG):
+def _run_batch(ctx, problems, S, noncentral, max_iter, seed, adaptive=False, ident=True, thr=synth.THR_5DEG, epnp=False):
     f, p, cam, n = _pack(problems, S, noncentral)
     dev = ctx.device
     tf, tp, tcam, tn = _to(dev, f, p, cam, n)
@@ -44,13 +44,13 @@ def _run_batch(ctx, problems, S, noncentral, max_iter, seed, adaptive=False, ide
     if noncentral:
         off, rot = _to(dev, problems[0]["cam_off"], problems[0]["cam_rot"])
         kw = dict(cam=tcam, cam_off=off, cam_rot=rot, cam_rot_identity=ident)
-    out = ctx.ransac_abs_pose(tf, tp, tn, thr, max_iter, seed=seed, adaptive=adaptive, want_counts=True, **kw)
+    out = ctx.ransac_abs_pose(tf, tp, tn, thr, max_iter, seed=seed, adaptive=adaptive, want_counts=True, epnp=epnp, **kw)
     ctx.synchronize()
     got = {k: v.cpu().numpy() for k, v in out.items()}
     for b, pr in enumerate(problems):
         okw = dict(cam=pr["cam"], cam_off=pr["cam_off"], cam_rot=pr["cam_rot"]) if noncentral else {}
         want = oracle.ransac_abs_pose(pr["f"], pr["p"], thr, max_iter, seed=seed + b, adaptive=adaptive,
-                                      want_counts=True, **okw)
+                                      want_counts=True, epnp=epnp, **okw)
         k = n[b]
         used = want["iters_used"]
         assert got["info"][b, 1] == used, "iterations drawn, problem %d" % b
@@ -170,3 +170,22 @@ def test_refine_noise_free_reaches_ground_truth(ctx):
         a0, t0 = synth.pose_error(T0[b], pr["R"], pr["t"])
         assert a1 < 1e-2 * a0 and t1 < 1e-2 * t0
         assert np.array_equal(T[b], want)
+
+
+def test_central_epnp_hypotheses_bit_exact(ctx):
+    """SOSVO_FLAG_EPNP: 6-point samples solved by EPnP (Jacobi eigen-decompositions, Gauss-Newton on the betas, ...)
+    reproduce the oracle's hypotheses bit for bit: per-hypothesis inlier counts, winning iteration, masks and pose;
+    with and without the adaptive stop (w^6); too few points -> no model; the planted pose is recovered."""
+    rng = np.random.default_rng(41)
+    probs = [synth.make_abs_pose_problem(rng, n, inlier_frac=fr, noise_deg=nz, noncentral=False)
+             for n, fr, nz in ((300, 0.6, 0.1), (700, 0.5, 0.2), (64, 0.9, 0.0), (5, 1.0, 0.0), (6, 1.0, 0.0))]
+    for adaptive in (False, True):
+        _, _, got = _run_batch(ctx, probs, 704, False, 300, 9, adaptive=adaptive, epnp=True)
+        assert got["info"][3, 2] == 1 and got["n_inliers"][3] == 0          # 5 points: no 6-point sample
+        assert got["info"][4, 2] == 0 and got["n_inliers"][4] == 6
+        for b in (0, 1, 2):
+            ang, terr = synth.pose_error(got["T"][b], probs[b]["R"], probs[b]["t"])
+            assert ang < np.deg2rad(3.0), (b, ang)
+    with pytest.raises(Exception):                                         # EPnP is for central problems
+        pr = synth.make_abs_pose_problem(rng, 50, inlier_frac=1.0, noise_deg=0.0, noncentral=True)
+        _run_batch(ctx, [pr], 64, True, 10, 1, epnp=True)

@@ -104,3 +104,36 @@ def test_refine_converges_to_known_pose():
                                           cam=None if pr["cam"] is None else pr["cam"][idx],
                                           cam_off=pr["cam_off"], cam_rot=pr["cam_rot"])
         assert np.array_equal(T2, T3)
+
+
+def test_epnp_recovers_known_poses_and_sampler_is_distinct():
+    """EPnP restatement (oracle/epnp_core.h): noise-free 5..8-point problems give the planted pose to 1e-9; the
+    6-index sampler returns distinct in-range indices, deterministic in (seed, iteration); RANSAC with EPnP
+    hypotheses finds the planted inliers of a contaminated central problem."""
+    rng = np.random.default_rng(3)
+    worst = 0.0
+    for trial in range(200):
+        n = int(rng.integers(5, 9))
+        P = rng.uniform(-2, 2, (n, 3)) + np.array([0.0, 0.0, 5.0])
+        R, t = synth.random_pose(rng)
+        pc = (P - t) @ R
+        if (pc[:, 2] <= 0.2).any():
+            continue
+        f = pc / np.linalg.norm(pc, axis=1, keepdims=True)
+        T = oracle.epnp(f, P)
+        assert T is not None
+        worst = max(worst, np.abs(T[:, :3] - R).max(), np.abs(T[:, 3] - t).max())
+    assert worst < 1e-9, worst
+    assert oracle.epnp(np.ones((4, 3)), np.ones((4, 3))) is None and oracle.sample_distinct(5, 6, 1, 0) is None
+    for it in range(50):
+        s = oracle.sample_distinct(9, 6, 123, it)
+        assert len(set(s.tolist())) == 6 and s.min() >= 0 and s.max() < 9
+        assert np.array_equal(s, oracle.sample_distinct(9, 6, 123, it))
+    seen = {tuple(oracle.sample_distinct(6, 6, 5, it)) for it in range(20)}
+    assert all(sorted(s) == list(range(6)) for s in seen) and len(seen) > 5
+    # 6-point samples: 0.7^6 = 12 % of the samples are outlier-free
+    pr = synth.make_abs_pose_problem(rng, 500, inlier_frac=0.7, noise_deg=0.1, noncentral=False)
+    r = oracle.ransac_abs_pose(pr["f"], pr["p"], synth.THR_5DEG, 200, seed=4, epnp=True)
+    assert r["status"] == 0 and r["n_inliers"] >= 340 and synth.pose_error(r["T"], pr["R"], pr["t"])[0] < np.deg2rad(3.0)
+    ra = oracle.ransac_abs_pose(pr["f"], pr["p"], synth.THR_5DEG, 2000, seed=4, epnp=True, adaptive=True)
+    assert ra["iters_used"] < 2000 and ra["n_inliers"] >= 340

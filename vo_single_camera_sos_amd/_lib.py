@@ -82,6 +82,7 @@ SIGNATURES = {
 }
 
 FLAG_CAM_ROT_IDENTITY = 1
+FLAG_EPNP = 2
 
 
 class Rig(ctypes.Structure):

@@ -21,6 +21,7 @@
 //                  reductions (deterministic run to run).
 #include "common.h"
 #include "ransac_core.h"
+#include "epnp_core.h"
 
 namespace {
 
@@ -116,6 +117,44 @@ __global__ __launch_bounds__(64) void ransac_hyp_kernel(const double* __restrict
   double* h = hyp + ((size_t)b * H + it) * kHypDoubles;
   if (ok) {
 #pragma unroll
+    for (int k = 0; k < 9; ++k) h[k] = R[k];
+    h[9] = t[0];
+    h[10] = t[1];
+    h[11] = t[2];
+    h[12] = -(((R[0] * t[0]) + (R[3] * t[1])) + (R[6] * t[2]));
+    h[13] = -(((R[1] * t[0]) + (R[4] * t[1])) + (R[7] * t[2]));
+    h[14] = -(((R[2] * t[0]) + (R[5] * t[1])) + (R[8] * t[2]));
+  } else {
+    h[0] = __longlong_as_double(0x7FF8000000000000LL);
+  }
+  counts[(size_t)b * H + it] = ok ? 0 : -1;
+}
+
+// The EPnP hypothesis generator (central problems, SOSVO_FLAG_EPNP): a kernel of its own -- its 12 x 12 work arrays
+// live in scratch memory and would otherwise cost the P3P generator of the hot path its occupancy.
+__global__ __launch_bounds__(64) void ransac_hyp_epnp_kernel(const double* __restrict__ f, const double* __restrict__ p,
+                                                             const int32_t* __restrict__ n_arr, int stride, int H,
+                                                             uint64_t seed, double* __restrict__ hyp,
+                                                             int32_t* __restrict__ counts) {
+  const int b = blockIdx.y;
+  const int it = blockIdx.x * blockDim.x + threadIdx.x;
+  if (it >= H) return;
+  const int n = min(n_arr[b], stride);
+  const size_t base = (size_t)b * stride;
+  double R[9], t[3];
+  int32_t s6[6];
+  double f6[18], p6[18];
+  int ok = sv_sample_distinct(n, 6, problem_seed(seed, b), (uint64_t)it, s6);
+  if (ok) {
+    for (int k = 0; k < 6; ++k)
+      for (int c = 0; c < 3; ++c) {
+        f6[3 * k + c] = f[3 * (base + s6[k]) + c];
+        p6[3 * k + c] = p[3 * (base + s6[k]) + c];
+      }
+    ok = sv_epnp(f6, p6, 6, R, t);
+  }
+  double* h = hyp + ((size_t)b * H + it) * kHypDoubles;
+  if (ok) {
     for (int k = 0; k < 9; ++k) h[k] = R[k];
     h[9] = t[0];
     h[10] = t[1];
@@ -326,7 +365,7 @@ __global__ __launch_bounds__(kThreads) void ransac_select_kernel(
       nv += redv[w];
     }
     s_nvalid = nv;
-    if (!adaptive) {
+    if (!(adaptive & 1)) {
       s_best_it = k < 0 ? -1 : (0x7FFFFFFF - (int)(k & 0xFFFFFFFFLL));
       s_used = H;
     } else {
@@ -341,7 +380,7 @@ __global__ __launch_bounds__(kThreads) void ransac_select_kernel(
         if (c > best_count) {
           best_count = c;
           best_it = it;
-          base = sv_adaptive_base(c, n);
+          base = (adaptive & 2) ? sv_adaptive_base6(c, n) : sv_adaptive_base(c, n);
         }
         iterations++;
       }
@@ -616,8 +655,15 @@ int32_t sosvo_ransac_abs_pose(sosvo_ctx* ctx, const double* f, const double* p, 
   SOSVO_LAUNCH(ctx,ransac_prepare_kernel, dim3(nprob), dim3(kThreads), 0, ctx->stream, cam, n, stride,
                      cam ? ncam : 1, perm, cinfo);
   SOSVO_LAUNCH_CHECK(ctx);
-  SOSVO_LAUNCH(ctx,ransac_hyp_kernel, dim3(cdiv(H, 64), nprob), dim3(64), 0, ctx->stream, f, p, cam, cam_off,
-                     cam_rot, n, stride, H, seed, perm, cinfo, hyp, counts);
+  const int epnp = (flags & SOSVO_FLAG_EPNP) != 0;
+  SOSVO_REQUIRE(ctx, !epnp || cam == nullptr, "SOSVO_FLAG_EPNP is for central problems (cam == NULL)");
+  if (epnp) adaptive = (adaptive ? 1 : 0) | 2;  // bit 1: the adaptive stop uses 6-point samples
+  if (epnp)
+    SOSVO_LAUNCH(ctx, ransac_hyp_epnp_kernel, dim3(cdiv(H, 64), nprob), dim3(64), 0, ctx->stream, f, p, n, stride, H, seed,
+                 hyp, counts);
+  else
+    SOSVO_LAUNCH(ctx, ransac_hyp_kernel, dim3(cdiv(H, 64), nprob), dim3(64), 0, ctx->stream, f, p, cam, cam_off, cam_rot, n,
+                 stride, H, seed, perm, cinfo, hyp, counts);
   SOSVO_LAUNCH_CHECK(ctx);
 
   const bool ident = (flags & SOSVO_FLAG_CAM_ROT_IDENTITY) != 0 || cam == nullptr;

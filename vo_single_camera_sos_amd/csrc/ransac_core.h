@@ -122,6 +122,17 @@ __device__ __forceinline__ static double sv_adaptive_base(int32_t best, int32_t 
   return pno;
 }
 
+// the same for 6-point samples (EPnP): 1 - w^6
+__device__ __forceinline__ static double sv_adaptive_base6(int32_t best, int32_t n) {
+  const double w = (double)best / (double)n;
+  const double w2 = w * w;
+  double pno = 1.0 - ((w2 * w2) * w2);
+  const double eps = 2.220446049250313e-16;
+  if (pno < eps) pno = eps;
+  if (pno > 1.0 - eps) pno = 1.0 - eps;
+  return pno;
+}
+
 __device__ __forceinline__ static int sv_ransac_continue(double base, int32_t iterations) {
   double result = 1.0, b = base;
   int32_t m = iterations;

@@ -360,8 +360,11 @@ class RGBDPairPipeline(object):
 
     def __init__(self, ctx, cam, n_pairs, image_shape=(480, 640), num_of_features=1000, kp_cap=None, frame_cap=None,
                  median_win_size=0, quality=0.01, min_distance=5.0, edge=31, thr=None, max_iter=2000, adaptive=False,
-                 seed=0, lm_iter=30, mask=None):
+                 seed=0, lm_iter=30, mask=None, pose_est_algorithm="EPNP"):
+        """pose_est_algorithm: TrackerSE3.pose_est_algorithm (pose_est_tools.py:697): "EPNP" = 6-point samples solved by
+        EPnP; "KNEIP" = P3P on 3 points + a 4th for disambiguation."""
         self.ctx, self.cam_cfg = ctx, cam
+        self.epnp = str(pose_est_algorithm).upper() == "EPNP"
         self.B, self.F = int(n_pairs), 2 * int(n_pairs)
         fe = RGBDFrontEnd(ctx, cam, self.F, image_shape, num_of_features, kp_cap, frame_cap, median_win_size, quality,
                           min_distance, edge, mask)
@@ -396,7 +399,7 @@ class RGBDPairPipeline(object):
                                pct_good_matches=cfg.pct_good_matches, max_hdiff=cfg.f2f_max_hdiff, out=self.corr)
         co = self.corr
         c.ransac_abs_pose(co["f"], co["p"], co["n"], self.thr, self.max_iter, seed=self.seed, adaptive=self.adaptive,
-                          out=self.ransac)                                                          # :915 (central)
+                          out=self.ransac, epnp=self.epnp)                                          # :915 (central)
         self.T.copy_(self.ransac["T"])
         c.refine_abs_pose(co["f"], co["p"], co["n"], self.T, idx=self.ransac["idx"], m=self.ransac["n_inliers"],
                           max_lm_iter=self.lm_iter, cost=self.lm_cost, iters=self.lm_iters)          # :937

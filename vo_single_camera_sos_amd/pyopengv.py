@@ -73,14 +73,15 @@ def _rig(ctx, cam_offsets, cam_rotations):
     return _dev(ctx, off, np.float64), _dev(ctx, rot, np.float64)
 
 
-def _ransac(b, p, threshold, max_iterations, cam_idx=None, cam_offsets=None, cam_rotations=None):
+def _ransac(b, p, threshold, max_iterations, cam_idx=None, cam_offsets=None, cam_rotations=None, epnp=False):
     ctx = _ctx()
     f_t, p_t, n_t, cam_t, n = _problem(ctx, b, p, cam_idx)
     kw = {}
     if cam_t is not None:
         off_t, rot_t = _rig(ctx, cam_offsets, cam_rotations)
         kw = dict(cam=cam_t, cam_off=off_t, cam_rot=rot_t)
-    out = ctx.ransac_abs_pose(f_t, p_t, n_t, float(threshold), int(max_iterations), seed=_next_seed(), adaptive=True, **kw)
+    out = ctx.ransac_abs_pose(f_t, p_t, n_t, float(threshold), int(max_iterations), seed=_next_seed(), adaptive=True,
+                              epnp=epnp, **kw)
     ctx.synchronize()
     k = int(out["n_inliers"][0].item())
     T = out["T"][0].cpu().numpy()
@@ -120,7 +121,8 @@ def absolute_pose_ransac(b, p, algo_name, threshold, max_iterations):
         raise NotImplementedError("TWOPT (translation from a known rotation) is not built")
     if name not in ("KNEIP", "GAO", "EPNP", "GP3P"):
         raise ValueError("unknown algorithm %r" % algo_name)
-    return _ransac(b, p, threshold, max_iterations)
+    # "EPNP": 6-point samples solved by EPnP, as in OpenGV; "KNEIP" / "GAO" / "GP3P": Kneip's P3P + a 4th point
+    return _ransac(b, p, threshold, max_iterations, epnp=(name == "EPNP"))
 
 
 def absolute_pose_optimize_nonlinear(b, p, t, R):
