@@ -60,6 +60,27 @@ def host_cores():
         return max(1, os.cpu_count() or 1)
 
 
+def valu_issue(kernel, pairs_per_launch, avg_launch_s):
+    """VALU instruction issue rate of `kernel` against the SIMDs' issue limit, from the newest committed SQ-counter
+    summary (profiles/*/*_sq_per_kernel.csv: rocprofv3 --pmc SQ_INSTS_VALU ... of this command at B = 64, one
+    stream): the figure that actually bounds the dominant kernel.  None without a summary."""
+    import csv
+    import glob
+    label = kernel.strip("()").split("<")[0]
+    for path in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*sq_per_kernel.csv")))):
+        with open(path) as fh:
+            for row in csv.DictReader(fh):
+                if row.get("label") == label:
+                    insts = float(row["valu_insts"]) * pairs_per_launch / 64.0  # the SQ pass ran 64 pairs per launch
+                    limit = 1024 * 2.4e9 / 4.3  # wave-instructions/s: 1024 SIMDs, 4.3 cycles per VOP3-class instruction
+                    return {"kernel": kernel, "valu_wave_insts_per_launch": insts, "achieved_ginst_s": insts / avg_launch_s / 1e9,
+                            "issue_limit_ginst_s": limit / 1e9, "frac": insts / avg_launch_s / limit,
+                            "source": os.path.relpath(path, ROOT),
+                            "note": "instruction count from the SQ pass (one stream); with two streams the launch "
+                                    "duration includes issue slots shared with the other stream's kernels"}
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -249,6 +270,7 @@ def main():
                          "algorithmic_bytes_per_pair": b_alg, "algorithmic_bytes_per_launch": b_alg_launch,
                          "note": "no contraction anywhere (no MFMA); the dominant kernel is VALU-bound integer/bit work, "
                                  "so the HBM fraction is small by construction (SURVEY 8d)"},
+            "valu_issue": valu_issue(dom[0], dom_pairs, dom_avg_s),
             "streams": eng.S,
             "kernels_ms_per_step": {k: v[1] / args.steps for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])},
             "kernel_ms_per_step_total": sum(v[1] for v in per_kernel.values()) / args.steps,
