@@ -85,6 +85,11 @@ class Context(object):
                                                msg.decode() if msg else ""))
 
     # ---- plumbing ----------------------------------------------------------------------
+    def set_stream(self, stream):
+        """Enqueue on `stream` (a torch.cuda.Stream) from now on, e.g. the capture stream of a HIP graph."""
+        self._call(self._lib.sosvo_set_stream, c_p(stream.cuda_stream))
+        self.stream = stream
+
     def synchronize(self):
         self._call(self._lib.sosvo_synchronize)
 
