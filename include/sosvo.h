@@ -93,8 +93,10 @@ int32_t sosvo_unwrap(sosvo_ctx* ctx, const uint8_t* omni, const uint8_t* masks, 
 
 /* Table-driven form of K1 for the batched path (identical results): sosvo_unwrap_prepare folds the
  * float maps, the 1/32-px rounding, the border test and the annulus masks into a packed table
- * [2, rows, cols, 2] u32 once per model; sosvo_unwrap_table then unwraps nframes frames with one 8-byte
- * table load and four 4-byte tap loads per panorama pixel.                                       */
+ * [2, rows, cols, 2] u32 once per model (an opaque 8-byte entry per panorama pixel: the byte offset of the first
+ * tap and the four blend weights; the table is specific to (H, W), and frames larger than 4 MB take a slower,
+ * still exact entry format); sosvo_unwrap_table then unwraps nframes frames with one 8-byte table load and two
+ * unaligned 8-byte tap loads per panorama pixel.  H * W * 3 >= 2 * 3 * W + 8.                              */
 int32_t sosvo_unwrap_prepare(sosvo_ctx* ctx, const uint8_t* masks, const float* map_x, const float* map_y,
                              int32_t H, int32_t W, int32_t rows, int32_t cols, uint32_t* table);
 int32_t sosvo_unwrap_table(sosvo_ctx* ctx, const uint8_t* omni, const uint32_t* table, int32_t nframes,
