@@ -1,0 +1,94 @@
+/* The C ABI of libsosvo.so used from plain C (no Python, no torch): the whole hot path for B frame pairs through
+ * sosvo_unwrap_prepare + sosvo_frame_pair_batch on buffers from hipMalloc.
+ *
+ *   c_abi_batch <input.bin> <output.bin>
+ *
+ * input.bin (written by tests/test_gpu_c_abi_example.py): struct sosvo_batch_cfg, struct sosvo_rig, then the raw
+ * arrays omni [2B,H,W,3] u8, annulus masks [2,H,W] u8, map_x, map_y [2,rows,cols] f32, mask_bits [2,rows,cols] u32,
+ * pattern [512,2] i8.  output.bin: results [B,16] f64.
+ * Build: gcc -O2 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude examples/c_abi_batch.c -o examples/c_abi_batch \
+ *            -Lvo_single_camera_sos_amd -l:libsosvo.so -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$ORIGIN/../vo_single_camera_sos_amd' */
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "sosvo.h"
+
+#define CHECK_HIP(x)                                                              \
+  do {                                                                            \
+    hipError_t e_ = (x);                                                          \
+    if (e_ != hipSuccess) {                                                       \
+      fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));                     \
+      return 2;                                                                   \
+    }                                                                             \
+  } while (0)
+#define CHECK_SOSVO(x)                                                            \
+  do {                                                                            \
+    int32_t rc_ = (x);                                                            \
+    if (rc_ != SOSVO_OK) {                                                        \
+      fprintf(stderr, "%s -> %d: %s\n", #x, rc_, sosvo_last_error(ctx));          \
+      return 3;                                                                   \
+    }                                                                             \
+  } while (0)
+
+static void* upload(FILE* f, size_t bytes) {
+  void* host = malloc(bytes);
+  void* dev = NULL;
+  if (!host || fread(host, 1, bytes, f) != bytes) {
+    fprintf(stderr, "short input file\n");
+    exit(4);
+  }
+  if (hipMalloc(&dev, bytes) != hipSuccess || hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+    fprintf(stderr, "device upload failed\n");
+    exit(5);
+  }
+  free(host);
+  return dev;
+}
+
+int main(int argc, char** argv) {
+  if (argc != 3) {
+    fprintf(stderr, "usage: %s input.bin output.bin\n", argv[0]);
+    return 1;
+  }
+  FILE* f = fopen(argv[1], "rb");
+  if (!f) return 1;
+  sosvo_batch_cfg cfg;
+  sosvo_rig rig;
+  if (fread(&cfg, sizeof(cfg), 1, f) != 1 || fread(&rig, sizeof(rig), 1, f) != 1) return 4;
+  const size_t B = (size_t)cfg.n_pairs, HW = (size_t)cfg.H * cfg.W, P = (size_t)cfg.rows * cfg.cols;
+  uint8_t* omni = (uint8_t*)upload(f, 2 * B * HW * 3);
+  uint8_t* masks = (uint8_t*)upload(f, 2 * HW);
+  float* map_x = (float*)upload(f, 2 * P * sizeof(float));
+  float* map_y = (float*)upload(f, 2 * P * sizeof(float));
+  uint32_t* mask_bits = (uint32_t*)upload(f, 2 * P * sizeof(uint32_t));
+  int8_t* pattern = (int8_t*)upload(f, 512 * 2);
+  fclose(f);
+
+  sosvo_ctx* ctx = NULL;
+  if (sosvo_create(&ctx, 0, NULL) != SOSVO_OK) {  /* device 0, the default stream */
+    fprintf(stderr, "sosvo_create failed\n");
+    return 3;
+  }
+  uint32_t* table = NULL;
+  void* workspace = NULL;
+  double* results = NULL;
+  CHECK_HIP(hipMalloc((void**)&table, 2 * P * 2 * sizeof(uint32_t)));
+  CHECK_SOSVO(sosvo_unwrap_prepare(ctx, masks, map_x, map_y, cfg.H, cfg.W, cfg.rows, cfg.cols, table));  /* once per model */
+  const size_t ws_bytes = sosvo_frame_pair_batch_workspace(&cfg);
+  CHECK_HIP(hipMalloc(&workspace, ws_bytes));
+  CHECK_HIP(hipMalloc((void**)&results, B * 16 * sizeof(double)));
+  CHECK_SOSVO(sosvo_frame_pair_batch(ctx, &rig, &cfg, omni, table, mask_bits, pattern, workspace, ws_bytes, results));
+  CHECK_SOSVO(sosvo_synchronize(ctx));
+  double* host = (double*)malloc(B * 16 * sizeof(double));
+  CHECK_HIP(hipMemcpy(host, results, B * 16 * sizeof(double), hipMemcpyDeviceToHost));
+  FILE* o = fopen(argv[2], "wb");
+  if (!o || fwrite(host, sizeof(double), B * 16, o) != B * 16) return 6;
+  fclose(o);
+  for (size_t i = 0; i < B; ++i)
+    printf("pair %zu: %d inliers of %d correspondences, status %d\n", i, (int)host[16 * i + 12], (int)host[16 * i + 13],
+           (int)host[16 * i + 14]);
+  sosvo_destroy(ctx);
+  return 0;
+}
