@@ -250,7 +250,8 @@ def main():
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8 (images, Hamming) + f32 (corner response) + f64 (geometry, RANSAC)", "data": "synthetic",
+            "dtype": "u8/f32/f64",  # images + Hamming in u8 / bits, corner response in f32, geometry + RANSAC + LM in f64
+            "data": "synthetic",
             "config": {"workload": "C2: 640x480 BGR omni frame pair -> 2 x %dx%d panoramas per frame, 11x11 median, "
                                    "%s detector (budget %d per azimuthal mask x %d masks) + ORB descriptors, "
                                    "%d bucket + 2 frame-to-frame BF Hamming matchings, midpoint triangulation, "

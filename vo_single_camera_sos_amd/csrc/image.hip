@@ -280,7 +280,6 @@ __global__ __launch_bounds__(kThreads) void median_gray_kernel(const uint8_t* __
   constexpr int R = K / 2;
   constexpr int NB = K * K;
   constexpr int NW = (NB + 31) / 32;      // words per bit-plane: 4 for 11 x 11
-  constexpr uint32_t LASTMASK = (NB & 31) ? ((1u << (NB & 31)) - 1u) : 0xFFFFFFFFu;  // window bits of the last word
   constexpr int OUTW = 64 - 2 * R;        // output columns per wave
   constexpr uint32_t ABOVE = NB - (NB / 2 + 1);  // window elements ranked above the median
   const int lane = threadIdx.x & 63;
@@ -359,7 +358,7 @@ __global__ __launch_bounds__(kThreads) void median_gray_kernel(const uint8_t* __
       uint32_t C[NW];
 #pragma unroll
       for (int j = 0; j < NW; ++j) C[j] = 0xFFFFFFFFu;
-      C[NW - 1] = LASTMASK;
+      // (the unused top bits of the last word are never set in a window register, so no mask is needed)
       uint32_t above = ABOVE, res = 0u;
 #pragma unroll
       for (int b = 7; b >= 0; --b) {
