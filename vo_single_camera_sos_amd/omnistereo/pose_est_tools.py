@@ -449,6 +449,7 @@ def run_VO(visualizer_3D_VO, camera_model, gt_poses_filename=None, est_poses_fil
     from .common_tools import get_poses_from_file
     if visualizer_3D_VO is not None:
         raise NotImplementedError("3-D visualisation is not built: pass visualizer_3D_VO=None")
+    pyopengv.set_seed(0)  # a run is a pure function of its inputs (OpenGV seeds its sampler from the clock)
     prefix = thread_name + ": " if len(thread_name) > 0 else ""
     rgbd = _is_rgbd_model(camera_model)
     trackerClass, KeyFrameClass = (TrackerRGBDSE3, RGBDKeyFrame) if rgbd else (TrackerStereoSE3, StereoPanoramicKeyFrame)

@@ -12,9 +12,10 @@ the frame the points are given in (points map by R^T (p - t), pose_est_tools.py:
 is 1 - cos(angle); inlier indices come back ascending (relied on at pose_est_tools.py:787-806).
 
 Differences from OpenGV, by design (DESIGN.md "RANSAC"):
-  * hypotheses always come from Kneip's P3P on three correspondences of one camera plus a fourth point for
-    disambiguation -- for the non-central call (OpenGV: GP3P) and for every `algo_name` of the central call
-    ("KNEIP", "GAO", "EPNP", "GP3P"; "TWOPT" needs a known rotation and is not built);
+  * hypotheses come from Kneip's P3P on three correspondences of one camera plus a fourth point for
+    disambiguation -- for the non-central call (OpenGV: GP3P) and for the central names "KNEIP", "GAO", "GP3P";
+    the central "EPNP" draws 6-point samples and solves them with EPnP, as OpenGV does ("TWOPT" needs a known
+    rotation and is not built);
   * sampling is a counter-based generator: results are a pure function of (inputs, seed).  `set_seed` fixes the
     seed of the next call; every call advances it by one (OpenGV seeds from the clock)."""
 import numpy as np
