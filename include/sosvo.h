@@ -259,7 +259,8 @@ int32_t sosvo_ransac_abs_pose(sosvo_ctx* ctx, const double* f, const double* p, 
 /* ---- K9: non-linear refinement --------------------------------------------------------------
  * Replaces pyopengv.absolute_pose_noncentral_optimize_nonlinear (pose_est_tools.py:830) and
  * absolute_pose_optimize_nonlinear (:937): Levenberg-Marquardt on (t, Cayley(R)), residual
- * 1 - f . f_hat per correspondence, forward-difference Jacobian.  Same layout as the RANSAC call;
+ * 1 - f . f_hat per correspondence, analytic Jacobian (OpenGV differentiates numerically).  Same layout as the
+ * RANSAC call;
  * idx/m (both or neither): the first m[b] entries of idx[b*stride ...] select the correspondences
  * (e.g. inlier_idx / n_inliers of sosvo_ransac_abs_pose); NULL = all n[b].
  * T_io [nprob,3,4] in: start pose, out: refined pose.  cost_out [nprob] f64 and iters_out
