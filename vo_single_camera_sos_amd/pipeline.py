@@ -57,15 +57,22 @@ class FramePairPipeline(object):
             self.n_top, self.n_bot = z((P,), torch.int32), z((P,), torch.int32)
         self.s_keys, self.s_order = z((P, bucket_cap, 1), torch.uint32), z((P, bucket_cap), torch.int32)
         Fc, Cc = self.frame_cap, self.corr_cap
+        # descriptors and counts of both views back to back (view-major): the two frame-to-frame matchings of a step
+        # (top with top, bottom with bottom) are ONE launch of 2B problems, and so are the two sorts
+        self._d2 = z((2, self.F, Fc, 32), torch.uint8)
+        self._M2 = z((2, self.F), torch.int32)
         self.frames = dict(m_top=z((self.F, Fc, 2), torch.float32), m_bot=z((self.F, Fc, 2), torch.float32),
-                           d_top=z((self.F, Fc, 32), torch.uint8), d_bot=z((self.F, Fc, 32), torch.uint8),
+                           d_top=self._d2[0], d_bot=self._d2[1],
                            X=z((self.F, Fc, 3), torch.float64), b_top=z((self.F, Fc, 3), torch.float64),
-                           b_bot=z((self.F, Fc, 3), torch.float64), M=z((self.F,), torch.int32),
+                           b_bot=z((self.F, Fc, 3), torch.float64), M=self._M2[0],
                            n_cand=z((self.F,), torch.int32))
         self.ref_frame = torch.arange(0, self.F, 2, dtype=torch.int32, device=dev)
         self.cur_frame = torch.arange(1, self.F, 2, dtype=torch.int32, device=dev)
-        self.k_top, self.k_bot = z((self.B, Fc, 1), torch.uint32), z((self.B, Fc, 1), torch.uint32)
-        self.o_top, self.o_bot = z((self.B, Fc), torch.int32), z((self.B, Fc), torch.int32)
+        self._q2 = torch.cat([self.cur_frame, self.cur_frame + self.F])   # problem i: top view, B + i: bottom view
+        self._t2 = torch.cat([self.ref_frame, self.ref_frame + self.F])
+        self._k2, self._o2 = z((2 * self.B, Fc, 1), torch.uint32), z((2 * self.B, Fc), torch.int32)
+        self.k_top, self.k_bot = self._k2[: self.B], self._k2[self.B:]
+        self.o_top, self.o_bot = self._o2[: self.B], self._o2[self.B:]
         self.corr = dict(f=z((self.B, Cc, 3), torch.float64), p=z((self.B, Cc, 3), torch.float64),
                          cam=z((self.B, Cc), torch.int32), q=z((self.B, Cc), torch.int32),
                          t=z((self.B, Cc), torch.int32), n=z((self.B,), torch.int32), n_top=z((self.B,), torch.int32))
@@ -94,12 +101,10 @@ class FramePairPipeline(object):
 
     def track(self):
         c, fr = self.ctx, self.frames
-        c.match_hamming(fr["d_top"], fr["d_top"], fr["M"], fr["M"], k=1, keys=self.k_top, q_slot=self.cur_frame,
-                        t_slot=self.ref_frame)
-        c.sort_matches(self.k_top, fr["M"], order=self.o_top, q_slot=self.cur_frame)
-        c.match_hamming(fr["d_bot"], fr["d_bot"], fr["M"], fr["M"], k=1, keys=self.k_bot, q_slot=self.cur_frame,
-                        t_slot=self.ref_frame)
-        c.sort_matches(self.k_bot, fr["M"], order=self.o_bot, q_slot=self.cur_frame)
+        self._M2[1].copy_(self._M2[0])                      # the bottom view's blocks have the same counts
+        d2, M2 = self._d2.view(2 * self.F, self.frame_cap, 32), self._M2.view(2 * self.F)
+        c.match_hamming(d2, d2, M2, M2, k=1, keys=self._k2, q_slot=self._q2, t_slot=self._t2)   # both views, 2B problems
+        c.sort_matches(self._k2, M2, order=self._o2, q_slot=self._q2)
         c.f2f_assemble(self.rig, fr, self.ref_frame, self.cur_frame, self.k_top, self.o_top, self.k_bot, self.o_bot,
                        self.corr_cap, out=self.corr)
         co = self.corr
