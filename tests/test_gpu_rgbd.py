@@ -21,8 +21,12 @@ def _render_rgbd(room, R, t, rng, depth_is_Z=True):
     return synthetic.render_rgbd(room, R, t, rng, FX, FY, CX, CY, depth_is_Z=depth_is_Z)
 
 
-@pytest.mark.parametrize("depth_is_Z,thr_deg", [(True, 5.0), (False, 0.5)])
-def test_rgbd_pairs_end_to_end_parity(ctx, depth_is_Z, thr_deg):
+YAW = np.deg2rad(40.0)  # the rig looks into a corner of the room: two walls in view (EPnP needs non-coplanar points)
+R_YAW = np.array([[np.cos(YAW), -np.sin(YAW), 0.0], [np.sin(YAW), np.cos(YAW), 0.0], [0.0, 0.0, 1.0]])
+
+
+@pytest.mark.parametrize("depth_is_Z,thr_deg,algo", [(True, 5.0, "EPNP"), (False, 0.5, "EPNP"), (True, 0.5, "KNEIP")])
+def test_rgbd_pairs_end_to_end_parity(ctx, depth_is_Z, thr_deg, algo):
     """thr_deg 5 is the reference's RANSAC threshold (pose_est_tools.py:675); with it the narrow-FOV pose is only
     loosely constrained (rotation trades against sideways translation), so the recovery of the planted motion
     is asserted on the 0.5-degree run."""
@@ -32,7 +36,7 @@ def test_rgbd_pairs_end_to_end_parity(ctx, depth_is_Z, thr_deg):
         rng = np.random.default_rng(900 + i)
         room = synthetic.Room(seed=900 + i, half_x=(1800.0, 2600.0), half_y=(2500.0, 3500.0), cells=(150.0, 40.0))
         R, t = synthetic.random_step(rng, max_t=80.0, max_deg=8.0)
-        for (Rw, tw) in ((np.eye(3), np.zeros(3)), (R, t)):
+        for (Rw, tw) in ((R_YAW, np.zeros(3)), (R_YAW @ R, R_YAW @ t)):   # pose of the current rig in the reference rig: (R, t)
             im, dp = _render_rgbd(room, Rw, tw, rng, depth_is_Z)
             bgr.append(im)
             depth.append(dp)
@@ -41,7 +45,7 @@ def test_rgbd_pairs_end_to_end_parity(ctx, depth_is_Z, thr_deg):
     depth[5] = 0.0                                            # pair 2: no depth in the current frame -> cannot track
     cam = RGBDCamConfig(fx=FX, fy=FY, center_x=CX, center_y=CY, depth_is_Z=depth_is_Z, min_range=0.8, max_range=7.0)
     pipe = RGBDPairPipeline(ctx, cam, B, num_of_features=nfeat, max_iter=400, seed=31,
-                            thr=1.0 - np.cos(np.deg2rad(thr_deg)))
+                            thr=1.0 - np.cos(np.deg2rad(thr_deg)), pose_est_algorithm=algo)
     assert pipe.kp_cap > 1024                                 # large-mask detector variant
     pipe.load_frames(bgr, depth)
     pipe.step()
@@ -63,14 +67,14 @@ def test_rgbd_pairs_end_to_end_parity(ctx, depth_is_Z, thr_deg):
     mask = pipe.ransac["mask"].cpu().numpy()
     cq, ct = pipe.corr["q"].cpu().numpy(), pipe.corr["t"].cpu().numpy()
     for i in range(B):
-        w = refflow.track_pair_rgbd(rc, frames[2 * i], frames[2 * i + 1], pipe.thr, 400, seed=31 + i)
+        w = refflow.track_pair_rgbd(rc, frames[2 * i], frames[2 * i + 1], pipe.thr, 400, seed=31 + i, epnp=(algo == "EPNP"))
         n = len(w["corr"]["q"])
         assert rec[i, 13] == n and np.array_equal(cq[i, :n], w["corr"]["q"]) and np.array_equal(ct[i, :n], w["corr"]["t"])
         assert rec[i, 14] == w["ransac"]["status"] and rec[i, 12] == w["ransac"]["n_inliers"]
         assert rec[i, 15] == w["ransac"]["best_iter"]
         assert np.array_equal(mask[i, :n].astype(bool), w["ransac"]["mask"])
         assert np.allclose(rec[i, :12].reshape(3, 4), w["T"], rtol=1e-6, atol=1e-9)
-    assert rec[2, 14] == 1 and rec[2, 13] == 0
+    assert rec[2, 14] == 1 and rec[2, 13] == 0 and (rec[:2, 14] == 0).all() and (rec[:2, 12] > 300).all()
     # the planted motion is recovered: pose of the current camera in the reference camera frame, metres
     C = np.array([[1.0, 0, 0], [0, 0, 1.0], [0, -1.0, 0]])
     for i in range(2 if thr_deg < 1.0 else 0):

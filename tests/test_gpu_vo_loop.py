@@ -72,4 +72,4 @@ def test_demo_vo_rgbd_end_to_end(ctx, tmp_path):
     # test_gpu_rgbd.py); the trajectory stays within a few degrees / decimetres of the planted one
     for i in range(1, n):
         E = tr.rpe(gt[i], est[i])
-        assert tr.rpe_rotation_metric(E) < np.deg2rad(12.0) and tr.rpe_translation_metric(E) < 0.8, (i, E)
+        assert tr.rpe_rotation_metric(E) < np.deg2rad(10.0) and tr.rpe_translation_metric(E) < 0.6, (i, E)

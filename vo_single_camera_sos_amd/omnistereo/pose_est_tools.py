@@ -419,6 +419,10 @@ class TrackerRGBDSE3(TrackerSE3):
                                                           self.max_ransac_iterations_3D_to_2D)
         self.num_tracked_correspondences = len(inliers)
         self.inlier_tracked_correspondences_ratio = float(self.num_tracked_correspondences) / float(num_initial_matches)
+        if self.num_tracked_correspondences < self.n_points_for_RANSAC_model:
+            # no consensus model (e.g. EPNP on an exactly coplanar point set, where it has no solution): report the
+            # frame as not tracked instead of refining from an empty inlier set
+            return False, "RANSAC (%s) found no model among %d correspondences" % (self.pose_est_algorithm, num_initial_matches)
         T_nl = pyopengv.absolute_pose_optimize_nonlinear(b[inliers], p[inliers], T_ransac[:3, 3], T_ransac[:3, :3])
         T_homo = np.identity(4)
         T_homo[:3] = T_nl

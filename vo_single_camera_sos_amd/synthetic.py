@@ -33,11 +33,15 @@ def _hash3(ix, iy, iz, salt):
 
 
 class Room(object):
-    """Axis-aligned room (mm) with a few interior pillars, textured by hashed multi-scale cells."""
+    """Box room (mm), textured by hashed multi-scale cells; axis-aligned in its own frame, which is the world frame
+    turned by yaw_deg about the vertical (so that a forward-looking pinhole camera at the identity pose sees a corner,
+    i.e. non-coplanar structure, rather than a single wall)."""
 
     def __init__(self, seed=0, half_x=(2600.0, 3400.0), half_y=(2100.0, 3900.0), z_floor=-1400.0, z_ceil=1500.0,
-                 cells=(260.0, 65.0)):
+                 cells=(260.0, 65.0), yaw_deg=0.0):
         rng = np.random.default_rng(seed)
+        a = np.deg2rad(yaw_deg)
+        self.R_room = np.array([[np.cos(a), -np.sin(a), 0.0], [np.sin(a), np.cos(a), 0.0], [0.0, 0.0, 1.0]])  # room -> world
         self.seed = int(seed)
         self.planes = [(0, -rng.uniform(*half_x)), (0, rng.uniform(*half_x)), (1, -rng.uniform(*half_y)),
                        (1, rng.uniform(*half_y)), (2, z_floor), (2, z_ceil)]
@@ -46,9 +50,10 @@ class Room(object):
     def cast(self, origins, dirs):
         """origins [3], dirs [n,3] -> hit points [n,3] (nearest plane in front of the ray)."""
         t_best = np.full(dirs.shape[0], np.inf)
+        o_room, d_room = np.asarray(origins) @ self.R_room, dirs @ self.R_room
         for axis, val in self.planes:
             with np.errstate(divide="ignore", invalid="ignore"):
-                t = (val - origins[axis]) / dirs[:, axis]
+                t = (val - o_room[axis]) / d_room[:, axis]
             t = np.where(t > 1e-6, t, np.inf)
             t_best = np.minimum(t_best, t)
         return origins + dirs * t_best[:, None], t_best
@@ -56,6 +61,7 @@ class Room(object):
     def colour(self, P):
         """World points [n,3] -> BGR uint8 [n,3]."""
         out = np.zeros((P.shape[0], 3), dtype=np.float64)
+        P = P @ self.R_room
         weights = (0.62, 0.38)
         for lvl, (cell, w) in enumerate(zip(self.cells, weights)):
             idx = np.floor(P / cell + 0.5 * lvl).astype(np.int64)
@@ -197,7 +203,7 @@ def write_sos_sequence(path, gums, n_frames=6, seed=0, max_t=40.0, max_deg=2.0):
     return poses
 
 
-def write_rgbd_sequence(path, n_frames=6, seed=0, max_t=40.0, max_deg=2.0, depth_is_Z=False):
+def write_rgbd_sequence(path, n_frames=6, seed=0, max_t=40.0, max_deg=2.0, depth_is_Z=False, yaw_deg=40.0):
     """<path>/rgbd/rgb/%04d.png, <path>/rgbd/depth/%04d.png (16-bit, mm) + gt_TUM.txt: what demo_vo_rgbd.py reads
     (its synthetic setting stores RADIAL depth, demo_vo_rgbd.py:68)."""
     import os
@@ -205,7 +211,7 @@ def write_rgbd_sequence(path, n_frames=6, seed=0, max_t=40.0, max_deg=2.0, depth
     from .omnistereo.common_cv import imwrite
     for sub in ("rgb", "depth"):
         os.makedirs(os.path.join(path, "rgbd", sub), exist_ok=True)
-    room = Room(seed=seed, half_x=(1800.0, 2600.0), half_y=(2500.0, 3500.0), cells=(150.0, 40.0))
+    room = Room(seed=seed, half_x=(1800.0, 2600.0), half_y=(2500.0, 3500.0), cells=(150.0, 40.0), yaw_deg=yaw_deg)
     poses = trajectory(n_frames, seed, max_t, max_deg)
     rng = np.random.default_rng(seed + 1)
     for i, (R, t) in enumerate(poses):
