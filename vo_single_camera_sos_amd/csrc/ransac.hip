@@ -199,6 +199,7 @@ __global__ __launch_bounds__(kThreads) void ransac_score_kernel(
     int32_t* __restrict__ counts) {
   __shared__ int lcnt[kScoreHypChunkMax];
   __shared__ double shyp[kScoreHypChunkMax][12];
+  __shared__ unsigned long long sok[(kScoreHypChunkMax + 63) / 64];  // bit = hypothesis of the chunk is a solved one
   const int tid = threadIdx.x, b = blockIdx.z;
   const int n = min(n_arr[b], stride);
   // XCD-aware grid: workgroups are dealt round-robin over the 8 XCDs by linear id, so the dimension with
@@ -211,19 +212,22 @@ __global__ __launch_bounds__(kThreads) void ransac_score_kernel(
 
   double fx[PPT], fy[PPT], fz[PPT], px[PPT], py[PPT], pz[PPT], ox[PPT], oy[PPT], oz[PPT];
   double Rc[IDENT ? 1 : 9];
-  bool valid[PPT];
-  const size_t base = (size_t)b * stride;
   // point sets of 64 are dealt round-robin over the 4 waves (set = r * 4 + wave): the live sets of a ragged
-  // problem spread evenly, and a wave skips its sets beyond n altogether (wave-uniform test)
-  const int wave = tid >> 6, lane = tid & 63;
+  // problem spread evenly, and a wave skips its sets beyond n altogether.  Everything that steers the hot loop
+  // is wave-uniform and kept in SGPRs (wave index by readfirstlane, ballots, popcounts): the loop has scalar
+  // branches only, no exec-mask juggling.
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const size_t base = (size_t)b * stride;
   bool live[PPT];
+  unsigned long long vmask[PPT];
 #pragma unroll
   for (int r = 0; r < PPT; ++r) {
     const int i0 = p0 + (r * (kThreads / 64) + wave) * 64;
     const int i = i0 + lane;
     live[r] = i0 < n;
-    valid[r] = i < n;
-    const size_t row = base + (valid[r] ? i : p0);
+    const bool valid = i < n;
+    vmask[r] = __ballot(valid);
+    const size_t row = base + (valid ? i : p0);
     fx[r] = f[3 * row + 0];
     fy[r] = f[3 * row + 1];
     fz[r] = f[3 * row + 2];
@@ -251,66 +255,81 @@ __global__ __launch_bounds__(kThreads) void ransac_score_kernel(
     const int hh = k / 12, e = k - hh * 12;
     shyp[hh][e] = hb[(size_t)hh * kHypDoubles + (e < 9 ? e : e + 3)];
   }
+  if (wave * 64 < h1 - h0) {  // wave w flags hypotheses [64 w, 64 w + 64): a failed minimal solve left a NaN in R[0]
+    const int hh = wave * 64 + lane;
+    const double r00 = hh < h1 - h0 ? hb[(size_t)hh * kHypDoubles] : 0.0;
+    const unsigned long long okb = __ballot(hh < h1 - h0 && r00 == r00);
+    if (lane == 0) sok[wave] = okb;
+  }
   __syncthreads();
 
-  for (int h = h0; h < h1; ++h) {
-    const double* hp = shyp[h - h0];
-    const double r0 = hp[0];
-    if (r0 != r0) continue;  // failed minimal solve
-    const double r1 = hp[1], r2 = hp[2], r3 = hp[3], r4 = hp[4], r5 = hp[5], r6 = hp[6], r7 = hp[7], r8 = hp[8];
-    const double ix = hp[9], iy = hp[10], iz = hp[11];
-    int wave_total = 0;
-#pragma unroll
-    for (int r = 0; r < PPT; ++r) {
-      if (!live[r]) continue;
+  for (int w64 = 0; w64 * 64 < h1 - h0; ++w64) {
+    const unsigned long long okw = sok[w64];
+    unsigned long long todo = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(okw >> 32)) << 32) |
+                              (uint32_t)__builtin_amdgcn_readfirstlane((int)okw);
+    while (todo) {
+      const int hh = w64 * 64 + __builtin_ctzll(todo);
+      todo &= todo - 1;
+      const double* hp = shyp[hh];
+      const double r0 = hp[0], r1 = hp[1], r2 = hp[2], r3 = hp[3], r4 = hp[4], r5 = hp[5], r6 = hp[6], r7 = hp[7], r8 = hp[8];
+      const double ix = hp[9], iy = hp[10], iz = hp[11];
       // Fast decision with fused multiply-adds (21 instead of 34 FP64 ops): squared-cosine test with a relative
       // guard band of 1e-9, five orders of magnitude above the rounding difference between this evaluation and
-      // the exact one below for |p| / |u| < 1e6.  Inside the band the oracle's formula decides, operation for
-      // operation (no contraction), so the counts are identical to the sequential reference.
-      bool inl = false, decided = false;
-      if (fast_ok) {
-        double ux = fma(r0, px[r], fma(r3, py[r], fma(r6, pz[r], ix - ox[r])));
-        double uy = fma(r1, px[r], fma(r4, py[r], fma(r7, pz[r], iy - oy[r])));
-        double uz = fma(r2, px[r], fma(r5, py[r], fma(r8, pz[r], iz - oz[r])));
-        if (!IDENT) {
-          const double wx = ux, wy = uy, wz = uz;
-          ux = fma(Rc[0], wx, fma(Rc[IDENT ? 0 : 3], wy, Rc[IDENT ? 0 : 6] * wz));
-          uy = fma(Rc[IDENT ? 0 : 1], wx, fma(Rc[IDENT ? 0 : 4], wy, Rc[IDENT ? 0 : 7] * wz));
-          uz = fma(Rc[IDENT ? 0 : 2], wx, fma(Rc[IDENT ? 0 : 5], wy, Rc[IDENT ? 0 : 8] * wz));
+      // the exact one for |p| / |u| < 1e6.  Lanes inside the band are left to the oracle's formula, operation for
+      // operation (no contraction), so the counts are identical to the sequential reference.  The predicates are
+      // combined without branches; one wave-wide test per hypothesis tells whether any lane is undecided.
+      int total = 0;
+      unsigned long long und[PPT], any = 0ULL;
+#pragma unroll
+      for (int r = 0; r < PPT; ++r) {
+        und[r] = 0ULL;
+        if (!live[r]) continue;  // scalar
+        if (fast_ok) {
+          double ux = fma(r0, px[r], fma(r3, py[r], fma(r6, pz[r], ix - ox[r])));
+          double uy = fma(r1, px[r], fma(r4, py[r], fma(r7, pz[r], iy - oy[r])));
+          double uz = fma(r2, px[r], fma(r5, py[r], fma(r8, pz[r], iz - oz[r])));
+          if (!IDENT) {
+            const double wx = ux, wy = uy, wz = uz;
+            ux = fma(Rc[0], wx, fma(Rc[IDENT ? 0 : 3], wy, Rc[IDENT ? 0 : 6] * wz));
+            uy = fma(Rc[IDENT ? 0 : 1], wx, fma(Rc[IDENT ? 0 : 4], wy, Rc[IDENT ? 0 : 7] * wz));
+            uz = fma(Rc[IDENT ? 0 : 2], wx, fma(Rc[IDENT ? 0 : 5], wy, Rc[IDENT ? 0 : 8] * wz));
+          }
+          const double s = fma(fx[r], ux, fma(fy[r], uy, fz[r] * uz));
+          const double q = fma(ux, ux, fma(uy, uy, uz * uz));
+          const double lhs = s * s;
+          // thr < 0.5: an inlier has cosine > 0.5, far from any rounding of s (NaN: not an inlier)
+          const unsigned long long pos = __ballot(s > 0.0) & vmask[r];
+          const unsigned long long hi = __ballot(lhs > c2hi * q);
+          const unsigned long long lo = __ballot(lhs < c2lo * q);
+          total += __popcll(pos & hi);
+          und[r] = pos & ~hi & ~lo;
+        } else {
+          und[r] = vmask[r];
         }
-        const double s = fma(fx[r], ux, fma(fy[r], uy, fz[r] * uz));
-        const double q = fma(ux, ux, fma(uy, uy, uz * uz));
-        const double lhs = s * s;
-        if (!(s > 0.0)) {  // thr < 0.5: an inlier has cosine > 0.5, far from any rounding of s (NaN: not an inlier)
-          inl = false;
-          decided = true;
-        } else if (lhs > c2hi * q) {
-          inl = true;
-          decided = true;
-        } else if (lhs < c2lo * q) {
-          inl = false;
-          decided = true;
+        any |= und[r];
+      }
+      if (any) {  // scalar; rare when fast_ok
+#pragma unroll
+        for (int r = 0; r < PPT; ++r) {
+          if (!und[r]) continue;  // scalar
+          const double vx = (((r0 * px[r]) + (r3 * py[r])) + (r6 * pz[r])) + ix;
+          const double vy = (((r1 * px[r]) + (r4 * py[r])) + (r7 * pz[r])) + iy;
+          const double vz = (((r2 * px[r]) + (r5 * py[r])) + (r8 * pz[r])) + iz;
+          const double wx = vx - ox[r], wy = vy - oy[r], wz = vz - oz[r];
+          double ux = wx, uy = wy, uz = wz;
+          if (!IDENT) {
+            ux = ((Rc[0] * wx) + (Rc[IDENT ? 0 : 3] * wy)) + (Rc[IDENT ? 0 : 6] * wz);
+            uy = ((Rc[IDENT ? 0 : 1] * wx) + (Rc[IDENT ? 0 : 4] * wy)) + (Rc[IDENT ? 0 : 7] * wz);
+            uz = ((Rc[IDENT ? 0 : 2] * wx) + (Rc[IDENT ? 0 : 5] * wy)) + (Rc[IDENT ? 0 : 8] * wz);
+          }
+          const double q = ((ux * ux) + (uy * uy)) + (uz * uz);
+          const double nrm = sqrt(q);
+          const double gx = ux / nrm, gy = uy / nrm, gz = uz / nrm;
+          total += __popcll(__ballot((1.0 - (((fx[r] * gx) + (fy[r] * gy)) + (fz[r] * gz))) < thr) & und[r]);
         }
       }
-      if (!decided) {
-        const double vx = (((r0 * px[r]) + (r3 * py[r])) + (r6 * pz[r])) + ix;
-        const double vy = (((r1 * px[r]) + (r4 * py[r])) + (r7 * pz[r])) + iy;
-        const double vz = (((r2 * px[r]) + (r5 * py[r])) + (r8 * pz[r])) + iz;
-        const double wx = vx - ox[r], wy = vy - oy[r], wz = vz - oz[r];
-        double ux = wx, uy = wy, uz = wz;
-        if (!IDENT) {
-          ux = ((Rc[0] * wx) + (Rc[3] * wy)) + (Rc[6] * wz);
-          uy = ((Rc[1] * wx) + (Rc[4] * wy)) + (Rc[7] * wz);
-          uz = ((Rc[2] * wx) + (Rc[5] * wy)) + (Rc[8] * wz);
-        }
-        const double q = ((ux * ux) + (uy * uy)) + (uz * uz);
-        const double nrm = sqrt(q);
-        const double gx = ux / nrm, gy = uy / nrm, gz = uz / nrm;
-        inl = (1.0 - (((fx[r] * gx) + (fy[r] * gy)) + (fz[r] * gz))) < thr;
-      }
-      wave_total += __popcll(__ballot(inl && valid[r]));
+      if (total && lane == 0) atomicAdd(&lcnt[hh], total);
     }
-    if ((tid & 63) == 0 && wave_total) atomicAdd(&lcnt[h - h0], wave_total);
   }
   __syncthreads();
   for (int k = tid; k < h1 - h0; k += kThreads) {
