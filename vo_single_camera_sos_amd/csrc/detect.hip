@@ -548,15 +548,20 @@ __global__ __launch_bounds__(kThreads) void orb_describe_kernel(const uint8_t* _
   }
   __syncthreads();
   const int R = s_R;
-  // Patch path: the (2R+1)^2 neighbourhood of a keypoint goes through LDS (rows of 64 bytes), fetched as
-  // unaligned dwords -- ~40 row segments per keypoint instead of 512 scattered byte loads.  The dword
-  // overrun past a patch row (<= 3 bytes) stays inside the image as long as the border rule keeps R + 1 px.
+  // Patch path: the (2R+1)^2 neighbourhood of a keypoint goes through LDS, fetched as unaligned dwords -- a few
+  // row segments per lane instead of 512 scattered byte loads.  Patch rows are `pstride` dwords apart with
+  // pstride ODD, so the rows spread over all 32 banks (a 64-byte row pitch would leave half of them unused and
+  // turn the scattered byte reads of the tests into 4-6-way conflicts).  The dword overrun past a patch row
+  // (<= 3 bytes) stays inside the image as long as the border rule keeps R + 1 px.
   const bool patch_ok = R <= kPatchMaxR && edge >= R + 1;
+  const int PR = 2 * R + 1;
+  const int pdw = (PR + 3) >> 2;      // dwords per patch row
+  const int pstride = pdw | 1;        // row pitch in dwords
   if (patch_ok)
     for (int i = tid; i < 512; i += kThreads) {
       const int dy = (off[i] + R * cols + R) / cols - R;  // recover (dx, dy): |dx| <= R < cols
       const int dx = off[i] - dy * cols;
-      poff[i] = (uint16_t)((dy + R) * kPatchStride + (dx + R));
+      poff[i] = (uint16_t)((dy + R) * (4 * pstride) + (dx + R));
     }
   for (int i0 = 0; i0 < n; i0 += kThreads) {
     const int i = i0 + tid;
@@ -581,18 +586,26 @@ __global__ __launch_bounds__(kThreads) void orb_describe_kernel(const uint8_t* _
   if (patch_ok) {
     uint32_t* patch32 = patch_lds[wid];
     const uint8_t* patch = reinterpret_cast<const uint8_t*>(patch32);
-    const int prow = lane >> 4, pk = lane & 15;  // 16 lanes (dwords) per patch row, 4 rows per round
-    const int PR = 2 * R + 1, nit = (PR + 3) >> 2;
-    const bool ld_lane = 4 * pk < PR;
+    // 8 lanes (dwords) per patch row and 8 rows per round while a row fits 32 bytes, else 16 lanes x 4 rows.  Lanes
+    // past the row's last dword / rows past the patch repeat the last one (same value to the same LDS word), so the
+    // loads and the LDS writes are unconditional: no exec-mask juggling around a dozen memory instructions.
+    const int lsh = pdw <= 8 ? 3 : 4;
+    const int prow = lane >> lsh, pk = min(lane & ((1 << lsh) - 1), pdw - 1);
+    const int rpr = 64 >> lsh, nit = (PR + rpr - 1) / rpr;  // rows per round, rounds (<= kPatchRows / 4)
     uint32_t reg[kPatchRows / 4];
+    int goff[kPatchRows / 4], lidx[kPatchRows / 4];  // per round: image byte offset / LDS word of this lane's dword
+#pragma unroll
+    for (int it = 0; it < kPatchRows / 4; ++it) {
+      const int r = min(rpr * it + prow, PR - 1);
+      goff[it] = r * cols;
+      lidx[it] = r * pstride + pk;
+    }
     auto issue = [&](int j) {
       const uint8_t* base =
           im + ((size_t)__float2int_rn(lds_kp[2 * j + 1]) - R) * cols + (__float2int_rn(lds_kp[2 * j]) - R) + 4 * pk;
 #pragma unroll
-      for (int it = 0; it < kPatchRows / 4; ++it) {
-        const int r = 4 * it + prow;
-        if (it < nit && ld_lane && r < PR) reg[it] = *reinterpret_cast<const u32_unaligned*>(base + (size_t)r * cols);
-      }
+      for (int it = 0; it < kPatchRows / 4; ++it)
+        if (it < nit) reg[it] = *reinterpret_cast<const u32_unaligned*>(base + goff[it]);  // uniform test
     };
     // this lane's eight patch offsets (tests lane, 64 + lane, 128 + lane, 192 + lane) never change: registers
     int pa[4], pb[4];
@@ -605,10 +618,8 @@ __global__ __launch_bounds__(kThreads) void orb_describe_kernel(const uint8_t* _
     if (j < m) issue(j);
     for (; j < m; j += kThreads / 64) {
 #pragma unroll
-      for (int it = 0; it < kPatchRows / 4; ++it) {
-        const int r = 4 * it + prow;
-        if (it < nit && ld_lane && r < PR) patch32[r * (kPatchStride / 4) + pk] = reg[it];
-      }
+      for (int it = 0; it < kPatchRows / 4; ++it)
+        if (it < nit) patch32[lidx[it]] = reg[it];
       if (j + kThreads / 64 < m) issue(j + kThreads / 64);  // next keypoint's rows fly while this one is tested
       unsigned long long* d = reinterpret_cast<unsigned long long*>(desc + ((size_t)p * cap + j) * 32);
       unsigned long long mine = 0ULL;
