@@ -61,21 +61,32 @@ def host_cores():
 
 
 def valu_issue(kernel, pairs_per_launch, avg_launch_s):
-    """VALU instruction issue rate of `kernel` against the SIMDs' issue limit, from the newest committed SQ-counter
-    summary (profiles/*/*_sq_per_kernel.csv: rocprofv3 --pmc SQ_INSTS_VALU ... of this command at B = 64, one
-    stream): the figure that actually bounds the dominant kernel.  None without a summary."""
+    """VALU instruction issue rate of `kernel` against the SIMDs' issue limit: the figure that actually bounds the
+    dominant kernel.  Instruction count per launch from the newest committed SQ-counter summary
+    (profiles/*/*_sq_per_kernel.csv: rocprofv3 --pmc SQ_INSTS_VALU ... of this command at B = 64, one stream); issue
+    cost per instruction from the kernel's static instruction mix (profiles/*/*_isa_mix.json, scripts/isa_mix.py:
+    2.8 SIMD-cycles for a plain VOP2 encoding, 4.4 for VOP3 / SDWA / DPP / 64-bit ops, both measured on the MI355X by
+    scripts/valu_rate.hip).  None without the summaries."""
     import csv
     import glob
     label = kernel.strip("()").split("<")[0]
+    cyc, mix_src = 4.4, None
+    for path in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*isa_mix.json")))):
+        mix = json.load(open(path))["kernels"]
+        key = {"unwrap_median_gray_kernel": "median_gray_kernel<11, 1>", "median_gray_kernel": "median_gray_kernel<11, 0>"}.get(label, label)
+        if key in mix:
+            cyc, mix_src = mix[key]["issue_cycles_per_valu_inst"], os.path.relpath(path, ROOT)
+            break
     for path in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*sq_per_kernel.csv")))):
         with open(path) as fh:
             for row in csv.DictReader(fh):
                 if row.get("label") == label:
                     insts = float(row["valu_insts"]) * pairs_per_launch / 64.0  # the SQ pass ran 64 pairs per launch
-                    limit = 1024 * 2.4e9 / 4.3  # wave-instructions/s: 1024 SIMDs, 4.3 cycles per VOP3-class instruction
+                    limit = 1024 * 2.4e9 / cyc  # wave-instructions/s of 1024 SIMDs at 2.4 GHz
                     return {"kernel": kernel, "valu_wave_insts_per_launch": insts, "achieved_ginst_s": insts / avg_launch_s / 1e9,
-                            "issue_limit_ginst_s": limit / 1e9, "frac": insts / avg_launch_s / limit,
-                            "source": os.path.relpath(path, ROOT),
+                            "issue_cycles_per_inst": cyc, "issue_limit_ginst_s": limit / 1e9,
+                            "frac": insts / avg_launch_s / limit,
+                            "source": os.path.relpath(path, ROOT), "mix_source": mix_src,
                             "note": "instruction count from the SQ pass (one stream); with two streams the launch "
                                     "duration includes issue slots shared with the other stream's kernels"}
     return None

@@ -98,3 +98,33 @@ def test_rig_json_round_trip():
     assert back.units == gs.units and back.top_model.panorama.cols == 1200
     with pytest.raises(ValueError):
         gums_from_dict({"format": "pickle"})
+
+
+def test_precalibration_bin_layout(tmp_path):
+    """gum.py:216-272: the toolbox's .bin is a run of float64 -- xi (3 or 1), k1 k2 p1 p2 k3, gamma1 gamma2 u v alpha,
+    ROI -- with the centre and ROI 1-based; checked against bytes packed by hand."""
+    import struct
+    from vo_single_camera_sos_amd.omnistereo.gum import GUMParams
+    vals = [0.01, -0.02, 0.93, 0.1, -0.05, 0.001, 0.002, 0.003, 151.5, 150.25, 320.5, 240.5, 0.0005, 11.0, 21.0, 631.0, 471.0]
+    fn = str(tmp_path / "new.bin")
+    with open(fn, "wb") as f:
+        f.write(struct.pack("17d", *vals))
+    p = GUMParams.from_precalibration_bin(fn, new_method=True)
+    assert (p.xi1, p.xi2, p.xi3) == (0.01, -0.02, 0.93)
+    assert (p.k1, p.k2, p.p1, p.p2, p.k3) == (0.1, -0.05, 0.001, 0.002, 0.003)
+    assert (p.gamma1, p.gamma2, p.u_center, p.v_center, p.alpha_c) == (151.5, 150.25, 319.5, 239.5, 0.0005)
+    assert (p.roi_min_x, p.roi_min_y, p.roi_max_x, p.roi_max_y) == (10.0, 20.0, 630.0, 470.0)
+    fn2 = str(tmp_path / "roundtrip.bin")
+    p.to_precalibration_bin(fn2)
+    assert open(fn2, "rb").read() == open(fn, "rb").read()
+    # old method: a single xi3 in front, xi1 = xi2 = 0
+    fn3 = str(tmp_path / "old.bin")
+    with open(fn3, "wb") as f:
+        f.write(struct.pack("15d", *vals[2:]))
+    q = GUMParams.from_precalibration_bin(fn3, new_method=False)
+    assert (q.xi1, q.xi2, q.xi3, q.k1, q.gamma2, q.v_center) == (0.0, 0.0, 0.93, 0.1, 150.25, 239.5)
+    with open(fn3, "ab") as f:
+        pass
+    import pytest
+    with pytest.raises(ValueError):
+        GUMParams.from_precalibration_bin(fn3, new_method=True)  # two values short

@@ -25,6 +25,49 @@ class GUMParams(object):
         self.gamma1, self.gamma2, self.alpha_c = float(gamma1), float(gamma2), float(alpha_c)
         self.u_center, self.v_center = float(u_center), float(v_center)
         self.use_distortion = bool(use_distortion)
+        self.p1 = self.p2 = 0.0                    # tangential terms: stored by the calibration toolbox, unused by the model
+        self.roi_min_x = self.roi_min_y = self.roi_max_x = self.roi_max_y = None
+
+    # The calibration toolbox's pre-calibration .bin (gum.py:216-272): native-endian float64 values, in order
+    #   xi1 xi2 xi3 (new method) | xi3 (old)  k1 k2 p1 p2 k3  gamma1 gamma2 u_center v_center alpha_c  roi_min_x roi_min_y roi_max_x roi_max_y
+    # with the centre and the ROI counted from 1 (MATLAB) -- the reader subtracts 1.
+    _BIN_TAIL = ("k1", "k2", "p1", "p2", "k3", "gamma1", "gamma2", "u_center", "v_center", "alpha_c",
+                 "roi_min_x", "roi_min_y", "roi_max_x", "roi_max_y")
+    _BIN_ONE_BASED = ("u_center", "v_center", "roi_min_x", "roi_min_y", "roi_max_x", "roi_max_y")
+
+    @classmethod
+    def from_precalibration_bin(cls, filename, new_method=True, z_axis=1.0):
+        """Reads a pre-calibration file.  A file that is too short raises ValueError (the reference prints the
+        error and carries on with half-initialised parameters, gum.py:273-275)."""
+        import struct
+        n_head = 3 if new_method else 1
+        n = n_head + len(cls._BIN_TAIL)
+        with open(filename, "rb") as f:
+            block = f.read(8 * n)
+        if len(block) < 8 * n:
+            raise ValueError("%s: %d bytes, a %s-method pre-calibration file has %d" % (filename, len(block),
+                                                                                        "new" if new_method else "old", 8 * n))
+        vals = struct.unpack("%dd" % n, block)
+        out = cls(xi3=1.0 * z_axis)
+        if new_method:
+            out.xi1, out.xi2, out.xi3 = vals[:3]
+        else:
+            out.xi1, out.xi2, out.xi3 = 0.0, 0.0, vals[0]
+        for k, v in zip(cls._BIN_TAIL, vals[n_head:]):
+            setattr(out, k, v - 1.0 if k in cls._BIN_ONE_BASED else v)
+        return out
+
+    def to_precalibration_bin(self, filename, new_method=True):
+        """The inverse of from_precalibration_bin (same layout, centre / ROI back to 1-based)."""
+        import struct
+        head = [self.xi1, self.xi2, self.xi3] if new_method else [self.xi3]
+        tail = []
+        for k in self._BIN_TAIL:
+            v = getattr(self, k)
+            v = 0.0 if v is None else float(v)
+            tail.append(v + 1.0 if k in self._BIN_ONE_BASED else v)
+        with open(filename, "wb") as f:
+            f.write(struct.pack("%dd" % (len(head) + len(tail)), *(head + tail)))
 
 
 class GUM(object):
