@@ -183,7 +183,9 @@ def main():
     workers = args.render_workers if args.render_workers > 0 else max(1, min(16, host_cores() // max(1, world)))
     omni, poses = synthetic.make_frame_pairs(gs, B, seed=args.seed + 100000 * rank, workers=workers)
     dist = None
-    if world > 1:
+    # (SOSVO_BENCH_FORCE_DIST=1: a launcher-started single rank also goes through init_process_group + the RCCL
+    # gather -- tests/test_gpu_bench_rccl.py rehearses the N > 1 code path on the one-GPU box that way)
+    if world > 1 or (os.environ.get("SOSVO_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         local_rank = local_rank % max(1, torch.cuda.device_count())  # (rehearsals with more ranks than GPUs)
