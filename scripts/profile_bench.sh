@@ -17,6 +17,12 @@ rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_${TAG}_fetch --output-format csv --
 echo "fetch pass done"
 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_${TAG}_write --output-format csv -- python3 bench.py $ARGS > gpurun_out/pmc_${TAG}_write.log 2>&1
 echo "write pass done"
+if [ "${SQ_PASS:-1}" = "1" ]; then
+  # 4. instruction counters (their own pass; one stream, 64 pairs per launch -- bench.py's valu_issue scales from that)
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES -d gpurun_out/pmc_${TAG}_sq --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu --render-workers 1 --streams 1 --pairs-per-gpu 64 > gpurun_out/pmc_${TAG}_sq.log 2>&1
+  echo "sq pass done"
+  python3 scripts/summarize_sq.py gpurun_out/pmc_${TAG}_sq > gpurun_out/${TAG}_sq_per_kernel.csv
+fi
 python3 scripts/summarize_pmc.py gpurun_out/pmc_${TAG}_fetch gpurun_out/pmc_${TAG}_write $PAIRS_PER_LAUNCH > gpurun_out/${TAG}_pmc_hbm_per_kernel.csv
 find gpurun_out/prof_$TAG -name "*kernel_stats.csv" -exec cp {} gpurun_out/${TAG}_kernel_stats.csv \;
 grep -h '^{"metric"' gpurun_out/prof_${TAG}_bench.log > gpurun_out/${TAG}_bench_under_rocprof.json || true

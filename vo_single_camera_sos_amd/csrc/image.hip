@@ -283,9 +283,14 @@ __global__ __launch_bounds__(kThreads) void median_gray_kernel(const uint8_t* __
   constexpr int OUTW = 64 - 2 * R;        // output columns per wave
   constexpr uint32_t ABOVE = NB - (NB / 2 + 1);  // window elements ranked above the median
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * kThreads + threadIdx.x) >> 6));  // in an SGPR: per-image bases become scalar
-  if (wave >= nimg * strips) return;  // wave-uniform
-  const int im = wave / strips, strip = wave - im * strips;
+  // XCD-aware grid: workgroups are dealt round-robin over the 8 XCDs by linear id.  XCD x = id % 8 walks its own
+  // list of (image, strip) pairs -- images x, x + 8, x + 16, ... strip by strip, 4 waves per workgroup -- so all
+  // strips of one image (which share the cache lines along their common sector borders and the image's part of the
+  // table) go through ONE XCD's L2, and no wave slot idles.  Everything here is scalar (SGPRs).
+  const int L = (int)(blockIdx.x >> 3) * (kThreads / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int il = L / strips, strip = L - il * strips;
+  const int im = il * 8 + (int)(blockIdx.x & 7);
+  if (im >= nimg) return;  // wave-uniform
   const int x0 = strip * OUTW;
   const int x_src = clampi(x0 - R + lane, 0, cols - 1);
   const int x_out = x0 + lane;
@@ -385,8 +390,7 @@ int32_t launch_median(sosvo_ctx* ctx, const uint8_t* img, const uint2* table, in
                              int rows, int cols, int ksize, uint8_t* gray) {
   const int outw = 64 - 2 * (ksize / 2);
   const int strips = cdiv(cols, outw);
-  const int waves = nimg * strips;
-  dim3 grid(cdiv(waves, kThreads / 64)), block(kThreads);
+  dim3 grid(8 * cdiv(cdiv(nimg, 8) * strips, kThreads / 64)), block(kThreads);  // see the kernel's XCD-aware mapping
   // (named aliases so that the profile labels tell the two forms apart)
   constexpr auto k11 = median_gray_kernel<11, FUSED>;
   constexpr auto k5 = median_gray_kernel<5, FUSED>;

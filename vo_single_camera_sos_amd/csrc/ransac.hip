@@ -204,8 +204,15 @@ __global__ __launch_bounds__(kThreads) void ransac_score_kernel(
   const int n = min(n_arr[b], stride);
   // XCD-aware grid: workgroups are dealt round-robin over the 8 XCDs by linear id, so the dimension with
   // early-exiting workgroups (point blocks beyond n) must NOT be the fastest one: x = hypothesis chunk.
-  const int p0 = blockIdx.y * (kThreads * PPT);
-  if (p0 >= n) return;
+  // Point sets of 64 are split EVENLY over the point blocks this problem needs (nb = sets / 16 rounded up, each block
+  // takes ceil(sets / nb) consecutive sets): a ragged problem (say 22 sets) runs as 11 + 11 instead of 16 + 6, so
+  // every block amortises its per-hypothesis work (LDS reads, the count atomic) over about the same number of sets.
+  const int nsets = (n + 63) >> 6;
+  const int nb = (nsets + (kThreads / 64) * PPT - 1) / ((kThreads / 64) * PPT);
+  if ((int)blockIdx.y >= nb) return;
+  const int spb = (nsets + nb - 1) / nb;
+  const int set0 = blockIdx.y * spb, set1 = min(set0 + spb, nsets);
+  const int p0 = set0 * 64;
   const int h0 = blockIdx.x * hchunk;
   const int h1 = min(H, h0 + hchunk);
   for (int k = tid; k < hchunk; k += kThreads) lcnt[k] = 0;
@@ -222,9 +229,10 @@ __global__ __launch_bounds__(kThreads) void ransac_score_kernel(
   unsigned long long vmask[PPT];
 #pragma unroll
   for (int r = 0; r < PPT; ++r) {
-    const int i0 = p0 + (r * (kThreads / 64) + wave) * 64;
+    const int set = set0 + r * (kThreads / 64) + wave;
+    const int i0 = set * 64;
     const int i = i0 + lane;
-    live[r] = i0 < n;
+    live[r] = set < set1;
     const bool valid = i < n;
     vmask[r] = __ballot(valid);
     const size_t row = base + (valid ? i : p0);
