@@ -434,6 +434,41 @@ int32_t sosvo_frame_pair_batch(sosvo_ctx* ctx, const sosvo_rig* rig_host, const 
                                const uint8_t* omni, const uint32_t* unwrap_table, const uint32_t* mask_bits,
                                const int8_t* pattern, void* workspace, size_t workspace_bytes, double* results);
 
+/* ---- The RGB-D path for B independent frame pairs behind ONE call (BASELINE config 5) ------------------
+ * RGBDFrame.establish_keypoints (omnistereo/pose_est_tools.py:600-623: [median,] gray, goodFeaturesToTrack on the
+ * whole image or on RGBDFrame.mask, ORB descriptors, depth back-projection, NaN / range filter, bearings) for the
+ * 2 B frames, then TrackerRGBDSE3.track_frame (:896-954: frame-to-frame matching, |du| gate, central RANSAC, LM)
+ * for every pair (pair i tracks frame 2i+1 against frame 2i).  Sequences the stage entry points above on the
+ * context's stream; same results as calling them one by one (vo_single_camera_sos_amd/pipeline.py:RGBDPairPipeline).
+ *   bgr       [2B, rows, cols, 3] u8, depth [2B, rows, cols] f32 (camera depth units, 0 = no reading)
+ *   mask_bits [1, rows, cols] u32 (bit 0 = pixel may hold a keypoint; all ones = RGBDFrame.mask None)
+ *   pattern   [512, 2] i8 (the 256 ORB test pairs), workspace: sosvo_rgbd_pair_batch_workspace(cfg) bytes, 256-aligned
+ *   results   [B, 16] f64 as sosvo_frame_pair_batch                                                             */
+typedef struct sosvo_rgbd_batch_cfg {
+  int32_t n_pairs;
+  int32_t rows, cols;
+  int32_t kp_cap;          /* keypoint capacity per frame; > 1024 selects the detector's whole-image variant */
+  int32_t frame_cap;       /* keypoints with valid depth kept per frame */
+  int32_t median_ksize;    /* 0: none (pose_est_tools.py:609 default) */
+  int32_t max_corners;     /* FeatureMatcher.num_of_features, 1000 (pose_est_tools.py:691) */
+  int32_t edge;            /* ORB border, 31 */
+  int32_t ransac_max_iter;
+  int32_t ransac_adaptive;
+  int32_t lm_max_iter;
+  int32_t flags;           /* SOSVO_FLAG_EPNP: "EPNP" (6-point samples); 0: "KNEIP" (P3P + 4th point) */
+  double quality, min_distance;        /* 0.01, 5 */
+  double ransac_threshold;             /* 1 - cos(5 deg) */
+  double pct_good_matches;             /* 1.0 (pose_est_tools.py:225) */
+  double f2f_max_hdiff;                /* |du| gate in pixels: 0.5 * 2 * center_x (:956-958); <= 0: none */
+  uint64_t seed;
+  float cos_a, sin_a;
+} sosvo_rgbd_batch_cfg;
+
+size_t sosvo_rgbd_pair_batch_workspace(const sosvo_rgbd_batch_cfg* cfg);
+int32_t sosvo_rgbd_pair_batch(sosvo_ctx* ctx, const sosvo_rgbd_cam* cam_host, const sosvo_rgbd_batch_cfg* cfg_host,
+                              const uint8_t* bgr, const float* depth, const uint32_t* mask_bits, const int8_t* pattern,
+                              void* workspace, size_t workspace_bytes, double* results);
+
 #ifdef __cplusplus
 }
 #endif

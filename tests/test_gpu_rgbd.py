@@ -53,6 +53,15 @@ def test_rgbd_pairs_end_to_end_parity(ctx, depth_is_Z, thr_deg, algo):
     ctx.synchronize()
     assert not pipe.status.cpu().numpy().any()
 
+    # the same step behind ONE C-ABI call (sosvo_rgbd_pair_batch) gives the same records, bit for bit
+    from vo_single_camera_sos_amd.pipeline import RGBDPairBatch
+    one = RGBDPairBatch(ctx, cam, B, num_of_features=nfeat, max_iter=400, seed=31, thr=1.0 - np.cos(np.deg2rad(thr_deg)),
+                        pose_est_algorithm=algo)
+    one.load_frames(bgr, depth)
+    rec1 = one.step()
+    ctx.synchronize()
+    assert np.array_equal(rec1.cpu().numpy(), rec.cpu().numpy())
+
     ca, sa = orb_pattern.angle_cos_sin(orb_pattern.GFT_KEYPOINT_ANGLE)
     rc = refflow.RGBDParams(FX, FY, CX, CY, cam.focal_length_m, depth_is_Z, 0.8, 7.0, cam.f2f_max_hdiff, 1.0)
     frames = [refflow.rgbd_frame(rc, bgr[f], depth[f], nfeat, orb_pattern.orb_pattern(), ca, sa) for f in range(2 * B)]

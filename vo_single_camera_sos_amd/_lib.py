@@ -79,6 +79,8 @@ SIGNATURES = {
                                            c_p, c_p, c_p, c_p, c_p]),
     "sosvo_frame_pair_batch_workspace": (ctypes.c_size_t, [c_p]),
     "sosvo_frame_pair_batch": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
+    "sosvo_rgbd_pair_batch_workspace": (ctypes.c_size_t, [c_p]),
+    "sosvo_rgbd_pair_batch": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
 }
 
 FLAG_CAM_ROT_IDENTITY = 1
@@ -105,6 +107,15 @@ class BatchCfg(ctypes.Structure):
                 ("kp_cap", c_i32), ("frame_cap", c_i32), ("median_ksize", c_i32), ("max_corners", c_i32), ("edge", c_i32),
                 ("ransac_max_iter", c_i32), ("ransac_adaptive", c_i32), ("lm_max_iter", c_i32), ("quality", c_f64),
                 ("min_distance", c_f64), ("ransac_threshold", c_f64), ("seed", c_u64), ("cos_a", c_f32), ("sin_a", c_f32)]
+
+
+class RgbdBatchCfg(ctypes.Structure):
+    """Mirror of `struct sosvo_rgbd_batch_cfg` (include/sosvo.h)."""
+    _fields_ = [("n_pairs", c_i32), ("rows", c_i32), ("cols", c_i32), ("kp_cap", c_i32), ("frame_cap", c_i32),
+                ("median_ksize", c_i32), ("max_corners", c_i32), ("edge", c_i32), ("ransac_max_iter", c_i32),
+                ("ransac_adaptive", c_i32), ("lm_max_iter", c_i32), ("flags", c_i32), ("quality", c_f64),
+                ("min_distance", c_f64), ("ransac_threshold", c_f64), ("pct_good_matches", c_f64), ("f2f_max_hdiff", c_f64),
+                ("seed", c_u64), ("cos_a", c_f32), ("sin_a", c_f32)]
 
 
 _lib = None

@@ -111,6 +111,59 @@ __global__ void batch_results_kernel(int npairs, const double* __restrict__ T, c
   out[16 * i + 15] = (double)info[4 * i + 0];
 }
 
+// ---- RGB-D variant (BASELINE config 5) ------------------------------------------------------------------
+struct RgbdBuffers {
+  uint8_t *gray, *desc, *d, *mask;
+  float *kp, *m;
+  int32_t *n, *status, *M, *ref_frame, *cur_frame, *order, *cq, *ct, *cn, *idx, *n_inl, *info, *lm_iters;
+  uint32_t* keys;
+  double *X, *b, *f, *p, *T_ransac, *T, *lm_cost;
+  size_t bytes;
+};
+
+RgbdBuffers carve_rgbd(const sosvo_rgbd_batch_cfg& c, void* ws) {
+  Carver cv{reinterpret_cast<char*>(ws)};
+  RgbdBuffers b;
+  const size_t B = c.n_pairs, F = 2 * B, cap = c.kp_cap, Fc = c.frame_cap, npx = (size_t)c.rows * c.cols;
+  b.gray = cv.take<uint8_t>(F * npx);
+  b.kp = cv.take<float>(F * cap * 2);
+  b.n = cv.take<int32_t>(F);
+  b.status = cv.take<int32_t>(F);
+  b.desc = cv.take<uint8_t>(F * cap * 32);
+  b.m = cv.take<float>(F * Fc * 2);
+  b.d = cv.take<uint8_t>(F * Fc * 32);
+  b.X = cv.take<double>(F * Fc * 3);
+  b.b = cv.take<double>(F * Fc * 3);
+  b.M = cv.take<int32_t>(F);
+  b.ref_frame = cv.take<int32_t>(B);
+  b.cur_frame = cv.take<int32_t>(B);
+  b.keys = cv.take<uint32_t>(B * Fc);
+  b.order = cv.take<int32_t>(B * Fc);
+  b.f = cv.take<double>(B * Fc * 3);
+  b.p = cv.take<double>(B * Fc * 3);
+  b.cq = cv.take<int32_t>(B * Fc);
+  b.ct = cv.take<int32_t>(B * Fc);
+  b.cn = cv.take<int32_t>(B);
+  b.T_ransac = cv.take<double>(B * 12);
+  b.mask = cv.take<uint8_t>(B * Fc);
+  b.idx = cv.take<int32_t>(B * Fc);
+  b.n_inl = cv.take<int32_t>(B);
+  b.info = cv.take<int32_t>(B * 4);
+  b.T = cv.take<double>(B * 12);
+  b.lm_cost = cv.take<double>(B);
+  b.lm_iters = cv.take<int32_t>(B);
+  b.bytes = cv.off;
+  return b;
+}
+
+__global__ void pair_index_kernel(int npairs, int32_t* __restrict__ ref_frame, int32_t* __restrict__ cur_frame) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < npairs) {
+    ref_frame[i] = 2 * i;
+    cur_frame[i] = 2 * i + 1;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -184,6 +237,57 @@ int32_t sosvo_frame_pair_batch(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo
   SOSVO_HIP(ctx, hipMemcpyAsync(b.T, b.T_ransac, sizeof(double) * 12 * B, hipMemcpyDeviceToDevice, ctx->stream));
   STAGE(sosvo_refine_abs_pose(ctx, b.f, b.p, b.cam, b.cam_off, b.cam_rot, 2, b.cn, B, Cc, b.idx, b.n_inl, cfg->lm_max_iter,
                               b.T, b.lm_cost, b.lm_iters));
+  SOSVO_LAUNCH(ctx, batch_results_kernel, dim3(cdiv(B, 256)), dim3(256), 0, ctx->stream, B, b.T, b.n_inl, b.cn, b.info,
+               results);
+  SOSVO_LAUNCH_CHECK(ctx);
+#undef STAGE
+  return SOSVO_OK;
+}
+
+size_t sosvo_rgbd_pair_batch_workspace(const sosvo_rgbd_batch_cfg* cfg) {
+  if (!cfg || cfg->n_pairs <= 0 || cfg->rows <= 0 || cfg->cols <= 0 || cfg->kp_cap <= 0 || cfg->frame_cap <= 0) return 0;
+  return carve_rgbd(*cfg, nullptr).bytes;
+}
+
+int32_t sosvo_rgbd_pair_batch(sosvo_ctx* ctx, const sosvo_rgbd_cam* cam, const sosvo_rgbd_batch_cfg* cfg,
+                              const uint8_t* bgr, const float* depth, const uint32_t* mask_bits, const int8_t* pattern,
+                              void* workspace, size_t workspace_bytes, double* results) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, cam && cfg && bgr && depth && mask_bits && pattern && workspace && results, "null pointer");
+  SOSVO_REQUIRE(ctx, cfg->n_pairs > 0 && cfg->n_pairs <= 8192, "n_pairs out of range (1..8192)");
+  SOSVO_REQUIRE(ctx, cfg->kp_cap > 0 && cfg->kp_cap <= 4096 && cfg->frame_cap > 0 && cfg->frame_cap <= 16384,
+                "kp_cap / frame_cap out of range");
+  SOSVO_REQUIRE(ctx, ((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
+  const RgbdBuffers b = carve_rgbd(*cfg, workspace);
+  SOSVO_REQUIRE(ctx, workspace_bytes >= b.bytes, "workspace too small (see sosvo_rgbd_pair_batch_workspace)");
+  const int B = cfg->n_pairs, F = 2 * B, cap = cfg->kp_cap, Fc = cfg->frame_cap;
+  int32_t rc;
+#define STAGE(call)              \
+  do {                           \
+    rc = (call);                 \
+    if (rc != SOSVO_OK) return rc; \
+  } while (0)
+  SOSVO_LAUNCH(ctx, pair_index_kernel, dim3(cdiv(B, 256)), dim3(256), 0, ctx->stream, B, b.ref_frame, b.cur_frame);
+  SOSVO_LAUNCH_CHECK(ctx);
+  // RGBDFrame.establish_keypoints for all 2 B frames: [median,] gray, whole-image GFT (one mask), ORB descriptors,
+  // depth back-projection + range filter + bearings
+  STAGE(sosvo_median_gray(ctx, bgr, F, cfg->rows, cfg->cols, cfg->median_ksize, b.gray));
+  STAGE(sosvo_detect_gft(ctx, b.gray, mask_bits, F, F, cfg->rows, cfg->cols, 1, cfg->quality, cfg->min_distance,
+                         cfg->max_corners, cap, b.kp, b.n, b.status));
+  STAGE(sosvo_describe_orb(ctx, b.gray, F, cfg->rows, cfg->cols, 1, cap, b.kp, b.n, cfg->cos_a, cfg->sin_a, pattern, cfg->edge,
+                           b.desc));
+  STAGE(sosvo_rgbd_assemble(ctx, cam, b.kp, b.desc, b.n, depth, F, cfg->rows, cfg->cols, cap, Fc, b.m, b.d, b.X, b.b, b.M));
+  // TrackerRGBDSE3.track_frame per pair: query = current frame, train = reference frame
+  STAGE(sosvo_match_hamming(ctx, b.d, b.d, b.M, b.M, b.cur_frame, b.ref_frame, B, Fc, Fc, 1, b.keys));
+  STAGE(sosvo_sort_matches(ctx, b.keys, b.M, b.cur_frame, B, Fc, b.order));
+  STAGE(sosvo_f2f_assemble_central(ctx, cfg->pct_good_matches, cfg->f2f_max_hdiff, b.m, b.X, b.b, b.M, Fc, b.ref_frame,
+                                   b.cur_frame, b.keys, b.order, B, Fc, b.f, b.p, b.cq, b.ct, b.cn));
+  STAGE(sosvo_ransac_abs_pose(ctx, b.f, b.p, nullptr, nullptr, nullptr, 1, cfg->flags & SOSVO_FLAG_EPNP, b.cn, B, Fc,
+                              cfg->ransac_threshold, cfg->ransac_max_iter, cfg->ransac_adaptive, cfg->seed, b.T_ransac,
+                              b.mask, b.idx, b.n_inl, b.info, nullptr));
+  SOSVO_HIP(ctx, hipMemcpyAsync(b.T, b.T_ransac, sizeof(double) * 12 * B, hipMemcpyDeviceToDevice, ctx->stream));
+  STAGE(sosvo_refine_abs_pose(ctx, b.f, b.p, nullptr, nullptr, nullptr, 1, b.cn, B, Fc, b.idx, b.n_inl, cfg->lm_max_iter, b.T,
+                              b.lm_cost, b.lm_iters));
   SOSVO_LAUNCH(ctx, batch_results_kernel, dim3(cdiv(B, 256)), dim3(256), 0, ctx->stream, B, b.T, b.n_inl, b.cn, b.info,
                results);
   SOSVO_LAUNCH_CHECK(ctx);

@@ -615,6 +615,26 @@ class Context(object):
                    _ptr(workspace), int(workspace.numel()), _ptr(results))
         return results
 
+    def rgbd_pair_batch_workspace(self, cfg):
+        return int(self._lib.sosvo_rgbd_pair_batch_workspace(ctypes.cast(ctypes.pointer(cfg), c_p)))
+
+    def rgbd_pair_batch(self, cam, cfg, bgr, depth, mask_bits, pattern, workspace, results=None):
+        """bgr [2B,rows,cols,3] u8, depth [2B,rows,cols] f32, mask_bits [1,rows,cols] u32, pattern [512,2] i8,
+        workspace u8 [>= rgbd_pair_batch_workspace(cfg)] -> results [B,16] f64 (see include/sosvo.h)."""
+        B = int(cfg.n_pairs)
+        _check(bgr, torch.uint8, "bgr", (2 * B, cfg.rows, cfg.cols, 3))
+        _check(depth, torch.float32, "depth", (2 * B, cfg.rows, cfg.cols))
+        _check(mask_bits, torch.uint32, "mask_bits", (1, cfg.rows, cfg.cols))
+        _check(pattern, torch.int8, "pattern", (512, 2))
+        _check(workspace, torch.uint8, "workspace", ndim=1)
+        if results is None:
+            results = torch.empty((B, 16), dtype=torch.float64, device=bgr.device)
+        _check(results, torch.float64, "results", (B, 16))
+        self._call(self._lib.sosvo_rgbd_pair_batch, ctypes.cast(ctypes.pointer(cam), c_p),
+                   ctypes.cast(ctypes.pointer(cfg), c_p), _ptr(bgr), _ptr(depth), _ptr(mask_bits), _ptr(pattern),
+                   _ptr(workspace), int(workspace.numel()), _ptr(results))
+        return results
+
     def f2f_assemble(self, rig, frames, ref_frame, cur_frame, keys_top, order_top, keys_bot, order_bot, corr_cap,
                      out=None):
         """frames = dict from stereo_assemble; ref_frame / cur_frame [NP] i32; keys_* [NP, frame_cap, 1] u32,

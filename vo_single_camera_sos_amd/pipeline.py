@@ -423,3 +423,53 @@ class RGBDPairPipeline(object):
         out[:, 14] = self.ransac["info"][:, 2].to(torch.float64)
         out[:, 15] = self.ransac["info"][:, 0].to(torch.float64)
         return out
+
+
+class RGBDPairBatch(object):
+    """RGBDPairPipeline behind ONE C-ABI call per step (sosvo_rgbd_pair_batch): what a non-Python host would bind for
+    BASELINE config 5.  Same arguments and results as RGBDPairPipeline; the workspace is allocated once."""
+
+    def __init__(self, ctx, cam, n_pairs, image_shape=(480, 640), num_of_features=1000, kp_cap=None, frame_cap=None,
+                 median_win_size=0, quality=0.01, min_distance=5.0, edge=31, thr=None, max_iter=2000, adaptive=False,
+                 seed=0, lm_iter=30, mask=None, pose_est_algorithm="EPNP"):
+        from . import _lib, orb_pattern
+        self.ctx, self.cam_cfg, self.cam = ctx, cam, cam.as_struct()
+        self.B = int(n_pairs)
+        rows, cols = int(image_shape[0]), int(image_shape[1])
+        kp_cap = int(kp_cap) if kp_cap else int(min(4096, max(1088, -(-int(num_of_features) // 64) * 64)))
+        cos_a, sin_a = orb_pattern.angle_cos_sin(orb_pattern.GFT_KEYPOINT_ANGLE)
+        c = _lib.RgbdBatchCfg()
+        c.n_pairs, c.rows, c.cols, c.kp_cap, c.frame_cap = self.B, rows, cols, kp_cap, int(frame_cap) if frame_cap else kp_cap
+        c.median_ksize, c.max_corners, c.edge = int(median_win_size), int(num_of_features), int(edge)
+        c.ransac_max_iter, c.ransac_adaptive, c.lm_max_iter = int(max_iter), 1 if adaptive else 0, int(lm_iter)
+        c.flags = _lib.FLAG_EPNP if str(pose_est_algorithm).upper() == "EPNP" else 0
+        c.quality, c.min_distance = float(quality), float(min_distance)
+        c.ransac_threshold = float(1.0 - np.cos(np.deg2rad(5.0))) if thr is None else float(thr)
+        c.pct_good_matches, c.f2f_max_hdiff = float(cam.pct_good_matches), float(cam.f2f_max_hdiff)
+        c.seed, c.cos_a, c.sin_a = int(seed), float(cos_a), float(sin_a)
+        self.cfg, self.thr = c, c.ransac_threshold
+        dev = ctx.device
+        mb = np.ones((1, rows, cols), np.uint32) if mask is None else (np.asarray(mask) != 0).astype(np.uint32).reshape(1, rows, cols)
+        self.mask_bits = torch.from_numpy(mb).to(dev)
+        self.pattern = torch.from_numpy(orb_pattern.orb_pattern()).to(dev)
+        nbytes = ctx.rgbd_pair_batch_workspace(c)
+        if nbytes <= 0:
+            raise ValueError("bad batch configuration")
+        self.workspace = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        self.bgr = torch.zeros((2 * self.B, rows, cols, 3), dtype=torch.uint8, device=dev)
+        self.depth = torch.zeros((2 * self.B, rows, cols), dtype=torch.float32, device=dev)
+        self.out = torch.zeros((self.B, 16), dtype=torch.float64, device=dev)
+
+    def load_frames(self, bgr, depth):
+        dev = self.ctx.device
+        self.bgr.copy_((torch.from_numpy(np.ascontiguousarray(bgr)) if isinstance(bgr, np.ndarray) else bgr).to(dev))
+        self.depth.copy_((torch.from_numpy(np.ascontiguousarray(depth, dtype=np.float32))
+                          if isinstance(depth, np.ndarray) else depth).to(dev))
+
+    def step(self):
+        """-> results [B,16] f64 (asynchronous)."""
+        return self.ctx.rgbd_pair_batch(self.cam, self.cfg, self.bgr, self.depth, self.mask_bits, self.pattern, self.workspace,
+                                        results=self.out)
+
+    def results(self):
+        return self.out
