@@ -1,0 +1,78 @@
+"""Soak run of the WHOLE hot path against the CPU oracle at the bench configuration (1440 x 146 panoramas, ~2000
+keypoints per view, 2000 RANSAC iterations): N rendered frame pairs through OverlappedFramePairs on the GPU and
+through the reference's control flow on the C oracle (tests/refflow.py, multi-process), every record compared --
+counts, status, best iteration exactly, refined pose at rel-tol 1e-6.  A tool, not part of the test suite:
+
+    python scripts/soak_parity.py --pairs 64 [--seed 7] [--workers 16]
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pairs", type=int, default=64)
+    ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--workers", type=int, default=16)
+    ap.add_argument("--iters", type=int, default=2000)
+    ap.add_argument("--pano-width", type=int, default=1440)
+    args = ap.parse_args()
+    import multiprocessing
+    import refflow
+    from vo_single_camera_sos_amd import orb_pattern, synthetic
+    from vo_single_camera_sos_amd.omnistereo.gum import synthetic_gums
+    from vo_single_camera_sos_amd.omnistereo.panorama import Panorama
+    gs = synthetic_gums()
+    for m in (gs.top_model, gs.bot_model):
+        m.panorama = Panorama(m, width=args.pano_width)
+    gs.make_annulus_masks((480, 640))
+    pano = gs.top_model.panorama
+    geo = (pano.cols, pano.rows, pano.pixel_size, pano.cyl_height_max)
+    rig_kw = dict(pano_top=geo, pano_bot=geo, F_top=gs.top_model.F[:3, 0], F_bot=gs.bot_model.F[:3, 0], min_range=500.0,
+                  max_range=7000.0, stereo_min_disp=1.0, stereo_max_hdiff=2.5, f2f_max_hdiff=0.125 * 0.5 * pano.cols,
+                  pct_good_matches=1.0)
+    B = args.pairs
+    omni, _ = synthetic.make_frame_pairs(gs, B, seed=args.seed, workers=args.workers)  # before the GPU is touched (fork)
+    import torch
+    from vo_single_camera_sos_amd.pipeline import OverlappedFramePairs, RigConfig
+    eng = OverlappedFramePairs(0, gs, (480, 640), RigConfig(**rig_kw), B, n_streams=2, num_of_features=1000, kp_cap=512,
+                               frame_cap=2048, max_iter=args.iters, adaptive=False, seed=args.seed)
+    eng.load_frames(omni)
+    eng.step()
+    rec = eng.results().cpu().numpy()
+    torch.cuda.synchronize()
+    model = eng.model
+    ca, sa = orb_pattern.angle_cos_sin(-1.0)
+    im_kw = dict(map_x=model.map_x.cpu().numpy(), map_y=model.map_y.cpu().numpy(), omni_masks=model.omni_masks.cpu().numpy(),
+                 mask_bits=model.mask_bits_host, nmask=model.nmask, max_corners=1000, pattern=model.pattern_host, cos_a=ca,
+                 sin_a=sa, kp_cap=512)
+    per = -(-B // args.workers)
+    jobs = [(rig_kw, im_kw, omni[2 * lo: 2 * min(B, lo + per)], eng.thr, args.iters, args.seed + lo) for lo in range(0, B, per)]
+    t0 = time.perf_counter()
+    with multiprocessing.get_context("spawn").Pool(len(jobs)) as pool:
+        outs = pool.map(refflow.pairs_records_worker, jobs)
+    want = np.concatenate(outs)
+    print("oracle: %d pairs in %.1f s on %d processes" % (B, time.perf_counter() - t0, len(jobs)))
+    bad = 0
+    for i in range(B):
+        exact = np.array_equal(rec[i, 12:], want[i, 12:])
+        close = np.allclose(rec[i, :12], want[i, :12], rtol=1e-6, atol=1e-9)
+        if not (exact and close):
+            bad += 1
+            print("pair %d differs: gpu %s\n               cpu %s" % (i, rec[i], want[i]))
+    print("soak: %d / %d pairs identical (counts, status, winning iteration exact; pose rel-tol 1e-6); inliers %.0f mean"
+          % (B - bad, B, rec[:, 12].mean()))
+    eng.close()
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
