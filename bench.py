@@ -121,6 +121,7 @@ def parse():
                          "tool initialises the GPU before this program forks)")
     ap.add_argument("--cpu-cores", type=int, default=0, help="processes of the all-cores CPU baseline (0 = os.cpu_count())")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the extra PCIe-inclusive measurement (N = 1 only)")
     ap.add_argument("--pmc-csv", default=None, help="per-kernel PMC summary for roofline.traffic (default: newest in profiles/)")
     ap.add_argument("--seed", type=int, default=1234)
     return ap.parse_args()
@@ -233,6 +234,31 @@ def main():
     eng.profile_enable(False)
     elapsed = max_over_ranks(elapsed, dev)
 
+    # PCIe-inclusive rate (never `value`): the same K steps with the omni frames handed over in pinned HOST memory and
+    # copied per step, double-buffered on copy streams (OverlappedFramePairs.step_from_host).  One rank only.
+    pcie = None
+    if world == 1 and not args.no_h2d:
+        rec_resident = rec.clone()
+        pinned = torch.from_numpy(omni).pin_memory()
+        for _ in range(2):
+            eng.step_from_host(pinned)
+            eng.results()
+            eng.consumed()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.step_from_host(pinned)
+            rec_h = eng.results()
+            eng.consumed()
+        torch.cuda.synchronize()
+        dt_h = time.perf_counter() - t0
+        pcie = {"value": B * args.steps / dt_h, "unit": "frame-pairs/s", "ms_per_step": 1e3 * dt_h / args.steps,
+                "host_bytes_per_pair": 2 * H * W * 3, "h2d_GBps": B * args.steps * 2 * H * W * 3 / dt_h / 1e9,
+                "same_results": bool(torch.equal(rec_h, rec_resident)),
+                "note": "omni frames copied from pinned host memory every step (copy streams, two device buffers per "
+                        "part: the copy of step k+1 overlaps the kernels of step k)"}
+        del pinned
+
     if rank == 0:
         rec = rec.cpu().numpy()
         n_kp = np.concatenate([p.fe.n.cpu().numpy().reshape(2, -1, model.nmask).sum(-1) for p in eng.parts], axis=1)  # [view, frame]
@@ -312,6 +338,8 @@ def main():
                                                                % (na, cores, dta)}
                 except Exception as e:  # the one-core figure above stays the reported baseline
                     out["cpu_baseline_all_cores"] = {"error": repr(e)}
+        if pcie is not None:
+            out["pcie_inclusive"] = pcie
         print(json.dumps(out))
     if dist:
         dist.barrier()

@@ -194,7 +194,35 @@ class OverlappedFramePairs(object):
                 p.fe.load_frames(omni[2 * p.lo:2 * p.hi])
         torch.cuda.synchronize(self.device)
 
-    def step(self):
+    def step_from_host(self, omni_pinned):
+        """One pass over all B pairs whose omni frames are handed over in (pinned) HOST memory [2B,H,W,3] u8: every part
+        copies its frames on a copy stream of its own into one of two device buffers (the copy for step k+1 overlaps the
+        kernels of step k; a buffer is reused once the median that read it has finished) and then runs step()'s
+        sequence.  This is the PCIe-inclusive form of the hot path."""
+        k = self._host_step = getattr(self, "_host_step", -1) + 1
+        j = k & 1
+        for p in self.parts:
+            if not hasattr(p, "omni_bufs"):
+                p.omni_bufs = [p.fe.omni, torch.empty_like(p.fe.omni)]
+                p.copy_stream = torch.cuda.Stream(self.device)
+                p.copied = [torch.cuda.Event(), torch.cuda.Event()]
+                p.omni_free = [None, None]
+            with torch.cuda.stream(p.copy_stream):
+                if p.omni_free[j] is not None:
+                    p.copy_stream.wait_event(p.omni_free[j])
+                p.omni_bufs[j].copy_(omni_pinned[2 * p.lo:2 * p.hi], non_blocking=True)
+                p.copied[j].record(p.copy_stream)
+            p.fe.omni = p.omni_bufs[j]
+            p.stream.wait_event(p.copied[j])
+        self.step(_after_median=lambda p: self._mark_free(p, j))
+
+    @staticmethod
+    def _mark_free(p, j):
+        ev = torch.cuda.Event()
+        ev.record(p.stream)
+        p.omni_free[j] = ev
+
+    def step(self, _after_median=None):
         """One pass of the whole hot path over all B pairs (asynchronous)."""
         for p in self.parts:
             with torch.cuda.stream(p.stream):
@@ -203,6 +231,8 @@ class OverlappedFramePairs(object):
                 p.fe.run_images()
                 p.median_done.record(p.stream)
                 self._token = p.median_done
+                if _after_median is not None:
+                    _after_median(p)
                 p.fe.run_features()
                 p.pipe.stereo()
                 p.pipe.track()
