@@ -96,4 +96,16 @@ def test_overlapped_streams_equal_single_pipeline(ctx, n_streams):
         eng.consumed()
         torch.cuda.synchronize()
         assert np.array_equal(got.cpu().numpy().view(np.uint64), want.view(np.uint64))
+    # the PCIe-inclusive form: frames handed over in pinned host memory, copied per step into alternating device
+    # buffers; frames that CHANGE from step to step give that step's records (pairs reversed here: a different result)
+    pinned = torch.from_numpy(omni).pin_memory()
+    swapped = torch.from_numpy(np.ascontiguousarray(omni.reshape(B, 2, *omni.shape[1:])[:, ::-1].reshape(omni.shape))).pin_memory()
+    recs = []
+    for k in range(4):
+        eng.step_from_host(pinned if k % 2 == 0 else swapped)
+        recs.append(eng.results().clone())
+        eng.consumed()
+    torch.cuda.synchronize()
+    assert np.array_equal(recs[0].cpu().numpy().view(np.uint64), want.view(np.uint64))
+    assert torch.equal(recs[2], recs[0]) and torch.equal(recs[3], recs[1]) and not torch.equal(recs[1], recs[0])
     eng.close()
