@@ -23,7 +23,9 @@
 #define ORC_EPNP_MAXN 8
 
 /* Cyclic Jacobi on a symmetric n x n matrix A (row-major, destroyed: its diagonal ends as the eigenvalues);
- * V (n x n) receives the eigenvectors as columns. */
+ * V (n x n) receives the eigenvectors as columns.  The classic symmetric update: a rotation in the (p, q) plane
+ * changes rows / columns p and q only -- a'kp = c akp - s akq, a'kq = s akp + c akq for k != p, q (mirrored),
+ * a'pp = app - t apq, a'qq = aqq + t apq, a'pq = 0 exactly. */
 static inline void orc_jacobi_sym(double* A, int n, double* V) {
   for (int i = 0; i < n; ++i)
     for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
@@ -38,20 +40,24 @@ static inline void orc_jacobi_sym(double* A, int n, double* V) {
       for (int q = p + 1; q < n; ++q) {
         const double apq = A[p * n + q];
         if (apq == 0.0) continue;
-        const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+        const double app = A[p * n + p], aqq = A[q * n + q];
+        const double theta = (aqq - app) / (2.0 * apq);
         const double at = theta < 0.0 ? -theta : theta;
         const double t = (theta < 0.0 ? -1.0 : 1.0) / (at + sqrt((theta * theta) + 1.0));
         const double c = 1.0 / sqrt((t * t) + 1.0), s = t * c;
         for (int k = 0; k < n; ++k) {
+          if (k == p || k == q) continue;
           const double akp = A[k * n + p], akq = A[k * n + q];
-          A[k * n + p] = (c * akp) - (s * akq);
-          A[k * n + q] = (s * akp) + (c * akq);
+          const double x = (c * akp) - (s * akq), y = (s * akp) + (c * akq);
+          A[k * n + p] = x;
+          A[p * n + k] = x;
+          A[k * n + q] = y;
+          A[q * n + k] = y;
         }
-        for (int k = 0; k < n; ++k) {
-          const double apk = A[p * n + k], aqk = A[q * n + k];
-          A[p * n + k] = (c * apk) - (s * aqk);
-          A[q * n + k] = (s * apk) + (c * aqk);
-        }
+        A[p * n + p] = app - (t * apq);
+        A[q * n + q] = aqq + (t * apq);
+        A[p * n + q] = 0.0;
+        A[q * n + p] = 0.0;
         for (int k = 0; k < n; ++k) {
           const double vkp = V[k * n + p], vkq = V[k * n + q];
           V[k * n + p] = (c * vkp) - (s * vkq);

@@ -6,8 +6,8 @@
 //
 // Only + - * / sqrt and comparisons, every expression fully parenthesised, built with -ffp-contract=off: the
 // hypotheses (hence inlier counts and the selected model) are bit-identical to an IEEE scalar evaluation of the same
-// formulas on the host.  One lane per hypothesis; the 12 x 12 work arrays are runtime-indexed and live in scratch
-// memory -- this generator serves the RGB-D path, not the benchmarked omnistereo path.
+// formulas on the host.  One lane per hypothesis; the two runtime-indexed 12 x 12 work arrays of the eigen-solver are kept in
+// LDS, interleaved over the wave's lanes (sv_epnp_s<64>), the small ones in private memory.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -15,45 +15,62 @@
 #include "ransac_core.h"
 
 #define SV_EPNP_MAXN 8
+#define SV_JACOBI_MAXN 12
 
 /* Cyclic Jacobi on a symmetric n x n matrix A (row-major, destroyed: its diagonal ends as the eigenvalues);
- * V (n x n) receives the eigenvectors as columns. */
-__device__ static void sv_jacobi_sym(double* A, int n, double* V) {
+ * V (n x n) receives the eigenvectors as columns; the classic symmetric update (see oracle/epnp_core.h).
+ * Element i of A and V lives at [i * S]: S = 1 for a private array, S > 1 for a lane-interleaved array in LDS (the
+ * 12 x 12 problem of sv_epnp: dynamically indexed private arrays would live in scratch memory, one dependent memory
+ * round trip per element).  Same operations in the same order either way.  The iterations of each inner loop touch
+ * disjoint elements: all their loads are issued before the stores so that the latencies overlap (with runtime p, q
+ * the compiler cannot prove that on its own). */
+template <int S>
+__device__ static void sv_jacobi_sym_s(double* A, int n, double* V) {
   for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+    for (int j = 0; j < n; ++j) V[(i * n + j) * S] = (i == j) ? 1.0 : 0.0;
   for (int sweep = 0; sweep < 60; ++sweep) {
     double off = 0.0, diag = 0.0;
     for (int p = 0; p < n; ++p) {
-      diag = diag + (A[p * n + p] * A[p * n + p]);
-      for (int q = p + 1; q < n; ++q) off = off + (A[p * n + q] * A[p * n + q]);
+      diag = diag + (A[(p * n + p) * S] * A[(p * n + p) * S]);
+      for (int q = p + 1; q < n; ++q) off = off + (A[(p * n + q) * S] * A[(p * n + q) * S]);
     }
     if (!(off > (1e-40 * diag))) break;
     for (int p = 0; p < n - 1; ++p)
       for (int q = p + 1; q < n; ++q) {
-        const double apq = A[p * n + q];
+        const double apq = A[(p * n + q) * S];
         if (apq == 0.0) continue;
-        const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+        const double app = A[(p * n + p) * S], aqq = A[(q * n + q) * S];
+        double xp[SV_JACOBI_MAXN], xq[SV_JACOBI_MAXN], yp[SV_JACOBI_MAXN], yq[SV_JACOBI_MAXN];
+        for (int k = 0; k < n; ++k) {  // (rows k of columns p, q: the values of k = p, q are loaded but not used)
+          xp[k] = A[(k * n + p) * S];
+          xq[k] = A[(k * n + q) * S];
+          yp[k] = V[(k * n + p) * S];
+          yq[k] = V[(k * n + q) * S];
+        }
+        const double theta = (aqq - app) / (2.0 * apq);
         const double at = theta < 0.0 ? -theta : theta;
         const double t = (theta < 0.0 ? -1.0 : 1.0) / (at + sqrt((theta * theta) + 1.0));
         const double c = 1.0 / sqrt((t * t) + 1.0), s = t * c;
         for (int k = 0; k < n; ++k) {
-          const double akp = A[k * n + p], akq = A[k * n + q];
-          A[k * n + p] = (c * akp) - (s * akq);
-          A[k * n + q] = (s * akp) + (c * akq);
+          if (k == p || k == q) continue;
+          const double x = (c * xp[k]) - (s * xq[k]), y = (s * xp[k]) + (c * xq[k]);
+          A[(k * n + p) * S] = x;
+          A[(p * n + k) * S] = x;
+          A[(k * n + q) * S] = y;
+          A[(q * n + k) * S] = y;
         }
+        A[(p * n + p) * S] = app - (t * apq);
+        A[(q * n + q) * S] = aqq + (t * apq);
+        A[(p * n + q) * S] = 0.0;
+        A[(q * n + p) * S] = 0.0;
         for (int k = 0; k < n; ++k) {
-          const double apk = A[p * n + k], aqk = A[q * n + k];
-          A[p * n + k] = (c * apk) - (s * aqk);
-          A[q * n + k] = (s * apk) + (c * aqk);
-        }
-        for (int k = 0; k < n; ++k) {
-          const double vkp = V[k * n + p], vkq = V[k * n + q];
-          V[k * n + p] = (c * vkp) - (s * vkq);
-          V[k * n + q] = (s * vkp) + (c * vkq);
+          V[(k * n + p) * S] = (c * yp[k]) - (s * yq[k]);
+          V[(k * n + q) * S] = (s * yp[k]) + (c * yq[k]);
         }
       }
   }
 }
+__device__ static void sv_jacobi_sym(double* A, int n, double* V) { sv_jacobi_sym_s<1>(A, n, V); }
 
 /* Least squares min |A x - b| for an m x k system (k <= 5) through the normal equations, Gaussian elimination
  * with partial pivoting.  A row-major with row stride lda.  Returns 0 on a vanishing pivot. */
@@ -177,7 +194,8 @@ __device__ static double sv_epnp_pose_from_betas(const double* betas, const doub
 
 /* f, p: n rows of 3 (bearings in the camera, points in the world), 5 <= n <= SV_EPNP_MAXN.
  * -> R, t: pose of the camera in the world (points map by R^T (p - t)), as pyopengv returns it.  0 on failure. */
-__device__ static int sv_epnp(const double* f, const double* p, int n, double* R, double* t) {
+template <int S>
+__device__ static int sv_epnp_s(const double* f, const double* p, int n, double* R, double* t, double* MtM, double* Ev) {
   if (n < 5 || n > SV_EPNP_MAXN) return 0; /* 4 points leave a 4-dimensional null space: not handled */
   double uv[2 * SV_EPNP_MAXN];
   for (int i = 0; i < n; ++i) {
@@ -224,8 +242,7 @@ __device__ static int sv_epnp(const double* f, const double* p, int n, double* R
     alphas[4 * i] = ((1.0 - alphas[4 * i + 1]) - alphas[4 * i + 2]) - alphas[4 * i + 3];
   }
   /* M^T M (12 x 12): two rows per point, [a_j, 0, -a_j u] and [0, a_j, -a_j v] for j = 0..3 */
-  double MtM[144], Ev[144];
-  for (int k = 0; k < 144; ++k) MtM[k] = 0.0;
+  for (int k = 0; k < 144; ++k) MtM[k * S] = 0.0;
   for (int i = 0; i < n; ++i) {
     double r1[12], r2[12];
     for (int j = 0; j < 4; ++j) {
@@ -238,23 +255,23 @@ __device__ static int sv_epnp(const double* f, const double* p, int n, double* R
       r2[3 * j + 2] = -(a * uv[2 * i + 1]);
     }
     for (int r = 0; r < 12; ++r)
-      for (int c = 0; c < 12; ++c) MtM[12 * r + c] = (MtM[12 * r + c] + (r1[r] * r1[c])) + (r2[r] * r2[c]);
+      for (int c = 0; c < 12; ++c) MtM[(12 * r + c) * S] = (MtM[(12 * r + c) * S] + (r1[r] * r1[c])) + (r2[r] * r2[c]);
   }
-  sv_jacobi_sym(MtM, 12, Ev);
+  sv_jacobi_sym_s<S>(MtM, 12, Ev);
   /* the four eigenvectors of the smallest eigenvalues: vv[0] smallest */
   int idx[12];
   for (int k = 0; k < 12; ++k) idx[k] = k;
   for (int a = 0; a < 4; ++a) { /* partial selection sort, ties keep the lower index */
     int m = a;
     for (int b = a + 1; b < 12; ++b)
-      if (MtM[13 * idx[b]] < MtM[13 * idx[m]]) m = b;
+      if (MtM[(13 * idx[b]) * S] < MtM[(13 * idx[m]) * S]) m = b;
     const int tmp = idx[a];
     idx[a] = idx[m];
     idx[m] = tmp;
   }
   double vv[48];
   for (int a = 0; a < 4; ++a)
-    for (int j = 0; j < 12; ++j) vv[12 * a + j] = Ev[12 * j + idx[a]];
+    for (int j = 0; j < 12; ++j) vv[12 * a + j] = Ev[(12 * j + idx[a]) * S];
   /* L (6 x 10) and rho (6) over the control-point pairs */
   const int pa[6] = {0, 0, 0, 1, 1, 2}, pb[6] = {1, 2, 3, 2, 3, 3};
   double L[60], rho[6];
@@ -357,6 +374,11 @@ __device__ static int sv_epnp(const double* f, const double* p, int n, double* R
   for (int k = 0; k < 3; ++k)
     if (!(t[k] == t[k])) return 0;
   return 1;
+}
+
+__device__ static int sv_epnp(const double* f, const double* p, int n, double* R, double* t) {
+  double MtM[144], Ev[144];
+  return sv_epnp_s<1>(f, p, n, R, t, MtM, Ev);
 }
 
 /* k distinct indices below n from the counter-based generator (draw numbers d0, d0 + 1, ...): the j-th draw picks
