@@ -73,3 +73,33 @@ def test_demo_vo_rgbd_end_to_end(ctx, tmp_path):
     for i in range(1, n):
         E = tr.rpe(gt[i], est[i])
         assert tr.rpe_rotation_metric(E) < np.deg2rad(10.0) and tr.rpe_translation_metric(E) < 0.6, (i, E)
+
+
+def test_live_vo_driver_on_a_replayed_camera(ctx, tmp_path):
+    """driver_VO_live / run_VO_live (pose_est_tools.py:960-1262, :1743-1797) on a camera thread that replays a rendered
+    sequence frame by frame (lock-step, so that the run is reproducible): result files, one pose per frame, the
+    trajectory follows the planted one, the camera thread is stopped and joined."""
+    from vo_single_camera_sos_amd.omnistereo.gum import load_gums_json
+    from vo_single_camera_sos_amd.omnistereo.pose_est_tools import driver_VO_live
+    from vo_single_camera_sos_amd.omnistereo.webcam_live import FrameSourceThread, ImageSequenceCam
+    gs = synthetic_gums()
+    for m in (gs.top_model, gs.bot_model):
+        m.panorama = Panorama(m, width=1200)
+    gs.make_annulus_masks((480, 640))
+    n = 5
+    seq = str(tmp_path / "seq_live")
+    poses = synthetic.write_sos_sequence(seq, gs, n_frames=n, seed=23, max_t=40.0, max_deg=2.0)
+    model = load_gums_json(os.path.join(seq, "gums-calibrated.json"))
+    cam_thread = FrameSourceThread(ImageSequenceCam(os.path.join(seq, "omni", "*.png")), lockstep=True)
+    results = str(tmp_path / "results-live")
+    out = driver_VO_live(model, results, cam_thread, visualize_VO=False, use_multithreads_for_VO=True, thread_name="LIVE")
+    assert not cam_thread.is_alive() and cam_thread.quit_flag and cam_thread.frames_delivered == n
+    assert [p[0] for p in out["poses"]] == list(range(n)) and out["tracked"] == n - 1
+    for name in ("estimated_frame_poses_TUM.txt", "keyframe_ids.txt", "printed_messages.log"):
+        assert os.path.exists(os.path.join(results, name)), name
+    for i in range(1, n):
+        R, t = poses[i]
+        T_gt = np.identity(4)
+        T_gt[:3, :3], T_gt[:3, 3] = R, t * 1e-3
+        E = tr.rpe(T_gt, out["poses"][i][1])
+        assert tr.rpe_rotation_metric(E) < np.deg2rad(3.0) and tr.rpe_translation_metric(E) < 0.05 * (i + 1), (i, E)

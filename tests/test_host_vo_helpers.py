@@ -128,3 +128,38 @@ def test_precalibration_bin_layout(tmp_path):
     import pytest
     with pytest.raises(ValueError):
         GUMParams.from_precalibration_bin(fn3, new_method=True)  # two values short
+
+
+def test_frame_source_thread_lockstep_and_free_running():
+    """webcam_live.FrameSourceThread (the CamAsWorkingThread contract, webcam_live.py:256-291): lock-step hands out
+    every frame exactly once and None at the end; free-running keeps only the most recent frame."""
+    import time
+    from vo_single_camera_sos_amd.omnistereo.webcam_live import FrameSourceThread
+
+    class Cam(object):
+        def __init__(self, n):
+            self.k, self.n = 0, n
+
+        def get_single_frame(self):
+            self.k += 1
+            return (self.k <= self.n, self.k)
+    t = FrameSourceThread(Cam(9), lockstep=True)
+    t.start()
+    got = []
+    while True:
+        f = t.current_frame
+        if f is None:
+            break
+        got.append(f)
+    t.quit_flag = True
+    t.join()
+    assert got == list(range(1, 10)) and t.frames_delivered == 9 and t.cam.show_img is False
+    t = FrameSourceThread(Cam(10 ** 9), min_period_s=0.002)
+    t.start()
+    time.sleep(0.05)
+    a = t.current_frame
+    time.sleep(0.05)
+    b = t.current_frame
+    t.quit_flag = True
+    t.join()
+    assert a is not None and b > a and t.current_frame is None

@@ -442,7 +442,8 @@ def _is_rgbd_model(camera_model):
 
 
 def run_VO(visualizer_3D_VO, camera_model, gt_poses_filename=None, est_poses_filename="estimated_frame_poses_TUM.txt",
-           img_filename_template=None, depth_filename_template=None, img_indices=(), results_path="~/temp", thread_name=""):
+           img_filename_template=None, depth_filename_template=None, img_indices=(), results_path="~/temp", thread_name="",
+           _live_frames=None, _keyframe_thresholds=None):
     """pose_est_tools.py:1264-1678 without the 3-D visualisation (visualizer_3D_VO must be None): the frame loop,
     the keyframe policy (translation 0.01-0.20 m or rotation 1-10 degrees wrt the keyframe, enough tracked
     correspondences and keypoints), pose chaining through the keyframes, and the result files
@@ -467,19 +468,31 @@ def run_VO(visualizer_3D_VO, camera_model, gt_poses_filename=None, est_poses_fil
 
     pose_output_file_units = "m"
     zero_up_gt_wrt_origin = True
-    # indoor thresholds (pose_est_tools.py:1308-1313)
-    pos_thr, pos_max = 0.01, 0.20
-    ang_thr, ang_max = np.deg2rad(1.0), np.deg2rad(10.0)
+    # indoor thresholds (pose_est_tools.py:1308-1313); run_VO_live passes its own (:991-1003)
+    pos_thr, pos_max, ang_thr, ang_max = _keyframe_thresholds or (0.01, 0.20, np.deg2rad(1.0), np.deg2rad(10.0))
     thr_tracked, thr_keypoints = 0.10, 0.10
 
-    image_names = get_images(img_filename_template, indices_list=img_indices, return_names_only=True)
-    depth_names = get_images(depth_filename_template, indices_list=img_indices, return_names_only=True) if rgbd else None
-    if img_indices is None or len(img_indices) == 0:
-        img_indices = list(range(len(image_names)))
+    if _live_frames is None:
+        image_names = get_images(img_filename_template, indices_list=img_indices, return_names_only=True)
+        depth_names = get_images(depth_filename_template, indices_list=img_indices, return_names_only=True) if rgbd else None
+        if img_indices is None or len(img_indices) == 0:
+            img_indices = list(range(len(image_names)))
+
+        def frames():   # (frame index, image, depth map or None) from the files of the sequence
+            for k, idx in enumerate(img_indices):
+                if rgbd:
+                    # the reference converts BGR -> RGB (:1430) and then treats the array as BGR (:531): reproduced as is
+                    yield idx, np.ascontiguousarray(imread(image_names[k])[..., ::-1]), \
+                        get_depthmap_float32_from_png(depth_names[k], camera_model.scaling_factor)
+                else:
+                    yield idx, imread(image_names[k]), None
+    else:
+        img_indices = [0]
+        frames = _live_frames
     tracker = trackerClass(camera_model=camera_model, show_3D_points=False, results_path=results_path)
     if gt_poses_filename is None or not os.path.exists(gt_poses_filename):
         n_gt = max(len(img_indices), img_indices[-1] + 1)
-        gt_list = n_gt * [np.identity(4)]
+        gt_list = n_gt * [np.identity(4)]   # (a live run has no ground truth: identity for every frame, as :1012)
     else:
         _, gt_list = get_poses_from_file(poses_filename=gt_poses_filename, input_units="m",
                                          output_working_units=pose_output_file_units, indices=[], pose_format="tum",
@@ -508,15 +521,16 @@ def run_VO(visualizer_3D_VO, camera_model, gt_poses_filename=None, est_poses_fil
     acc = dict(read=0., setup=0., track=0., vo=0., corr=0., ratio=0.)
     poses_out, keyframe_ids = [], []
     n_done = 0
-    for img_index_number, idx in enumerate(img_indices):
+    frame_iter = iter(frames())
+    img_index_number = -1
+    while True:
         t_frame = time.process_time()
         t0 = time.process_time()
-        if rgbd:
-            # the reference converts BGR -> RGB (:1430) and then treats the array as BGR (:531): reproduced as is
-            img = np.ascontiguousarray(imread(image_names[img_index_number])[..., ::-1])
-            depth_map = get_depthmap_float32_from_png(depth_names[img_index_number], camera_model.scaling_factor)
-        else:
-            img = imread(image_names[img_index_number])
+        try:
+            idx, img, depth_map = next(frame_iter)
+        except StopIteration:
+            break
+        img_index_number += 1
         if img_index_number > 0:
             acc["read"] += time.process_time() - t0
         t0 = time.process_time()
@@ -528,7 +542,7 @@ def run_VO(visualizer_3D_VO, camera_model, gt_poses_filename=None, est_poses_fil
             current_frame = StereoPanoramicFrame(stereo_camera_model=camera_model, frame_id=idx, parent_id=current_keyframe_id)
         if img_index_number > 0:
             acc["setup"] += time.process_time() - t0
-        T_gt = gt_list[idx] if idx < len(gt_list) else np.full((4, 4), np.nan)
+        T_gt = gt_list[idx] if idx < len(gt_list) else (np.identity(4) if _live_frames is not None else np.full((4, 4), np.nan))
         if T_Rgt_wrt_S is not None:
             T_gt = tr.concatenate_matrices(T_Rgt_wrt_S, T_gt, T_S_wrt_Rgt)   # :1472
         if img_index_number > 0:
@@ -615,6 +629,71 @@ def run_VO(visualizer_3D_VO, camera_model, gt_poses_filename=None, est_poses_fil
     for f in (est_file, gt_file, kf_file, log):
         f.close()
     return dict(poses=poses_out, keyframe_ids=keyframe_ids, tracked=n_done, message=summary)
+
+
+def run_VO_live(visualizer_3D_VO, camera_model, cam_working_thread, est_poses_filename="estimated_frame_poses_TUM.txt",
+                results_path="~/temp", thread_name=""):
+    """pose_est_tools.py:960-1262: the VO loop on the frames of a running camera thread.  `cam_working_thread` is the
+    reference's CamAsWorkingThread contract (webcam_live.py:256-291; `omnistereo.webcam_live.FrameSourceThread` here):
+    `.current_frame` = the most recent omni image (None when the source ends), `.quit_flag`.  Each pass of the loop
+    takes whatever frame is current (frames arriving faster than the tracker are skipped, a frame still current is
+    processed again, as in the reference), numbers it 0, 1, 2, ... and runs run_VO's frame body with the live keyframe
+    thresholds (:998-1003: translation 0.05-0.50 m or rotation 5-60 degrees); omnistereo models only (:1066-1073)."""
+    if _is_rgbd_model(camera_model):
+        raise NotImplementedError("run_VO_live tracks omnistereo models only (the RGB-D branch of the reference is commented out, :1069-1073)")
+
+    def frames():
+        idx = 0
+        while not cam_working_thread.quit_flag:   # :1051
+            img = cam_working_thread.current_frame
+            if img is None:
+                break
+            yield idx, img, None
+            idx += 1
+    return run_VO(visualizer_3D_VO, camera_model, gt_poses_filename=None, est_poses_filename=est_poses_filename,
+                  results_path=results_path, thread_name=thread_name, _live_frames=frames,
+                  _keyframe_thresholds=(0.05, 0.50, np.deg2rad(5.0), np.deg2rad(60.0)))
+
+
+def driver_VO_live(camera_model, scene_path_vo_results, cam_working_thread, visualize_VO=False, use_multithreads_for_VO=True,
+                   thread_name="LIVE"):
+    """pose_est_tools.py:1743-1797: start the camera thread, run run_VO_live (on a worker thread or inline), then stop
+    and join the camera thread."""
+    if visualize_VO:
+        raise NotImplementedError("3-D visualisation is not built: visualize_VO must be False")
+    if use_multithreads_for_VO:
+        est_poses_filename = "estimated_frame_poses_TUM.txt"
+    else:
+        from datetime import datetime
+        now = datetime.now()
+        est_poses_filename = "estimated_frame_poses_TUM-%d-%d-%d-%d-%d-%d.txt" % (now.year, now.month, now.day, now.hour,
+                                                                                   now.minute, now.second)
+    cam_working_thread.start()
+    if not getattr(cam_working_thread, "lockstep", False):
+        while cam_working_thread.current_frame is None and cam_working_thread.is_alive() and not cam_working_thread.quit_flag:
+            time.sleep(0.001)   # (the reference starts tracking at once and stops if no frame has arrived yet)
+    kwargs = dict(visualizer_3D_VO=None, camera_model=camera_model, cam_working_thread=cam_working_thread,
+                  est_poses_filename=est_poses_filename, results_path=scene_path_vo_results, thread_name=thread_name)
+    result, failure = {}, []
+    try:
+        if use_multithreads_for_VO:
+            def work():
+                try:
+                    result.update(run_VO_live(**kwargs))
+                except BaseException as e:  # noqa: B902 -- handed to the calling thread
+                    failure.append(e)
+            th = threading.Thread(target=work)
+            th.start()
+            th.join()
+        else:
+            result.update(run_VO_live(**kwargs))
+    finally:
+        cam_working_thread.quit_flag = True   # :1792-1793
+        cam_working_thread.join()
+    if failure:
+        raise failure[0]
+    print("DONE")
+    return result
 
 
 def driver_VO(camera_model, scene_path, scene_path_vo_results, scene_img_filename_template, depth_filename_template,
