@@ -36,6 +36,33 @@ def normalized(v):
     return v / np.linalg.norm(v)
 
 
+def pose_relative_ransac_2D_to_2D(bearing_vectors1, bearing_vectors2, model_error_threshold=0.001,
+                                  rel_pose_est_algorithm="STEWENIUS", outlier_fraction_known=0.50):
+    """pose_est_tools.py:54-90 (pyopengv.relative_pose_ransac with a 5 / 7 / 8-point solver).  Not reached by the VO
+    drivers and not built: raises instead of answering with something else."""
+    raise NotImplementedError("2D-2D relative-pose RANSAC (%s) is not built; the VO drivers use the 3D-2D absolute pose"
+                              % rel_pose_est_algorithm)
+
+
+def pose_absolute_ransac_3D_to_2D(bearing_vectors, points3D, model_error_threshold=0.001, pose_est_algorithm="EPNP",
+                                  outlier_fraction_known=0.50, max_iterations=-1):
+    """pose_est_tools.py:92-129: central absolute-pose RANSAC with the iteration budget N = log(0.01) / log(1 - w^n)
+    + 3 std (n = 2 for "TWOPT", else 3 -- as written there, also for "EPNP") when max_iterations < 0
+    -> (T 4x4, inlier indices)."""
+    from math import log10, sqrt
+    if max_iterations < 0:
+        n_points_for_model = 2 if pose_est_algorithm == "TWOPT" else 3
+        w = 1.0 - outlier_fraction_known
+        num_of_iters = log10(1.0 - 0.99) / log10(1.0 - w ** n_points_for_model)
+        std_of_k = sqrt(1.0 - w ** n_points_for_model) / (w ** n_points_for_model)
+        max_iterations = int(num_of_iters + 3 * std_of_k)
+    T, inliers = pyopengv.absolute_pose_ransac(bearing_vectors[..., :3], points3D[..., :3], pose_est_algorithm,
+                                               model_error_threshold, max_iterations)
+    T_homo = np.identity(4)
+    T_homo[:3] = T
+    return T_homo, inliers
+
+
 def get_selected_distances_to_model(model, indices, bearing_vectors1, bearing_vectors2, is_relative_2D_to_2D_case,
                                     verbose_debug=False):
     """pose_est_tools.py:150-203: OpenGV's absolute-pose score 1 - f . normalize(R^T (p - t)) per index (the
