@@ -57,8 +57,14 @@ __global__ __launch_bounds__(kThreads) void match_hamming_kernel(
 
   uint4 qa[QPT], qb[QPT];
   uint32_t best[QPT], second[QPT];
+  // One query per lane (the small per-bucket problems): a wave whose 64 rows all lie beyond nq sits out the distance
+  // loop (wave-uniform, scalar test per train tile); it still loads its share of the tile.  With 4 queries per lane the
+  // same test inside the unrolled loop costs more than the ragged tail it saves (measured), so it is not applied there.
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  bool live[QPT];
 #pragma unroll
   for (int r = 0; r < QPT; ++r) {
+    live[r] = q0 + r * kThreads + wave * 64 < nqp;
     const int qi = q0 + r * kThreads + tid;
     const bool valid = qi < nqp;
     const size_t row = (size_t)qs * q_stride + (valid ? qi : q0);
@@ -74,6 +80,7 @@ __global__ __launch_bounds__(kThreads) void match_hamming_kernel(
     __syncthreads();
     for (int i = tid; i < lim * 2; i += kThreads) tile[i] = tsrc[(size_t)t0 * 2 + i];
     __syncthreads();
+    if (QPT == 1 && !live[0]) continue;
 #pragma unroll 4
     for (int j = 0; j < lim; ++j) {
       const uint4 ta = tile[2 * j + 0];
