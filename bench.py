@@ -92,6 +92,33 @@ def valu_issue(kernel, pairs_per_launch, avg_launch_s):
     return None
 
 
+def valu_issue_step(pairs_per_step, ms_per_step, dominant_cycles):
+    """The whole step against the SIMDs' VALU issue rate: VALU wave-instructions of ALL kernels of a step (newest SQ
+    summary, scaled from its 64 pairs per launch) x issue cycles per instruction (the dominant kernel's measured mix,
+    4.4 for the others: a lower bound for the FP64-heavy ones) over 1024 SIMDs at 2.4 GHz = the time the step would
+    take if every issue slot were used.  frac = that bound / the measured time per step."""
+    import csv
+    import glob
+    for path in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*sq_per_kernel.csv")))):
+        cyc, total, dom = 0.0, 0.0, 0.0
+        with open(path) as fh:
+            for row in csv.DictReader(fh):
+                if not row["label"].endswith("_kernel"):
+                    continue  # (torch's own fill / copy kernels of the set-up)
+                per_step = float(row["valu_insts"]) * float(row["dispatches"]) / 5.0  # the SQ pass timed 5 steps (2 warm-up + 3)
+                is_dom = row["label"] in ("unwrap_median_gray_kernel", "median_gray_kernel")
+                cyc += per_step * (dominant_cycles if is_dom else 4.4)
+                total += per_step
+                dom += per_step if is_dom else 0.0
+        if total > 0:
+            scale = pairs_per_step / 64.0
+            bound_ms = cyc * scale / (1024 * 2.4e9) * 1e3
+            return {"valu_wave_insts_per_step": total * scale, "dominant_kernel_share": dom / total,
+                    "issue_bound_ms_per_step": bound_ms, "measured_ms_per_step": ms_per_step, "frac": bound_ms / ms_per_step,
+                    "source": os.path.relpath(path, ROOT)}
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -311,6 +338,7 @@ def main():
                          "note": "no contraction anywhere (no MFMA); the dominant kernel is VALU-bound integer/bit work, "
                                  "so the HBM fraction is small by construction (SURVEY 8d)"},
             "valu_issue": valu_issue(dom[0], dom_pairs, dom_avg_s),
+            "valu_issue_step": None,
             "streams": eng.S,
             "kernels_ms_per_step": {k: v[1] / args.steps for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])},
             "kernel_ms_per_step_total": sum(v[1] for v in per_kernel.values()) / args.steps,
@@ -338,6 +366,8 @@ def main():
                                                                % (na, cores, dta)}
                 except Exception as e:  # the one-core figure above stays the reported baseline
                     out["cpu_baseline_all_cores"] = {"error": repr(e)}
+        if out["valu_issue"]:
+            out["valu_issue_step"] = valu_issue_step(B, out["ms_per_step"], out["valu_issue"]["issue_cycles_per_inst"])
         if pcie is not None:
             out["pcie_inclusive"] = pcie
         print(json.dumps(out))
