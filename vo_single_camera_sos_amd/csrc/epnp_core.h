@@ -12,6 +12,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "ransac_core.h"
 
 #define SV_EPNP_MAXN 8
@@ -192,9 +195,157 @@ __device__ static double sv_epnp_pose_from_betas(const double* betas, const doub
   return (err == err) ? err : -1.0;
 }
 
+/* The four eigenvectors of M^T M with the smallest eigenvalues (vv[0] the smallest), work arrays in memory:
+ * MtM, Ev = 144 doubles each at stride S (private arrays or lane-interleaved LDS). */
+template <int S>
+__device__ static void sv_epnp_null4_mem(const double* alphas, const double* uv, int n, double* MtM, double* Ev, double* vv) {
+  /* M^T M (12 x 12): two rows per point, [a_j, 0, -a_j u] and [0, a_j, -a_j v] for j = 0..3 */
+  for (int k = 0; k < 144; ++k) MtM[k * S] = 0.0;
+  for (int i = 0; i < n; ++i) {
+    double r1[12], r2[12];
+    for (int j = 0; j < 4; ++j) {
+      const double a = alphas[4 * i + j];
+      r1[3 * j] = a;
+      r1[3 * j + 1] = 0.0;
+      r1[3 * j + 2] = -(a * uv[2 * i]);
+      r2[3 * j] = 0.0;
+      r2[3 * j + 1] = a;
+      r2[3 * j + 2] = -(a * uv[2 * i + 1]);
+    }
+    for (int r = 0; r < 12; ++r)
+      for (int c = 0; c < 12; ++c) MtM[(12 * r + c) * S] = (MtM[(12 * r + c) * S] + (r1[r] * r1[c])) + (r2[r] * r2[c]);
+  }
+  sv_jacobi_sym_s<S>(MtM, 12, Ev);
+  /* the four eigenvectors of the smallest eigenvalues: vv[0] smallest */
+  int idx[12];
+  for (int k = 0; k < 12; ++k) idx[k] = k;
+  for (int a = 0; a < 4; ++a) { /* partial selection sort, ties keep the lower index */
+    int m = a;
+    for (int b = a + 1; b < 12; ++b)
+      if (MtM[(13 * idx[b]) * S] < MtM[(13 * idx[m]) * S]) m = b;
+    const int tmp = idx[a];
+    idx[a] = idx[m];
+    idx[m] = tmp;
+  }
+  for (int a = 0; a < 4; ++a)
+    for (int j = 0; j < 12; ++j) vv[12 * a + j] = Ev[(12 * j + idx[a]) * S];
+}
+
+/* The same stage with the symmetric matrix in REGISTERS (upper triangle, 78 doubles) and only the eigenvector matrix
+ * in LDS (Vl, 144 doubles at stride S): every index into the matrix is a compile-time constant -- the 66 rotation
+ * pairs of a sweep are unrolled by a fold -- so the matrix needs no memory at all, a rotation costs 24 LDS loads + 24
+ * stores instead of 64 + 64, and a 64-lane wave needs 72 KB of LDS instead of 144.  Operation for operation the
+ * arithmetic of sv_epnp_null4_mem / sv_jacobi_sym_s (mirrored entries are the same value there). */
+__device__ constexpr int sv_tri(int i, int j) { return i <= j ? i * 12 - i * (i - 1) / 2 + (j - i) : j * 12 - j * (j - 1) / 2 + (i - j); }
+__device__ constexpr int sv_pair_p(int idx) {
+  int p = 0;
+  while (idx >= 11 - p) {
+    idx -= 11 - p;
+    ++p;
+  }
+  return p;
+}
+__device__ constexpr int sv_pair_q(int idx) {
+  int p = 0;
+  while (idx >= 11 - p) {
+    idx -= 11 - p;
+    ++p;
+  }
+  return p + 1 + idx;
+}
+template <typename F, int... I>
+__device__ __forceinline__ void sv_for_each_pair(F& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, sv_pair_p(I)>{}, std::integral_constant<int, sv_pair_q(I)>{}), ...);
+}
+
+template <int S>
+__device__ static void sv_epnp_null4_reg(const double* alphas, const double* uv, int n, double* Vl, double* vv) {
+  double a[78];
+#pragma unroll
+  for (int k = 0; k < 78; ++k) a[k] = 0.0;
+  for (int i = 0; i < n; ++i) {
+    double r1[12], r2[12];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const double al = alphas[4 * i + j];
+      r1[3 * j] = al;
+      r1[3 * j + 1] = 0.0;
+      r1[3 * j + 2] = -(al * uv[2 * i]);
+      r2[3 * j] = 0.0;
+      r2[3 * j + 1] = al;
+      r2[3 * j + 2] = -(al * uv[2 * i + 1]);
+    }
+#pragma unroll
+    for (int r = 0; r < 12; ++r)
+#pragma unroll
+      for (int c = r; c < 12; ++c) a[sv_tri(r, c)] = (a[sv_tri(r, c)] + (r1[r] * r1[c])) + (r2[r] * r2[c]);
+  }
+#pragma unroll
+  for (int i = 0; i < 12; ++i)
+#pragma unroll
+    for (int j = 0; j < 12; ++j) Vl[(i * 12 + j) * S] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0, diag = 0.0;
+#pragma unroll
+    for (int p = 0; p < 12; ++p) {
+      diag = diag + (a[sv_tri(p, p)] * a[sv_tri(p, p)]);
+#pragma unroll
+      for (int q = p + 1; q < 12; ++q) off = off + (a[sv_tri(p, q)] * a[sv_tri(p, q)]);
+    }
+    if (!(off > (1e-40 * diag))) break;
+    auto rotate = [&](auto p_tag, auto q_tag) __attribute__((always_inline)) {
+      constexpr int P = decltype(p_tag)::value, Q = decltype(q_tag)::value;
+      const double apq = a[sv_tri(P, Q)];
+      if (apq == 0.0) return;
+      const double app = a[sv_tri(P, P)], aqq = a[sv_tri(Q, Q)];
+      double yp[12], yq[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        yp[k] = Vl[(k * 12 + P) * S];
+        yq[k] = Vl[(k * 12 + Q) * S];
+      }
+      const double theta = (aqq - app) / (2.0 * apq);
+      const double at = theta < 0.0 ? -theta : theta;
+      const double t = (theta < 0.0 ? -1.0 : 1.0) / (at + sqrt((theta * theta) + 1.0));
+      const double c = 1.0 / sqrt((t * t) + 1.0), s = t * c;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        if (k == P || k == Q) continue;
+        const double akp = a[sv_tri(k, P)], akq = a[sv_tri(k, Q)];
+        a[sv_tri(k, P)] = (c * akp) - (s * akq);
+        a[sv_tri(k, Q)] = (s * akp) + (c * akq);
+      }
+      a[sv_tri(P, P)] = app - (t * apq);
+      a[sv_tri(Q, Q)] = aqq + (t * apq);
+      a[sv_tri(P, Q)] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        Vl[(k * 12 + P) * S] = (c * yp[k]) - (s * yq[k]);
+        Vl[(k * 12 + Q) * S] = (s * yp[k]) + (c * yq[k]);
+      }
+    };
+    sv_for_each_pair(rotate, std::make_integer_sequence<int, 66>{});
+  }
+  double ev[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) ev[k] = a[sv_tri(k, k)];
+  int idx[12];
+  for (int k = 0; k < 12; ++k) idx[k] = k;
+  for (int a4 = 0; a4 < 4; ++a4) { /* partial selection sort, ties keep the lower index */
+    int m = a4;
+    for (int b = a4 + 1; b < 12; ++b)
+      if (ev[idx[b]] < ev[idx[m]]) m = b;
+    const int tmp = idx[a4];
+    idx[a4] = idx[m];
+    idx[m] = tmp;
+  }
+  for (int a4 = 0; a4 < 4; ++a4)
+    for (int j = 0; j < 12; ++j) vv[12 * a4 + j] = Vl[(12 * j + idx[a4]) * S];
+}
+
 /* f, p: n rows of 3 (bearings in the camera, points in the world), 5 <= n <= SV_EPNP_MAXN.
  * -> R, t: pose of the camera in the world (points map by R^T (p - t)), as pyopengv returns it.  0 on failure. */
-template <int S>
+template <int S, bool REG = false>
 __device__ static int sv_epnp_s(const double* f, const double* p, int n, double* R, double* t, double* MtM, double* Ev) {
   if (n < 5 || n > SV_EPNP_MAXN) return 0; /* 4 points leave a 4-dimensional null space: not handled */
   double uv[2 * SV_EPNP_MAXN];
@@ -241,37 +392,11 @@ __device__ static int sv_epnp_s(const double* f, const double* p, int n, double*
     for (int j = 0; j < 3; ++j) alphas[4 * i + 1 + j] = ((Ci[3 * j] * d0) + (Ci[3 * j + 1] * d1)) + (Ci[3 * j + 2] * d2);
     alphas[4 * i] = ((1.0 - alphas[4 * i + 1]) - alphas[4 * i + 2]) - alphas[4 * i + 3];
   }
-  /* M^T M (12 x 12): two rows per point, [a_j, 0, -a_j u] and [0, a_j, -a_j v] for j = 0..3 */
-  for (int k = 0; k < 144; ++k) MtM[k * S] = 0.0;
-  for (int i = 0; i < n; ++i) {
-    double r1[12], r2[12];
-    for (int j = 0; j < 4; ++j) {
-      const double a = alphas[4 * i + j];
-      r1[3 * j] = a;
-      r1[3 * j + 1] = 0.0;
-      r1[3 * j + 2] = -(a * uv[2 * i]);
-      r2[3 * j] = 0.0;
-      r2[3 * j + 1] = a;
-      r2[3 * j + 2] = -(a * uv[2 * i + 1]);
-    }
-    for (int r = 0; r < 12; ++r)
-      for (int c = 0; c < 12; ++c) MtM[(12 * r + c) * S] = (MtM[(12 * r + c) * S] + (r1[r] * r1[c])) + (r2[r] * r2[c]);
-  }
-  sv_jacobi_sym_s<S>(MtM, 12, Ev);
-  /* the four eigenvectors of the smallest eigenvalues: vv[0] smallest */
-  int idx[12];
-  for (int k = 0; k < 12; ++k) idx[k] = k;
-  for (int a = 0; a < 4; ++a) { /* partial selection sort, ties keep the lower index */
-    int m = a;
-    for (int b = a + 1; b < 12; ++b)
-      if (MtM[(13 * idx[b]) * S] < MtM[(13 * idx[m]) * S]) m = b;
-    const int tmp = idx[a];
-    idx[a] = idx[m];
-    idx[m] = tmp;
-  }
   double vv[48];
-  for (int a = 0; a < 4; ++a)
-    for (int j = 0; j < 12; ++j) vv[12 * a + j] = Ev[(12 * j + idx[a]) * S];
+  if (REG)
+    sv_epnp_null4_reg<S>(alphas, uv, n, Ev, vv);
+  else
+    sv_epnp_null4_mem<S>(alphas, uv, n, MtM, Ev, vv);
   /* L (6 x 10) and rho (6) over the control-point pairs */
   const int pa[6] = {0, 0, 0, 1, 1, 2}, pb[6] = {1, 2, 3, 2, 3, 3};
   double L[60], rho[6];

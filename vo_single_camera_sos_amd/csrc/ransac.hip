@@ -132,22 +132,19 @@ __global__ __launch_bounds__(64) void ransac_hyp_kernel(const double* __restrict
 
 // The EPnP hypothesis generator (central problems, SOSVO_FLAG_EPNP): a kernel of its own -- its work arrays (LDS and
 // scratch) would otherwise cost the P3P generator of the hot path its occupancy.
-__global__ __launch_bounds__(256) void ransac_hyp_epnp_kernel(const double* __restrict__ f, const double* __restrict__ p,
-                                                              const int32_t* __restrict__ n_arr, int stride, int H,
-                                                              uint64_t seed, double* __restrict__ hyp,
-                                                              int32_t* __restrict__ counts) {
-  // The eigen-solver's two 12 x 12 arrays of every hypothesis live in LDS, element-major ([element][lane]): 2.3 KB per
-  // hypothesis, so a CU holds 64 of them.  They are spread over the CU's FOUR SIMDs -- a workgroup of 4 waves, each
-  // running 16 hypotheses in its first 16 lanes -- rather than over the 64 lanes of one wave: the generator is one long
-  // dependent chain per hypothesis (Jacobi rotations, square roots, divisions), so four instruction streams per CU
-  // finish the same 64 hypotheses ~4x sooner than one.
-  __shared__ double epnp_lds[4 * 2 * 144 * 16];
+__global__ __launch_bounds__(64) void ransac_hyp_epnp_kernel(const double* __restrict__ f, const double* __restrict__ p,
+                                                             const int32_t* __restrict__ n_arr, int stride, int H,
+                                                             uint64_t seed, double* __restrict__ hyp,
+                                                             int32_t* __restrict__ counts) {
+  // One hypothesis per lane.  The 12 x 12 symmetric matrix of the eigen-solver lives in registers (rotation pairs
+  // unrolled: sv_epnp_null4_reg), only the eigenvector matrix in LDS, element-major ([element][lane]): 72 KB per wave,
+  // two waves per CU.  The generator is one long dependent chain per hypothesis (Jacobi rotations, square roots,
+  // divisions): what counts is how many hypotheses a CU holds and how few instructions a rotation takes.
+  __shared__ double epnp_lds[144 * 64];
   const int b = blockIdx.y;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane >= 16) return;
-  const int it = blockIdx.x * 64 + wave * 16 + lane;
+  const int it = blockIdx.x * blockDim.x + threadIdx.x;
   if (it >= H) return;
-  double* lds = epnp_lds + wave * (2 * 144 * 16) + lane;
+  double* lds = epnp_lds + threadIdx.x;
   const int n = min(n_arr[b], stride);
   const size_t base = (size_t)b * stride;
   double R[9], t[3];
@@ -160,7 +157,7 @@ __global__ __launch_bounds__(256) void ransac_hyp_epnp_kernel(const double* __re
         f6[3 * k + c] = f[3 * (base + s6[k]) + c];
         p6[3 * k + c] = p[3 * (base + s6[k]) + c];
       }
-    ok = sv_epnp_s<16>(f6, p6, 6, R, t, lds, lds + 144 * 16);
+    ok = sv_epnp_s<64, true>(f6, p6, 6, R, t, nullptr, lds);
   }
   double* h = hyp + ((size_t)b * H + it) * kHypDoubles;
   if (ok) {
@@ -695,7 +692,7 @@ int32_t sosvo_ransac_abs_pose(sosvo_ctx* ctx, const double* f, const double* p, 
   SOSVO_REQUIRE(ctx, !epnp || cam == nullptr, "SOSVO_FLAG_EPNP is for central problems (cam == NULL)");
   if (epnp) adaptive = (adaptive ? 1 : 0) | 2;  // bit 1: the adaptive stop uses 6-point samples
   if (epnp)
-    SOSVO_LAUNCH(ctx, ransac_hyp_epnp_kernel, dim3(cdiv(H, 64), nprob), dim3(256), 0, ctx->stream, f, p, n, stride, H, seed,
+    SOSVO_LAUNCH(ctx, ransac_hyp_epnp_kernel, dim3(cdiv(H, 64), nprob), dim3(64), 0, ctx->stream, f, p, n, stride, H, seed,
                  hyp, counts);
   else
     SOSVO_LAUNCH(ctx, ransac_hyp_kernel, dim3(cdiv(H, 64), nprob), dim3(64), 0, ctx->stream, f, p, cam, cam_off, cam_rot, n,
