@@ -29,21 +29,28 @@
  * the compiler cannot prove that on its own). */
 template <int S>
 __device__ static void sv_jacobi_sym_s(double* A, int n, double* V) {
+  #pragma unroll
   for (int i = 0; i < n; ++i)
+    #pragma unroll
     for (int j = 0; j < n; ++j) V[(i * n + j) * S] = (i == j) ? 1.0 : 0.0;
   for (int sweep = 0; sweep < 60; ++sweep) {
     double off = 0.0, diag = 0.0;
+    #pragma unroll
     for (int p = 0; p < n; ++p) {
       diag = diag + (A[(p * n + p) * S] * A[(p * n + p) * S]);
+      #pragma unroll
       for (int q = p + 1; q < n; ++q) off = off + (A[(p * n + q) * S] * A[(p * n + q) * S]);
     }
     if (!(off > (1e-40 * diag))) break;
+    #pragma unroll
     for (int p = 0; p < n - 1; ++p)
+      #pragma unroll
       for (int q = p + 1; q < n; ++q) {
         const double apq = A[(p * n + q) * S];
         if (apq == 0.0) continue;
         const double app = A[(p * n + p) * S], aqq = A[(q * n + q) * S];
         double xp[SV_JACOBI_MAXN], xq[SV_JACOBI_MAXN], yp[SV_JACOBI_MAXN], yq[SV_JACOBI_MAXN];
+        #pragma unroll
         for (int k = 0; k < n; ++k) {  // (rows k of columns p, q: the values of k = p, q are loaded but not used)
           xp[k] = A[(k * n + p) * S];
           xq[k] = A[(k * n + q) * S];
@@ -54,6 +61,7 @@ __device__ static void sv_jacobi_sym_s(double* A, int n, double* V) {
         const double at = theta < 0.0 ? -theta : theta;
         const double t = (theta < 0.0 ? -1.0 : 1.0) / (at + sqrt((theta * theta) + 1.0));
         const double c = 1.0 / sqrt((t * t) + 1.0), s = t * c;
+        #pragma unroll
         for (int k = 0; k < n; ++k) {
           if (k == p || k == q) continue;
           const double x = (c * xp[k]) - (s * xq[k]), y = (s * xp[k]) + (c * xq[k]);
@@ -66,6 +74,7 @@ __device__ static void sv_jacobi_sym_s(double* A, int n, double* V) {
         A[(q * n + q) * S] = aqq + (t * apq);
         A[(p * n + q) * S] = 0.0;
         A[(q * n + p) * S] = 0.0;
+        #pragma unroll
         for (int k = 0; k < n; ++k) {
           V[(k * n + p) * S] = (c * yp[k]) - (s * yq[k]);
           V[(k * n + q) * S] = (s * yp[k]) + (c * yq[k]);
@@ -79,19 +88,25 @@ __device__ static void sv_jacobi_sym(double* A, int n, double* V) { sv_jacobi_sy
  * with partial pivoting.  A row-major with row stride lda.  Returns 0 on a vanishing pivot. */
 __device__ static int sv_lsq_small(const double* A, int lda, const double* b, int m, int k, double* x) {
   double N[5 * 6];
+  #pragma unroll
   for (int i = 0; i < k; ++i) {
+    #pragma unroll
     for (int j = 0; j < k; ++j) {
       double s = 0.0;
+      #pragma unroll
       for (int r = 0; r < m; ++r) s = s + (A[r * lda + i] * A[r * lda + j]);
       N[i * 6 + j] = s;
     }
     double s = 0.0;
+    #pragma unroll
     for (int r = 0; r < m; ++r) s = s + (A[r * lda + i] * b[r]);
     N[i * 6 + 5] = s;
   }
+  #pragma unroll
   for (int c = 0; c < k; ++c) {
     int piv = c;
     double best = N[c * 6 + c] < 0.0 ? -N[c * 6 + c] : N[c * 6 + c];
+    #pragma unroll
     for (int r = c + 1; r < k; ++r) {
       const double v = N[r * 6 + c] < 0.0 ? -N[r * 6 + c] : N[r * 6 + c];
       if (v > best) {
@@ -100,20 +115,28 @@ __device__ static int sv_lsq_small(const double* A, int lda, const double* b, in
       }
     }
     if (!(best > 0.0)) return 0;
-    if (piv != c)
+    #pragma unroll
+    for (int r = c + 1; r < k; ++r) { /* swap rows c and piv; written over static row numbers (registers, not scratch) */
+      const bool sw = piv == r;
+      #pragma unroll
       for (int j = 0; j < 6; ++j) {
-        const double tmp = N[c * 6 + j];
-        N[c * 6 + j] = N[piv * 6 + j];
-        N[piv * 6 + j] = tmp;
+        const double tc = N[c * 6 + j], tr = N[r * 6 + j];
+        N[c * 6 + j] = sw ? tr : tc;
+        N[r * 6 + j] = sw ? tc : tr;
       }
+    }
+    #pragma unroll
     for (int r = c + 1; r < k; ++r) {
       const double fct = N[r * 6 + c] / N[c * 6 + c];
+      #pragma unroll
       for (int j = c; j < k; ++j) N[r * 6 + j] = N[r * 6 + j] - (fct * N[c * 6 + j]);
       N[r * 6 + 5] = N[r * 6 + 5] - (fct * N[c * 6 + 5]);
     }
   }
+  #pragma unroll
   for (int c = k - 1; c >= 0; --c) {
     double s = N[c * 6 + 5];
+    #pragma unroll
     for (int j = c + 1; j < k; ++j) s = s - (N[c * 6 + j] * x[j]);
     x[c] = s / N[c * 6 + c];
   }
@@ -125,65 +148,95 @@ __device__ static int sv_lsq_small(const double* A, int lda, const double* b, in
 __device__ static double sv_epnp_pose_from_betas(const double* betas, const double* vv /*[4][12]*/, const double* alphas,
                                               const double* pw, const double* uv, int n, double* Rcw, double* tcw) {
   double ccs[12], pcs[3 * SV_EPNP_MAXN];
+  #pragma unroll
   for (int j = 0; j < 12; ++j)
     ccs[j] = (((betas[0] * vv[j]) + (betas[1] * vv[12 + j])) + (betas[2] * vv[24 + j])) + (betas[3] * vv[36 + j]);
+  #pragma unroll
   for (int i = 0; i < n; ++i)
+    #pragma unroll
     for (int k = 0; k < 3; ++k)
       pcs[3 * i + k] = (((alphas[4 * i] * ccs[k]) + (alphas[4 * i + 1] * ccs[3 + k])) + (alphas[4 * i + 2] * ccs[6 + k])) +
                        (alphas[4 * i + 3] * ccs[9 + k]);
   if (pcs[2] < 0.0) { /* the points must lie in front of the camera */
+    #pragma unroll
     for (int j = 0; j < 12; ++j) ccs[j] = -ccs[j];
+    #pragma unroll
     for (int j = 0; j < 3 * n; ++j) pcs[j] = -pcs[j];
   }
   /* absolute orientation: H = sum (pc - pc0)(pw - pw0)^T, R = U V^T of its SVD made proper */
   double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};
+  #pragma unroll
   for (int i = 0; i < n; ++i)
+    #pragma unroll
     for (int k = 0; k < 3; ++k) {
       pc0[k] = pc0[k] + pcs[3 * i + k];
       pw0[k] = pw0[k] + pw[3 * i + k];
     }
+  #pragma unroll
   for (int k = 0; k < 3; ++k) {
     pc0[k] = pc0[k] / (double)n;
     pw0[k] = pw0[k] / (double)n;
   }
   double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  #pragma unroll
   for (int i = 0; i < n; ++i)
+    #pragma unroll
     for (int r = 0; r < 3; ++r)
+      #pragma unroll
       for (int c = 0; c < 3; ++c) H[3 * r + c] = H[3 * r + c] + ((pcs[3 * i + r] - pc0[r]) * (pw[3 * i + c] - pw0[c]));
   double S[9], V[9];
+  #pragma unroll
   for (int r = 0; r < 3; ++r)
+    #pragma unroll
     for (int c = 0; c < 3; ++c) S[3 * r + c] = ((H[r] * H[c]) + (H[3 + r] * H[3 + c])) + (H[6 + r] * H[6 + c]); /* H^T H */
   sv_jacobi_sym(S, 3, V);
-  int o0 = 0, o1 = 1, o2 = 2, tmp; /* eigenvalues descending */
-  if (S[4 * o0] < S[4 * o1]) { tmp = o0; o0 = o1; o1 = tmp; }
-  if (S[4 * o1] < S[4 * o2]) { tmp = o1; o1 = o2; o2 = tmp; }
-  if (S[4 * o0] < S[4 * o1]) { tmp = o0; o0 = o1; o1 = tmp; }
-  if (!(S[4 * o1] > 0.0)) return -1.0; /* rank < 2: no orientation */
-  double v0[3] = {V[o0], V[3 + o0], V[6 + o0]}, v1[3] = {V[o1], V[3 + o1], V[6 + o1]}, v2[3];
+  /* eigenvalues descending, with their eigenvectors (columns of V): a three-element sorting network on the values
+   * instead of runtime indices into S and V (same comparisons, same outcome; keeps everything in registers) */
+  double e0 = S[0], e1 = S[4], e2 = S[8];
+  double v0[3] = {V[0], V[3], V[6]}, v1[3] = {V[1], V[4], V[7]}, v2[3] = {V[2], V[5], V[8]};
+#define SV_CSWAP(ea, va, eb, vb)                   \
+  if (ea < eb) {                                   \
+    double t_ = ea; ea = eb; eb = t_;              \
+    t_ = va[0]; va[0] = vb[0]; vb[0] = t_;         \
+    t_ = va[1]; va[1] = vb[1]; vb[1] = t_;         \
+    t_ = va[2]; va[2] = vb[2]; vb[2] = t_;         \
+  }
+  SV_CSWAP(e0, v0, e1, v1)
+  SV_CSWAP(e1, v1, e2, v2)
+  SV_CSWAP(e0, v0, e1, v1)
+#undef SV_CSWAP
+  if (!(e1 > 0.0)) return -1.0; /* rank < 2: no orientation */
   v2[0] = (v0[1] * v1[2]) - (v0[2] * v1[1]);
   v2[1] = (v0[2] * v1[0]) - (v0[0] * v1[2]);
   v2[2] = (v0[0] * v1[1]) - (v0[1] * v1[0]);
   double u0[3], u1[3], u2[3];
-  const double s0 = sqrt(S[4 * o0]), s1 = sqrt(S[4 * o1]);
+  const double s0 = sqrt(e0), s1 = sqrt(e1);
+  #pragma unroll
   for (int r = 0; r < 3; ++r) {
     u0[r] = (((H[3 * r] * v0[0]) + (H[3 * r + 1] * v0[1])) + (H[3 * r + 2] * v0[2])) / s0;
     u1[r] = (((H[3 * r] * v1[0]) + (H[3 * r + 1] * v1[1])) + (H[3 * r + 2] * v1[2])) / s1;
   }
   { /* re-orthonormalise u1 against u0 (they are orthogonal up to rounding) */
     const double d = ((u0[0] * u1[0]) + (u0[1] * u1[1])) + (u0[2] * u1[2]);
+    #pragma unroll
     for (int r = 0; r < 3; ++r) u1[r] = u1[r] - (d * u0[r]);
     const double nn = sqrt(((u1[0] * u1[0]) + (u1[1] * u1[1])) + (u1[2] * u1[2]));
     if (!(nn > 0.0)) return -1.0;
+    #pragma unroll
     for (int r = 0; r < 3; ++r) u1[r] = u1[r] / nn;
   }
   u2[0] = (u0[1] * u1[2]) - (u0[2] * u1[1]);
   u2[1] = (u0[2] * u1[0]) - (u0[0] * u1[2]);
   u2[2] = (u0[0] * u1[1]) - (u0[1] * u1[0]);
+  #pragma unroll
   for (int r = 0; r < 3; ++r)
+    #pragma unroll
     for (int c = 0; c < 3; ++c) Rcw[3 * r + c] = ((u0[r] * v0[c]) + (u1[r] * v1[c])) + (u2[r] * v2[c]);
+  #pragma unroll
   for (int r = 0; r < 3; ++r)
     tcw[r] = pc0[r] - (((Rcw[3 * r] * pw0[0]) + (Rcw[3 * r + 1] * pw0[1])) + (Rcw[3 * r + 2] * pw0[2]));
   double err = 0.0;
+  #pragma unroll
   for (int i = 0; i < n; ++i) {
     const double X = (((Rcw[0] * pw[3 * i]) + (Rcw[1] * pw[3 * i + 1])) + (Rcw[2] * pw[3 * i + 2])) + tcw[0];
     const double Y = (((Rcw[3] * pw[3 * i]) + (Rcw[4] * pw[3 * i + 1])) + (Rcw[5] * pw[3 * i + 2])) + tcw[1];
@@ -349,6 +402,7 @@ template <int S, bool REG = false>
 __device__ static int sv_epnp_s(const double* f, const double* p, int n, double* R, double* t, double* MtM, double* Ev) {
   if (n < 5 || n > SV_EPNP_MAXN) return 0; /* 4 points leave a 4-dimensional null space: not handled */
   double uv[2 * SV_EPNP_MAXN];
+  #pragma unroll
   for (int i = 0; i < n; ++i) {
     if (!(f[3 * i + 2] != 0.0)) return 0;
     uv[2 * i] = f[3 * i] / f[3 * i + 2];
@@ -356,22 +410,32 @@ __device__ static int sv_epnp_s(const double* f, const double* p, int n, double*
   }
   /* control points: centroid + principal axes scaled by sqrt(eigenvalue / n) */
   double cw[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  #pragma unroll
   for (int i = 0; i < n; ++i)
+    #pragma unroll
     for (int k = 0; k < 3; ++k) cw[k] = cw[k] + p[3 * i + k];
+  #pragma unroll
   for (int k = 0; k < 3; ++k) cw[k] = cw[k] / (double)n;
   double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, E[9];
+  #pragma unroll
   for (int i = 0; i < n; ++i)
+    #pragma unroll
     for (int r = 0; r < 3; ++r)
+      #pragma unroll
       for (int c = 0; c < 3; ++c) C[3 * r + c] = C[3 * r + c] + ((p[3 * i + r] - cw[r]) * (p[3 * i + c] - cw[c]));
   sv_jacobi_sym(C, 3, E);
+  #pragma unroll
   for (int a = 0; a < 3; ++a) {
     const double lam = C[4 * a] > 0.0 ? C[4 * a] : 0.0;
     const double kk = sqrt(lam / (double)n);
+    #pragma unroll
     for (int k = 0; k < 3; ++k) cw[3 * (a + 1) + k] = cw[k] + (kk * E[3 * k + a]);
   }
   /* barycentric coordinates: CC a = p - c0, CC columns = c_j - c_0 */
   double CC[9];
+  #pragma unroll
   for (int r = 0; r < 3; ++r)
+    #pragma unroll
     for (int c = 0; c < 3; ++c) CC[3 * r + c] = cw[3 * (c + 1) + r] - cw[r];
   const double det = ((CC[0] * ((CC[4] * CC[8]) - (CC[5] * CC[7]))) - (CC[1] * ((CC[3] * CC[8]) - (CC[5] * CC[6])))) +
                      (CC[2] * ((CC[3] * CC[7]) - (CC[4] * CC[6])));
@@ -387,8 +451,10 @@ __device__ static int sv_epnp_s(const double* f, const double* p, int n, double*
   Ci[7] = ((CC[1] * CC[6]) - (CC[0] * CC[7])) / det;
   Ci[8] = ((CC[0] * CC[4]) - (CC[1] * CC[3])) / det;
   double alphas[4 * SV_EPNP_MAXN];
+  #pragma unroll
   for (int i = 0; i < n; ++i) {
     const double d0 = p[3 * i] - cw[0], d1 = p[3 * i + 1] - cw[1], d2 = p[3 * i + 2] - cw[2];
+    #pragma unroll
     for (int j = 0; j < 3; ++j) alphas[4 * i + 1 + j] = ((Ci[3 * j] * d0) + (Ci[3 * j + 1] * d1)) + (Ci[3 * j + 2] * d2);
     alphas[4 * i] = ((1.0 - alphas[4 * i + 1]) - alphas[4 * i + 2]) - alphas[4 * i + 3];
   }
@@ -400,9 +466,12 @@ __device__ static int sv_epnp_s(const double* f, const double* p, int n, double*
   /* L (6 x 10) and rho (6) over the control-point pairs */
   const int pa[6] = {0, 0, 0, 1, 1, 2}, pb[6] = {1, 2, 3, 2, 3, 3};
   double L[60], rho[6];
+  #pragma unroll
   for (int j = 0; j < 6; ++j) {
     double dv[4][3];
+    #pragma unroll
     for (int a = 0; a < 4; ++a)
+      #pragma unroll
       for (int k = 0; k < 3; ++k) dv[a][k] = vv[12 * a + 3 * pa[j] + k] - vv[12 * a + 3 * pb[j] + k];
 #define SV_D(a, b) (((dv[a][0] * dv[b][0]) + (dv[a][1] * dv[b][1])) + (dv[a][2] * dv[b][2]))
     L[10 * j + 0] = SV_D(0, 0);
@@ -421,10 +490,12 @@ __device__ static int sv_epnp_s(const double* f, const double* p, int n, double*
     rho[j] = ((e0 * e0) + (e1 * e1)) + (e2 * e2);
   }
   double best_err = -1.0, Rb[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tb[3] = {0, 0, 0};
+  #pragma unroll
   for (int variant = 0; variant < 3; ++variant) {
     double betas[4] = {0, 0, 0, 0}, A[6 * 5], x[5];
     int ok;
     if (variant == 0) { /* betas10 = [B11 B12 B13 B14] */
+      #pragma unroll
       for (int j = 0; j < 6; ++j) {
         A[5 * j] = L[10 * j];
         A[5 * j + 1] = L[10 * j + 1];
@@ -447,7 +518,9 @@ __device__ static int sv_epnp_s(const double* f, const double* p, int n, double*
       }
     } else { /* [B11 B12 B22] and [B11 B12 B22 B13 B23] */
       const int k = variant == 1 ? 3 : 5;
+      #pragma unroll
       for (int j = 0; j < 6; ++j)
+        #pragma unroll
         for (int c = 0; c < k; ++c) A[5 * j + c] = L[10 * j + c];
       ok = sv_lsq_small(A, 5, rho, 6, k, x);
       if (ok) {
@@ -464,8 +537,10 @@ __device__ static int sv_epnp_s(const double* f, const double* p, int n, double*
       }
     }
     if (!ok) continue;
+    #pragma unroll
     for (int itn = 0; itn < 5; ++itn) { /* Gauss-Newton on the six distance constraints */
       double J[6 * 5], r[6], dx[4];
+      #pragma unroll
       for (int j = 0; j < 6; ++j) {
         const double* l = L + 10 * j;
         J[5 * j] = (((2.0 * l[0]) * betas[0]) + (l[1] * betas[1])) + ((l[3] * betas[2]) + (l[6] * betas[3]));
@@ -479,23 +554,31 @@ __device__ static int sv_epnp_s(const double* f, const double* p, int n, double*
                            (((l[8] * betas[2]) * betas[3]) + ((l[9] * betas[3]) * betas[3])))));
       }
       if (!sv_lsq_small(J, 5, r, 6, 4, dx)) break;
+      #pragma unroll
       for (int a = 0; a < 4; ++a) betas[a] = betas[a] + dx[a];
     }
     double Rc[9], tc[3];
     const double err = sv_epnp_pose_from_betas(betas, vv, alphas, p, uv, n, Rc, tc);
     if (err >= 0.0 && (best_err < 0.0 || err < best_err)) {
       best_err = err;
+      #pragma unroll
       for (int k = 0; k < 9; ++k) Rb[k] = Rc[k];
+      #pragma unroll
       for (int k = 0; k < 3; ++k) tb[k] = tc[k];
     }
   }
   if (best_err < 0.0) return 0;
   /* camera pose in the world: R = Rcw^T, t = -Rcw^T tcw */
+  #pragma unroll
   for (int r = 0; r < 3; ++r)
+    #pragma unroll
     for (int c = 0; c < 3; ++c) R[3 * r + c] = Rb[3 * c + r];
+  #pragma unroll
   for (int r = 0; r < 3; ++r) t[r] = -(((Rb[r] * tb[0]) + (Rb[3 + r] * tb[1])) + (Rb[6 + r] * tb[2]));
+  #pragma unroll
   for (int k = 0; k < 9; ++k)
     if (!(R[k] == R[k])) return 0;
+  #pragma unroll
   for (int k = 0; k < 3; ++k)
     if (!(t[k] == t[k])) return 0;
   return 1;
