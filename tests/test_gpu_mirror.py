@@ -38,6 +38,14 @@ def test_feature_matcher_best_match_sorted(ctx):
         assert [m.distance for m in ms] == [float(d) for d in di]
         assert np.all(np.diff(ms.distances) >= 0) and ms.distances.dtype == np.float32
     assert len(FeatureMatcher("GFT", "BF", 1, context=ctx).match(np.zeros((0, 32), np.uint8), t)) == 0
+    # the batched form (one launch for all azimuthal buckets of a frame) equals the per-pair calls, ragged sizes included
+    fm = FeatureMatcher("GFT", "BF", 1, context=ctx)
+    pairs = [_descs(rng, nq, nt) for nq, nt in ((120, 170), (1, 9), (300, 2), (77, 77))] + [(np.zeros((0, 32), np.uint8), t)]
+    many = fm.match_arrays_many(pairs)
+    assert len(many) == len(pairs)
+    for (q, t2), got in zip(pairs, many):
+        want = fm.match_arrays(q, t2)
+        assert all(np.array_equal(a, b) and a.dtype == b.dtype for a, b in zip(got, want))
 
 
 def test_feature_matcher_two_best_flattened_and_ratio_rule(ctx):

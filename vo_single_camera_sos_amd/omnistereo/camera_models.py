@@ -172,6 +172,45 @@ class FeatureMatcher(object):
             buf[0, :n] = t.to(ctx.device)
         return buf, n
 
+    def match_arrays_many(self, pairs):
+        """[(query_descriptors, train_descriptors), ...] -> [(query_idx, train_idx, distance), ...]: match_arrays for
+        every pair, but as ONE batched launch + one copy back when the matcher is in its best-match mode (the per-bucket
+        loop of match_features_panoramic_top_bottom costs a dozen launch / synchronise round trips per frame otherwise)."""
+        import torch
+        if self.use_radius_match or self.k_best != 1 or len(pairs) == 0:
+            return [self.match_arrays(q, t) for q, t in pairs]
+        ctx = self._context()
+        qs = [np.ascontiguousarray(np.asarray(q)) for q, _ in pairs]
+        ts = [np.ascontiguousarray(np.asarray(t)) for _, t in pairs]
+        for name, arrs in (("query_descriptors", qs), ("train_descriptors", ts)):
+            for a in arrs:
+                if a.dtype != np.uint8:
+                    raise NotImplementedError("%s: dtype %s -- only uint8 (binary, Hamming) descriptors are built" % (name, a.dtype))
+                if a.ndim != 2 or a.shape[1] != 32:
+                    raise ValueError("%s: expected [n, 32] uint8 descriptors, got %s" % (name, a.shape))
+        P = len(pairs)
+        nq, nt = np.array([a.shape[0] for a in qs], np.int32), np.array([a.shape[0] for a in ts], np.int32)
+        cq, ct = max(1, int(nq.max())), max(1, int(nt.max()))
+        hq, ht = np.zeros((P, cq, 32), np.uint8), np.zeros((P, ct, 32), np.uint8)
+        for i in range(P):
+            hq[i, :nq[i]] = qs[i]
+            ht[i, :nt[i]] = ts[i]
+        dev = ctx.device
+        nq_d, nt_d = torch.from_numpy(nq).to(dev), torch.from_numpy(nt).to(dev)
+        keys = ctx.match_hamming(torch.from_numpy(hq).to(dev), torch.from_numpy(ht).to(dev), nq_d, nt_d, k=1)
+        order = ctx.sort_matches(keys, nq_d)
+        from .._lib import KEY_SHIFT, KEY_IDX_MASK
+        kh, oh = keys[:, :, 0].cpu().numpy().astype(np.int64), order.cpu().numpy().astype(np.int64)
+        out = []
+        for i in range(P):
+            if nq[i] == 0 or nt[i] == 0:
+                out.append((np.empty(0, np.int64),) * 2 + (np.empty(0, np.float32),))
+                continue
+            o = oh[i, :nq[i]]
+            k = kh[i][o]
+            out.append((o, k & KEY_IDX_MASK, (k >> KEY_SHIFT).astype(np.float32)))
+        return out
+
     def match_arrays(self, query_descriptors, train_descriptors, max_descriptor_distance_radius=-1):
         """-> (query_idx, train_idx, distance) numpy arrays in the order of match()."""
         import torch

@@ -289,10 +289,9 @@ class GUMStereo(object):
         from .common_cv import filter_pixel_correspondences
         fm = self.feature_matcher_for_static_stereo
         sel_top, sel_bot, dsel_top, dsel_bot = [], [], [], []
-        for top_k, top_d, bot_k, bot_d in zip(keypts_list_top, desc_list_top, keypts_list_bot, desc_list_bot):
-            if len(top_k) == 0 or len(bot_k) == 0:
-                continue
-            q, t, _ = fm.match_arrays(bot_d, top_d)
+        buckets = [b for b in zip(keypts_list_top, desc_list_top, keypts_list_bot, desc_list_bot) if len(b[0]) and len(b[2])]
+        matched = fm.match_arrays_many([(bot_d, top_d) for _, top_d, _, bot_d in buckets])   # all buckets in one launch
+        for (top_k, top_d, bot_k, bot_d), (q, t, _) in zip(buckets, matched):
             good = int(fm.percentage_good_matches * len(q))
             if good > 0:
                 sel_top.append(np.array(top_k, dtype=object)[t[:good]])
