@@ -505,14 +505,22 @@ def run_VO(visualizer_3D_VO, camera_model, gt_poses_filename=None, est_poses_fil
         if img_indices is None or len(img_indices) == 0:
             img_indices = list(range(len(image_names)))
 
-        def frames():   # (frame index, image, depth map or None) from the files of the sequence
-            for k, idx in enumerate(img_indices):
-                if rgbd:
-                    # the reference converts BGR -> RGB (:1430) and then treats the array as BGR (:531): reproduced as is
-                    yield idx, np.ascontiguousarray(imread(image_names[k])[..., ::-1]), \
-                        get_depthmap_float32_from_png(depth_names[k], camera_model.scaling_factor)
-                else:
-                    yield idx, imread(image_names[k]), None
+        def load(k):
+            if rgbd:
+                # the reference converts BGR -> RGB (:1430) and then treats the array as BGR (:531): reproduced as is
+                return img_indices[k], np.ascontiguousarray(imread(image_names[k])[..., ::-1]), \
+                    get_depthmap_float32_from_png(depth_names[k], camera_model.scaling_factor)
+            return img_indices[k], imread(image_names[k]), None
+
+        def frames():   # (frame index, image, depth map or None) from the files of the sequence; the next frame is
+            # decoded on a helper thread while the current one is tracked (the decoder releases the GIL)
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=1) as pool:
+                pending = pool.submit(load, 0) if len(img_indices) else None
+                for k in range(len(img_indices)):
+                    item = pending.result()
+                    pending = pool.submit(load, k + 1) if k + 1 < len(img_indices) else None
+                    yield item
     else:
         img_indices = [0]
         frames = _live_frames
