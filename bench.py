@@ -87,8 +87,9 @@ def valu_issue(kernel, pairs_per_launch, avg_launch_s):
                             "issue_cycles_per_inst": cyc, "issue_limit_ginst_s": limit / 1e9,
                             "frac": insts / avg_launch_s / limit,
                             "source": os.path.relpath(path, ROOT), "mix_source": mix_src,
-                            "note": "instruction count from the SQ pass (one stream); with two streams the launch "
-                                    "duration includes issue slots shared with the other stream's kernels"}
+                            "note": "instruction count from the SQ pass; duration of isolated launches of the kernel "
+                                    "(roofline.isolated_launch_ms): in the timed region the launches share the SIMDs with "
+                                    "the other streams' kernels -- the whole step is accounted in valu_issue_step"}
     return None
 
 
@@ -124,7 +125,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs-per-gpu", type=int, default=512,
+    ap.add_argument("--pairs-per-gpu", type=int, default=768,
                     help="B: independent frame pairs per GPU per step (weak scaling: fixed per GPU; C4's 512 pairs "
                          "over 8 GPUs is --pairs-per-gpu 64)")
     ap.add_argument("--detector", default="GFT", choices=["GFT", "ORB"],
@@ -138,7 +139,7 @@ def parse():
                          "1440 -> 1440 x 146 gives the ~2000 keypoints per view BASELINE's metric is quoted on")
     ap.add_argument("--iters", type=int, default=2000, help="RANSAC iterations, fixed (C2: 2000)")
     ap.add_argument("--cpu-pairs", type=int, default=32, help="frame pairs timed on the host for cpu_baseline")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams per GPU the batch is split over (the median launches take turns, the latency-bound "
                          "stages of the other parts overlap them); 1 = one stream")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -261,6 +262,25 @@ def main():
     eng.profile_enable(False)
     elapsed = max_over_ranks(elapsed, dev)
 
+    # The dominant kernel on its own (nothing else on the chip): in the timed region its launches share the SIMDs with the
+    # other streams' kernels, at the lowest wave priority, so their durations say how the step is scheduled, not how good
+    # the kernel is.  A few isolated launches of one part's K1+K2+K3 give the kernel's own duration.
+    iso_ms = None
+    if rank == 0:
+        part = eng.parts[0]
+        torch.cuda.synchronize()
+        evs = []
+        with torch.cuda.stream(part.stream):
+            for _ in range(6):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(part.stream)
+                part.fe.run_images()
+                e1.record(part.stream)
+                evs.append((e0, e1))
+        torch.cuda.synchronize()
+        iso_ms = float(np.median([a.elapsed_time(b) for a, b in evs[1:]]))
+        iso_pairs = part.hi - part.lo
+
     # PCIe-inclusive rate (never `value`): the same K steps with the omni frames handed over in pinned HOST memory and
     # copied per step, double-buffered on copy streams (OverlappedFramePairs.step_from_host).  One rank only.
     pcie = None
@@ -334,10 +354,13 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": dom_avg_s * 1e3, "launches": dom[1][0],
+                         "isolated_launch_ms": iso_ms,
+                         "achieved_isolated": b_alg * iso_pairs / (iso_ms * 1e-3) / 1e9,
+                         "frac_isolated": b_alg * iso_pairs / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_pair": b_alg, "algorithmic_bytes_per_launch": b_alg_launch,
                          "note": "no contraction anywhere (no MFMA); the dominant kernel is VALU-bound integer/bit work, "
                                  "so the HBM fraction is small by construction (SURVEY 8d)"},
-            "valu_issue": valu_issue(dom[0], dom_pairs, dom_avg_s),
+            "valu_issue": valu_issue(dom[0], iso_pairs, iso_ms * 1e-3),
             "valu_issue_step": None,
             "streams": eng.S,
             "kernels_ms_per_step": {k: v[1] / args.steps for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])},

@@ -7,7 +7,7 @@
 # under the profiler.  Then: python scripts/summarize_pmc.py ... > profiles/roundN/<tag>_pmc_hbm_per_kernel.csv
 set -e -o pipefail
 TAG=${1:-run}
-PAIRS_PER_LAUNCH=${2:-256}   # pairs one kernel launch covers = pairs-per-gpu / streams (bench defaults: 512 / 2)
+PAIRS_PER_LAUNCH=${2:-256}   # pairs one kernel launch covers = pairs-per-gpu / streams (bench defaults: 768 / 3)
 ARGS="--steps 10 --warmup 2 --no-cpu --no-h2d --render-workers 1"
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp

@@ -84,6 +84,12 @@ static inline int32_t sosvo_fail(sosvo_ctx* ctx, int32_t code, const char* what,
     SOSVO_HIP((ctx), hipSetDevice((ctx)->device));         \
   } while (0)
 
+// Wave priority of the latency-bound kernels: when they share the chip with the VALU-saturating median kernel of another
+// stream, their few instructions should issue ahead of its many (s_setprio: arbitration among the waves of a SIMD).
+// (measured: +4 % with two streams; 3 for the latency-bound kernels, 2 for the two streaming image kernels, the median 0)
+#define SOSVO_LATENCY_BOUND_PRIO() __builtin_amdgcn_s_setprio(3)
+#define SOSVO_STREAMING_PRIO() __builtin_amdgcn_s_setprio(2)
+
 #define SOSVO_LAUNCH_CHECK(ctx) SOSVO_HIP((ctx), hipGetLastError())
 
 static inline int32_t sosvo_ws_reserve(sosvo_ctx* ctx, size_t bytes) {

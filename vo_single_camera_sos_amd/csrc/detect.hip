@@ -77,6 +77,7 @@ __global__ __launch_bounds__(kThreads) void min_eigen_kernel(const uint8_t* __re
                                                              float* __restrict__ eig,
                                                              unsigned long long* __restrict__ flags,
                                                              uint32_t* __restrict__ mstat) {
+  SOSVO_STREAMING_PRIO();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * kThreads + threadIdx.x) >> 6));  // in an SGPR: per-image bases become scalar
   if (wave >= nimg * strips * nchunks) return;  // wave-uniform
@@ -239,6 +240,7 @@ __global__ __launch_bounds__(kThreads) void gft_select_kernel(const float* __res
                                                               float* __restrict__ kp, int32_t* __restrict__ n_out,
                                                               int32_t* __restrict__ status, int32_t* __restrict__ redo,
                                                               int redo_pass) {
+  SOSVO_LATENCY_BOUND_PRIO();
   // Two-pass scheme (redo != nullptr): pass 0 runs the small variant (half the LDS: twice the workgroups per CU of
   // this latency-bound kernel) and hands the few problems that do not fit it -- more candidates than CAND, or a
   // mask bounding box larger than its cell grid -- to pass 1, which runs the full-size variant on those only.
@@ -460,6 +462,7 @@ __global__ __launch_bounds__(kThreads) void gft_select_kernel(const float* __res
 __global__ __launch_bounds__(kThreads) void gauss7_kernel(const uint8_t* __restrict__ gray, int nimg, int rows, int cols,
                                                           int strips, int nchunks, int chunk_rows,
                                                           uint8_t* __restrict__ out) {
+  SOSVO_STREAMING_PRIO();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * kThreads + threadIdx.x) >> 6));  // in an SGPR: per-image bases become scalar
   if (wave >= nimg * strips * nchunks) return;  // wave-uniform
@@ -525,6 +528,7 @@ __global__ __launch_bounds__(kThreads) void orb_describe_kernel(const uint8_t* _
                                                                 int32_t* __restrict__ n_io, float cos_a, float sin_a,
                                                                 const int8_t* __restrict__ pattern, int edge,
                                                                 uint8_t* __restrict__ desc) {
+  SOSVO_LATENCY_BOUND_PRIO();
   extern __shared__ float lds_kp[];  // [cap][2] compacted keypoints
   __shared__ int off[512];
   __shared__ uint16_t poff[512];

@@ -126,6 +126,7 @@ __global__ __launch_bounds__(kThreads) void stereo_assemble_kernel(
     int cap, int out_cap, float* __restrict__ m_top, float* __restrict__ m_bot, uint4* __restrict__ d_top,
     uint4* __restrict__ d_bot, double* __restrict__ X, double* __restrict__ b_top, double* __restrict__ b_bot,
     int32_t* __restrict__ M, int32_t* __restrict__ n_cand) {
+  SOSVO_LATENCY_BOUND_PRIO();
   __shared__ int wave_off[kThreads / 64 + 1];
   __shared__ int s_running;
   const int tid = threadIdx.x, fr = blockIdx.x;
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(kThreads) void f2f_assemble_kernel(
     const uint32_t* __restrict__ keys_bot, const int32_t* __restrict__ order_bot, int corr_cap,
     double* __restrict__ f, double* __restrict__ p, int32_t* __restrict__ cam, int32_t* __restrict__ corr_q,
     int32_t* __restrict__ corr_t, int32_t* __restrict__ n, int32_t* __restrict__ n_topview) {
+  SOSVO_LATENCY_BOUND_PRIO();
   __shared__ int wave_off[kThreads / 64 + 1];
   __shared__ int s_running;
   const int tid = threadIdx.x, pr = blockIdx.x;

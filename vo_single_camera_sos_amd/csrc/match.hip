@@ -36,6 +36,7 @@ __global__ __launch_bounds__(kThreads) void match_hamming_kernel(
     const uint4* __restrict__ q_desc, const uint4* __restrict__ t_desc, const int32_t* __restrict__ nq,
     const int32_t* __restrict__ nt, const int32_t* __restrict__ q_slot, const int32_t* __restrict__ t_slot,
     int q_stride, int t_stride, int nsplit, uint32_t* __restrict__ keys) {
+  SOSVO_LATENCY_BOUND_PRIO();
   __shared__ uint4 tile[kTrainTile * 2];
   const int tid = threadIdx.x;
   // XCD-aware grid: workgroups go round-robin over the 8 XCDs by linear id, so the problem index (all
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(kThreads) void sort_matches_kernel(const uint32_t* 
                                                                 const int32_t* __restrict__ nq,
                                                                 const int32_t* __restrict__ q_slot, int q_stride,
                                                                 int32_t* __restrict__ order) {
+  SOSVO_LATENCY_BOUND_PRIO();
   extern __shared__ uint32_t sk[];
   const int tid = threadIdx.x;
   const int p = blockIdx.x;  // problem fastest, tile second (see match_hamming_kernel)

@@ -40,6 +40,7 @@ __global__ __launch_bounds__(kThreads) void ransac_prepare_kernel(const int32_t*
                                                                   const int32_t* __restrict__ n_arr, int stride,
                                                                   int ncam, int32_t* __restrict__ perm,
                                                                   int32_t* __restrict__ cinfo) {
+  SOSVO_LATENCY_BOUND_PRIO();
   __shared__ int cnt[kThreads][kMaxCam];
   __shared__ int cstart[kMaxCam + 1];
   const int tid = threadIdx.x, b = blockIdx.x;
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(64) void ransac_hyp_kernel(const double* __restrict
                                                         uint64_t seed, const int32_t* __restrict__ perm,
                                                         const int32_t* __restrict__ cinfo, double* __restrict__ hyp,
                                                         int32_t* __restrict__ counts) {
+  SOSVO_LATENCY_BOUND_PRIO();
   const int b = blockIdx.y;
   const int it = blockIdx.x * blockDim.x + threadIdx.x;
   if (it >= H) return;
@@ -203,6 +205,7 @@ __global__ __launch_bounds__(kThreads) void ransac_score_kernel(
     const double* __restrict__ cam_off, const double* __restrict__ cam_rot, const int32_t* __restrict__ n_arr,
     int stride, int H, int hchunk, double thr, int fast_ok, const double* __restrict__ hyp,
     int32_t* __restrict__ counts) {
+  SOSVO_LATENCY_BOUND_PRIO();
   __shared__ int lcnt[kScoreHypChunkMax];
   __shared__ double shyp[kScoreHypChunkMax][12];
   __shared__ unsigned long long sok[(kScoreHypChunkMax + 63) / 64];  // bit = hypothesis of the chunk is a solved one
@@ -360,6 +363,7 @@ __global__ __launch_bounds__(kThreads) void ransac_select_kernel(
     int stride, int H, double thr, int adaptive, const double* __restrict__ hyp, const int32_t* __restrict__ counts,
     double* __restrict__ T_out, uint8_t* __restrict__ mask, int32_t* __restrict__ inl_idx,
     int32_t* __restrict__ n_inl, int32_t* __restrict__ info) {
+  SOSVO_LATENCY_BOUND_PRIO();
   __shared__ long long red[kThreads / 64];
   __shared__ int redv[kThreads / 64];
   __shared__ int s_best_it, s_used, s_nvalid;
@@ -494,6 +498,7 @@ __global__ __launch_bounds__(kThreads) void refine_kernel(
     const double* __restrict__ cam_off, const double* __restrict__ cam_rot, const int32_t* __restrict__ n_arr,
     int stride, const int32_t* __restrict__ idx, const int32_t* __restrict__ m_arr, int max_lm_iter,
     double* __restrict__ T_io, double* __restrict__ cost_out, int32_t* __restrict__ iters_out) {
+  SOSVO_LATENCY_BOUND_PRIO();
   __shared__ double scratch[4];
   __shared__ double sred[28][4];
   __shared__ double sx[6], sxn[6], sdx[6];
