@@ -150,6 +150,9 @@ def parse():
     ap.add_argument("--cpu-cores", type=int, default=0, help="processes of the all-cores CPU baseline (0 = os.cpu_count())")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the extra PCIe-inclusive measurement (N = 1 only)")
+    ap.add_argument("--no-isolated", action="store_true",
+                    help="skip the isolated launches of the dominant kernel after the timed region (profile passes: the "
+                         "per-kernel averages then cover the timed region only)")
     ap.add_argument("--pmc-csv", default=None, help="per-kernel PMC summary for roofline.traffic (default: newest in profiles/)")
     ap.add_argument("--seed", type=int, default=1234)
     return ap.parse_args()
@@ -265,8 +268,8 @@ def main():
     # The dominant kernel on its own (nothing else on the chip): in the timed region its launches share the SIMDs with the
     # other streams' kernels, at the lowest wave priority, so their durations say how the step is scheduled, not how good
     # the kernel is.  A few isolated launches of one part's K1+K2+K3 give the kernel's own duration.
-    iso_ms = None
-    if rank == 0:
+    iso_ms, iso_pairs = None, None
+    if rank == 0 and not args.no_isolated:
         part = eng.parts[0]
         torch.cuda.synchronize()
         evs = []
@@ -355,12 +358,12 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": dom_avg_s * 1e3, "launches": dom[1][0],
                          "isolated_launch_ms": iso_ms,
-                         "achieved_isolated": b_alg * iso_pairs / (iso_ms * 1e-3) / 1e9,
-                         "frac_isolated": b_alg * iso_pairs / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "achieved_isolated": b_alg * iso_pairs / (iso_ms * 1e-3) / 1e9 if iso_ms else None,
+                         "frac_isolated": b_alg * iso_pairs / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if iso_ms else None,
                          "algorithmic_bytes_per_pair": b_alg, "algorithmic_bytes_per_launch": b_alg_launch,
                          "note": "no contraction anywhere (no MFMA); the dominant kernel is VALU-bound integer/bit work, "
                                  "so the HBM fraction is small by construction (SURVEY 8d)"},
-            "valu_issue": valu_issue(dom[0], iso_pairs, iso_ms * 1e-3),
+            "valu_issue": valu_issue(dom[0], iso_pairs, iso_ms * 1e-3) if iso_ms else valu_issue(dom[0], dom_pairs, dom_avg_s),
             "valu_issue_step": None,
             "streams": eng.S,
             "kernels_ms_per_step": {k: v[1] / args.steps for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])},
