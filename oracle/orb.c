@@ -25,6 +25,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include "trig_core.h"
 
 #define ORB_LEVELS 8
 #define ORB_EDGE 31
@@ -330,7 +331,9 @@ int32_t orc_orb_describe_levels(const uint8_t* gray, int32_t rows, int32_t cols,
     const float scale = 1.f / (float)pow(1.2, (double)l);
     float angle = kp[4 * i + 2];
     angle *= (float)(3.14159265358979323846 / 180.0);
-    const float ca = (float)cos((double)angle), sa = (float)sin((double)angle);
+    double sd, cd; /* trig_core.h: the same arithmetic as on the device */
+    orc_sincos((double)angle, &sd, &cd);
+    const float ca = (float)cd, sa = (float)sd;
     const int cx = (int)lrintf(x * scale), cy = (int)lrintf(y * scale);
     const int hh = hs[l], ww = ws[l];
     uint8_t* d = desc + 32 * (int64_t)kept;

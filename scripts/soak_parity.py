@@ -62,14 +62,15 @@ def main():
     want = np.concatenate(outs)
     print("oracle: %d pairs in %.1f s on %d processes" % (B, time.perf_counter() - t0, len(jobs)))
     bad = 0
+    exact_pose = int(sum(np.array_equal(rec[i, :12], want[i, :12]) for i in range(B)))
     for i in range(B):
         exact = np.array_equal(rec[i, 12:], want[i, 12:])
         close = np.allclose(rec[i, :12], want[i, :12], rtol=1e-6, atol=1e-9)
         if not (exact and close):
             bad += 1
             print("pair %d differs: gpu %s\n               cpu %s" % (i, rec[i], want[i]))
-    print("soak: %d / %d pairs identical (counts, status, winning iteration exact; pose rel-tol 1e-6); inliers %.0f mean"
-          % (B - bad, B, rec[:, 12].mean()))
+    print("soak: %d / %d pairs identical (counts, status, winning iteration exact; pose rel-tol 1e-6); %d / %d refined poses "
+          "bit-identical; inliers %.0f mean" % (B - bad, B, exact_pose, B, rec[:, 12].mean()))
     eng.close()
     sys.exit(1 if bad else 0)
 

@@ -42,8 +42,10 @@ def test_pano_to_bearing_vs_reference_fixture(ctx):
         assert np.allclose(az, G["az_" + name], equal_nan=True, **RT)
         assert np.allclose(el, G["el_" + name], equal_nan=True, **RT)
         assert np.allclose(b, G["bearing_" + name][:, :3], equal_nan=True, **RT)
+        # against the oracle: the same bits (both sides evaluate trig_core.h's sin / cos / atan, not their math libraries)
         oaz, oel = oracle.pano_to_angles(m[:, 0], m[:, 1], *_pano(name))
-        assert np.allclose(az, oaz, equal_nan=True, **RT) and np.allclose(el, oel, equal_nan=True, **RT)
+        assert np.array_equal(az, oaz, equal_nan=True) and np.array_equal(el, oel, equal_nan=True)
+        assert np.array_equal(b, oracle.angles_to_bearing(oaz, oel), equal_nan=True)
 
 
 def test_triangulation_and_range_filter_vs_reference_fixture(ctx):
@@ -56,8 +58,8 @@ def test_triangulation_and_range_filter_vs_reference_fixture(ctx):
     want = G["tri_X_homo"][:, :3]
     assert np.array_equal(np.isnan(Xn).any(1), np.isnan(want).any(1))
     assert np.allclose(Xn, want, equal_nan=True, rtol=1e-9, atol=1e-7)  # Cramer vs LAPACK solve
-    assert np.allclose(Xn, oracle.triangulate_midpoint(G["az_top"], G["el_top"], G["az_bot"], G["el_bot"],
-                                                       G["top_F"], G["bot_F"]), equal_nan=True, rtol=1e-11, atol=1e-9)
+    assert np.array_equal(Xn, oracle.triangulate_midpoint(G["az_top"], G["el_top"], G["az_bot"], G["el_bot"],
+                                                          G["top_F"], G["bot_F"]), equal_nan=True)  # bit for bit
     assert np.array_equal(ok.cpu().numpy().astype(bool), G["range_ok_500_7000"])
     assert np.array_equal(ok2.cpu().numpy().astype(bool), G["range_ok_min_only"])
 
@@ -100,8 +102,8 @@ def _check_frames(out, want_frames):
         assert got["n_cand"][fi] == w["n_cand"]
         assert np.array_equal(got["m_top"][fi, :M], w["m_top"]) and np.array_equal(got["m_bot"][fi, :M], w["m_bot"])
         assert np.array_equal(got["d_top"][fi, :M], w["d_top"]) and np.array_equal(got["d_bot"][fi, :M], w["d_bot"])
-        assert np.allclose(got["X"][fi, :M], w["X"], rtol=1e-11, atol=1e-9)
-        assert np.allclose(got["b_top"][fi, :M], w["b_top"], **RT) and np.allclose(got["b_bot"][fi, :M], w["b_bot"], **RT)
+        assert np.array_equal(got["X"][fi, :M], w["X"])                      # FP64 geometry: bit for bit
+        assert np.array_equal(got["b_top"][fi, :M], w["b_top"]) and np.array_equal(got["b_bot"][fi, :M], w["b_bot"])
     return got
 
 

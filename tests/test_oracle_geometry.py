@@ -97,3 +97,19 @@ def test_rgbd_backprojection(tag, is_z):
 def test_score_matches_reference_restatement():
     got = oracle.score_points(G["score_f"], G["score_p"], G["score_T"])
     assert np.allclose(got, G["score_expected"], rtol=0, atol=5e-16)
+
+
+def test_trig_core_against_the_host_math_library():
+    """oracle/trig_core.h (sin / cos / atan from + - * / only, shared with the device): within one ulp of numpy over the
+    arguments of the path (azimuth in [0, 2 pi], elevation within +-pi/2, tan(elevation) a few units), exact at the
+    awkward points."""
+    import ctypes
+    L = oracle.lib()
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-7.0, 7.0, 200000), np.linspace(0, 2 * np.pi, 1441), [np.pi, 2 * np.pi, np.pi / 2, 0.0, -0.0]])
+    s, c, a = np.empty_like(x), np.empty_like(x), np.empty_like(x)
+    L.orc_trig_eval(x.ctypes.data_as(ctypes.c_void_p), ctypes.c_int32(x.size), s.ctypes.data_as(ctypes.c_void_p),
+                    c.ctypes.data_as(ctypes.c_void_p), a.ctypes.data_as(ctypes.c_void_p))
+    for got, want in ((s, np.sin(x)), (c, np.cos(x)), (a, np.arctan(x))):
+        assert np.all(np.abs(got - want) <= np.spacing(np.abs(want))), np.abs(got - want).max()
+    assert s[-5] == np.sin(np.pi) and s[-4] == np.sin(2 * np.pi) and c[-3] == np.cos(np.pi / 2)

@@ -4,14 +4,15 @@
 //   omnistereo/camera_models.py:3333-3340, :2437-2490  rays on the unit cylinder, midpoint triangulation
 //   omnistereo/camera_models.py:3309-3319      range filter on the homogeneous row (norm includes the 1)
 //   omnistereo/common_cv.py:177-186            pixel gates
-// FP64 throughout; sin/cos/tan/atan2 come from the device math library (the CPU oracle uses
-// libm), so values are compared with rel-tol 1e-12, not bit for bit.
+// FP64 throughout; sin / cos / atan are trig_core.h's (the text of oracle/trig_core.h: + - * / only), not the device math
+// library's, so that the angles, bearings and triangulated points equal the CPU oracle's bit for bit.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
 
 #include "sosvo.h"
+#include "trig_core.h"
 
 #define SV_TWO_PI (2 * 3.14159265358979323846 * 1.0) /* cyl_circumference, panorama.py:152 */
 
@@ -20,20 +21,27 @@ __device__ __forceinline__ static double sv_nan() { return __longlong_as_double(
 // pano = {cols, rows, pixel_size, cyl_height_max}
 __device__ __forceinline__ static void sv_pano_angles(double u, double v, const double* pano, double* az, double* el) {
   *az = (0.0 <= u && u < pano[0]) ? SV_TWO_PI - pano[2] * u : sv_nan();
-  *el = (0.0 <= v && v < pano[1]) ? atan2(pano[3] - pano[2] * v, 1.0) : sv_nan();
+  *el = (0.0 <= v && v < pano[1]) ? sv_atan(pano[3] - pano[2] * v) : sv_nan();  // atan2(h, 1)
 }
 
 __device__ __forceinline__ static void sv_bearing(double az, double el, double* b3) {
-  const double b = cos(el), z = sin(el);
-  b3[0] = b * cos(az);
-  b3[1] = b * sin(az);
+  double b, z, ca, sa;
+  sv_sincos(el, &z, &b);
+  sv_sincos(az, &sa, &ca);
+  b3[0] = b * ca;
+  b3[1] = b * sa;
   b3[2] = z;
 }
 
 __device__ __forceinline__ static void sv_triangulate(double az1, double el1, double az2, double el2, const double* F1,
                                                        const double* F2, double* X) {
-  const double v1[3] = {cos(az1), sin(az1), tan(el1)};
-  const double v2[3] = {cos(az2), sin(az2), tan(el2)};
+  double sa1, ca1, se1, ce1, sa2, ca2, se2, ce2;
+  sv_sincos(az1, &sa1, &ca1);
+  sv_sincos(el1, &se1, &ce1);
+  sv_sincos(az2, &sa2, &ca2);
+  sv_sincos(el2, &se2, &ce2);
+  const double v1[3] = {ca1, sa1, se1 / ce1};  // (cos psi, sin psi, tan theta)
+  const double v2[3] = {ca2, sa2, se2 / ce2};
   const double pv[3] = {v1[1] * v2[2] - v1[2] * v2[1], v1[2] * v2[0] - v1[0] * v2[2], v1[0] * v2[1] - v1[1] * v2[0]};
   const double mag = sqrt(pv[0] * pv[0] + pv[1] * pv[1] + pv[2] * pv[2]);
   const double nh[3] = {pv[0] / mag, pv[1] / mag, pv[2] / mag};

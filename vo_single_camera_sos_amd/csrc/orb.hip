@@ -17,6 +17,7 @@
 // Integer work except the Harris/angle float32 arithmetic, whose operation order is pinned -> bit-exact against
 // the oracle (cos/sin of the angle are double-precision library calls rounded to float32 on both sides).
 #include "common.h"
+#include "trig_core.h"
 
 namespace {
 
@@ -505,7 +506,9 @@ __global__ __launch_bounds__(kThreads) void orb_describe_levels_kernel(const uin
     const float inv = 1.f / P.scale[l];
     float angle = lds_kp[4 * j + 2];
     angle *= (float)(3.14159265358979323846 / 180.0);
-    const float ca = (float)cos((double)angle), sa = (float)sin((double)angle);
+    double sd, cd;  // trig_core.h's sincos: the same bits as the oracle's, then one rounding to float on both sides
+    sv_sincos((double)angle, &sd, &cd);
+    const float ca = (float)cd, sa = (float)sd;
     const int cx = __float2int_rn(lds_kp[4 * j] * inv), cy = __float2int_rn(lds_kp[4 * j + 1] * inv);
     const uint8_t* im = blur + (size_t)img * P.total + P.off[l];
     unsigned long long* d = reinterpret_cast<unsigned long long*>(desc + ((size_t)p * cap + j) * 32);
