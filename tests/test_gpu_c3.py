@@ -92,9 +92,10 @@ def test_c3_stereo_front_end_ratio_matching_triangulation(ctx):
     a2, e2 = oracle.pano_to_angles(mb[:, 0], mb[:, 1], *geo)
     Xo = oracle.triangulate_midpoint(a1, e1, a2, e2, F_top, F_bot)
     RT = dict(rtol=1e-12, atol=1e-12)
-    assert np.allclose(az_t.cpu().numpy(), a1, **RT) and np.allclose(el_b.cpu().numpy(), e2, **RT)
-    assert np.allclose(b_t.cpu().numpy(), oracle.angles_to_bearing(a1, e1), **RT)
-    assert np.allclose(X.cpu().numpy(), Xo, rtol=1e-9, atol=1e-6)  # the 3x3 solve amplifies the 1e-12 angle difference
+    # bit for bit: both sides evaluate trig_core.h's sin / cos / atan
+    assert np.array_equal(az_t.cpu().numpy(), a1) and np.array_equal(el_b.cpu().numpy(), e2)
+    assert np.array_equal(b_t.cpu().numpy(), oracle.angles_to_bearing(a1, e1))
+    assert np.array_equal(X.cpu().numpy(), Xo)
     go = oracle.range_filter_homo(Xo, 500.0, 7000.0)
     assert np.array_equal(good.cpu().numpy().astype(bool), go)
     assert go.sum() > 300

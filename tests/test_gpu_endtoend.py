@@ -86,7 +86,8 @@ def test_full_hot_path_from_images(ctx, method, nfeat):
         n = len(w["corr"]["cam"])
         assert rec[i, 13] == n and rec[i, 14] == w["ransac"]["status"] and rec[i, 12] == w["ransac"]["n_inliers"]
         assert np.array_equal(mask[i, :n].astype(bool), w["ransac"]["mask"])
-        assert np.allclose(rec[i, :12].reshape(3, 4), w["T"], rtol=1e-6, atol=1e-9)
+        assert np.allclose(rec[i, :12].reshape(3, 4), w["T"], rtol=1e-6, atol=1e-9)   # north_star's bar for the pose ...
+        assert np.array_equal(rec[i, :12].reshape(3, 4), w["T"])                        # ... which is met bit for bit
     assert rec[2, 14] == 1 and rec[2, 13] == 0           # black frame: no correspondences, status "no model"
     for i in range(2 if method == "GFT" else 0):          # the planted motion is recovered (loosely: 5 deg threshold)
         R, t = poses[i]

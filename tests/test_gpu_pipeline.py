@@ -43,5 +43,6 @@ def test_pipeline_end_to_end_parity(ctx):
         assert rec[i, 14] == w["ransac"]["status"] and rec[i, 15] == w["ransac"]["best_iter"]
         assert rec[i, 12] == w["ransac"]["n_inliers"]
         assert np.array_equal(mask[i, :n].astype(bool), w["ransac"]["mask"])
-        assert np.allclose(rec[i, :12].reshape(3, 4), w["T"], rtol=1e-6, atol=1e-9)
+        assert np.allclose(rec[i, :12].reshape(3, 4), w["T"], rtol=1e-6, atol=1e-9)   # north_star's bar for the pose ...
+        assert np.array_equal(rec[i, :12].reshape(3, 4), w["T"])                        # ... which is met bit for bit
     assert (rec[1:, 14] == 0).all() and (rec[1:, 12] > 1000).all()
