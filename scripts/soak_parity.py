@@ -24,7 +24,11 @@ def main():
     ap.add_argument("--workers", type=int, default=16)
     ap.add_argument("--iters", type=int, default=2000)
     ap.add_argument("--pano-width", type=int, default=1440)
+    ap.add_argument("--rgbd", choices=["EPNP", "KNEIP"], default=None,
+                    help="soak the RGB-D path (BASELINE config 5: sosvo_rgbd_pair_batch) with this pose algorithm instead")
     args = ap.parse_args()
+    if args.rgbd:
+        return main_rgbd(args)
     import multiprocessing
     import refflow
     from vo_single_camera_sos_amd import orb_pattern, synthetic
@@ -73,6 +77,50 @@ def main():
           "bit-identical; inliers %.0f mean" % (B - bad, B, exact_pose, B, rec[:, 12].mean()))
     eng.close()
     sys.exit(1 if bad else 0)
+
+
+def main_rgbd(args):
+    import multiprocessing
+    import refflow
+    from vo_single_camera_sos_amd import synthetic
+    B = args.pairs
+    fx = fy = 554.256258
+    bgr, depth = [], []
+    for i in range(B):
+        rng = np.random.default_rng(args.seed + i)
+        room = synthetic.Room(seed=args.seed + i, half_x=(1800.0, 2600.0), half_y=(2500.0, 3500.0), cells=(150.0, 40.0), yaw_deg=40.0)
+        R, t = synthetic.random_step(rng, max_t=80.0, max_deg=8.0)
+        for (Rw, tw) in ((np.eye(3), np.zeros(3)), (R, t)):
+            im, dp = synthetic.render_rgbd(room, Rw, tw, rng, depth_is_Z=True)
+            bgr.append(im)
+            depth.append(dp)
+    bgr, depth = np.stack(bgr), np.stack(depth)
+    import torch
+    from vo_single_camera_sos_amd.device import Context
+    from vo_single_camera_sos_amd.pipeline import RGBDCamConfig, RGBDPairBatch
+    ctx = Context(0)
+    cam = RGBDCamConfig(fx=fx, fy=fy, center_x=319.5, center_y=239.5, depth_is_Z=True, min_range=0.8, max_range=7.0)
+    one = RGBDPairBatch(ctx, cam, B, num_of_features=2000, max_iter=args.iters, seed=args.seed, pose_est_algorithm=args.rgbd)
+    one.load_frames(bgr, depth)
+    rec = one.step().cpu().numpy()
+    torch.cuda.synchronize()
+    cam_kw = dict(fx=fx, fy=fy, cx=319.5, cy=239.5, focal_length_m=cam.focal_length_m, depth_is_Z=True, min_range=0.8,
+                  max_range=7.0, f2f_max_hdiff=cam.f2f_max_hdiff, pct_good_matches=1.0)
+    per = -(-B // args.workers)
+    jobs = [(cam_kw, bgr[2 * lo: 2 * min(B, lo + per)], depth[2 * lo: 2 * min(B, lo + per)], 2000, one.thr, args.iters,
+             args.seed + lo, args.rgbd == "EPNP") for lo in range(0, B, per)]
+    t0 = time.perf_counter()
+    with multiprocessing.get_context("spawn").Pool(len(jobs)) as pool:
+        want = np.concatenate(pool.map(refflow.rgbd_pairs_records_worker, jobs))
+    print("oracle: %d RGB-D pairs in %.1f s on %d processes" % (B, time.perf_counter() - t0, len(jobs)))
+    exact = int(sum(np.array_equal(rec[i], want[i]) for i in range(B)))
+    for i in range(B):
+        if not np.array_equal(rec[i], want[i]):
+            print("pair %d differs: gpu %s\n               cpu %s" % (i, rec[i], want[i]))
+    print("soak (RGB-D, %s): %d / %d records bit-identical (pose, counts, status, winning iteration); inliers %.0f mean, %d tracked"
+          % (args.rgbd, exact, B, rec[:, 12].mean(), int((rec[:, 14] == 0).sum())))
+    ctx.close()
+    sys.exit(0 if exact == B else 1)
 
 
 if __name__ == "__main__":

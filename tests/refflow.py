@@ -252,3 +252,22 @@ def pairs_records_worker(job):
         out[i, 12], out[i, 13] = w["ransac"]["n_inliers"], len(w["corr"]["cam"])
         out[i, 14], out[i, 15] = w["ransac"]["status"], w["ransac"]["best_iter"]
     return out
+
+
+def rgbd_pairs_records_worker(job):
+    """RGB-D counterpart of pairs_records_worker: job = (cam_kw, bgr [2n,...], depth [2n,...], nfeat, thr, iters, seed0,
+    epnp) -> [n,16] records (scripts/soak_parity.py --rgbd)."""
+    from vo_single_camera_sos_amd import orb_pattern
+    cam_kw, bgr, depth, nfeat, thr, iters, seed0, epnp = job
+    cam = RGBDParams(**cam_kw)
+    ca, sa = orb_pattern.angle_cos_sin(orb_pattern.GFT_KEYPOINT_ANGLE)
+    pat = orb_pattern.orb_pattern()
+    out = np.zeros((bgr.shape[0] // 2, 16))
+    for i in range(bgr.shape[0] // 2):
+        ref = rgbd_frame(cam, bgr[2 * i], depth[2 * i], nfeat, pat, ca, sa)
+        cur = rgbd_frame(cam, bgr[2 * i + 1], depth[2 * i + 1], nfeat, pat, ca, sa)
+        w = track_pair_rgbd(cam, ref, cur, thr, iters, seed=seed0 + i, epnp=epnp)
+        out[i, :12] = np.asarray(w["T"]).reshape(12)
+        out[i, 12], out[i, 13] = w["ransac"]["n_inliers"], len(w["corr"]["q"])
+        out[i, 14], out[i, 15] = w["ransac"]["status"], w["ransac"]["best_iter"]
+    return out
