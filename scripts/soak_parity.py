@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--workers", type=int, default=16)
     ap.add_argument("--iters", type=int, default=2000)
     ap.add_argument("--pano-width", type=int, default=1440)
+    ap.add_argument("--detector", default="GFT", choices=["GFT", "ORB", "FAST"])
+    ap.add_argument("--kp-cap", type=int, default=512, help="keypoint capacity per (frame, mirror, mask)")
     ap.add_argument("--rgbd", choices=["EPNP", "KNEIP"], default=None,
                     help="soak the RGB-D path (BASELINE config 5: sosvo_rgbd_pair_batch) with this pose algorithm instead")
     args = ap.parse_args()
@@ -47,8 +49,9 @@ def main():
     omni, _ = synthetic.make_frame_pairs(gs, B, seed=args.seed, workers=args.workers)  # before the GPU is touched (fork)
     import torch
     from vo_single_camera_sos_amd.pipeline import OverlappedFramePairs, RigConfig
-    eng = OverlappedFramePairs(0, gs, (480, 640), RigConfig(**rig_kw), B, n_streams=2, num_of_features=1000, kp_cap=512,
-                               frame_cap=2048, max_iter=args.iters, adaptive=False, seed=args.seed)
+    eng = OverlappedFramePairs(0, gs, (480, 640), RigConfig(**rig_kw), B, n_streams=2, num_of_features=1000, kp_cap=args.kp_cap,
+                               frame_cap=2048, max_iter=args.iters, adaptive=False, seed=args.seed, detection_method=args.detector)
+    assert not any(int(p.fe.status.max().item()) for p in eng.parts) or args.detector != "GFT"
     eng.load_frames(omni)
     eng.step()
     rec = eng.results().cpu().numpy()
@@ -57,7 +60,7 @@ def main():
     ca, sa = orb_pattern.angle_cos_sin(-1.0)
     im_kw = dict(map_x=model.map_x.cpu().numpy(), map_y=model.map_y.cpu().numpy(), omni_masks=model.omni_masks.cpu().numpy(),
                  mask_bits=model.mask_bits_host, nmask=model.nmask, max_corners=1000, pattern=model.pattern_host, cos_a=ca,
-                 sin_a=sa, kp_cap=512)
+                 sin_a=sa, kp_cap=args.kp_cap, method=args.detector)
     per = -(-B // args.workers)
     jobs = [(rig_kw, im_kw, omni[2 * lo: 2 * min(B, lo + per)], eng.thr, args.iters, args.seed + lo) for lo in range(0, B, per)]
     t0 = time.perf_counter()
@@ -73,6 +76,7 @@ def main():
         if not (exact and close):
             bad += 1
             print("pair %d differs: gpu %s\n               cpu %s" % (i, rec[i], want[i]))
+    print("detector %s:" % args.detector, end=" ")
     print("soak: %d / %d pairs identical (counts, status, winning iteration exact; pose rel-tol 1e-6); %d / %d refined poses "
           "bit-identical; inliers %.0f mean" % (B - bad, B, exact_pose, B, rec[:, 12].mean()))
     eng.close()
