@@ -48,10 +48,11 @@ static void* upload(FILE* f, size_t bytes) {
 }
 
 int main(int argc, char** argv) {
-  if (argc != 3) {
-    fprintf(stderr, "usage: %s input.bin output.bin\n", argv[0]);
+  if (argc != 3 && argc != 4) {
+    fprintf(stderr, "usage: %s input.bin output.bin [internal streams, 1..4]\n", argv[0]);
     return 1;
   }
+  const int n_streams = argc == 4 ? atoi(argv[3]) : 1;
   FILE* f = fopen(argv[1], "rb");
   if (!f) return 1;
   sosvo_batch_cfg cfg;
@@ -76,10 +77,15 @@ int main(int argc, char** argv) {
   double* results = NULL;
   CHECK_HIP(hipMalloc((void**)&table, 2 * P * 2 * sizeof(uint32_t)));
   CHECK_SOSVO(sosvo_unwrap_prepare(ctx, masks, map_x, map_y, cfg.H, cfg.W, cfg.rows, cfg.cols, table));  /* once per model */
-  const size_t ws_bytes = sosvo_frame_pair_batch_workspace(&cfg);
+  /* one stream, or the batch split over the library's internal streams (same results, more overlap) */
+  const size_t ws_bytes = n_streams > 1 ? sosvo_frame_pair_batch_streams_workspace(&cfg, n_streams) : sosvo_frame_pair_batch_workspace(&cfg);
   CHECK_HIP(hipMalloc(&workspace, ws_bytes));
   CHECK_HIP(hipMalloc((void**)&results, B * 16 * sizeof(double)));
-  CHECK_SOSVO(sosvo_frame_pair_batch(ctx, &rig, &cfg, omni, table, mask_bits, pattern, workspace, ws_bytes, results));
+  if (n_streams > 1)
+    CHECK_SOSVO(sosvo_frame_pair_batch_streams(ctx, &rig, &cfg, n_streams, omni, table, mask_bits, pattern, workspace, ws_bytes,
+                                               results));
+  else
+    CHECK_SOSVO(sosvo_frame_pair_batch(ctx, &rig, &cfg, omni, table, mask_bits, pattern, workspace, ws_bytes, results));
   CHECK_SOSVO(sosvo_synchronize(ctx));
   double* host = (double*)malloc(B * 16 * sizeof(double));
   CHECK_HIP(hipMemcpy(host, results, B * 16 * sizeof(double), hipMemcpyDeviceToHost));

@@ -434,6 +434,19 @@ int32_t sosvo_frame_pair_batch(sosvo_ctx* ctx, const sosvo_rig* rig_host, const 
                                const uint8_t* omni, const uint32_t* unwrap_table, const uint32_t* mask_bits,
                                const int8_t* pattern, void* workspace, size_t workspace_bytes, double* results);
 
+/* The same batch split over n_streams (1..4) INTERNAL HIP streams: the VALU-bound median of one part overlaps the
+ * latency-bound stages of the others (the medians take turns), which is worth ~15 % over one stream at a few hundred
+ * pairs.  Part s = pairs [lo_s, hi_s) (contiguous, sizes differ by at most one) samples with seed + pair index, so the
+ * results are those of sosvo_frame_pair_batch, bit for bit.  The parts start after the work already queued on the context's
+ * stream and the context's stream continues after all of them (events; no host synchronisation); the internal streams
+ * and their scratch memory are created on first use and live as long as the context.
+ * workspace: sosvo_frame_pair_batch_streams_workspace(cfg, n_streams) bytes, 256-aligned; n_pairs >= n_streams. */
+size_t sosvo_frame_pair_batch_streams_workspace(const sosvo_batch_cfg* cfg, int32_t n_streams);
+int32_t sosvo_frame_pair_batch_streams(sosvo_ctx* ctx, const sosvo_rig* rig_host, const sosvo_batch_cfg* cfg_host,
+                                       int32_t n_streams, const uint8_t* omni, const uint32_t* unwrap_table,
+                                       const uint32_t* mask_bits, const int8_t* pattern, void* workspace,
+                                       size_t workspace_bytes, double* results);
+
 /* ---- The RGB-D path for B independent frame pairs behind ONE call (BASELINE config 5) ------------------
  * RGBDFrame.establish_keypoints (omnistereo/pose_est_tools.py:600-623: [median,] gray, goodFeaturesToTrack on the
  * whole image or on RGBDFrame.mask, ORB descriptors, depth back-projection, NaN / range filter, bearings) for the

@@ -52,6 +52,16 @@ def test_one_call_equals_stage_sequence(ctx):
     got2 = batch.step()
     ctx.synchronize()
     assert np.array_equal(got2.cpu().numpy().view(np.uint64), want.view(np.uint64))
+    # the same call split over the library's internal HIP streams (sosvo_frame_pair_batch_streams): same records, step
+    # after step, also with more streams than the 4 pairs divide evenly into
+    for ns in (2, 3):
+        multi = FramePairBatch(ctx, model, rig, B, num_of_features=nfeat, kp_cap=cap, frame_cap=1024, max_iter=300, seed=11,
+                               n_streams=ns)
+        multi.load_frames(omni)
+        for _ in range(3):
+            got3 = multi.step().clone()
+            ctx.synchronize()
+            assert np.array_equal(got3.cpu().numpy().view(np.uint64), want.view(np.uint64)), ns
 
 
 def test_argument_errors(ctx):

@@ -50,3 +50,7 @@ def test_plain_c_program_matches_ctypes_path(ctx, tmp_path):
     got = np.fromfile(outp, dtype=np.float64).reshape(B, 16)
     assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
     assert "inliers" in r.stdout and (got[:, 14] == 0).all() and (got[:, 12] > 50).all()
+    # the same program with the batch split over two internal streams of the library
+    r2 = subprocess.run([exe, inp, outp, "2"], capture_output=True, text=True, timeout=120)
+    assert r2.returncode == 0, r2.stderr
+    assert np.array_equal(np.fromfile(outp, dtype=np.float64).reshape(B, 16).view(np.uint64), want.view(np.uint64))

@@ -79,6 +79,8 @@ SIGNATURES = {
                                            c_p, c_p, c_p, c_p, c_p]),
     "sosvo_frame_pair_batch_workspace": (ctypes.c_size_t, [c_p]),
     "sosvo_frame_pair_batch": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
+    "sosvo_frame_pair_batch_streams_workspace": (ctypes.c_size_t, [c_p, c_i32]),
+    "sosvo_frame_pair_batch_streams": (c_i32, [c_p, c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
     "sosvo_rgbd_pair_batch_workspace": (ctypes.c_size_t, [c_p]),
     "sosvo_rgbd_pair_batch": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
 }

@@ -14,6 +14,8 @@ struct sosvo_prof_entry {
 
 constexpr int kSosvoProfMax = 16384;
 
+constexpr int kSosvoMaxSubStreams = 4;
+
 struct sosvo_ctx {
   int32_t device;
   hipStream_t stream;
@@ -27,6 +29,10 @@ struct sosvo_ctx {
   int32_t prof_n;        // entries recorded since the last enable/reset
   int32_t prof_created;  // event pairs that exist
   sosvo_prof_entry* prof;
+  // sosvo_frame_pair_batch_streams: internal sub-contexts (own stream, own scratch), created on first use
+  sosvo_ctx* sub[kSosvoMaxSubStreams];
+  hipEvent_t sub_done[kSosvoMaxSubStreams], sub_median[kSosvoMaxSubStreams], sub_begin;
+  int32_t n_sub;
 };
 
 // Brackets the kernel launches of the enclosing scope with a HIP event pair when profiling is on.

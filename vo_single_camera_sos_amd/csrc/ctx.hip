@@ -34,6 +34,17 @@ int32_t sosvo_create(sosvo_ctx** out, int32_t device, void* stream) {
 int32_t sosvo_destroy(sosvo_ctx* ctx) {
   if (!ctx) return SOSVO_OK;
   (void)hipSetDevice(ctx->device);
+  for (int i = 0; i < ctx->n_sub; ++i) {  // internal streams of sosvo_frame_pair_batch_streams
+    if (ctx->sub[i]) {
+      hipStream_t st = ctx->sub[i]->stream;
+      (void)hipStreamSynchronize(st);
+      (void)sosvo_destroy(ctx->sub[i]);
+      (void)hipStreamDestroy(st);
+    }
+    (void)hipEventDestroy(ctx->sub_done[i]);
+    (void)hipEventDestroy(ctx->sub_median[i]);
+  }
+  if (ctx->n_sub) (void)hipEventDestroy(ctx->sub_begin);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->prof) {
     for (int i = 0; i < ctx->prof_created; ++i) {

@@ -175,9 +175,12 @@ size_t sosvo_frame_pair_batch_workspace(const sosvo_batch_cfg* cfg) {
   return carve(*cfg, nullptr).bytes;
 }
 
-int32_t sosvo_frame_pair_batch(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo_batch_cfg* cfg, const uint8_t* omni,
+// (median_wait / median_done: the token that serialises the VALU-bound median launches of the parts of a multi-stream
+// batch, see sosvo_frame_pair_batch_streams; nullptr for a plain call)
+static int32_t run_frame_pairs(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo_batch_cfg* cfg, const uint8_t* omni,
                                const uint32_t* unwrap_table, const uint32_t* mask_bits, const int8_t* pattern,
-                               void* workspace, size_t workspace_bytes, double* results) {
+                               void* workspace, size_t workspace_bytes, double* results, hipEvent_t median_wait,
+                               hipEvent_t median_done) {
   SOSVO_ENTER(ctx);
   SOSVO_REQUIRE(ctx, rig && cfg && omni && unwrap_table && mask_bits && pattern && workspace && results, "null pointer");
   SOSVO_REQUIRE(ctx, cfg->n_pairs > 0 && cfg->n_pairs <= 8192, "n_pairs out of range (1..8192)");
@@ -204,6 +207,7 @@ int32_t sosvo_frame_pair_batch(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo
                b.cur_frame, b.cam_off, b.cam_rot);
   SOSVO_LAUNCH_CHECK(ctx);
   // image front end: K1, K2 + K3, K4, K6 over all 2 * F panoramas
+  if (median_wait) SOSVO_HIP(ctx, hipStreamWaitEvent(ctx->stream, median_wait, 0));
   if (cfg->median_ksize == 3 || cfg->median_ksize == 5 || cfg->median_ksize == 11) {
     STAGE(sosvo_unwrap_median_gray(ctx, omni, unwrap_table, F, cfg->H, cfg->W, cfg->rows, cfg->cols, cfg->median_ksize,
                                    b.gray));
@@ -211,6 +215,7 @@ int32_t sosvo_frame_pair_batch(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo
     STAGE(sosvo_unwrap_table(ctx, omni, unwrap_table, F, cfg->H, cfg->W, cfg->rows, cfg->cols, b.pano));
     STAGE(sosvo_median_gray(ctx, b.pano, NI, cfg->rows, cfg->cols, cfg->median_ksize, b.gray));
   }
+  if (median_done) SOSVO_HIP(ctx, hipEventRecord(median_done, ctx->stream));
   STAGE(sosvo_detect_gft(ctx, b.gray, mask_bits, NI, F, cfg->rows, cfg->cols, NM, cfg->quality, cfg->min_distance,
                          cfg->max_corners, cap, b.kp, b.n, b.status));
   STAGE(sosvo_describe_orb(ctx, b.gray, NI, cfg->rows, cfg->cols, NM, cap, b.kp, b.n, cfg->cos_a, cfg->sin_a, pattern,
@@ -241,6 +246,87 @@ int32_t sosvo_frame_pair_batch(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo
                results);
   SOSVO_LAUNCH_CHECK(ctx);
 #undef STAGE
+  return SOSVO_OK;
+}
+
+int32_t sosvo_frame_pair_batch(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo_batch_cfg* cfg, const uint8_t* omni,
+                               const uint32_t* unwrap_table, const uint32_t* mask_bits, const int8_t* pattern,
+                               void* workspace, size_t workspace_bytes, double* results) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, rig && cfg && omni && unwrap_table && mask_bits && pattern && workspace && results, "null pointer");
+  return run_frame_pairs(ctx, rig, cfg, omni, unwrap_table, mask_bits, pattern, workspace, workspace_bytes, results, nullptr,
+                         nullptr);
+}
+
+// ---- the same batch split over internal HIP streams ------------------------------------------------------
+static void part_range(int n, int part, int parts, int* lo, int* hi) {  // contiguous blocks, sizes differ by at most one
+  const int base = n / parts, extra = n % parts;
+  *lo = part * base + (part < extra ? part : extra);
+  *hi = *lo + base + (part < extra ? 1 : 0);
+}
+
+size_t sosvo_frame_pair_batch_streams_workspace(const sosvo_batch_cfg* cfg, int32_t n_streams) {
+  if (!cfg || n_streams < 1 || n_streams > kSosvoMaxSubStreams || cfg->n_pairs < n_streams) return 0;
+  size_t total = 0;
+  for (int s = 0; s < n_streams; ++s) {
+    int lo, hi;
+    part_range(cfg->n_pairs, s, n_streams, &lo, &hi);
+    sosvo_batch_cfg c = *cfg;
+    c.n_pairs = hi - lo;
+    const size_t bytes = sosvo_frame_pair_batch_workspace(&c);
+    if (bytes == 0) return 0;
+    total += (bytes + 255) & ~(size_t)255;
+  }
+  return total;
+}
+
+int32_t sosvo_frame_pair_batch_streams(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo_batch_cfg* cfg, int32_t n_streams,
+                                       const uint8_t* omni, const uint32_t* unwrap_table, const uint32_t* mask_bits,
+                                       const int8_t* pattern, void* workspace, size_t workspace_bytes, double* results) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, rig && cfg && omni && unwrap_table && mask_bits && pattern && workspace && results, "null pointer");
+  SOSVO_REQUIRE(ctx, n_streams >= 1 && n_streams <= kSosvoMaxSubStreams, "n_streams out of range (1..4)");
+  SOSVO_REQUIRE(ctx, cfg->n_pairs >= n_streams && cfg->n_pairs <= 8192, "n_pairs out of range (n_streams..8192)");
+  SOSVO_REQUIRE(ctx, ((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
+  const size_t need = sosvo_frame_pair_batch_streams_workspace(cfg, n_streams);
+  SOSVO_REQUIRE(ctx, need > 0 && workspace_bytes >= need, "workspace too small (see sosvo_frame_pair_batch_streams_workspace)");
+  // internal sub-contexts: one stream and one scratch workspace each, created on first use, kept for the context's life
+  while (ctx->n_sub < n_streams) {
+    const int i = ctx->n_sub;
+    if (i == 0) SOSVO_HIP(ctx, hipEventCreateWithFlags(&ctx->sub_begin, hipEventDisableTiming));
+    hipStream_t st;
+    SOSVO_HIP(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    const int32_t rc = sosvo_create(&ctx->sub[i], ctx->device, st);
+    if (rc != SOSVO_OK) {
+      (void)hipStreamDestroy(st);
+      return sosvo_fail(ctx, rc, __func__, "cannot create an internal stream context");
+    }
+    SOSVO_HIP(ctx, hipEventCreateWithFlags(&ctx->sub_done[i], hipEventDisableTiming));
+    SOSVO_HIP(ctx, hipEventCreateWithFlags(&ctx->sub_median[i], hipEventDisableTiming));
+    ctx->n_sub = i + 1;
+  }
+  // every part starts after the work already queued on the caller's stream ...
+  SOSVO_HIP(ctx, hipEventRecord(ctx->sub_begin, ctx->stream));
+  char* ws = reinterpret_cast<char*>(workspace);
+  hipEvent_t token = nullptr;  // ... and the medians take turns: part s waits for the median of part s - 1
+  for (int s = 0; s < n_streams; ++s) {
+    int lo, hi;
+    part_range(cfg->n_pairs, s, n_streams, &lo, &hi);
+    sosvo_batch_cfg c = *cfg;
+    c.n_pairs = hi - lo;
+    c.seed = cfg->seed + (uint64_t)lo;  // pair i samples with seed + i, whatever the split
+    const size_t bytes = (sosvo_frame_pair_batch_workspace(&c) + 255) & ~(size_t)255;
+    sosvo_ctx* sc = ctx->sub[s];
+    SOSVO_HIP(ctx, hipStreamWaitEvent(sc->stream, ctx->sub_begin, 0));
+    const int32_t rc = run_frame_pairs(sc, rig, &c, omni + (size_t)2 * lo * cfg->H * cfg->W * 3, unwrap_table, mask_bits, pattern,
+                                       ws, bytes, results + (size_t)16 * lo, token, ctx->sub_median[s]);
+    if (rc != SOSVO_OK) return sosvo_fail(ctx, rc, __func__, sc->err);
+    token = ctx->sub_median[s];
+    SOSVO_HIP(ctx, hipEventRecord(ctx->sub_done[s], sc->stream));
+    ws += bytes;
+  }
+  // ... and the caller's stream continues after all of them
+  for (int s = 0; s < n_streams; ++s) SOSVO_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->sub_done[s], 0));
   return SOSVO_OK;
 }
 

@@ -598,7 +598,10 @@ class Context(object):
     def frame_pair_batch_workspace(self, cfg):
         return int(self._lib.sosvo_frame_pair_batch_workspace(ctypes.cast(ctypes.pointer(cfg), c_p)))
 
-    def frame_pair_batch(self, rig, cfg, omni, unwrap_table, mask_bits, pattern, workspace, results=None):
+    def frame_pair_batch_streams_workspace(self, cfg, n_streams):
+        return int(self._lib.sosvo_frame_pair_batch_streams_workspace(ctypes.cast(ctypes.pointer(cfg), c_p), int(n_streams)))
+
+    def frame_pair_batch(self, rig, cfg, omni, unwrap_table, mask_bits, pattern, workspace, results=None, n_streams=1):
         """omni [2B,H,W,3] u8, unwrap_table [2,rows,cols,2] u32, mask_bits [2,rows,cols] u32, pattern [512,2] i8,
         workspace u8 [>= frame_pair_batch_workspace(cfg)] -> results [B,16] f64 (see include/sosvo.h)."""
         B = int(cfg.n_pairs)
@@ -610,6 +613,11 @@ class Context(object):
         if results is None:
             results = torch.empty((B, 16), dtype=torch.float64, device=omni.device)
         _check(results, torch.float64, "results", (B, 16))
+        if int(n_streams) > 1:   # the batch split over internal HIP streams of the library
+            self._call(self._lib.sosvo_frame_pair_batch_streams, ctypes.cast(ctypes.pointer(rig), c_p),
+                       ctypes.cast(ctypes.pointer(cfg), c_p), int(n_streams), _ptr(omni), _ptr(unwrap_table), _ptr(mask_bits),
+                       _ptr(pattern), _ptr(workspace), int(workspace.numel()), _ptr(results))
+            return results
         self._call(self._lib.sosvo_frame_pair_batch, ctypes.cast(ctypes.pointer(rig), c_p),
                    ctypes.cast(ctypes.pointer(cfg), c_p), _ptr(omni), _ptr(unwrap_table), _ptr(mask_bits), _ptr(pattern),
                    _ptr(workspace), int(workspace.numel()), _ptr(results))

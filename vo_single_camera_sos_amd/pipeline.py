@@ -280,10 +280,12 @@ class FramePairBatch(object):
     bind.  `model` is a DeviceImageModel (model constants in HBM); the workspace is allocated once."""
 
     def __init__(self, ctx, model, rig, n_pairs, num_of_features=1000, kp_cap=None, frame_cap=2048, median_win_size=11,
-                 quality=0.01, min_distance=5.0, edge=31, thr=None, max_iter=2000, adaptive=False, seed=0, lm_iter=30):
+                 quality=0.01, min_distance=5.0, edge=31, thr=None, max_iter=2000, adaptive=False, seed=0, lm_iter=30,
+                 n_streams=1):
+        """n_streams > 1: sosvo_frame_pair_batch_streams (the batch split over internal HIP streams of the library)."""
         from . import _lib, orb_pattern
         self.ctx, self.model, self.rig_cfg, self.rig = ctx, model, rig, rig.as_struct()
-        self.B = int(n_pairs)
+        self.B, self.n_streams = int(n_pairs), max(1, min(int(n_streams), int(n_pairs)))
         if kp_cap is None:
             kp_cap = int(min(1024, max(64, -(-int(num_of_features) // 64) * 64)))
         cos_a, sin_a = orb_pattern.angle_cos_sin(orb_pattern.GFT_KEYPOINT_ANGLE)
@@ -298,7 +300,7 @@ class FramePairBatch(object):
         self.cfg = c
         if getattr(model, "unwrap_table", None) is None:  # once per model
             model.unwrap_table = ctx.unwrap_prepare(model.omni_masks, model.map_x, model.map_y, (model.H, model.W))
-        nbytes = ctx.frame_pair_batch_workspace(c)
+        nbytes = ctx.frame_pair_batch_workspace(c) if self.n_streams == 1 else ctx.frame_pair_batch_streams_workspace(c, self.n_streams)
         if nbytes <= 0:
             raise ValueError("bad batch configuration")
         self.workspace = torch.empty((nbytes,), dtype=torch.uint8, device=ctx.device)
@@ -313,7 +315,7 @@ class FramePairBatch(object):
         """-> results [B,16] f64 (asynchronous)."""
         m = self.model
         return self.ctx.frame_pair_batch(self.rig, self.cfg, self.omni, m.unwrap_table, m.mask_bits, m.pattern, self.workspace,
-                                         results=self.out)
+                                         results=self.out, n_streams=self.n_streams)
 
     def results(self):
         return self.out
