@@ -12,6 +12,8 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+#include <time.h>
 
 #include "sosvo.h"
 
@@ -49,10 +51,11 @@ static void* upload(FILE* f, size_t bytes) {
 
 int main(int argc, char** argv) {
   if (argc != 3 && argc != 4) {
-    fprintf(stderr, "usage: %s input.bin output.bin [internal streams, 1..4]\n", argv[0]);
+    fprintf(stderr, "usage: %s input.bin output.bin [internal streams 1..4 | graph]\n", argv[0]);
     return 1;
   }
-  const int n_streams = argc == 4 ? atoi(argv[3]) : 1;
+  const int use_graph = argc == 4 && strcmp(argv[3], "graph") == 0;
+  const int n_streams = argc == 4 && !use_graph ? atoi(argv[3]) : 1;
   FILE* f = fopen(argv[1], "rb");
   if (!f) return 1;
   sosvo_batch_cfg cfg;
@@ -68,7 +71,9 @@ int main(int argc, char** argv) {
   fclose(f);
 
   sosvo_ctx* ctx = NULL;
-  if (sosvo_create(&ctx, 0, NULL) != SOSVO_OK) {  /* device 0, the default stream */
+  hipStream_t stream = NULL;
+  if (use_graph) CHECK_HIP(hipStreamCreate(&stream)); /* a capture needs a stream of its own */
+  if (sosvo_create(&ctx, 0, stream) != SOSVO_OK) {  /* device 0, the default stream unless capturing */
     fprintf(stderr, "sosvo_create failed\n");
     return 3;
   }
@@ -81,7 +86,43 @@ int main(int argc, char** argv) {
   const size_t ws_bytes = n_streams > 1 ? sosvo_frame_pair_batch_streams_workspace(&cfg, n_streams) : sosvo_frame_pair_batch_workspace(&cfg);
   CHECK_HIP(hipMalloc(&workspace, ws_bytes));
   CHECK_HIP(hipMalloc((void**)&results, B * 16 * sizeof(double)));
-  if (n_streams > 1)
+  if (use_graph) {
+    /* "graph": the call only enqueues work, so it can be captured into a HIP graph and replayed.  One eager call first
+     * (the library sizes its scratch memory on first use), then capture, then REPLAYS replays, each checked against the
+     * eager records bit for bit, with the host time per replay. */
+    enum { REPLAYS = 20 };
+    CHECK_SOSVO(sosvo_frame_pair_batch(ctx, &rig, &cfg, omni, table, mask_bits, pattern, workspace, ws_bytes, results));
+    CHECK_SOSVO(sosvo_synchronize(ctx));
+    double* eager = (double*)malloc(B * 16 * sizeof(double));
+    double* again = (double*)malloc(B * 16 * sizeof(double));
+    CHECK_HIP(hipMemcpy(eager, results, B * 16 * sizeof(double), hipMemcpyDeviceToHost));
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    CHECK_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeGlobal));
+    CHECK_SOSVO(sosvo_frame_pair_batch(ctx, &rig, &cfg, omni, table, mask_bits, pattern, workspace, ws_bytes, results));
+    CHECK_HIP(hipStreamEndCapture(stream, &graph));
+    CHECK_HIP(hipGraphInstantiate(&exec, graph, NULL, NULL, 0));
+    int mismatches = 0;
+    struct timespec t0, t1;
+    double total_ms = 0.0;
+    for (int r = 0; r < REPLAYS; ++r) {
+      CHECK_HIP(hipMemsetAsync(results, 0xFF, B * 16 * sizeof(double), stream));
+      CHECK_HIP(hipStreamSynchronize(stream));
+      clock_gettime(CLOCK_MONOTONIC, &t0);
+      CHECK_HIP(hipGraphLaunch(exec, stream));
+      CHECK_HIP(hipStreamSynchronize(stream));
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      total_ms += (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
+      CHECK_HIP(hipMemcpy(again, results, B * 16 * sizeof(double), hipMemcpyDeviceToHost));
+      if (memcmp(again, eager, B * 16 * sizeof(double)) != 0) ++mismatches;
+    }
+    printf("graph: %d of %d replays differ from the eager records; %.3f ms per replay\n", mismatches, REPLAYS, total_ms / REPLAYS);
+    free(eager);
+    free(again);
+    CHECK_HIP(hipGraphExecDestroy(exec));
+    CHECK_HIP(hipGraphDestroy(graph));
+    if (mismatches) return 7;
+  } else if (n_streams > 1)
     CHECK_SOSVO(sosvo_frame_pair_batch_streams(ctx, &rig, &cfg, n_streams, omni, table, mask_bits, pattern, workspace, ws_bytes,
                                                results));
   else

@@ -50,6 +50,12 @@ def test_plain_c_program_matches_ctypes_path(ctx, tmp_path):
     got = np.fromfile(outp, dtype=np.float64).reshape(B, 16)
     assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
     assert "inliers" in r.stdout and (got[:, 14] == 0).all() and (got[:, 12] > 50).all()
+    # "graph": the call captured into a HIP graph with the plain runtime API and replayed 20 times (exit code 7 = a replay
+    # differed from the eager records)
+    r3 = subprocess.run([exe, inp, outp, "graph"], capture_output=True, text=True, timeout=120)
+    print(r3.stdout[-300:])
+    assert r3.returncode == 0, r3.stdout[-500:] + r3.stderr[-500:]
+    assert "0 of 20 replays differ" in r3.stdout
     # the same program with the batch split over two internal streams of the library
     r2 = subprocess.run([exe, inp, outp, "2"], capture_output=True, text=True, timeout=120)
     assert r2.returncode == 0, r2.stderr
