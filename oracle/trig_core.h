@@ -1,5 +1,5 @@
 /* TEST INFRASTRUCTURE (CPU oracle) -- shared arithmetic, restated on the device as vo_single_camera_sos_amd/csrc/trig_core.h
- * (same text with the orc_ prefix replaced; scripts/gen_device_headers.py).
+ * (same text with the orc_ prefix replaced; tests/gen_device_headers.py).
  *
  * sin / cos / atan in double precision from + - * / and comparisons only, every expression fully parenthesised and built
  * without contraction, so that the CPU oracle and the GPU evaluate the panorama geometry (pixel -> angles -> bearing,

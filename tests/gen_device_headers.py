@@ -1,6 +1,6 @@
 """Device headers that are the TEXT of an oracle header (same arithmetic on both sides, by construction):
     oracle/trig_core.h -> vo_single_camera_sos_amd/csrc/trig_core.h   (orc_ -> sv_, static inline -> __device__ static)
-Run after editing the oracle header:   python scripts/gen_device_headers.py   (tests/test_abi.py checks that it was)."""
+Run after editing the oracle header:   python tests/gen_device_headers.py   (tests/test_abi.py checks that it was)."""
 import os
 import re
 
@@ -10,7 +10,7 @@ PAIRS = [("oracle/trig_core.h", "vo_single_camera_sos_amd/csrc/trig_core.h")]
 
 def device_text(src_text, src_name):
     t = src_text
-    t = re.sub(r"/\* TEST INFRASTRUCTURE.*?\*/", "// Generated from %s by scripts/gen_device_headers.py -- do not edit; see that file for\n"
+    t = re.sub(r"/\* TEST INFRASTRUCTURE.*?\*/", "// Generated from %s by tests/gen_device_headers.py -- do not edit; see that file for\n"
                "// the description of the algorithms." % src_name, t, count=1, flags=re.S)
     t = t.replace("#pragma once\n", "#pragma once\n#include <hip/hip_runtime.h>\n", 1)
     t = t.replace("static inline", "__device__ static")

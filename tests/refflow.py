@@ -239,7 +239,7 @@ def pairs_worker(job):
 
 def pairs_records_worker(job):
     """As pairs_worker, but returns the [n,16] result records (3x4 refined pose, inliers, correspondences, status,
-    winning iteration) -- scripts/soak_parity.py compares them with the GPU's."""
+    winning iteration) -- tests/soak_parity.py compares them with the GPU's."""
     rig_kw, im_kw, omni, thr, iters, seed0 = job
     rp = RigParams(**rig_kw)
     im = ImageModel(**im_kw)
@@ -256,7 +256,7 @@ def pairs_records_worker(job):
 
 def rgbd_pairs_records_worker(job):
     """RGB-D counterpart of pairs_records_worker: job = (cam_kw, bgr [2n,...], depth [2n,...], nfeat, thr, iters, seed0,
-    epnp) -> [n,16] records (scripts/soak_parity.py --rgbd)."""
+    epnp) -> [n,16] records (tests/soak_parity.py --rgbd)."""
     from vo_single_camera_sos_amd import orb_pattern
     cam_kw, bgr, depth, nfeat, thr, iters, seed0, epnp = job
     cam = RGBDParams(**cam_kw)

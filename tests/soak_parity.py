@@ -3,7 +3,7 @@ keypoints per view, 2000 RANSAC iterations): N rendered frame pairs through Over
 through the reference's control flow on the C oracle (tests/refflow.py, multi-process), every record compared --
 counts, status, best iteration exactly, refined pose at rel-tol 1e-6.  A tool, not part of the test suite:
 
-    python scripts/soak_parity.py --pairs 64 [--seed 7] [--workers 16]
+    python tests/soak_parity.py --pairs 64 [--seed 7] [--workers 16]
 """
 import argparse
 import os
@@ -12,7 +12,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # (this file lives in tests/: it drives the CPU oracle, which only tests may)
 
 import numpy as np  # noqa: E402
 

@@ -32,11 +32,11 @@ def test_abi_version_and_loud_failure_without_gpu():
 
 
 def test_generated_device_headers_are_current():
-    """csrc/trig_core.h is the text of oracle/trig_core.h (scripts/gen_device_headers.py): same arithmetic on both sides."""
+    """csrc/trig_core.h is the text of oracle/trig_core.h (tests/gen_device_headers.py): same arithmetic on both sides."""
     import importlib.util
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("gen_device_headers", os.path.join(root, "scripts", "gen_device_headers.py"))
+    spec = importlib.util.spec_from_file_location("gen_device_headers", os.path.join(root, "tests", "gen_device_headers.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    assert mod.main(check=True), "run python scripts/gen_device_headers.py"
+    assert mod.main(check=True), "run python tests/gen_device_headers.py"

@@ -1,4 +1,4 @@
-"""GPU: scripts/soak_parity.py at a small size -- the bench configuration itself (1440 x 146 panoramas, ~2000 keypoints
+"""GPU: tests/soak_parity.py at a small size -- the bench configuration itself (1440 x 146 panoramas, ~2000 keypoints
 per view, 2000 RANSAC iterations) through the GPU engine and through the oracle flow on host processes, every record
 compared (the tool exits non-zero on any difference); likewise the RGB-D path with the reference's default "EPNP"."""
 import os
@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("extra", [[], ["--rgbd", "EPNP"]])
 def test_soak_parity_small(extra):
-    cmd = [sys.executable, os.path.join(ROOT, "scripts", "soak_parity.py"), "--pairs", "16", "--workers", "4", "--seed", "12321"] + extra
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "soak_parity.py"), "--pairs", "16", "--workers", "4", "--seed", "12321"] + extra
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     last = [l for l in out.stdout.splitlines() if "soak" in l][-1]

@@ -1,4 +1,4 @@
-// Generated from oracle/trig_core.h by scripts/gen_device_headers.py -- do not edit; see that file for
+// Generated from oracle/trig_core.h by tests/gen_device_headers.py -- do not edit; see that file for
 // the description of the algorithms.
 #pragma once
 #include <hip/hip_runtime.h>
