@@ -10,8 +10,10 @@ PAIRS = [("oracle/trig_core.h", "vo_single_camera_sos_amd/csrc/trig_core.h")]
 
 def device_text(src_text, src_name):
     t = src_text
-    t = re.sub(r"/\* TEST INFRASTRUCTURE.*?\*/", "// Generated from %s by tests/gen_device_headers.py -- do not edit; see that file for\n"
-               "// the description of the algorithms." % src_name, t, count=1, flags=re.S)
+    t = re.sub(r"/\* TEST INFRASTRUCTURE.*?\*/", "// sin / cos / atan in double precision from + - * / and comparisons only (Cody-Waite reduction, minimax\n"
+               "// polynomials): the panorama geometry of the device code.  The CPU oracle evaluates the SAME text (%s, orc_\n"
+               "// prefix) so that both sides agree to the bit; tests/gen_device_headers.py keeps the two files identical\n"
+               "// and tests/test_abi.py checks it.  Edit both through that script." % src_name, t, count=1, flags=re.S)
     t = t.replace("#pragma once\n", "#pragma once\n#include <hip/hip_runtime.h>\n", 1)
     t = t.replace("static inline", "__device__ static")
     t = re.sub(r"\borc_", "sv_", t)
