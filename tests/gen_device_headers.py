@@ -11,8 +11,8 @@ PAIRS = [("oracle/trig_core.h", "vo_single_camera_sos_amd/csrc/trig_core.h")]
 def device_text(src_text, src_name):
     t = src_text
     t = re.sub(r"/\* TEST INFRASTRUCTURE.*?\*/", "// sin / cos / atan in double precision from + - * / and comparisons only (Cody-Waite reduction, minimax\n"
-               "// polynomials): the panorama geometry of the device code.  The CPU oracle evaluates the SAME text (%s, orc_\n"
-               "// own prefix) so that both sides agree to the bit; tests/gen_device_headers.py keeps the two files identical\n"
+               "// polynomials): the panorama geometry of the device code.  The CPU oracle evaluates the SAME text (%s, with\n"
+               "// its own prefix) so that both sides agree to the bit; tests/gen_device_headers.py keeps the two files identical\n"
                "// and tests/test_abi.py checks it.  Edit both through that script." % src_name, t, count=1, flags=re.S)
     t = t.replace("#pragma once\n", "#pragma once\n#include <hip/hip_runtime.h>\n", 1)
     t = t.replace("static inline", "__device__ static")

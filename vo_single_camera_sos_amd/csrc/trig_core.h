@@ -1,6 +1,6 @@
 // sin / cos / atan in double precision from + - * / and comparisons only (Cody-Waite reduction, minimax
-// polynomials): the panorama geometry of the device code.  The CPU oracle evaluates the SAME text (oracle/trig_core.h, sv_
-// own prefix) so that both sides agree to the bit; tests/gen_device_headers.py keeps the two files identical
+// polynomials): the panorama geometry of the device code.  The CPU oracle evaluates the SAME text (oracle/trig_core.h, with
+// its own prefix) so that both sides agree to the bit; tests/gen_device_headers.py keeps the two files identical
 // and tests/test_abi.py checks it.  Edit both through that script.
 #pragma once
 #include <hip/hip_runtime.h>
