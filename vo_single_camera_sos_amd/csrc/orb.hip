@@ -115,17 +115,25 @@ __device__ __forceinline__ int fast_score(const uint8_t* __restrict__ im, int w,
   const int ry[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
 #pragma unroll
   for (int k = 0; k < 16; ++k) d[k] = (int)im[(size_t)(y + ry[k]) * w + x + rx[k]] - v;
+  // max over the 16 arcs of 9 consecutive circle pixels of min(d) (brighter) and of min(-d) = -max(d) (darker), by
+  // doubling: windows of 2, 4, 8, then 9 -- 4 min + 4 max per start instead of 8 + 8
+  int lo2[16], hi2[16], lo4[16], hi4[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    lo2[k] = min(d[k], d[(k + 1) & 15]);
+    hi2[k] = max(d[k], d[(k + 1) & 15]);
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    lo4[k] = min(lo2[k], lo2[(k + 2) & 15]);
+    hi4[k] = max(hi2[k], hi2[(k + 2) & 15]);
+  }
   int best = 0;
 #pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    int mn_b = 1 << 20, mn_d = 1 << 20;
-#pragma unroll
-    for (int j = 0; j < 9; ++j) {
-      const int dd = d[(s + j) & 15];
-      mn_b = min(mn_b, dd);
-      mn_d = min(mn_d, -dd);
-    }
-    best = max(best, max(mn_b, mn_d));
+  for (int k = 0; k < 16; ++k) {
+    const int mn_b = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);   // min of d over k .. k + 8
+    const int mx = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);     // max of d over k .. k + 8
+    best = max(best, max(mn_b, -mx));
   }
   return best > thr ? best - 1 : 0;
 }
