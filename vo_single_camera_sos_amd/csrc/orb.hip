@@ -282,9 +282,47 @@ __device__ __forceinline__ float harris_response(const uint8_t* __restrict__ im,
   return (((fa * fb) - (fc * fc)) - ((0.04f * (fa + fb)) * (fa + fb))) * s4;
 }
 
+// Bounding box of every mask on every pyramid level of every mask set (depends on the masks only; cheap enough to
+// redo per call): bbox[((set * kLevels + l) * 32 + m) * 4 + {0,1,2,3}] = {~xmin, ~ymin, xmax + 1, ymax + 1} grown by
+// atomicMax from zero (field 2 == 0: the mask is empty on that level).  One workgroup per (pyramid row, set).
+__global__ __launch_bounds__(kThreads) void orb_mask_bbox_kernel(const uint32_t* __restrict__ mask_pyr, Pyr P, int nmask,
+                                                                 uint32_t* __restrict__ bbox) {
+  __shared__ uint32_t sb[2][32];
+  const int tid = threadIdx.x, set = blockIdx.y;
+  int row = blockIdx.x, l = 0;
+  while (l < P.nlev && row >= P.h[l]) {
+    row -= P.h[l];
+    ++l;
+  }
+  if (l >= P.nlev) return;  // uniform
+  if (tid < 64) (&sb[0][0])[tid] = 0u;
+  __syncthreads();
+  const int w = P.w[l];
+  const uint32_t* mk = mask_pyr + (size_t)set * P.total + P.off[l] + (size_t)row * w;
+  const uint32_t mask_all = nmask < 32 ? (1u << nmask) - 1u : 0xFFFFFFFFu;
+  for (int x = tid; x < w; x += kThreads) {
+    uint32_t b = mk[x] & mask_all;
+    while (b) {
+      const int m = __ffs(b) - 1;
+      b &= b - 1;
+      atomicMax(&sb[0][m], 0xFFFFFFFFu - (uint32_t)x);
+      atomicMax(&sb[1][m], (uint32_t)x + 1u);
+    }
+  }
+  __syncthreads();
+  if (tid < nmask && sb[1][tid]) {
+    uint32_t* o = bbox + (((size_t)set * kLevels + l) * 32 + tid) * 4;
+    atomicMax(&o[0], sb[0][tid]);
+    atomicMax(&o[1], 0xFFFFFFFFu - (uint32_t)row);
+    atomicMax(&o[2], sb[1][tid]);
+    atomicMax(&o[3], (uint32_t)row + 1u);
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void orb_select_kernel(const uint8_t* __restrict__ pyr,
                                                               const uint8_t* __restrict__ score,
-                                                              const uint32_t* __restrict__ mask_pyr, Pyr P,
+                                                              const uint32_t* __restrict__ mask_pyr,
+                                                              const uint32_t* __restrict__ bbox, Pyr P,
                                                               int images_per_maskset, int nmask, int cap,
                                                               float* __restrict__ kp4, float* __restrict__ resp_out,
                                                               int32_t* __restrict__ n_out) {
@@ -311,10 +349,14 @@ __global__ __launch_bounds__(kThreads) void orb_select_kernel(const uint8_t* __r
     if (tid == 0) s_nc = 0;
     for (int k = tid; k < 256; k += kThreads) hist[k] = 0;
     __syncthreads();
-    // 1. NMS + border + mask -> candidates (unordered)
-    const int rw = w - 2 * kEdge, rh = h - 2 * kEdge;
+    // 1. NMS + border + mask -> candidates (unordered); only the mask's bounding box on this level is scanned (the
+    // azimuthal masks are column bands: a twelfth of the level each)
+    const uint32_t* bb = bbox + (((size_t)(img / images_per_maskset) * kLevels + l) * 32 + m) * 4;
+    const int bx0 = max(kEdge, (int)(0xFFFFFFFFu - bb[0])), by0 = max(kEdge, (int)(0xFFFFFFFFu - bb[1]));
+    const int bx1 = min(w - kEdge, (int)bb[2]), by1 = min(h - kEdge, (int)bb[3]);  // exclusive
+    const int rw = bb[2] ? max(0, bx1 - bx0) : 0, rh = bb[2] ? max(0, by1 - by0) : 0;
     for (int i = tid; i < rw * rh; i += kThreads) {
-      const int y = kEdge + i / rw, x = kEdge + i % rw;
+      const int y = by0 + i / rw, x = bx0 + i % rw;
       const int s = sc[(size_t)y * w + x];
       if (!s || !((mk[(size_t)y * w + x] >> m) & 1u)) continue;
       bool is_max = true;
@@ -614,17 +656,25 @@ int32_t sosvo_detect_orb(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* ma
   if (nimg == 0) return SOSVO_OK;
   const Pyr P = make_pyr(rows, cols, nfeatures);
   const size_t bytes = (size_t)nimg * P.total;
-  int32_t rc = sosvo_ws_reserve(ctx, 2 * ((bytes + 255) & ~(size_t)255));
+  const int nsets = cdiv(nimg, images_per_maskset);
+  const size_t bbox_bytes = ((size_t)nsets * kLevels * 32 * 4 * sizeof(uint32_t) + 255) & ~(size_t)255;
+  int32_t rc = sosvo_ws_reserve(ctx, 2 * ((bytes + 255) & ~(size_t)255) + bbox_bytes);
   if (rc != SOSVO_OK) return rc;
   uint8_t* pyr = (uint8_t*)ctx->ws;
   uint8_t* score = pyr + ((bytes + 255) & ~(size_t)255);
+  uint32_t* bbox = (uint32_t*)(score + ((bytes + 255) & ~(size_t)255));
   rc = build_pyramid(ctx, gray, nimg, rows, cols, P, pyr);
   if (rc != SOSVO_OK) return rc;
+  SOSVO_HIP(ctx, hipMemsetAsync(bbox, 0, bbox_bytes, ctx->stream));
+  int total_rows = 0;
+  for (int l = 0; l < P.nlev; ++l) total_rows += P.h[l];
+  SOSVO_LAUNCH(ctx, orb_mask_bbox_kernel, dim3(total_rows, nsets), dim3(kThreads), 0, ctx->stream, mask_pyr, P, nmask, bbox);
+  SOSVO_LAUNCH_CHECK(ctx);
   SOSVO_LAUNCH(ctx, fast_score_kernel, dim3((unsigned)((P.total + kThreads - 1) / kThreads), nimg), dim3(kThreads), 0,
                ctx->stream, pyr, P, score);
   SOSVO_LAUNCH_CHECK(ctx);
   SOSVO_LAUNCH(ctx, orb_select_kernel, dim3((unsigned)((size_t)nimg * nmask)), dim3(kThreads), 0, ctx->stream, pyr, score,
-               mask_pyr, P, images_per_maskset, nmask, cap, kp4, resp, n);
+               mask_pyr, bbox, P, images_per_maskset, nmask, cap, kp4, resp, n);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
 }
