@@ -144,3 +144,7 @@ __device__ __forceinline__ int sosvo_block_compact_pos(bool valid, int* wave_off
   return wave_off[wid] + __popcll(bal & ((1ULL << lane) - 1ULL));
 }
 #endif
+
+// detect.hip: the rolling 7x7 blur on images that lie img_stride bytes apart (also used by orb.hip for the pyramid levels)
+int32_t sosvo_launch_gauss7(sosvo_ctx* ctx, const uint8_t* in, long long img_stride, int nimg, int rows, int cols,
+                            uint8_t* out);

@@ -459,8 +459,8 @@ __global__ __launch_bounds__(kThreads) void gft_select_kernel(const float* __res
 // Same rolling layout as min_eigen_kernel: a wave owns a 64-column strip (58 output columns) and walks down a
 // chunk of rows; the six horizontal neighbours come from neighbouring lanes (mirrored lanes at the image
 // border = reflect-101), the seven rows of horizontal sums live in a register ring.
-__global__ __launch_bounds__(kThreads) void gauss7_kernel(const uint8_t* __restrict__ gray, int nimg, int rows, int cols,
-                                                          int strips, int nchunks, int chunk_rows,
+__global__ __launch_bounds__(kThreads) void gauss7_kernel(const uint8_t* __restrict__ gray, long long img_stride, int nimg,
+                                                          int rows, int cols, int strips, int nchunks, int chunk_rows,
                                                           uint8_t* __restrict__ out) {
   SOSVO_STREAMING_PRIO();
   const int lane = threadIdx.x & 63;
@@ -477,8 +477,8 @@ __global__ __launch_bounds__(kThreads) void gauss7_kernel(const uint8_t* __restr
   for (int k = 0; k < 7; ++k) src[k] = clampi(refl101(xs + k - 3, cols) - xb, 0, 63);
   const bool out_lane = lane >= kEigHalo && lane < 64 - kEigHalo && xc < cols;
   const int ys = chunk * chunk_rows, ye = min(rows, ys + chunk_rows);
-  const uint8_t* g = gray + (size_t)img * rows * cols;
-  uint8_t* o = out + (size_t)img * rows * cols;
+  const uint8_t* g = gray + (size_t)img * img_stride;  // (img_stride = rows * cols for a dense batch; a pyramid level of
+  uint8_t* o = out + (size_t)img * img_stride;        //  the ORB detector sits at a fixed offset of a larger per-image block)
   // seven-deep ring of horizontal sums indexed by (row mod 7): the row loop is unrolled seven times by a fold
   uint32_t h[7] = {0, 0, 0, 0, 0, 0, 0};
   const bool edge_strip = xb < 3 || xb + 64 > cols - 3;  // wave-uniform: some lane's x-3 .. x+3 are mirrored columns
@@ -660,6 +660,18 @@ static void rolling_chunks(int nimg, int rows, int strips, int* nchunks, int* ch
 
 }  // namespace
 
+// 7x7 sigma-2 blur (8.8 fixed point) of nimg images that lie img_stride bytes apart (shared with the ORB pyramid levels)
+int32_t sosvo_launch_gauss7(sosvo_ctx* ctx, const uint8_t* in, long long img_stride, int nimg, int rows, int cols,
+                            uint8_t* out) {
+  const int strips = cdiv(cols, kEigStripW);
+  int nchunks, chunk_rows;
+  rolling_chunks(nimg, rows, strips, &nchunks, &chunk_rows);
+  SOSVO_LAUNCH(ctx, gauss7_kernel, dim3(cdiv(nimg * strips * nchunks, kThreads / 64)), dim3(kThreads), 0, ctx->stream, in,
+               img_stride, nimg, rows, cols, strips, nchunks, chunk_rows, out);
+  SOSVO_LAUNCH_CHECK(ctx);
+  return SOSVO_OK;
+}
+
 extern "C" {
 
 int32_t sosvo_detect_gft(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* mask_bits, int32_t nimg,
@@ -742,14 +754,8 @@ int32_t sosvo_describe_orb(sosvo_ctx* ctx, const uint8_t* gray, int32_t nimg, in
   int32_t rc = sosvo_ws_reserve(ctx, bytes);
   if (rc != SOSVO_OK) return rc;
   uint8_t* blurred = (uint8_t*)ctx->ws;
-  {
-    const int strips = cdiv(cols, kEigStripW);
-    int nchunks, chunk_rows;
-    rolling_chunks(nimg, rows, strips, &nchunks, &chunk_rows);
-    SOSVO_LAUNCH(ctx, gauss7_kernel, dim3(cdiv(nimg * strips * nchunks, kThreads / 64)), dim3(kThreads), 0, ctx->stream, gray,
-                 nimg, rows, cols, strips, nchunks, chunk_rows, blurred);
-    SOSVO_LAUNCH_CHECK(ctx);
-  }
+  rc = sosvo_launch_gauss7(ctx, gray, (long long)rows * cols, nimg, rows, cols, blurred);
+  if (rc != SOSVO_OK) return rc;
   SOSVO_LAUNCH(ctx, orb_describe_kernel, dim3((unsigned)((size_t)nimg * nmask)), dim3(kThreads),
                (size_t)cap * 2 * sizeof(float), ctx->stream, blurred, rows, cols, nmask, cap, kp, n, cos_a, sin_a, pattern,
                edge, desc);

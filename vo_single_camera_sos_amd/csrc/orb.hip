@@ -466,42 +466,6 @@ __global__ __launch_bounds__(kThreads) void orb_select_kernel(const uint8_t* __r
   if (tid == 0) n_out[p] = s_nout;
 }
 
-// ---- blur of every level (7x7 sigma 2, 8.8 fixed point) -----------------------------------------------------
-constexpr int kBlurTW = 64, kBlurTH = 16;
-
-__global__ __launch_bounds__(kThreads) void gauss7_level_kernel(const uint8_t* __restrict__ pyr, long long total,
-                                                                long long off, int rows, int cols,
-                                                                uint8_t* __restrict__ out) {
-  __shared__ uint8_t tile[kBlurTH + 6][kBlurTW + 6];
-  __shared__ uint16_t hrow[kBlurTH + 6][kBlurTW];
-  const int kw[7] = {18, 34, 49, 54, 49, 34, 18};
-  const int tid = threadIdx.x, img = blockIdx.z;
-  const int x0 = blockIdx.x * kBlurTW, y0 = blockIdx.y * kBlurTH;
-  const uint8_t* g = pyr + (size_t)img * total + off;
-  for (int i = tid; i < (kBlurTH + 6) * (kBlurTW + 6); i += kThreads) {
-    const int ty = i / (kBlurTW + 6), tx = i - ty * (kBlurTW + 6);
-    tile[ty][tx] = g[(size_t)refl101(y0 + ty - 3, rows) * cols + refl101(x0 + tx - 3, cols)];
-  }
-  __syncthreads();
-  for (int i = tid; i < (kBlurTH + 6) * kBlurTW; i += kThreads) {
-    const int ty = i / kBlurTW, tx = i - ty * kBlurTW;
-    int s = 0;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) s += kw[k] * tile[ty][tx + k];
-    hrow[ty][tx] = (uint16_t)s;
-  }
-  __syncthreads();
-  for (int i = tid; i < kBlurTH * kBlurTW; i += kThreads) {
-    const int ty = i / kBlurTW, tx = i - ty * kBlurTW;
-    const int y = y0 + ty, x = x0 + tx;
-    if (y >= rows || x >= cols) continue;
-    uint32_t s = 0;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) s += (uint32_t)kw[k] * hrow[ty + k][tx];
-    out[(size_t)img * total + off + (size_t)y * cols + x] = (uint8_t)((s + 32768u) >> 16);
-  }
-}
-
 // ---- descriptors of oriented multi-level keypoints ------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void orb_describe_levels_kernel(const uint8_t* __restrict__ blur, Pyr P, int rows,
                                                                        int cols, int nmask, int cap,
@@ -697,10 +661,9 @@ int32_t sosvo_describe_orb_levels(sosvo_ctx* ctx, const uint8_t* gray, int32_t n
   uint8_t* blur = pyr + ((bytes + 255) & ~(size_t)255);
   rc = build_pyramid(ctx, gray, nimg, rows, cols, P, pyr);
   if (rc != SOSVO_OK) return rc;
-  for (int l = 0; l < P.nlev; ++l) {
-    SOSVO_LAUNCH(ctx, gauss7_level_kernel, dim3(cdiv(P.w[l], kBlurTW), cdiv(P.h[l], kBlurTH), nimg), dim3(kThreads), 0,
-                 ctx->stream, pyr, P.total, P.off[l], P.h[l], P.w[l], blur);
-    SOSVO_LAUNCH_CHECK(ctx);
+  for (int l = 0; l < P.nlev; ++l) {  // the rolling strip kernel of detect.hip, level by level (same integer arithmetic)
+    rc = sosvo_launch_gauss7(ctx, pyr + P.off[l], P.total, nimg, P.h[l], P.w[l], blur + P.off[l]);
+    if (rc != SOSVO_OK) return rc;
   }
   SOSVO_LAUNCH(ctx, orb_describe_levels_kernel, dim3((unsigned)((size_t)nimg * nmask)), dim3(kThreads),
                (size_t)cap * 4 * sizeof(float), ctx->stream, blur, P, rows, cols, nmask, cap, kp4, n, pattern, desc, kp_xy);
