@@ -165,7 +165,11 @@ int32_t sosvo_describe_orb(sosvo_ctx* ctx, const uint8_t* gray, int32_t nimg, in
  * Replaces .compute(image, keypoints) on ORB's own keypoints (camera_models.py:1765): keypoints within
  * 31 px of the level-0 border are removed (kp4 / n compacted in place), each level is blurred 7x7 sigma 2,
  * the pattern is rotated by the keypoint's angle.  desc [nimg*nmask, cap, 32] u8; kp_xy (optional)
- * [nimg*nmask, cap, 2] f32 receives the compacted (x, y) for the matching stages.                 */
+ * [nimg*nmask, cap, 2] f32 receives the compacted (x, y) for the matching stages.
+ * Called directly after sosvo_detect_orb on the same context with the same `gray` pointer and sizes -- detect, then
+ * compute, as the reference does -- it reuses the detector's image pyramid (still in the context's scratch memory)
+ * instead of building it again: the images at `gray` must not have been modified in between.  Any other library
+ * call that uses scratch memory in between makes it rebuild the pyramid.                                          */
 int64_t sosvo_orb_pyramid_pixels(int32_t rows, int32_t cols);
 int32_t sosvo_orb_mask_pyramid(sosvo_ctx* ctx, const uint32_t* mask_bits, int32_t nsets, int32_t rows,
                                int32_t cols, int32_t nmask, uint32_t* mask_pyr);

@@ -33,6 +33,10 @@ struct sosvo_ctx {
   sosvo_ctx* sub[kSosvoMaxSubStreams];
   hipEvent_t sub_done[kSosvoMaxSubStreams], sub_median[kSosvoMaxSubStreams], sub_begin;
   int32_t n_sub;
+  // sosvo_detect_orb leaves the image pyramid at the start of the scratch workspace; sosvo_describe_orb_levels called
+  // right after it on the same images reuses it instead of building it again (tag cleared by any other scratch user)
+  const void* pyr_gray;
+  int32_t pyr_nimg, pyr_rows, pyr_cols;
 };
 
 // Brackets the kernel launches of the enclosing scope with a HIP event pair when profiling is on.
@@ -99,6 +103,7 @@ static inline int32_t sosvo_fail(sosvo_ctx* ctx, int32_t code, const char* what,
 #define SOSVO_LAUNCH_CHECK(ctx) SOSVO_HIP((ctx), hipGetLastError())
 
 static inline int32_t sosvo_ws_reserve(sosvo_ctx* ctx, size_t bytes) {
+  ctx->pyr_gray = nullptr;  // whoever reserves scratch may overwrite a pyramid left there (see orb.hip)
   if (bytes <= ctx->ws_bytes) return SOSVO_OK;
   if (ctx->ws) {
     SOSVO_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -640,6 +640,10 @@ int32_t sosvo_detect_orb(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* ma
   SOSVO_LAUNCH(ctx, orb_select_kernel, dim3((unsigned)((size_t)nimg * nmask)), dim3(kThreads), 0, ctx->stream, pyr, score,
                mask_pyr, bbox, P, images_per_maskset, nmask, cap, kp4, resp, n);
   SOSVO_LAUNCH_CHECK(ctx);
+  ctx->pyr_gray = gray;  // the pyramid stays at the start of the scratch workspace for sosvo_describe_orb_levels
+  ctx->pyr_nimg = nimg;
+  ctx->pyr_rows = rows;
+  ctx->pyr_cols = cols;
   return SOSVO_OK;
 }
 
@@ -655,12 +659,17 @@ int32_t sosvo_describe_orb_levels(sosvo_ctx* ctx, const uint8_t* gray, int32_t n
   if (nimg == 0) return SOSVO_OK;
   const Pyr P = make_pyr(rows, cols, 0);
   const size_t bytes = (size_t)nimg * P.total;
+  // the pyramid sosvo_detect_orb built from the same images, if nothing has used the scratch workspace since
+  const bool have_pyr = ctx->pyr_gray == (const void*)gray && ctx->pyr_nimg == nimg && ctx->pyr_rows == rows && ctx->pyr_cols == cols;
+  const void* ws_before = ctx->ws;
   int32_t rc = sosvo_ws_reserve(ctx, 2 * ((bytes + 255) & ~(size_t)255));
   if (rc != SOSVO_OK) return rc;
   uint8_t* pyr = (uint8_t*)ctx->ws;
   uint8_t* blur = pyr + ((bytes + 255) & ~(size_t)255);
-  rc = build_pyramid(ctx, gray, nimg, rows, cols, P, pyr);
-  if (rc != SOSVO_OK) return rc;
+  if (!(have_pyr && ctx->ws == ws_before)) {
+    rc = build_pyramid(ctx, gray, nimg, rows, cols, P, pyr);
+    if (rc != SOSVO_OK) return rc;
+  }
   for (int l = 0; l < P.nlev; ++l) {  // the rolling strip kernel of detect.hip, level by level (same integer arithmetic)
     rc = sosvo_launch_gauss7(ctx, pyr + P.off[l], P.total, nimg, P.h[l], P.w[l], blur + P.off[l]);
     if (rc != SOSVO_OK) return rc;
