@@ -108,15 +108,10 @@ __global__ __launch_bounds__(kThreads) void mask_level_kernel(uint32_t* __restri
 }
 
 // ---- FAST-9/16 score map over the whole pyramid ------------------------------------------------------------
-__device__ __forceinline__ int fast_score(const uint8_t* __restrict__ im, int w, int y, int x, int thr = kFastThr) {
-  const int v = im[(size_t)y * w + x];
-  int d[16];
-  const int rx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
-  const int ry[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
-#pragma unroll
-  for (int k = 0; k < 16; ++k) d[k] = (int)im[(size_t)(y + ry[k]) * w + x + rx[k]] - v;
-  // max over the 16 arcs of 9 consecutive circle pixels of min(d) (brighter) and of min(-d) = -max(d) (darker), by
-  // doubling: windows of 2, 4, 8, then 9 -- 4 min + 4 max per start instead of 8 + 8
+// d[k] = circle pixel k minus the centre pixel -> corner score: the largest threshold for which the pixel is still a FAST-9
+// corner, minus 1 (0: not a corner at `thr`).  Max over the 16 arcs of 9 consecutive circle pixels of min(d) (brighter) and
+// of min(-d) = -max(d) (darker), by doubling: windows of 2, 4, 8, then 9 -- 4 min + 4 max per start instead of 8 + 8.
+__device__ __forceinline__ int fast_score_from_diffs(const int (&d)[16], int thr) {
   int lo2[16], hi2[16], lo4[16], hi4[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
@@ -138,22 +133,79 @@ __device__ __forceinline__ int fast_score(const uint8_t* __restrict__ im, int w,
   return best > thr ? best - 1 : 0;
 }
 
-__global__ __launch_bounds__(kThreads) void fast_score_kernel(const uint8_t* __restrict__ pyr, Pyr P,
-                                                              uint8_t* __restrict__ score) {
-  const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
-  const int img = blockIdx.y;
-  if (i >= P.total) return;
-  int l = 0;
-#pragma unroll
-  for (int k = 1; k < kLevels; ++k)
-    if (k < P.nlev && i >= P.off[k]) l = k;
-  const int h = P.h[l], w = P.w[l];
-  const int j = (int)(i - P.off[l]), y = j / w, x = j - y * w;
-  int s = 0;
-  // only levels that can hold a keypoint (31-px border) and have a quota are scored
-  if (P.quota[l] > 0 && h > 2 * kEdge && w > 2 * kEdge && y >= 3 && y < h - 3 && x >= 3 && x < w - 3)
-    s = fast_score(pyr + (size_t)img * P.total + P.off[l], w, y, x);
-  score[(size_t)img * P.total + i] = (uint8_t)s;
+// FAST-9/16 score map of nimg images that lie img_stride bytes apart (a dense batch, or one pyramid level): a wave owns a
+// 64-column strip (58 output columns, 3 halo columns each side) and walks down the rows with the last seven rows of its
+// column in a register ring; the 16 circle pixels of a row come from the ring slots of neighbouring lanes (one
+// cross-lane read each) instead of 16 scattered byte loads per pixel.  3-pixel image border (and everything when
+// `enabled` is 0: a pyramid level that cannot hold a keypoint) scores 0.
+constexpr int kFsHalo = 3, kFsStripW = 64 - 2 * kFsHalo;
+__global__ __launch_bounds__(kThreads) void fast_score_rolling_kernel(const uint8_t* __restrict__ in, long long img_stride,
+                                                                      int nimg, int rows, int cols, int strips, int thr,
+                                                                      int enabled, uint8_t* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * kThreads + threadIdx.x) >> 6));
+  if (wave >= nimg * strips) return;  // wave-uniform
+  const int img = wave / strips, strip = wave - img * strips;
+  const int xb = strip * kFsStripW - kFsHalo;
+  const int xc = xb + lane;
+  const int xs = min(max(xc, 0), cols - 1);
+  const bool out_lane = lane >= kFsHalo && lane < 64 - kFsHalo && xc < cols;
+  const bool interior_x = xc >= 3 && xc < cols - 3;
+  const uint8_t* g = in + (size_t)img * img_stride;
+  uint8_t* o = out + (size_t)img * img_stride;
+  int v[7] = {0, 0, 0, 0, 0, 0, 0};  // rows t-6 .. t of this lane's column, slot = row mod 7 (compile-time after unrolling)
+  const int t_last = rows - 1 + 3;
+  int c_next = (int)g[(uint32_t)xs];
+  auto step = [&](auto phase_tag, const int t) __attribute__((always_inline)) {
+    constexpr int P = decltype(phase_tag)::value;
+    if (t > t_last) return;  // uniform
+    v[P] = c_next;           // row t (rows past the image repeat the last one: they are never used as circle pixels)
+    c_next = (int)g[(uint32_t)(min(t + 1, rows - 1) * cols) + (uint32_t)xs];
+    const int y = t - 3;
+    if (y < 0) return;  // uniform
+    int s = 0;
+    if (enabled && y >= 3 && y < rows - 3) {  // uniform
+      // row y + dy lives in slot (P + 4 + dy) mod 7; circle pixel k = (rx[k], ry[k]) as in OpenCV's table
+      const int c = v[(P + 4) % 7];
+      int d[16];
+      d[0] = v[(P + 7) % 7] - c;                                   // ( 0,  3)
+      d[1] = __shfl(v[(P + 7) % 7], lane + 1) - c;                 // ( 1,  3)
+      d[2] = __shfl(v[(P + 6) % 7], lane + 2) - c;                 // ( 2,  2)
+      d[3] = __shfl(v[(P + 5) % 7], lane + 3) - c;                 // ( 3,  1)
+      d[4] = __shfl(v[(P + 4) % 7], lane + 3) - c;                 // ( 3,  0)
+      d[5] = __shfl(v[(P + 3) % 7], lane + 3) - c;                 // ( 3, -1)
+      d[6] = __shfl(v[(P + 2) % 7], lane + 2) - c;                 // ( 2, -2)
+      d[7] = __shfl(v[(P + 1) % 7], lane + 1) - c;                 // ( 1, -3)
+      d[8] = v[(P + 1) % 7] - c;                                   // ( 0, -3)
+      d[9] = __shfl(v[(P + 1) % 7], lane - 1) - c;                 // (-1, -3)
+      d[10] = __shfl(v[(P + 2) % 7], lane - 2) - c;                // (-2, -2)
+      d[11] = __shfl(v[(P + 3) % 7], lane - 3) - c;                // (-3, -1)
+      d[12] = __shfl(v[(P + 4) % 7], lane - 3) - c;                // (-3,  0)
+      d[13] = __shfl(v[(P + 5) % 7], lane - 3) - c;                // (-3,  1)
+      d[14] = __shfl(v[(P + 6) % 7], lane - 2) - c;                // (-2,  2)
+      d[15] = __shfl(v[(P + 7) % 7], lane - 1) - c;                // (-1,  3)
+      s = interior_x ? fast_score_from_diffs(d, thr) : 0;
+    }
+    if (out_lane) o[(uint32_t)(y * cols) + (uint32_t)xc] = (uint8_t)s;
+  };
+  for (int t = 0; t <= t_last; t += 7) {
+    step(std::integral_constant<int, 0>{}, t);
+    step(std::integral_constant<int, 1>{}, t + 1);
+    step(std::integral_constant<int, 2>{}, t + 2);
+    step(std::integral_constant<int, 3>{}, t + 3);
+    step(std::integral_constant<int, 4>{}, t + 4);
+    step(std::integral_constant<int, 5>{}, t + 5);
+    step(std::integral_constant<int, 6>{}, t + 6);
+  }
+}
+
+static int32_t launch_fast_score(sosvo_ctx* ctx, const uint8_t* in, long long img_stride, int nimg, int rows, int cols, int thr,
+                                 int enabled, uint8_t* out) {
+  const int strips = cdiv(cols, kFsStripW);
+  SOSVO_LAUNCH(ctx, fast_score_rolling_kernel, dim3(cdiv(nimg * strips, kThreads / 64)), dim3(kThreads), 0, ctx->stream, in,
+               img_stride, nimg, rows, cols, strips, thr, enabled, out);
+  SOSVO_LAUNCH_CHECK(ctx);
+  return SOSVO_OK;
 }
 
 // ---- FAST as a detector of its own (feature_detection_method "FAST") ------------------------------------------
@@ -162,16 +214,6 @@ __global__ __launch_bounds__(kThreads) void fast_score_kernel(const uint8_t* __r
 // non-maximum suppression on the corner score (strictly greater than the 8 neighbours), keypoints kept where the
 // mask is set, in raster order.  Three launches: score map, NMS flags (one u64 per 64 pixels of a row), and one
 // WAVE per (image, mask) that walks the rows and compacts the flagged, masked pixels in order.
-__global__ __launch_bounds__(kThreads) void fast_image_score_kernel(const uint8_t* __restrict__ gray, int rows, int cols,
-                                                                    int thr, uint8_t* __restrict__ score) {
-  const int i = blockIdx.x * kThreads + threadIdx.x, img = blockIdx.y;
-  if (i >= rows * cols) return;
-  const int y = i / cols, x = i - y * cols;
-  int s = 0;
-  if (y >= 3 && y < rows - 3 && x >= 3 && x < cols - 3) s = fast_score(gray + (size_t)img * rows * cols, cols, y, x, thr);
-  score[(size_t)img * rows * cols + i] = (uint8_t)s;
-}
-
 __global__ __launch_bounds__(kThreads) void fast_nms_flags_kernel(const uint8_t* __restrict__ score, int rows, int cols,
                                                                   int words, unsigned long long* __restrict__ flags) {
   // one wave per (row, 64-pixel word): grid.x covers rows * words waves, grid.y = image
@@ -634,9 +676,11 @@ int32_t sosvo_detect_orb(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* ma
   for (int l = 0; l < P.nlev; ++l) total_rows += P.h[l];
   SOSVO_LAUNCH(ctx, orb_mask_bbox_kernel, dim3(total_rows, nsets), dim3(kThreads), 0, ctx->stream, mask_pyr, P, nmask, bbox);
   SOSVO_LAUNCH_CHECK(ctx);
-  SOSVO_LAUNCH(ctx, fast_score_kernel, dim3((unsigned)((P.total + kThreads - 1) / kThreads), nimg), dim3(kThreads), 0,
-               ctx->stream, pyr, P, score);
-  SOSVO_LAUNCH_CHECK(ctx);
+  for (int l = 0; l < P.nlev; ++l) {  // only levels that can hold a keypoint (31-px border) and have a quota are scored
+    const int enabled = P.quota[l] > 0 && P.h[l] > 2 * kEdge && P.w[l] > 2 * kEdge;
+    rc = launch_fast_score(ctx, pyr + P.off[l], P.total, nimg, P.h[l], P.w[l], kFastThr, enabled, score + P.off[l]);
+    if (rc != SOSVO_OK) return rc;
+  }
   SOSVO_LAUNCH(ctx, orb_select_kernel, dim3((unsigned)((size_t)nimg * nmask)), dim3(kThreads), 0, ctx->stream, pyr, score,
                mask_pyr, bbox, P, images_per_maskset, nmask, cap, kp4, resp, n);
   SOSVO_LAUNCH_CHECK(ctx);
@@ -697,9 +741,10 @@ int32_t sosvo_detect_fast(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* m
   if (rc != SOSVO_OK) return rc;
   uint8_t* score = (uint8_t*)ctx->ws;
   unsigned long long* flags = (unsigned long long*)((char*)ctx->ws + score_bytes);
-  SOSVO_LAUNCH(ctx, fast_image_score_kernel, dim3(cdiv(rows * cols, kThreads), nimg), dim3(kThreads), 0, ctx->stream, gray, rows,
-               cols, threshold, score);
-  SOSVO_LAUNCH_CHECK(ctx);
+  {
+    const int32_t rc2 = launch_fast_score(ctx, gray, (long long)rows * cols, nimg, rows, cols, threshold, 1, score);
+    if (rc2 != SOSVO_OK) return rc2;
+  }
   SOSVO_LAUNCH(ctx, fast_nms_flags_kernel, dim3(cdiv(rows * words, kThreads / 64), nimg), dim3(kThreads), 0, ctx->stream, score,
                rows, cols, words, flags);
   SOSVO_LAUNCH_CHECK(ctx);
