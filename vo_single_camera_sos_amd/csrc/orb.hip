@@ -70,6 +70,7 @@ __device__ __forceinline__ ResizeTap resize_tap(int d, double scale, int n0) {
 
 __global__ __launch_bounds__(kThreads) void copy_level0_kernel(const uint8_t* __restrict__ gray, int npix,
                                                                long long total, uint8_t* __restrict__ pyr) {
+  SOSVO_STREAMING_PRIO();
   const int i = blockIdx.x * kThreads + threadIdx.x, img = blockIdx.y;
   if (i < npix) pyr[(size_t)img * total + i] = gray[(size_t)img * npix + i];
 }
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(kThreads) void copy_level0_kernel(const uint8_t* __
 __global__ __launch_bounds__(kThreads) void resize_level_kernel(uint8_t* __restrict__ pyr, long long total,
                                                                 long long off0, int h0, int w0, long long off1, int h1,
                                                                 int w1) {
+  SOSVO_STREAMING_PRIO();
   const int i = blockIdx.x * kThreads + threadIdx.x, img = blockIdx.y;
   if (i >= h1 * w1) return;
   const int dy = i / w1, dx = i - dy * w1;
@@ -142,6 +144,7 @@ constexpr int kFsHalo = 3, kFsStripW = 64 - 2 * kFsHalo;
 __global__ __launch_bounds__(kThreads) void fast_score_rolling_kernel(const uint8_t* __restrict__ in, long long img_stride,
                                                                       int nimg, int rows, int cols, int strips, int thr,
                                                                       int enabled, uint8_t* __restrict__ out) {
+  SOSVO_STREAMING_PRIO();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * kThreads + threadIdx.x) >> 6));
   if (wave >= nimg * strips) return;  // wave-uniform
@@ -216,6 +219,7 @@ static int32_t launch_fast_score(sosvo_ctx* ctx, const uint8_t* in, long long im
 // WAVE per (image, mask) that walks the rows and compacts the flagged, masked pixels in order.
 __global__ __launch_bounds__(kThreads) void fast_nms_flags_kernel(const uint8_t* __restrict__ score, int rows, int cols,
                                                                   int words, unsigned long long* __restrict__ flags) {
+  SOSVO_STREAMING_PRIO();
   // one wave per (row, 64-pixel word): grid.x covers rows * words waves, grid.y = image
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * kThreads + threadIdx.x) >> 6));
@@ -243,6 +247,7 @@ __global__ __launch_bounds__(64) void fast_collect_kernel(const unsigned long lo
                                                           int nmask, int rows, int cols, int words, int cap,
                                                           float* __restrict__ kp, int32_t* __restrict__ n_out,
                                                           int32_t* __restrict__ status) {
+  SOSVO_STREAMING_PRIO();
   const int lane = threadIdx.x, p = blockIdx.x;
   const int img = p / nmask, m = p - img * nmask;
   const uint32_t* mb = mask_bits + (size_t)(img / images_per_maskset) * rows * cols;
@@ -368,6 +373,7 @@ __global__ __launch_bounds__(kThreads) void orb_select_kernel(const uint8_t* __r
                                                               int images_per_maskset, int nmask, int cap,
                                                               float* __restrict__ kp4, float* __restrict__ resp_out,
                                                               int32_t* __restrict__ n_out) {
+  SOSVO_LATENCY_BOUND_PRIO();
   __shared__ uint32_t cxy[kCandMax];            // (y << 16) | x
   __shared__ uint8_t cfast[kCandMax];
   __shared__ unsigned long long ckey[kCandMax];  // ordered(harris) << 32 | (0xFFFFFFFF - linear index)
@@ -516,6 +522,7 @@ __global__ __launch_bounds__(kThreads) void orb_describe_levels_kernel(const uin
                                                                        const int8_t* __restrict__ pattern,
                                                                        uint8_t* __restrict__ desc,
                                                                        float* __restrict__ kp_xy) {
+  SOSVO_LATENCY_BOUND_PRIO();
   extern __shared__ float lds_kp[];  // [cap][4]
   __shared__ int8_t spat[1024];
   __shared__ int wave_off[5];
