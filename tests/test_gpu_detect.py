@@ -131,3 +131,27 @@ def test_fast_detector_raster_order_masks_and_cap(ctx):
                 assert n[p] == min(len(want), cap) and status[p] == (1 if len(want) > cap else 0), (cap, i, m, n[p], len(want))
                 assert np.array_equal(kp[p, : n[p]], want[:cap]), (cap, i, m)
         assert n[0] >= min(cap, 100) and n[2] == 0 and n[8:].sum() == 0
+
+
+def test_detect_gft_reports_candidate_overflow(ctx):
+    """More 3x3 local maxima above the threshold than the selection holds (4096 for cap <= 1024): status bit 0 is set
+    (include/sosvo.h: "the result then depends on which were kept"); the call still returns cap corners that respect the
+    minimum distance, and the large-mask variant (cap > 1024: 16384 candidates) handles the same image without the flag
+    and equals the oracle."""
+    rng = np.random.default_rng(77)
+    rows, cols = 200, 420
+    img = rng.integers(0, 256, (1, rows, cols), dtype=np.uint8)          # white noise: a local maximum every ~9 pixels
+    bits = np.ones((1, rows, cols), dtype=np.uint32)
+    t_img, t_bits = _to(ctx.device, img, bits)
+    kp, n, status = ctx.detect_gft(t_img, t_bits, 1, 1, 512, quality=1e-4, max_corners=0)
+    ctx.synchronize()
+    kp, n, status = kp.cpu().numpy(), n.cpu().numpy(), status.cpu().numpy()
+    assert status[0] & 1 and n[0] == 512
+    d = np.linalg.norm(kp[0, :512, None, :] - kp[0, None, :512, :], axis=-1) + 1e9 * np.eye(512)
+    assert d.min() >= 5.0
+    kp2, n2, status2 = ctx.detect_gft(t_img, t_bits, 1, 1, 2048, quality=1e-4, max_corners=0)
+    ctx.synchronize()
+    assert not (status2.cpu().numpy()[0] & 1)
+    want, _ = oracle.gft_select(oracle.min_eigen(img[0]), bits[0], 0, 1e-4, 5.0, 0)
+    m = min(2048, len(want))
+    assert n2.cpu().numpy()[0] == m and np.array_equal(kp2.cpu().numpy()[0, :m], want[:m])
