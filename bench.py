@@ -138,7 +138,7 @@ def parse():
                          "GFT's minDistance 5 and ORB.compute's 31-px border cap the count at ~1250 keypoints per view; "
                          "1440 -> 1440 x 146 gives the ~2000 keypoints per view BASELINE's metric is quoted on")
     ap.add_argument("--iters", type=int, default=2000, help="RANSAC iterations, fixed (C2: 2000)")
-    ap.add_argument("--cpu-pairs", type=int, default=32, help="frame pairs timed on the host for cpu_baseline")
+    ap.add_argument("--cpu-pairs", type=int, default=64, help="frame pairs timed on the host for cpu_baseline")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams per GPU the batch is split over (the median launches take turns, the latency-bound "
                          "stages of the other parts overlap them); 1 = one stream")
