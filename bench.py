@@ -5,10 +5,12 @@
 
 A "step" is one pass of the WHOLE hot path (unwrap -> median -> gray -> detect -> describe -> stereo
 match -> triangulate -> frame-to-frame match -> RANSAC -> LM) over one batch of B independent synthetic
-frame pairs per GPU; the omni frames are resident in HBM when the timed region starts.  For N > 1 the
-driver launches one rank per GPU through torch.distributed.run; ranks shard the pairs (no data-path
-collective) and all-gather the per-pair pose records (16 doubles each) over RCCL at the end of every
-step.  Rank 0 prints ONE JSON line.
+frame pairs per GPU; the omni frames are resident in HBM when the timed region starts.  For N > 1 there is
+one rank per GPU: either a launcher (torch.distributed.run) started them, or -- `python bench.py --gpus N`
+on its own -- this program starts them itself as child processes before it touches the GPU.  Ranks shard the
+pairs (rank r owns the global pairs [r*B, (r+1)*B); no data-path collective) and all-gather the per-pair
+pose records (16 doubles each) over RCCL at the end of every step.  Rank 0 prints ONE JSON line.
+BASELINE config 4 (512 pairs over 8 GPUs) is `python bench.py --gpus 8 --pairs-per-gpu 64`.
 """
 import argparse
 import json
@@ -155,7 +157,27 @@ def parse():
                          "per-kernel averages then cover the timed region only)")
     ap.add_argument("--pmc-csv", default=None, help="per-kernel PMC summary for roofline.traffic (default: newest in profiles/)")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--dump-records", default=None,
+                    help="rank 0 writes the last step's gathered [N*B,16] records (global pair order) to this .npy file")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks ourselves, as CHILD
+    processes through torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1), and return their exit code.
+    Runs before this process has made any GPU call (importing torch does not initialise the GPU) and never replaces
+    the running program."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(omni, im, rig_kw, thr, iters, seed, n_pairs):
@@ -191,7 +213,11 @@ def cpu_baseline_all_cores(omni, im_kw, rig_kw, thr, iters, seed, cores, pairs_p
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     from vo_single_camera_sos_amd import synthetic
@@ -213,7 +239,9 @@ def main():
                   f2f_max_hdiff=0.125 * 0.5 * pano.cols, pct_good_matches=1.0)
     # frames are rendered on the host (forked workers) BEFORE this process touches the GPU
     workers = args.render_workers if args.render_workers > 0 else max(1, min(16, host_cores() // max(1, world)))
-    omni, poses = synthetic.make_frame_pairs(gs, B, seed=args.seed + 100000 * rank, workers=workers)
+    # rank r owns the global pairs [r*B, (r+1)*B) of ONE job of world*B pairs: pair g is rendered from seed + g and
+    # its RANSAC samples from seed + g, so the gathered records equal those of a single process over the same pairs
+    omni, poses = synthetic.make_frame_pairs(gs, B, seed=args.seed, workers=workers, first=rank * B)
     dist = None
     # (SOSVO_BENCH_FORCE_DIST=1: a launcher-started single rank also goes through init_process_group + the RCCL
     # gather -- tests/test_gpu_bench_rccl.py rehearses the N > 1 code path on the one-GPU box that way)
@@ -226,14 +254,12 @@ def main():
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=args.dist_backend, rank=rank, world_size=world)
-    n_gpus = world if world > 1 else 1
-    if args.gpus != n_gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d; using %d" % (args.gpus, world, n_gpus), file=sys.stderr)
+    n_gpus = world
 
     torch.cuda.set_device(local_rank)
     eng = OverlappedFramePairs(local_rank, gs, (H, W), RigConfig(**rig_kw), B, n_streams=args.streams,
                                num_of_features=args.features_per_mask, kp_cap=512, frame_cap=2048, max_iter=args.iters,
-                               adaptive=False, seed=args.seed, detection_method=args.detector)
+                               adaptive=False, seed=args.seed + rank * B, detection_method=args.detector)
     model, dev = eng.model, eng.device
     eng.load_frames(omni)
     gathered = torch.empty((n_gpus * B, 16), dtype=torch.float64, device=dev) if dist else None
@@ -309,6 +335,8 @@ def main():
                         "part: the copy of step k+1 overlaps the kernels of step k)"}
         del pinned
 
+    if rank == 0 and args.dump_records:
+        np.save(args.dump_records, (gathered if dist else rec).cpu().numpy())
     if rank == 0:
         rec = rec.cpu().numpy()
         n_kp = np.concatenate([p.fe.n.cpu().numpy().reshape(2, -1, model.nmask).sum(-1) for p in eng.parts], axis=1)  # [view, frame]

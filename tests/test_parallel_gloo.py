@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from vo_single_camera_sos_amd.parallel import RECORD_WIDTH, gather_records, max_over_ranks, shard_range
+from vo_single_camera_sos_amd.parallel import RECORD_WIDTH, gather_records, max_over_ranks, shard_range, shard_rows_max
 
 
 def test_shard_range_is_a_contiguous_partition():
@@ -19,6 +19,7 @@ def test_shard_range_is_a_contiguous_partition():
         sizes = [b - a for a, b in spans]
         assert max(sizes) - min(sizes) <= 1
     assert shard_range(512, 3, 8) == (192, 256)  # C4: 512 pairs over 8 GPUs, blocks of 64
+    assert shard_rows_max(10, 3) == 4 and shard_rows_max(512, 8) == 64
 
 
 def _free_port():
@@ -37,15 +38,26 @@ def _worker(rank, world, port, n_total, q):
     # the record of global pair g carries g in every column (what a rank's pipeline.results() would hold)
     rec = (torch.arange(lo, hi, dtype=torch.float64)[:, None].repeat(1, RECORD_WIDTH)
            + torch.arange(RECORD_WIDTH, dtype=torch.float64) * 1e-3)
-    full = gather_records(rec)
+    full = gather_records(rec) if n_total % world == 0 else gather_records(rec, n_total=n_total)
+    if n_total % world != 0:
+        # shards whose sizes differ by one must be refused by the equal-count form, on every rank, before the
+        # collective that would hang on RCCL
+        try:
+            gather_records(rec)
+            full = None
+        except ValueError:
+            pass
     slowest = max_over_ranks(1.0 + rank, torch.device("cpu"))
     dist.barrier()
-    q.put((rank, full.numpy(), slowest))
+    q.put((rank, None if full is None else full.numpy(), slowest))
     dist.destroy_process_group()
 
 
-def test_gather_records_world_size_2():
-    world, n_total = 2, 12
+import pytest
+
+
+@pytest.mark.parametrize("world,n_total", [(2, 12), (2, 7), (3, 10)])
+def test_gather_records_in_global_pair_order(world, n_total):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -58,6 +70,7 @@ def test_gather_records_world_size_2():
         assert p.exitcode == 0
     want = np.arange(n_total, dtype=np.float64)[:, None] + np.arange(RECORD_WIDTH) * 1e-3
     for rank, full, slowest in results:
+        assert full is not None, "the equal-count gather accepted uneven shards"
         assert full.shape == (n_total, RECORD_WIDTH)
         assert np.array_equal(full, want)      # rank order == global pair order
-        assert slowest == 2.0                  # max over ranks
+        assert slowest == float(world)        # max over ranks

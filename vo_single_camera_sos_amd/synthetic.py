@@ -119,17 +119,18 @@ def _render_pair_pooled(args):
     return _render_pair((_POOL_GUMS,) + args)
 
 
-def make_frame_pairs(gums, n_pairs, seed=1234, noise_sigma=2.0, workers=1):
+def make_frame_pairs(gums, n_pairs, seed=1234, noise_sigma=2.0, workers=1, first=0):
     """-> (omni [2*n_pairs, H, W, 3] u8, poses list of (R, t)): pair i = frames 2i (reference, identity pose)
     and 2i+1 (current, pose (R, t) in the reference frame); one room per pair.  workers > 1 renders the pairs in
-    forked worker processes (same frames; call it BEFORE the process touches the GPU)."""
+    forked worker processes (same frames; call it BEFORE the process touches the GPU).  `first`: global index of
+    pair 0 (a rank of a sharded job renders pairs first .. first + n_pairs - 1 of the job's sequence)."""
     global _POOL_GUMS
     W, H = gums.top_model.image_size
     if gums.top_model.mask is None:
         gums.make_annulus_masks((H, W))
     omni = np.zeros((2 * n_pairs, H, W, 3), dtype=np.uint8)
     poses = []
-    jobs = [(seed, i, noise_sigma) for i in range(n_pairs)]
+    jobs = [(seed, int(first) + i, noise_sigma) for i in range(n_pairs)]
     if workers > 1 and n_pairs > 1:
         import multiprocessing
         _POOL_GUMS = gums
