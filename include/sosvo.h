@@ -75,6 +75,11 @@ int32_t sosvo_profile_enable(sosvo_ctx* ctx, int32_t on);
 int32_t sosvo_profile_count(sosvo_ctx* ctx);
 int32_t sosvo_profile_get(sosvo_ctx* ctx, int32_t i, char* name_out, int32_t name_cap, float* ms);
 
+/* Test hook: fills the context's internal scratch memory (response maps, sort keys, RANSAC hypotheses, blurred images;
+ * the internal sub-contexts of sosvo_frame_pair_batch_streams included) with `byte`, on the context's stream(s).  No
+ * entry point may read scratch it has not written in the same call, so results must not depend on this.            */
+int32_t sosvo_debug_fill_scratch(sosvo_ctx* ctx, int32_t byte);
+
 /* ---- K1: unwrap (a1 + a2) ---------------------------------------------------------------------
  * Replaces Panorama.get_panoramic_image's cv2.remap(omni, map_x, map_y, INTER_LINEAR,
  * BORDER_CONSTANT, 0) (omnistereo/panorama.py:293) for both mirrors of every frame, with
@@ -117,6 +122,23 @@ int32_t sosvo_median_gray(sosvo_ctx* ctx, const uint8_t* img, int32_t nimg, int3
  *   (view-major).  ksize in {3, 5, 11}.                                                            */
 int32_t sosvo_unwrap_median_gray(sosvo_ctx* ctx, const uint8_t* omni, const uint32_t* table, int32_t nframes,
                                  int32_t H, int32_t W, int32_t rows, int32_t cols, int32_t ksize, uint8_t* gray);
+
+/* The same with the output restricted to the rows a consumer can reach: row_range = int32 [2][2] in DEVICE memory
+ * (view-major: first row, last row + 1 of the top and of the bottom panoramas), written by sosvo_gray_rows_needed;
+ * NULL = all rows (sosvo_unwrap_median_gray).  Rows outside a view's range are neither computed nor written (the
+ * caller's buffer keeps what it held); inside, the result is sosvo_unwrap_median_gray's bit for bit. */
+int32_t sosvo_unwrap_median_gray_rows(sosvo_ctx* ctx, const uint8_t* omni, const uint32_t* table, int32_t nframes,
+                                      int32_t H, int32_t W, int32_t rows, int32_t cols, int32_t ksize,
+                                      const int32_t* row_range, uint8_t* gray);
+
+/* Rows of the gray panoramas that goodFeaturesToTrack on the azimuthal masks (camera_models.py:1739: the response at
+ * the masked pixels and its 3x3 dilation, i.e. gray within 3 rows of a masked row) and ORB.compute on its keypoints
+ * (camera_models.py:1765: keypoints edge <= y < rows - edge inside the masks, rotated pattern on the 7x7-blurred
+ * image) can reach, per mask set: mask_bits [nsets, rows, cols] u32 -> row_range [nsets][2] int32 (device): first row,
+ * last row + 1 (0, 0 for an empty set).  Model constant: compute once per (masks, edge, pattern, angle). */
+int32_t sosvo_gray_rows_needed(sosvo_ctx* ctx, const uint32_t* mask_bits, int32_t nsets, int32_t rows, int32_t cols,
+                               int32_t nmask, int32_t edge, const int8_t* pattern, float cos_a, float sin_a,
+                               int32_t* row_range);
 
 /* ---- K4: goodFeaturesToTrack per azimuthal mask (a4, the reference's default detector) ---------
  * Replaces cv2.goodFeaturesToTrack(image, maxCorners, qualityLevel, minDistance, mask, useHarris=False)

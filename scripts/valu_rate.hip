@@ -36,6 +36,45 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, int iters, uint32_t seed
   if (OP == 29) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                  \
   if (OP == 30) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a[i]) : "v"(b));                              \
   if (OP == 31) asm volatile("v_sad_u8 %0, %0, %1, %0" : "+v"(a[i]) : "v"(b));                               \
+  if (OP == 32) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x90" : "+v"(a[i]) : "v"(b), "v"(c));        \
+  if (OP == 33) asm volatile("v_xnor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                 \
+  if (OP == 34) asm volatile("v_or_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                   \
+  if (OP == 35) asm volatile("v_not_b32 %0, %0" : "+v"(a[i]) : );                                            \
+  if (OP == 36) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                  \
+  if (OP == 37) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                  \
+  if (OP == 38) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));                     \
+  if (OP == 39) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));                     \
+  if (OP == 40) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));                     \
+  if (OP == 41) asm volatile("v_pk_min_f16 %0, %0, %1" : "+v"(a[i]) : "v"(b));                               \
+  if (OP == 42) asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(a[i]) : "v"(b));                               \
+  if (OP == 43) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b));                               \
+  if (OP == 44) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));                     \
+  if (OP == 45) asm volatile("v_cvt_f32_ubyte0 %0, %0" : "+v"(a[i]) : );                                     \
+  if (OP == 46) asm volatile("v_cmp_gt_u32 vcc, %0, %1" : : "v"(a[i]), "v"(b) : "vcc");                      \
+  if (OP == 47) asm volatile("v_cmp_lt_i16_sdwa %0, sext(%1), %2 src0_sel:BYTE_0 src1_sel:DWORD" : "=s"(bal) : "v"(a[i]), "v"(b)); \
+  if (OP == 48) asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc");           \
+  if (OP == 49) asm volatile("v_sub_co_u32 %0, vcc, %0, %1" : "+v"(a[i]) : "v"(b) : "vcc");                 \
+  if (OP == 50) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(a[i]) : );                                     \
+  if (OP == 51) asm volatile("v_ashrrev_i32 %0, 31, %0" : "+v"(a[i]) : );                                    \
+  if (OP == 52) asm volatile("v_max_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                  \
+  if (OP == 53) asm volatile("v_min_i32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                  \
+  if (OP == 54) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));                     \
+  if (OP == 55) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(b));                                      \
+  if (OP == 56) asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "=v"(a[i]) : "v"(b)); \
+  if (OP == 57) asm volatile("v_and_b32 %0, 0x7ff07ff, %0" : "+v"(a[i]) : );                                 \
+  if (OP == 58) asm volatile("v_med3_i32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));                     \
+  if (OP == 59) asm volatile("v_dot4_u32_u8 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));                  \
+  if (OP == 60) asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(d[i]) : "v"(dd));                          \
+  if (OP == 61) asm volatile("v_min_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                  \
+  if (OP == 62) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(a[i]) : "v"(b));                               \
+  if (OP == 63) asm volatile("v_mbcnt_lo_u32_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b));                         \
+  if (OP == 64) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b));                         \
+  if (OP == 65) asm volatile("v_and_b32 %0, %0, %1\n v_bcnt_u32_b32 %0, %0, %2" : "+v"(a[i]) : "v"(b), "v"(c)); \
+  if (OP == 66) asm volatile("v_alignbyte_b32 %0, %0, %1, 1" : "+v"(a[i]) : "v"(b));                         \
+  if (OP == 67) asm volatile("v_sub_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                  \
+  if (OP == 68) asm volatile("v_pk_sub_i16 %0, %0, %1" : "+v"(a[i]) : "v"(b));                               \
+  if (OP == 69) asm volatile("v_pk_lshrrev_b16 %0, 15, %0" : "+v"(a[i]) : );                                 \
+  if (OP == 70) asm volatile("v_max_f16 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                  \
   if (OP == 4) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                   \
   if (OP == 5) asm volatile("v_lshrrev_b64 %0, %1, %2" : "=v"(bal) : "v"(a[i] & 63), "s"(bal2));             \
   if (OP == 6) asm volatile("v_cmp_ne_u32 %0, %1, %2" : "=s"(bal) : "v"(a[i]), "v"(b));                      \
@@ -117,5 +156,44 @@ int main() {
   run<29>("v_mul_f32", out);
   run<30>("v_mul_u32_u24", out);
   run<31>("v_sad_u8", out);
+  run<32>("v_bitop3_b32", out);
+  run<33>("v_xnor_b32", out);
+  run<34>("v_or_b32", out);
+  run<35>("v_not_b32", out);
+  run<36>("v_min_f32", out);
+  run<37>("v_max_f32", out);
+  run<38>("v_med3_f32", out);
+  run<39>("v_min3_f32", out);
+  run<40>("v_max3_f32", out);
+  run<41>("v_pk_min_f16", out);
+  run<42>("v_pk_max_f16", out);
+  run<43>("v_pk_add_u16", out);
+  run<44>("v_perm_b32", out);
+  run<45>("v_cvt_f32_ubyte0", out);
+  run<46>("v_cmp_gt_u32 vcc", out);
+  run<47>("v_cmp_lt_i16_sdwa", out);
+  run<48>("v_addc_co_u32", out);
+  run<49>("v_sub_co_u32", out);
+  run<50>("v_lshlrev_b32", out);
+  run<51>("v_ashrrev_i32", out);
+  run<52>("v_max_u32", out);
+  run<53>("v_min_i32", out);
+  run<54>("v_add3_u32", out);
+  run<55>("v_mov_b32", out);
+  run<56>("v_mov_dpp row_shr", out);
+  run<57>("v_and_b32 literal", out);
+  run<58>("v_med3_i32", out);
+  run<59>("v_dot4_u32_u8", out);
+  run<60>("v_pk_fma_f32", out);
+  run<61>("v_min_u16", out);
+  run<62>("v_pk_max_i16", out);
+  run<63>("v_mbcnt_lo", out);
+  run<64>("v_cndmask vcc", out);
+  run<65>("and+bcnt pair (x2)", out);
+  run<66>("v_alignbyte_b32", out);
+  run<67>("v_sub_u16", out);
+  run<68>("v_pk_sub_i16", out);
+  run<69>("v_pk_lshrrev_b16", out);
+  run<70>("v_max_f16", out);
   return 0;
 }

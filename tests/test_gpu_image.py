@@ -164,10 +164,53 @@ def test_fused_front_end_c2(ctx, rig):
     omni = np.stack([_textured(rng, (480, 640, 3)) for _ in range(2)])
     model = DeviceImageModel(ctx, rig, (480, 640))
     a = ImageFrontEnd(ctx, model, 2, num_of_features=50)
-    b = ImageFrontEnd(ctx, model, 2, num_of_features=50, keep_panoramas=False)
-    for fe in (a, b):
+    b = ImageFrontEnd(ctx, model, 2, num_of_features=50, keep_panoramas=False, skip_unreachable_rows=False)
+    c = ImageFrontEnd(ctx, model, 2, num_of_features=50, keep_panoramas=False)   # + rows no consumer reaches skipped
+    for fe in (a, b, c):
         fe.load_frames(omni)
         fe.run()
     ctx.synchronize()
     assert b.pano is None and torch.equal(a.gray, b.gray) and torch.equal(a.kp, b.kp) and torch.equal(a.desc, b.desc)
     assert int(a.n.sum()) > 100
+    # the row-restricted form: identical keypoints and descriptors; gray identical inside each view's range, untouched
+    # (the buffer's zeros) outside; the ranges are what the masks, the GFT halo and the descriptor border imply
+    assert torch.equal(a.kp, c.kp) and torch.equal(a.n, c.n) and torch.equal(a.desc, c.desc)
+    rr = c.gray_rows.cpu().numpy()
+    full, part = a.gray.cpu().numpy().reshape(2, 2, model.rows, model.cols), c.gray.cpu().numpy().reshape(2, 2, model.rows, model.cols)
+    pat = model.pattern_host.astype(np.float32)
+    ca, sa = np.float32(c.cos_a), np.float32(c.sin_a)
+    Rp = int(max(np.abs(np.rint(pat[:, 0] * ca - pat[:, 1] * sa)).max(), np.abs(np.rint(pat[:, 0] * sa + pat[:, 1] * ca)).max()))
+    for v in range(2):
+        mrows = np.where((model.mask_bits_host[v] != 0).any(axis=1))[0]
+        mlo, mhi = int(mrows[0]), int(mrows[-1])
+        ylo, yhi = max(31, mlo), min(model.rows - 32, mhi)
+        lo = max(0, min(mlo - 3, ylo - Rp - 3))
+        hi = min(model.rows, max(mhi + 3, yhi + Rp + 3) + 1)
+        assert (int(rr[v, 0]), int(rr[v, 1])) == (lo, hi), (v, rr[v], lo, hi)
+        assert np.array_equal(part[v, :, lo:hi], full[v, :, lo:hi])
+        assert not part[v, :, :lo].any() and not part[v, :, hi:].any()
+    assert (rr[:, 1] - rr[:, 0]).sum() < 2 * model.rows      # something is actually skipped
+
+
+def test_unwrap_median_gray_rows_api(ctx):
+    """sosvo_unwrap_median_gray_rows: inside the per-view row range the result is the full call's, outside the
+    caller's buffer is left alone; an empty range writes nothing."""
+    rng = np.random.default_rng(12)
+    omni = rng.integers(0, 256, (3, 37, 53, 3), dtype=np.uint8)
+    pshape = (40, 150)
+    mx = rng.uniform(-2, 55, (2,) + pshape).astype(np.float32)
+    my = rng.uniform(-2, 39, (2,) + pshape).astype(np.float32)
+    t_omni, t_mx, t_my = _to(ctx.device, omni, mx, my)
+    table = ctx.unwrap_prepare(None, t_mx, t_my, (37, 53))
+    full = ctx.unwrap_median_gray(t_omni, table, 11)
+    for rng_rows in ([[7, 29], [0, 40]], [[0, 1], [39, 40]], [[5, 5], [12, 30]], [[-3, 90], [20, 10]]):
+        rr = torch.tensor(rng_rows, dtype=torch.int32, device=ctx.device)
+        out = torch.full_like(full, 77)
+        ctx.unwrap_median_gray(t_omni, table, 11, gray=out, row_range=rr)
+        ctx.synchronize()
+        f, o = full.cpu().numpy().reshape(2, 3, *pshape), out.cpu().numpy().reshape(2, 3, *pshape)
+        for v in range(2):
+            lo = max(0, min(pshape[0], rng_rows[v][0]))
+            hi = max(lo, min(pshape[0], rng_rows[v][1]))
+            assert np.array_equal(o[v, :, lo:hi], f[v, :, lo:hi]), (rng_rows, v)
+            assert (o[v, :, :lo] == 77).all() and (o[v, :, hi:] == 77).all(), (rng_rows, v)

@@ -44,12 +44,15 @@ SIGNATURES = {
     "sosvo_timer_elapsed_ms": (c_i32, [c_p, ctypes.POINTER(c_f32)]),
     "sosvo_profile_enable": (c_i32, [c_p, c_i32]),
     "sosvo_profile_count": (c_i32, [c_p]),
+    "sosvo_debug_fill_scratch": (c_i32, [c_p, c_i32]),
     "sosvo_profile_get": (c_i32, [c_p, c_i32, ctypes.c_char_p, c_i32, ctypes.POINTER(c_f32)]),
     "sosvo_unwrap": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]),
     "sosvo_unwrap_prepare": (c_i32, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p]),
     "sosvo_unwrap_table": (c_i32, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]),
     "sosvo_median_gray": (c_i32, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p]),
     "sosvo_unwrap_median_gray": (c_i32, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]),
+    "sosvo_unwrap_median_gray_rows": (c_i32, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p]),
+    "sosvo_gray_rows_needed": (c_i32, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_f32, c_f32, c_p]),
     "sosvo_detect_gft": (c_i32, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_f64, c_f64, c_i32, c_i32, c_p,
                                  c_p, c_p]),
     "sosvo_describe_orb": (c_i32, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_f32, c_f32, c_p, c_i32,

@@ -108,6 +108,18 @@ int32_t sosvo_profile_get(sosvo_ctx* ctx, int32_t i, char* name_out, int32_t nam
   return SOSVO_OK;
 }
 
+int32_t sosvo_debug_fill_scratch(sosvo_ctx* ctx, int32_t byte) {
+  SOSVO_ENTER(ctx);
+  ctx->pyr_gray = nullptr;
+  if (ctx->ws && ctx->ws_bytes) SOSVO_HIP(ctx, hipMemsetAsync(ctx->ws, byte & 0xFF, ctx->ws_bytes, ctx->stream));
+  for (int i = 0; i < ctx->n_sub; ++i) {
+    if (!ctx->sub[i]) continue;
+    const int32_t rc = sosvo_debug_fill_scratch(ctx->sub[i], byte);
+    if (rc != SOSVO_OK) return sosvo_fail(ctx, rc, __func__, ctx->sub[i]->err);
+  }
+  return SOSVO_OK;
+}
+
 int32_t sosvo_timer_elapsed_ms(sosvo_ctx* ctx, float* ms) {
   SOSVO_ENTER(ctx);
   SOSVO_REQUIRE(ctx, ms != nullptr, "ms is null");

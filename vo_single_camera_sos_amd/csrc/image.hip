@@ -276,6 +276,7 @@ template <int K, bool FUSED>
 __global__ __launch_bounds__(kThreads) void median_gray_kernel(const uint8_t* __restrict__ img,
                                                                const uint2* __restrict__ table, int nframes, int H, int W,
                                                                int nimg, int rows, int cols, int strips,
+                                                               const int32_t* __restrict__ row_range,
                                                                uint8_t* __restrict__ gray) {
   constexpr int R = K / 2;
   constexpr int NB = K * K;
@@ -300,6 +301,14 @@ __global__ __launch_bounds__(kThreads) void median_gray_kernel(const uint8_t* __
   // ---- source pixel of (row, x_src) as B | G << 8 | R << 16, fetched one row ahead of its use
   const int view = FUSED ? im / nframes : 0, frame = FUSED ? im - view * nframes : 0;
   const uint8_t* src = FUSED ? img + (size_t)frame * H * W * 3 : img + (size_t)im * rows * cols * 3;
+  // output rows [out_lo, out_hi) of this image's view (row_range: the rows a consumer can reach, see
+  // sosvo_gray_rows_needed; nullptr = all): rows outside are neither computed nor written
+  int out_lo = 0, out_hi = rows;
+  if (FUSED && row_range) {
+    out_lo = max(0, min(rows, row_range[2 * view]));
+    out_hi = max(out_lo, min(rows, row_range[2 * view + 1]));
+  }
+  if (out_hi <= out_lo) return;  // wave-uniform
   const uint2* tab = FUSED ? table + (size_t)view * rows * cols + x_src : nullptr;
   const int frame_bytes = H * W * 3;
   const bool last_image = im == nimg - 1;
@@ -314,8 +323,8 @@ __global__ __launch_bounds__(kThreads) void median_gray_kernel(const uint8_t* __
     return (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16);  // the buffer's last 3 bytes
   };
   if (FUSED) {
-    e_cur = tab[(size_t)row_of(-R) * cols];
-    e_nxt = tab[(size_t)row_of(-R + 1) * cols];
+    e_cur = tab[(size_t)row_of(out_lo - R) * cols];
+    e_nxt = tab[(size_t)row_of(out_lo - R + 1) * cols];
     unwrap_gather(src, frame_bytes, W, e_cur, taps);
   } else {
     raw = load_raw(-R);
@@ -334,7 +343,7 @@ __global__ __launch_bounds__(kThreads) void median_gray_kernel(const uint8_t* __
   // one source row: ring slot = compile-time constant (the row loop below is unrolled K times by a fold)
   auto row_step = [&](auto slot_tag, const int r_src) __attribute__((always_inline)) {
     constexpr int slot = decltype(slot_tag)::value;
-    if (r_src >= rows + R) return;  // uniform (the tail of the last group)
+    if (r_src >= out_hi + R) return;  // uniform (the tail of the last group)
     uint32_t pix;
     if (FUSED) {
       pix = unwrap_blend(frame_bytes, W, e_cur, taps);
@@ -354,7 +363,7 @@ __global__ __launch_bounds__(kThreads) void median_gray_kernel(const uint8_t* __
         ring_insert<K, NW>(Wp[c][b], (uint32_t)(ballot_byte_sign(sh, c, vzero) >> lane), slot);
     }
     const int r_out = r_src - R;
-    if (r_out < 0) return;  // window not complete yet (uniform)
+    if (r_out < out_lo) return;  // window not complete yet (uniform)
     int med[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -381,13 +390,14 @@ __global__ __launch_bounds__(kThreads) void median_gray_kernel(const uint8_t* __
     }
     if (out_ok) dst[(size_t)r_out * cols + x_out] = bgr2gray(med[0], med[1], med[2]);
   };
-  for (int r_base = -R; r_base < rows + R; r_base += K) for_each_slot(row_step, r_base, std::make_integer_sequence<int, K>{});
+  for (int r_base = out_lo - R; r_base < out_hi + R; r_base += K)
+    for_each_slot(row_step, r_base, std::make_integer_sequence<int, K>{});
 }
 
 // launches the K-templated strip kernel; FUSED takes the omni batch + unwrap table instead of panoramas
 template <bool FUSED>
 int32_t launch_median(sosvo_ctx* ctx, const uint8_t* img, const uint2* table, int nframes, int H, int W, int nimg,
-                             int rows, int cols, int ksize, uint8_t* gray) {
+                             int rows, int cols, int ksize, const int32_t* row_range, uint8_t* gray) {
   const int outw = 64 - 2 * (ksize / 2);
   const int strips = cdiv(cols, outw);
   dim3 grid(8 * cdiv(cdiv(nimg, 8) * strips, kThreads / 64)), block(kThreads);  // see the kernel's XCD-aware mapping
@@ -397,9 +407,61 @@ int32_t launch_median(sosvo_ctx* ctx, const uint8_t* img, const uint2* table, in
   constexpr auto k3 = median_gray_kernel<3, FUSED>;
   SosvoProfScope prof(ctx, FUSED ? "unwrap_median_gray_kernel" : "median_gray_kernel");
   hipLaunchKernelGGL(ksize == 11 ? k11 : (ksize == 5 ? k5 : k3), grid, block, 0, ctx->stream, img, table, nframes, H, W, nimg,
-                     rows, cols, strips, gray);
+                     rows, cols, strips, row_range, gray);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
+}
+
+// Rows of the gray panoramas that the detector + descriptor stages can reach, per mask set (= view):
+//   goodFeaturesToTrack reads the response at masked pixels and their 3x3 neighbours (dilation), the response reads
+//   a 3x3 box of 3x3 Sobel products: gray rows [mlo - 3, mhi + 3] for mask rows mlo..mhi;
+//   ORB.compute keeps keypoints (integer rows inside the masks) with edge <= y < rows - edge and reads the rotated
+//   pattern (radius Rp, computed exactly as orb_describe_kernel does) on the 7x7-blurred image:
+//   gray rows [max(edge, mlo) - Rp - 3, min(rows - edge - 1, mhi) + Rp + 3].
+// One workgroup per set; out[2 * set] = first row, out[2 * set + 1] = last row + 1 (0, 0 for an empty mask set).
+__global__ __launch_bounds__(kThreads) void gray_rows_kernel(const uint32_t* __restrict__ mask_bits, int rows, int cols,
+                                                             int nmask, int edge, const int8_t* __restrict__ pattern,
+                                                             float cos_a, float sin_a, int32_t* __restrict__ out) {
+  __shared__ int s_lo, s_hi, s_R;
+  const int tid = threadIdx.x, set = blockIdx.x;
+  if (tid == 0) {
+    s_lo = rows;
+    s_hi = -1;
+    s_R = 0;
+  }
+  __syncthreads();
+  const uint32_t mask_all = nmask < 32 ? (1u << nmask) - 1u : 0xFFFFFFFFu;
+  const uint32_t* mb = mask_bits + (size_t)set * rows * cols;
+  for (int y = 0; y < rows; ++y) {
+    bool any = false;
+    for (int x = tid; x < cols; x += kThreads) any = any || (mb[(size_t)y * cols + x] & mask_all) != 0u;
+    if (__ballot(any) != 0ULL && (tid & 63) == 0) {
+      atomicMin(&s_lo, y);
+      atomicMax(&s_hi, y);
+    }
+  }
+  for (int i = tid; i < 512; i += kThreads) {
+    const float px = (float)pattern[2 * i], py = (float)pattern[2 * i + 1];
+    const float xr = (px * cos_a) - (py * sin_a), yr = (px * sin_a) + (py * cos_a);
+    atomicMax(&s_R, max(abs(__float2int_rn(xr)), abs(__float2int_rn(yr))));
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int lo = 0, hi = 0;
+    if (s_hi >= s_lo) {
+      lo = s_lo - 3;
+      hi = s_hi + 3;
+      const int ylo = max(edge, s_lo), yhi = min(rows - edge - 1, s_hi);
+      if (yhi >= ylo) {
+        lo = min(lo, ylo - s_R - 3);
+        hi = max(hi, yhi + s_R + 3);
+      }
+      lo = max(lo, 0);
+      hi = min(hi + 1, rows);
+    }
+    out[2 * set] = lo;
+    out[2 * set + 1] = hi;
+  }
 }
 
 }  // namespace
@@ -464,11 +526,30 @@ int32_t sosvo_median_gray(sosvo_ctx* ctx, const uint8_t* img, int32_t nimg, int3
     SOSVO_LAUNCH_CHECK(ctx);
     return SOSVO_OK;
   }
-  return launch_median<false>(ctx, img, nullptr, 0, 0, 0, nimg, rows, cols, ksize, gray);
+  return launch_median<false>(ctx, img, nullptr, 0, 0, 0, nimg, rows, cols, ksize, nullptr, gray);
+}
+
+int32_t sosvo_gray_rows_needed(sosvo_ctx* ctx, const uint32_t* mask_bits, int32_t nsets, int32_t rows, int32_t cols,
+                               int32_t nmask, int32_t edge, const int8_t* pattern, float cos_a, float sin_a,
+                               int32_t* row_range) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, mask_bits && pattern && row_range, "null pointer");
+  SOSVO_REQUIRE(ctx, nsets >= 1 && nsets <= 65535 && nmask >= 1 && nmask <= 32, "nsets / nmask out of range");
+  SOSVO_REQUIRE(ctx, rows > 0 && cols > 0 && rows * (int64_t)cols < (1 << 28) && edge >= 0, "image sizes out of range");
+  SOSVO_LAUNCH(ctx, gray_rows_kernel, dim3((unsigned)nsets), dim3(kThreads), 0, ctx->stream, mask_bits, rows, cols, nmask, edge,
+               pattern, cos_a, sin_a, row_range);
+  SOSVO_LAUNCH_CHECK(ctx);
+  return SOSVO_OK;
 }
 
 int32_t sosvo_unwrap_median_gray(sosvo_ctx* ctx, const uint8_t* omni, const uint32_t* table, int32_t nframes, int32_t H,
                                  int32_t W, int32_t rows, int32_t cols, int32_t ksize, uint8_t* gray) {
+  return sosvo_unwrap_median_gray_rows(ctx, omni, table, nframes, H, W, rows, cols, ksize, nullptr, gray);
+}
+
+int32_t sosvo_unwrap_median_gray_rows(sosvo_ctx* ctx, const uint8_t* omni, const uint32_t* table, int32_t nframes, int32_t H,
+                                      int32_t W, int32_t rows, int32_t cols, int32_t ksize, const int32_t* row_range,
+                                      uint8_t* gray) {
   SOSVO_ENTER(ctx);
   SOSVO_REQUIRE(ctx, omni && table && gray, "null pointer");
   SOSVO_REQUIRE(ctx, nframes >= 0 && nframes <= 32767, "nframes out of range");
@@ -478,7 +559,7 @@ int32_t sosvo_unwrap_median_gray(sosvo_ctx* ctx, const uint8_t* omni, const uint
   SOSVO_REQUIRE(ctx, ksize == 3 || ksize == 5 || ksize == 11, "ksize must be 3, 5 or 11");
   if (nframes == 0) return SOSVO_OK;
   return launch_median<true>(ctx, omni, reinterpret_cast<const uint2*>(table), nframes, H, W, 2 * nframes, rows, cols, ksize,
-                             gray);
+                             row_range, gray);
 }
 
 }  // extern "C"

@@ -23,7 +23,7 @@ struct Buffers {
   uint8_t *pano, *gray, *desc, *d_top, *d_bot, *mask;
   float *kp, *m_top, *m_bot;
   int32_t *n, *status, *s_order, *M, *n_cand, *ref_frame, *cur_frame, *o_top, *o_bot, *cam, *cq, *ct, *cn, *cn_top, *idx,
-      *n_inl, *info, *lm_iters;
+      *n_inl, *info, *lm_iters, *gray_rows;
   uint32_t *s_keys, *k_top, *k_bot;
   double *X, *b_top, *b_bot, *f, *p, *T_ransac, *T, *cam_off, *cam_rot, *lm_cost;
   size_t bytes;
@@ -75,6 +75,7 @@ Buffers carve(const sosvo_batch_cfg& c, void* ws) {
   b.cam_rot = cv.take<double>(2 * 9);
   b.lm_cost = cv.take<double>(B);
   b.lm_iters = cv.take<int32_t>(B);
+  b.gray_rows = cv.take<int32_t>(4);
   b.bytes = cv.off;
   return b;
 }
@@ -209,8 +210,12 @@ static int32_t run_frame_pairs(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo
   // image front end: K1, K2 + K3, K4, K6 over all 2 * F panoramas
   if (median_wait) SOSVO_HIP(ctx, hipStreamWaitEvent(ctx->stream, median_wait, 0));
   if (cfg->median_ksize == 3 || cfg->median_ksize == 5 || cfg->median_ksize == 11) {
-    STAGE(sosvo_unwrap_median_gray(ctx, omni, unwrap_table, F, cfg->H, cfg->W, cfg->rows, cfg->cols, cfg->median_ksize,
-                                   b.gray));
+    // rows beyond the reach of GFT on the masks and of ORB.compute on its keypoints are not computed (the range is a
+    // model constant; a 2-workgroup kernel per call keeps this entry point free of caller-side state)
+    STAGE(sosvo_gray_rows_needed(ctx, mask_bits, 2, cfg->rows, cfg->cols, NM, cfg->edge, pattern, cfg->cos_a, cfg->sin_a,
+                                 b.gray_rows));
+    STAGE(sosvo_unwrap_median_gray_rows(ctx, omni, unwrap_table, F, cfg->H, cfg->W, cfg->rows, cfg->cols, cfg->median_ksize,
+                                        b.gray_rows, b.gray));
   } else {
     STAGE(sosvo_unwrap_table(ctx, omni, unwrap_table, F, cfg->H, cfg->W, cfg->rows, cfg->cols, b.pano));
     STAGE(sosvo_median_gray(ctx, b.pano, NI, cfg->rows, cfg->cols, cfg->median_ksize, b.gray));
@@ -320,7 +325,13 @@ int32_t sosvo_frame_pair_batch_streams(sosvo_ctx* ctx, const sosvo_rig* rig, con
     SOSVO_HIP(ctx, hipStreamWaitEvent(sc->stream, ctx->sub_begin, 0));
     const int32_t rc = run_frame_pairs(sc, rig, &c, omni + (size_t)2 * lo * cfg->H * cfg->W * 3, unwrap_table, mask_bits, pattern,
                                        ws, bytes, results + (size_t)16 * lo, token, ctx->sub_median[s]);
-    if (rc != SOSVO_OK) return sosvo_fail(ctx, rc, __func__, sc->err);
+    if (rc != SOSVO_OK) {
+      // the parts launched so far (and whatever this one enqueued before failing) still run: the caller's stream must
+      // not overtake them
+      (void)hipEventRecord(ctx->sub_done[s], sc->stream);
+      for (int k = 0; k <= s; ++k) (void)hipStreamWaitEvent(ctx->stream, ctx->sub_done[k], 0);
+      return sosvo_fail(ctx, rc, __func__, sc->err);
+    }
     token = ctx->sub_median[s];
     SOSVO_HIP(ctx, hipEventRecord(ctx->sub_done[s], sc->stream));
     ws += bytes;

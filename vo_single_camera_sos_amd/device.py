@@ -104,6 +104,10 @@ class Context(object):
         self._call(self._lib.sosvo_timer_elapsed_ms, ctypes.byref(ms))
         return float(ms.value)
 
+    def debug_fill_scratch(self, byte=0xFF):
+        """Test hook: overwrite the library's internal scratch memory of this context (results must not change)."""
+        self._call(self._lib.sosvo_debug_fill_scratch, int(byte))
+
     def profile_enable(self, on=True):
         """Start (and clear) / stop the per-kernel HIP-event record."""
         self._call(self._lib.sosvo_profile_enable, 1 if on else 0)
@@ -174,9 +178,21 @@ class Context(object):
         self._call(self._lib.sosvo_median_gray, _ptr(img), nimg, rows, cols, int(ksize), _ptr(gray))
         return gray
 
-    def unwrap_median_gray(self, omni, table, ksize, gray=None):
+    def gray_rows_needed(self, mask_bits, nmask, edge, pattern, cos_a, sin_a):
+        """Rows of the gray panoramas that GFT on the azimuthal masks + ORB.compute can reach: mask_bits
+        [nsets,rows,cols] u32 -> row_range [nsets,2] i32 on the device (first row, last row + 1).  Model constant."""
+        _check(mask_bits, torch.uint32, "mask_bits", (None, None, None))
+        _check(pattern, torch.int8, "pattern")
+        nsets, rows, cols = mask_bits.shape
+        out = torch.zeros((nsets, 2), dtype=torch.int32, device=mask_bits.device)
+        self._call(self._lib.sosvo_gray_rows_needed, _ptr(mask_bits), nsets, rows, cols, int(nmask), int(edge), _ptr(pattern),
+                   float(cos_a), float(sin_a), _ptr(out))
+        return out
+
+    def unwrap_median_gray(self, omni, table, ksize, gray=None, row_range=None):
         """K1 + K2 + K3 fused: omni [F,H,W,3] u8, table from unwrap_prepare -> gray [2F,rows,cols] u8 (view-major);
-        the colour panoramas are never materialised.  Same result as unwrap_table + median_gray."""
+        the colour panoramas are never materialised.  Same result as unwrap_table + median_gray.  row_range
+        ([2,2] i32 from gray_rows_needed): only those rows of each view are computed and written."""
         _check(omni, torch.uint8, "omni", (None, None, None, 3))
         F, H, W = omni.shape[0], omni.shape[1], omni.shape[2]
         _check(table, torch.uint32, "table", (2, None, None, 2))
@@ -184,7 +200,12 @@ class Context(object):
         if gray is None:
             gray = torch.empty((2 * F, rows, cols), dtype=torch.uint8, device=omni.device)
         _check(gray, torch.uint8, "gray", (2 * F, rows, cols))
-        self._call(self._lib.sosvo_unwrap_median_gray, _ptr(omni), _ptr(table), F, H, W, rows, cols, int(ksize), _ptr(gray))
+        if row_range is None:
+            self._call(self._lib.sosvo_unwrap_median_gray, _ptr(omni), _ptr(table), F, H, W, rows, cols, int(ksize), _ptr(gray))
+        else:
+            _check(row_range, torch.int32, "row_range", (2, 2))
+            self._call(self._lib.sosvo_unwrap_median_gray_rows, _ptr(omni), _ptr(table), F, H, W, rows, cols, int(ksize),
+                       _ptr(row_range), _ptr(gray))
         return gray
 
     def detect_fast(self, gray, mask_bits, images_per_maskset, nmask, cap, threshold=10, kp=None, n=None, status=None):

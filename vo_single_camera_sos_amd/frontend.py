@@ -50,7 +50,8 @@ class DeviceImageModel(object):
 
 class ImageFrontEnd(object):
     def __init__(self, ctx, model, nframes, detection_method="GFT", num_of_features=1000, kp_cap=None,
-                 median_win_size=11, quality=0.01, min_distance=5.0, edge=31, keep_panoramas=True):
+                 median_win_size=11, quality=0.01, min_distance=5.0, edge=31, keep_panoramas=True,
+                 skip_unreachable_rows=True):
         """num_of_features: per azimuthal mask (FeatureMatcher.num_of_features, pose_est_tools.py:862).
         keep_panoramas=False: K1 is fused into the median kernel and the colour panoramas are not materialised
         (nothing downstream of K3 reads them); identical gray images."""
@@ -61,6 +62,7 @@ class ImageFrontEnd(object):
         self.method = detection_method.upper()
         self.num_of_features, self.median_win_size = int(num_of_features), int(median_win_size)
         self.quality, self.min_distance, self.edge = float(quality), float(min_distance), int(edge)
+        self.skip_unreachable_rows = bool(skip_unreachable_rows)
         if kp_cap:
             self.kp_cap = int(kp_cap)
         elif self.method == "FAST":  # every corner is kept (num_of_features only names the ORB descriptor object)
@@ -80,6 +82,17 @@ class ImageFrontEnd(object):
         self.status = torch.zeros((P,), dtype=torch.int32, device=dev)
         self.desc = torch.zeros((P, self.kp_cap, 32), dtype=torch.uint8, device=dev)
         self.cos_a, self.sin_a = orb_pattern.angle_cos_sin(orb_pattern.GFT_KEYPOINT_ANGLE)
+        # Rows no consumer can reach (beyond the masks' elevation padding + the GFT halo and the descriptor border) are
+        # not computed by the fused K1-K3 kernel.  Model constant, keyed by what it depends on; computed here (and
+        # waited for) so that front ends on other streams that share the model find it ready.
+        self.gray_rows = None
+        if self.method == "GFT" and skip_unreachable_rows and not self.keep_panoramas:
+            key = (self.edge, self.cos_a, self.sin_a)
+            cache = m.__dict__.setdefault("_gray_rows", {})
+            if key not in cache:
+                cache[key] = ctx.gray_rows_needed(m.mask_bits, m.nmask, self.edge, m.pattern, self.cos_a, self.sin_a)
+                ctx.synchronize()
+            self.gray_rows = cache[key]
         if self.method == "ORB":
             self.kp4 = torch.zeros((P, self.kp_cap, 4), dtype=torch.float32, device=dev)
             self.resp = torch.zeros((P, self.kp_cap), dtype=torch.float32, device=dev)
@@ -104,7 +117,8 @@ class ImageFrontEnd(object):
             c.unwrap_table(self.omni, m.unwrap_table, pano=self.pano)                                 # K1 (a1 + a2)
             c.median_gray(self.pano.view(2 * self.F, m.rows, m.cols, 3), self.median_win_size, gray=self.gray)  # K2 + K3
         else:
-            c.unwrap_median_gray(self.omni, m.unwrap_table, self.median_win_size, gray=self.gray)    # K1 + K2 + K3
+            c.unwrap_median_gray(self.omni, m.unwrap_table, self.median_win_size, gray=self.gray,
+                                 row_range=self.gray_rows)                                           # K1 + K2 + K3
 
     def run_features(self):
         """K4 / K5 + K6: keypoints and descriptors per azimuthal mask on the gray panoramas."""

@@ -210,7 +210,10 @@ class OverlappedFramePairs(object):
             if not hasattr(p, "omni_bufs"):
                 p.omni_bufs = [p.fe.omni, torch.empty_like(p.fe.omni)]
                 p.copied = [torch.cuda.Event(), torch.cuda.Event()]
-                p.omni_free = [None, None]
+                # buffer 0 is the resident one: a preceding step()'s median on p.stream may still be reading it
+                busy = torch.cuda.Event()
+                busy.record(p.stream)
+                p.omni_free = [busy, None]
             with torch.cuda.stream(cs):
                 if p.omni_free[j] is not None:
                     cs.wait_event(p.omni_free[j])
@@ -244,6 +247,30 @@ class OverlappedFramePairs(object):
                     p.stream.wait_event(self._consumed)   # the previous step's records have been read
                 p.pipe.results(out=self.out[p.lo:p.hi])
                 p.done.record(p.stream)
+
+    def capture_graph(self):
+        """One step() + results() of ALL parts captured into a torch.cuda.CUDAGraph; replay() then re-runs the whole
+        hot path on the frames resident in the parts' buffers and leaves the records in self.out.
+        What a correct capture needs: the parts' streams must JOIN the capture -- each waits on
+        an event recorded on the capturing stream -- otherwise their kernels run eagerly, outside the graph, and a replay
+        returns whatever the buffers hold; no wait may refer to an event recorded before the capture (the median token
+        and the "records consumed" event of an earlier eager step); the per-kernel profile must be off (its event pairs
+        would be captured and re-recorded); the library's scratch must have its final size (one eager step first)."""
+        torch.cuda.synchronize(self.device)
+        self.profile_enable(False)
+        self._token, self._consumed = None, None
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            cur = torch.cuda.current_stream(self.device)
+            fork = torch.cuda.Event()
+            fork.record(cur)
+            for p in self.parts:
+                p.stream.wait_event(fork)
+            self.step()
+            self.results()          # the capturing stream waits for every part: the join
+        self._token, self._consumed = None, None   # events recorded while capturing are nodes of the graph, not events
+        torch.cuda.synchronize(self.device)
+        return g
 
     def results(self):
         """[B,16] f64 records of the last step, valid on torch's current stream (which is made to wait for every
