@@ -242,18 +242,45 @@ __device__ __forceinline__ uint32_t keep_equal(uint32_t c, uint32_t m, uint32_t 
   return r;
 }
 
-// Writes the K-bit row slice `x` (bits above K are ignored) into ring slot `slot` of one bit-plane's window:
-// slot s occupies bits [K * s, K * s + K) of the NW-word register; a slot that straddles two words takes a
-// second shift + v_bfi.  `slot` is a compile-time constant after unrolling: masks and shifts become literals.
+// (a & ~m) | (x & m) as ONE v_bitop3 (table 0xD8: m ? x : a).  v_bfi_b32 computes the same but issues at the slow
+// VALU rate (4.3 SIMD-cycles against 2.7, scripts/valu_rate.hip); m is a wave-uniform literal (an SGPR).
+__device__ __forceinline__ uint32_t merge_field(uint32_t a, uint32_t x, uint32_t m) {
+  uint32_t r;
+  asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xd8" : "=v"(r) : "v"(a), "v"(x), "s"(m));
+  return r;
+}
+// a | (b & k): one fast v_bitop3 (table 0xF8) instead of v_and_or_b32
+__device__ __forceinline__ uint32_t or_and(uint32_t a, uint32_t b, uint32_t k) {
+  uint32_t r;
+  asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xf8" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+  return r;
+}
+// ~(a ^ b): v_xnor_b32 issues at the slow rate, v_bitop3 (table 0xC3) at the fast one
+__device__ __forceinline__ uint32_t xnor_fast(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_bitop3_b32 %0, %1, %2, %2 bitop3:0xc3" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// Writes lane l's K-bit slice of a row ballot -- bits [l, l + K) of `bal` -- into ring slot `slot` of one bit-plane's
+// window: slot s occupies bits [K * s, K * s + K) of the NW-word register.  `slot` is a compile-time constant after
+// unrolling: masks and shifts are literals.
+//   slot inside one word: the ballot is shifted LEFT by sh_up = 64 - K - l, which puts the slice into the top K bits of
+//     the high word, and a 32-bit RIGHT shift (fast VALU rate; v_lshlrev_b32 issues at the slow one) drops it onto the
+//     slot; whatever lands below the slot is cut by the merge mask;
+//   slot straddling two words: slice = bal >> l, then a shift + merge per word.
 template <int K, int NW>
-__device__ __forceinline__ void ring_insert(uint32_t (&Wp)[NW], uint32_t x, int slot) {
+__device__ __forceinline__ void ring_insert(uint32_t (&Wp)[NW], unsigned long long bal, int lane, int sh_up, int slot) {
   const int bit = K * slot, w = bit >> 5, pos = bit & 31;
   const uint32_t field = (1u << K) - 1u;
-  const uint32_t m0 = field << pos;
-  Wp[w] = (Wp[w] & ~m0) | ((x << pos) & m0);
-  if (pos + K > 32) {
-    const uint32_t m1 = field >> (32 - pos);
-    Wp[w + 1] = (Wp[w + 1] & ~m1) | ((x >> (32 - pos)) & m1);
+  if (pos + K <= 32) {
+    const uint32_t hi = (uint32_t)((bal << sh_up) >> 32);
+    const uint32_t t = (32 - K - pos) ? hi >> (32 - K - pos) : hi;
+    Wp[w] = merge_field(Wp[w], t, field << pos);
+  } else {
+    const uint32_t x = (uint32_t)(bal >> lane);
+    Wp[w] = merge_field(Wp[w], x << pos, field << pos);
+    Wp[w + 1] = merge_field(Wp[w + 1], x >> (32 - pos), field >> (32 - pos));
   }
 }
 
@@ -332,6 +359,7 @@ __global__ __launch_bounds__(kThreads) void median_gray_kernel(const uint8_t* __
 
   uint32_t vzero;
   asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));  // SDWA compares take no constant operand
+  const int sh_up = (64 - K - lane) & 63;         // see ring_insert (lanes beyond OUTW hold no output)
   uint32_t Wp[3][8][NW];
 #pragma unroll
   for (int c = 0; c < 3; ++c)
@@ -355,12 +383,14 @@ __global__ __launch_bounds__(kThreads) void median_gray_kernel(const uint8_t* __
       raw = load_raw(r_src + 1);
     }
     // overwrite the oldest row slot with the new row's 24 bit-plane slices
+    uint32_t sh = pix;  // bit b of every channel sits in the sign position of its byte
 #pragma unroll
     for (int b = 7; b >= 0; --b) {
-      const uint32_t sh = pix << (7 - b);  // bit b of every channel now sits in the sign position of its byte
 #pragma unroll
       for (int c = 0; c < 3; ++c)
-        ring_insert<K, NW>(Wp[c][b], (uint32_t)(ballot_byte_sign(sh, c, vzero) >> lane), slot);
+        ring_insert<K, NW>(Wp[c][b], ballot_byte_sign(sh, c, vzero), lane, sh_up, slot);
+      // next plane: sh <<= 1 as an add (fast VALU rate; the shift issues at the slow one)
+      if (b > 0) asm("v_add_u32 %0, %1, %1" : "=v"(sh) : "v"(sh));
     }
     const int r_out = r_src - R;
     if (r_out < out_lo) return;  // window not complete yet (uniform)
@@ -381,10 +411,12 @@ __global__ __launch_bounds__(kThreads) void median_gray_kernel(const uint8_t* __
         for (int j = 0; j < NW; ++j) n1 = popc_add(C[j] & Wp[c][b][j], n1);
         const uint32_t d = above - n1;
         const uint32_t ones = (uint32_t)((int32_t)d >> 31);  // all-ones: the wanted element has bit b set
-        above = min(above, d);                                // (unsigned) d wraps above `above` exactly then
-        res |= ones & (1u << b);
+        // above = min(above, d) as a 16-bit minimum (v_min_u16 issues at the fast rate, v_min_u32 at the slow one):
+        // above <= NB, and a negative d has its low half >= 0x10000 - NB > above
+        above = (uint32_t)min((uint16_t)above, (uint16_t)d);
+        res = or_and(res, ones, 1u << b);
 #pragma unroll
-        for (int j = 0; j < NW; ++j) C[j] = b == 7 ? (C[j] & ~(Wp[c][b][j] ^ ones)) : keep_equal(C[j], ones, Wp[c][b][j]);
+        for (int j = 0; j < NW; ++j) C[j] = b == 7 ? xnor_fast(Wp[c][b][j], ones) : keep_equal(C[j], ones, Wp[c][b][j]);
       }
       med[c] = (int)res;
     }
