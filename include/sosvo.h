@@ -188,10 +188,11 @@ int32_t sosvo_describe_orb(sosvo_ctx* ctx, const uint8_t* gray, int32_t nimg, in
  * 31 px of the level-0 border are removed (kp4 / n compacted in place), each level is blurred 7x7 sigma 2,
  * the pattern is rotated by the keypoint's angle.  desc [nimg*nmask, cap, 32] u8; kp_xy (optional)
  * [nimg*nmask, cap, 2] f32 receives the compacted (x, y) for the matching stages.
- * Called directly after sosvo_detect_orb on the same context with the same `gray` pointer and sizes -- detect, then
- * compute, as the reference does -- it reuses the detector's image pyramid (still in the context's scratch memory)
- * instead of building it again: the images at `gray` must not have been modified in between.  Any other library
- * call that uses scratch memory in between makes it rebuild the pyramid.                                          */
+ * sosvo_describe_orb_levels builds its own pyramid (all 8 levels: the keypoints may come from anywhere).
+ *   sosvo_detect_describe_orb: detect, then compute, as the reference does (camera_models.py:1755, :1765), in ONE call
+ *       that builds ONE pyramid -- only as far as a keypoint can come from (levels with a quota and more than the 31-px
+ *       border) -- and shares it between the two halves.  Same outputs as sosvo_detect_orb followed by
+ *       sosvo_describe_orb_levels, bit for bit; cap <= 2048.                                                        */
 int64_t sosvo_orb_pyramid_pixels(int32_t rows, int32_t cols);
 int32_t sosvo_orb_mask_pyramid(sosvo_ctx* ctx, const uint32_t* mask_bits, int32_t nsets, int32_t rows,
                                int32_t cols, int32_t nmask, uint32_t* mask_pyr);
@@ -200,6 +201,10 @@ int32_t sosvo_detect_orb(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* ma
                          int32_t nfeatures, int32_t cap, float* kp4, float* resp, int32_t* n);
 int32_t sosvo_describe_orb_levels(sosvo_ctx* ctx, const uint8_t* gray, int32_t nimg, int32_t rows,
                                   int32_t cols, int32_t nmask, int32_t cap, float* kp4, int32_t* n,
+                                  const int8_t* pattern, uint8_t* desc, float* kp_xy);
+int32_t sosvo_detect_describe_orb(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* mask_pyr, int32_t nimg,
+                                  int32_t images_per_maskset, int32_t rows, int32_t cols, int32_t nmask,
+                                  int32_t nfeatures, int32_t cap, float* kp4, float* resp, int32_t* n,
                                   const int8_t* pattern, uint8_t* desc, float* kp_xy);
 
 /* ---- FAST as a detector of its own (a4, feature_detection_method "FAST") -------------------------------

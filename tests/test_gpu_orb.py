@@ -102,3 +102,60 @@ def test_describe_orb_levels_matches_oracle(ctx):
         assert np.array_equal(desc[p, : len(kept)], wd), p
         kept_total += len(kept)
     assert kept_total > 200
+
+
+def test_describe_does_not_reuse_a_stale_pyramid(ctx):
+    """detect, OVERWRITE the gray buffer in place, describe: the descriptors must come from the new images (the
+    describe call builds its own pyramid; round 1 reused the detector's by pointer identity)."""
+    rng = np.random.default_rng(9)
+    NI, nmask, cap, rows, cols = 2, 2, 128, 122, 400
+    imgs = np.stack([_contrast(rng, (rows, cols)) for _ in range(NI)])
+    imgs2 = np.stack([_contrast(rng, (rows, cols)) for _ in range(NI)])
+    bits = np.stack([_sector_masks(rows, cols, nmask, rng)])
+    t_img, t_bits, t_pat, t_img2 = _to(ctx.device, imgs, bits, orb_pattern.orb_pattern(), imgs2)
+    mask_pyr = ctx.orb_mask_pyramid(t_bits, nmask)
+    kp4, resp, n = ctx.detect_orb(t_img, mask_pyr, NI, nmask, 100, cap)
+    kp_before, n_before = kp4.cpu().numpy().copy(), n.cpu().numpy().copy()
+    t_img.copy_(t_img2)                      # same pointer, new content
+    desc, kp_xy = ctx.describe_orb_levels(t_img, kp4, n, nmask, t_pat)
+    ctx.synchronize()
+    desc = desc.cpu().numpy()
+    differs = 0
+    for p in range(NI * nmask):
+        wd, kept = oracle.orb_describe_levels(imgs2[p // nmask], kp_before[p, : n_before[p]])
+        assert np.array_equal(desc[p, : len(kept)], wd), p
+        stale, _ = oracle.orb_describe_levels(imgs[p // nmask], kp_before[p, : n_before[p]])
+        differs += int((stale != wd).any())
+    assert differs > 0                       # the test can tell the two pyramids apart
+
+
+@pytest.mark.parametrize("shape,nmask,nfeatures,cap", [((146, 1440), 12, 300, 384), ((122, 600), 4, 60, 96), ((64, 300), 2, 50, 64)])
+def test_detect_describe_orb_equals_the_two_calls(ctx, shape, nmask, nfeatures, cap):
+    """sosvo_detect_describe_orb (one pyramid, built only as far as a keypoint can come from) == detect, then describe;
+    and both equal the oracle."""
+    rng = np.random.default_rng(shape[1] * 3 + nmask)
+    NI = 4
+    imgs = np.stack([_contrast(rng, shape) for _ in range(NI)])
+    imgs[1] = oracle.median_gray(_textured(rng, shape + (3,)), 0)
+    bits = np.stack([_sector_masks(shape[0], shape[1], nmask, rng), _sector_masks(shape[0], shape[1], nmask, rng, False)])
+    t_img, t_bits, t_pat = _to(ctx.device, imgs, bits, orb_pattern.orb_pattern())
+    mask_pyr = ctx.orb_mask_pyramid(t_bits, nmask)
+    kp4, resp, n = ctx.detect_orb(t_img, mask_pyr, 2, nmask, nfeatures, cap)
+    det_kp, det_n = kp4.cpu().numpy().copy(), n.cpu().numpy().copy()
+    desc, kp_xy = ctx.describe_orb_levels(t_img, kp4, n, nmask, t_pat)
+    P = NI * nmask
+    z = lambda shp, dt: torch.full(shp, 7, dtype=dt, device=ctx.device)  # noqa: E731  (dirty output buffers)
+    kp4_f, resp_f, n_f = z((P, cap, 4), torch.float32), z((P, cap), torch.float32), z((P,), torch.int32)
+    desc_f, kp_xy_f = z((P, cap, 32), torch.uint8), z((P, cap, 2), torch.float32)
+    ctx.detect_describe_orb(t_img, mask_pyr, 2, nmask, nfeatures, t_pat, kp4_f, resp_f, n_f, desc_f, kp_xy=kp_xy_f)
+    ctx.synchronize()
+    assert torch.equal(n, n_f)
+    nn = n.cpu().numpy()
+    for p in range(P):
+        k = int(nn[p])
+        assert torch.equal(kp4[p, :k], kp4_f[p, :k]) and torch.equal(desc[p, :k], desc_f[p, :k]), p
+        assert torch.equal(kp_xy[p, :k], kp_xy_f[p, :k]), p
+        want_d, kept = oracle.orb_describe_levels(imgs[p // nmask], det_kp[p, : det_n[p]])
+        assert k == len(kept) and np.array_equal(desc_f[p, :k].cpu().numpy(), want_d), p
+    if shape[0] > 62:
+        assert int(nn.sum()) > 5 * nmask

@@ -33,10 +33,6 @@ struct sosvo_ctx {
   sosvo_ctx* sub[kSosvoMaxSubStreams];
   hipEvent_t sub_done[kSosvoMaxSubStreams], sub_median[kSosvoMaxSubStreams], sub_begin;
   int32_t n_sub;
-  // sosvo_detect_orb leaves the image pyramid at the start of the scratch workspace; sosvo_describe_orb_levels called
-  // right after it on the same images reuses it instead of building it again (tag cleared by any other scratch user)
-  const void* pyr_gray;
-  int32_t pyr_nimg, pyr_rows, pyr_cols;
 };
 
 // Brackets the kernel launches of the enclosing scope with a HIP event pair when profiling is on.
@@ -103,7 +99,6 @@ static inline int32_t sosvo_fail(sosvo_ctx* ctx, int32_t code, const char* what,
 #define SOSVO_LAUNCH_CHECK(ctx) SOSVO_HIP((ctx), hipGetLastError())
 
 static inline int32_t sosvo_ws_reserve(sosvo_ctx* ctx, size_t bytes) {
-  ctx->pyr_gray = nullptr;  // whoever reserves scratch may overwrite a pyramid left there (see orb.hip)
   if (bytes <= ctx->ws_bytes) return SOSVO_OK;
   if (ctx->ws) {
     SOSVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -153,3 +148,6 @@ __device__ __forceinline__ int sosvo_block_compact_pos(bool valid, int* wave_off
 // detect.hip: the rolling 7x7 blur on images that lie img_stride bytes apart (also used by orb.hip for the pyramid levels)
 int32_t sosvo_launch_gauss7(sosvo_ctx* ctx, const uint8_t* in, long long img_stride, int nimg, int rows, int cols,
                             uint8_t* out);
+// ... with the output images out_stride bytes apart (level 0 of the ORB pyramid is read from the dense gray batch)
+int32_t sosvo_launch_gauss7_to(sosvo_ctx* ctx, const uint8_t* in, long long in_stride, int nimg, int rows, int cols,
+                               uint8_t* out, long long out_stride);

@@ -110,7 +110,6 @@ int32_t sosvo_profile_get(sosvo_ctx* ctx, int32_t i, char* name_out, int32_t nam
 
 int32_t sosvo_debug_fill_scratch(sosvo_ctx* ctx, int32_t byte) {
   SOSVO_ENTER(ctx);
-  ctx->pyr_gray = nullptr;
   if (ctx->ws && ctx->ws_bytes) SOSVO_HIP(ctx, hipMemsetAsync(ctx->ws, byte & 0xFF, ctx->ws_bytes, ctx->stream));
   for (int i = 0; i < ctx->n_sub; ++i) {
     if (!ctx->sub[i]) continue;

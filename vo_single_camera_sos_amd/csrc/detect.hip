@@ -461,7 +461,7 @@ __global__ __launch_bounds__(kThreads) void gft_select_kernel(const float* __res
 // border = reflect-101), the seven rows of horizontal sums live in a register ring.
 __global__ __launch_bounds__(kThreads) void gauss7_kernel(const uint8_t* __restrict__ gray, long long img_stride, int nimg,
                                                           int rows, int cols, int strips, int nchunks, int chunk_rows,
-                                                          uint8_t* __restrict__ out) {
+                                                          uint8_t* __restrict__ out, long long out_stride) {
   SOSVO_STREAMING_PRIO();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * kThreads + threadIdx.x) >> 6));  // in an SGPR: per-image bases become scalar
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(kThreads) void gauss7_kernel(const uint8_t* __restr
   const bool out_lane = lane >= kEigHalo && lane < 64 - kEigHalo && xc < cols;
   const int ys = chunk * chunk_rows, ye = min(rows, ys + chunk_rows);
   const uint8_t* g = gray + (size_t)img * img_stride;  // (img_stride = rows * cols for a dense batch; a pyramid level of
-  uint8_t* o = out + (size_t)img * img_stride;        //  the ORB detector sits at a fixed offset of a larger per-image block)
+  uint8_t* o = out + (size_t)img * out_stride;        //  the ORB detector sits at a fixed offset of a larger per-image block)
   // seven-deep ring of horizontal sums indexed by (row mod 7): the row loop is unrolled seven times by a fold
   uint32_t h[7] = {0, 0, 0, 0, 0, 0, 0};
   const bool edge_strip = xb < 3 || xb + 64 > cols - 3;  // wave-uniform: some lane's x-3 .. x+3 are mirrored columns
@@ -661,15 +661,19 @@ static void rolling_chunks(int nimg, int rows, int strips, int* nchunks, int* ch
 }  // namespace
 
 // 7x7 sigma-2 blur (8.8 fixed point) of nimg images that lie img_stride bytes apart (shared with the ORB pyramid levels)
-int32_t sosvo_launch_gauss7(sosvo_ctx* ctx, const uint8_t* in, long long img_stride, int nimg, int rows, int cols,
-                            uint8_t* out) {
+int32_t sosvo_launch_gauss7_to(sosvo_ctx* ctx, const uint8_t* in, long long in_stride, int nimg, int rows, int cols,
+                               uint8_t* out, long long out_stride) {
   const int strips = cdiv(cols, kEigStripW);
   int nchunks, chunk_rows;
   rolling_chunks(nimg, rows, strips, &nchunks, &chunk_rows);
   SOSVO_LAUNCH(ctx, gauss7_kernel, dim3(cdiv(nimg * strips * nchunks, kThreads / 64)), dim3(kThreads), 0, ctx->stream, in,
-               img_stride, nimg, rows, cols, strips, nchunks, chunk_rows, out);
+               in_stride, nimg, rows, cols, strips, nchunks, chunk_rows, out, out_stride);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
+}
+int32_t sosvo_launch_gauss7(sosvo_ctx* ctx, const uint8_t* in, long long img_stride, int nimg, int rows, int cols,
+                            uint8_t* out) {
+  return sosvo_launch_gauss7_to(ctx, in, img_stride, nimg, rows, cols, out, img_stride);
 }
 
 extern "C" {

@@ -35,7 +35,23 @@ struct Pyr {
   int quota[kLevels];
   int nlev;          // levels that exist (h, w >= 1)
   long long total;   // pixels of one image's pyramid
+  // detection: levels that can hold a keypoint (a quota and more than the 31-px border); local-maximum flags of their
+  // FAST score maps, one u64 per (row, 56-column strip): foff = first word of a level inside an image's ftotal words
+  int det[kLevels], ndet;  // ndet = 1 + the highest such level (the pyramid is only built that far for detection)
+  int fstrips[kLevels];
+  long long foff[kLevels], ftotal;
+  int toff[kLevels], ttotal;  // resize tap table: level l >= 1 holds w[l] x taps, then h[l] y taps, at toff[l]
 };
+
+// image of level l: level 0 is the caller's gray batch itself (no copy), levels >= 1 live in the pyramid workspace
+struct LevelSrc {
+  const uint8_t* gray;  // [nimg, rows * cols]
+  const uint8_t* pyr;   // [nimg, total] (level 0's slot is unused)
+  long long npix0, total;
+};
+__device__ __forceinline__ const uint8_t* level_image(const LevelSrc& S, const Pyr& P, int img, int l) {
+  return l == 0 ? S.gray + (size_t)img * S.npix0 : S.pyr + (size_t)img * S.total + P.off[l];
+}
 
 __device__ __forceinline__ int refl101(int i, int n) {
   if (n == 1) return 0;
@@ -68,25 +84,67 @@ __device__ __forceinline__ ResizeTap resize_tap(int d, double scale, int n0) {
   return t;
 }
 
-__global__ __launch_bounds__(kThreads) void copy_level0_kernel(const uint8_t* __restrict__ gray, int npix,
-                                                               long long total, uint8_t* __restrict__ pyr) {
-  SOSVO_STREAMING_PRIO();
-  const int i = blockIdx.x * kThreads + threadIdx.x, img = blockIdx.y;
-  if (i < npix) pyr[(size_t)img * total + i] = gray[(size_t)img * npix + i];
+// Tap table of the bilinear resizes (depends on the image size only): entry = i0 | w1 << 16 (i1 = min(i0 + 1, n0 - 1),
+// w0 = 2048 - w1), computed once per call instead of twice per output pixel (double-precision arithmetic).
+__global__ __launch_bounds__(kThreads) void resize_taps_kernel(Pyr P, uint32_t* __restrict__ taps) {
+  const int i = blockIdx.x * kThreads + threadIdx.x, l = blockIdx.y + 1;
+  if (l >= P.nlev || i >= P.w[l] + P.h[l]) return;
+  const bool isx = i < P.w[l];
+  const int d = isx ? i : i - P.w[l];
+  const int n0 = isx ? P.w[l - 1] : P.h[l - 1], n1 = isx ? P.w[l] : P.h[l];
+  const ResizeTap t = resize_tap(d, (double)n0 / n1, n0);
+  taps[P.toff[l] + i] = (uint32_t)t.i0 | ((uint32_t)t.w1 << 16);
 }
 
-__global__ __launch_bounds__(kThreads) void resize_level_kernel(uint8_t* __restrict__ pyr, long long total,
-                                                                long long off0, int h0, int w0, long long off1, int h1,
-                                                                int w1) {
+// level l from level l - 1: a thread produces FOUR neighbouring output pixels of one row (grid: 1024 output columns x
+// output row x image; the row's y tap is scalar).  Their eight source columns span at most 7 bytes (scale 1.2), so each
+// of the two source rows is ONE unaligned 8-byte load (clamped to stay inside the row) and the result ONE dword store
+// -- against 16 byte loads and 4 byte stores; rows narrower than 8 pixels and a row's ragged tail go pixel by pixel.
+typedef unsigned long long __attribute__((aligned(1))) orb_u64_unaligned;
+__global__ __launch_bounds__(kThreads) void resize_level_kernel(const uint8_t* __restrict__ src, long long src_stride,
+                                                                int h0, int w0, uint8_t* __restrict__ dst,
+                                                                long long dst_stride, int h1, int w1,
+                                                                const uint32_t* __restrict__ taps) {
   SOSVO_STREAMING_PRIO();
-  const int i = blockIdx.x * kThreads + threadIdx.x, img = blockIdx.y;
-  if (i >= h1 * w1) return;
-  const int dy = i / w1, dx = i - dy * w1;
-  const ResizeTap ty = resize_tap(dy, (double)h0 / h1, h0), tx = resize_tap(dx, (double)w0 / w1, w0);
-  const uint8_t* s = pyr + (size_t)img * total + off0;
-  const long long top = (long long)tx.w0 * s[(size_t)ty.i0 * w0 + tx.i0] + (long long)tx.w1 * s[(size_t)ty.i0 * w0 + tx.i1];
-  const long long bot = (long long)tx.w0 * s[(size_t)ty.i1 * w0 + tx.i0] + (long long)tx.w1 * s[(size_t)ty.i1 * w0 + tx.i1];
-  pyr[(size_t)img * total + off1 + i] = (uint8_t)((ty.w0 * top + ty.w1 * bot + (1 << 21)) >> 22);
+  const int dx4 = 4 * (blockIdx.x * kThreads + threadIdx.x), dy = blockIdx.y, img = blockIdx.z;
+  if (dx4 >= w1) return;
+  const uint32_t ty = taps[w1 + dy];
+  const int y0 = (int)(ty & 0xFFFFu), y1 = y0 + 1 < h0 ? y0 + 1 : h0 - 1;
+  const uint32_t wy1 = ty >> 16, wy0 = 2048u - wy1;
+  const uint8_t* s = src + (size_t)img * src_stride;
+  const uint8_t* r0 = s + (size_t)y0 * w0;
+  const uint8_t* r1 = s + (size_t)y1 * w0;
+  uint8_t* out = dst + (size_t)img * dst_stride + (size_t)dy * w1 + dx4;
+  // (wy0 * top + wy1 * bot + 2^21) >> 22 with top, bot <= 2048 * 255: 32-bit arithmetic is exact
+  auto blend = [&](uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, uint32_t wx1) {
+    const uint32_t wx0 = 2048u - wx1;
+    return ((wy0 * (wx0 * a0 + wx1 * a1) + wy1 * (wx0 * b0 + wx1 * b1)) + (1u << 21)) >> 22;
+  };
+  const bool dword_ok = ((uintptr_t)out & 3) == 0;
+  if (w0 >= 8 && dx4 + 3 < w1 && dword_ok) {
+    uint32_t t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = taps[dx4 + k];
+    const int base = min((int)(t[0] & 0xFFFFu), w0 - 8);
+    const unsigned long long va = *reinterpret_cast<const orb_u64_unaligned*>(r0 + base);
+    const unsigned long long vb = *reinterpret_cast<const orb_u64_unaligned*>(r1 + base);
+    uint32_t res = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int x0 = (int)(t[k] & 0xFFFFu), x1 = x0 + 1 < w0 ? x0 + 1 : w0 - 1;
+      const int o0 = 8 * (x0 - base), o1 = 8 * (x1 - base);
+      res |= blend((uint32_t)(va >> o0) & 0xFFu, (uint32_t)(va >> o1) & 0xFFu, (uint32_t)(vb >> o0) & 0xFFu,
+                   (uint32_t)(vb >> o1) & 0xFFu, t[k] >> 16)
+             << (8 * k);
+    }
+    *reinterpret_cast<uint32_t*>(out) = res;
+    return;
+  }
+  for (int k = 0; k < 4 && dx4 + k < w1; ++k) {
+    const uint32_t tx = taps[dx4 + k];
+    const int x0 = (int)(tx & 0xFFFFu), x1 = x0 + 1 < w0 ? x0 + 1 : w0 - 1;
+    out[k] = (uint8_t)blend(r0[x0], r0[x1], r1[x0], r1[x1], tx >> 16);
+  }
 }
 
 // mask level l from level l-1: every mask bit is resized as a 0/255 image and kept where the result is > 254
@@ -109,41 +167,54 @@ __global__ __launch_bounds__(kThreads) void mask_level_kernel(uint32_t* __restri
   mp[(size_t)set * total + off1 + i] = out;
 }
 
-// ---- FAST-9/16 score map over the whole pyramid ------------------------------------------------------------
-// d[k] = circle pixel k minus the centre pixel -> corner score: the largest threshold for which the pixel is still a FAST-9
-// corner, minus 1 (0: not a corner at `thr`).  Max over the 16 arcs of 9 consecutive circle pixels of min(d) (brighter) and
-// of min(-d) = -max(d) (darker), by doubling: windows of 2, 4, 8, then 9 -- 4 min + 4 max per start instead of 8 + 8.
-__device__ __forceinline__ int fast_score_from_diffs(const int (&d)[16], int thr) {
-  int lo2[16], hi2[16], lo4[16], hi4[16];
+// ---- FAST-9/16 score map (+ local-maximum flags) ----------------------------------------------------------------
+// Neighbouring lane's value through the DPP operand path (a VALU move; 0 beyond the wave's ends: halo lanes only).
+__device__ __forceinline__ int fs_from_left(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, true); }
+__device__ __forceinline__ int fs_from_right(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t min16(uint32_t a, uint32_t b) { return (uint32_t)min((uint16_t)a, (uint16_t)b); }
+__device__ __forceinline__ uint32_t max16(uint32_t a, uint32_t b) { return (uint32_t)max((uint16_t)a, (uint16_t)b); }
+
+// e[k] = 256 + circle pixel k - centre pixel (1 .. 511, so that 16-bit UNSIGNED minima / maxima -- the fast-rate VALU
+// forms -- order them) -> corner score: the largest threshold for which the pixel is still a FAST-9 corner, minus 1
+// (0: not a corner at `thr`).  Over the 16 arcs of 9 consecutive circle pixels: A = max of the arcs' minima (brighter),
+// B = min of the arcs' maxima (darker), by doubling (windows of 2, 4, 8, then 9); best = max(A - 256, 256 - B).
+__device__ __forceinline__ int fast_score_from_biased(const uint32_t (&e)[16], int thr) {
+  uint32_t lo2[16], hi2[16], lo4[16], hi4[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    lo2[k] = min(d[k], d[(k + 1) & 15]);
-    hi2[k] = max(d[k], d[(k + 1) & 15]);
+    lo2[k] = min16(e[k], e[(k + 1) & 15]);
+    hi2[k] = max16(e[k], e[(k + 1) & 15]);
   }
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    lo4[k] = min(lo2[k], lo2[(k + 2) & 15]);
-    hi4[k] = max(hi2[k], hi2[(k + 2) & 15]);
+    lo4[k] = min16(lo2[k], lo2[(k + 2) & 15]);
+    hi4[k] = max16(hi2[k], hi2[(k + 2) & 15]);
   }
-  int best = 0;
+  uint32_t A = 0u, B = 0xFFFFu;
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    const int mn_b = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);   // min of d over k .. k + 8
-    const int mx = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);     // max of d over k .. k + 8
-    best = max(best, max(mn_b, -mx));
+    A = max16(A, min16(min16(lo4[k], lo4[(k + 4) & 15]), e[(k + 8) & 15]));
+    B = min16(B, max16(max16(hi4[k], hi4[(k + 4) & 15]), e[(k + 8) & 15]));
   }
+  const int best = max((int)A - 256, 256 - (int)B);
   return best > thr ? best - 1 : 0;
 }
 
-// FAST-9/16 score map of nimg images that lie img_stride bytes apart (a dense batch, or one pyramid level): a wave owns a
-// 64-column strip (58 output columns, 3 halo columns each side) and walks down the rows with the last seven rows of its
-// column in a register ring; the 16 circle pixels of a row come from the ring slots of neighbouring lanes (one
-// cross-lane read each) instead of 16 scattered byte loads per pixel.  3-pixel image border (and everything when
-// `enabled` is 0: a pyramid level that cannot hold a keypoint) scores 0.
-constexpr int kFsHalo = 3, kFsStripW = 64 - 2 * kFsHalo;
+// FAST-9/16 score map of nimg images that lie img_stride bytes apart (a dense batch, or one pyramid level), rows
+// [r0, r1) only: a wave owns a 64-column strip (56 output columns, 4 halo columns each side) and walks down the rows
+// with the last seven rows of its column in a register ring.  A row's value travels to the six neighbouring lanes that
+// will need it (lane +-1, +-2, +-3: six chained DPP moves when the row arrives) and stays there for the seven steps the
+// row lives, so the 16 circle pixels of every step are plain register reads.  3-pixel image border scores 0.
+// flags (optional): bit = lane of a u64 per (row, strip): score > 0 and strictly greater than its 8 neighbours (the 3x3
+// non-maximum suppression of the detectors), for rows (r0, r1 - 1); the halo of 4 makes the scores of an output lane's
+// neighbours exact.
+constexpr int kFsHalo = 4, kFsStripW = 64 - 2 * kFsHalo;
 __global__ __launch_bounds__(kThreads) void fast_score_rolling_kernel(const uint8_t* __restrict__ in, long long img_stride,
                                                                       int nimg, int rows, int cols, int strips, int thr,
-                                                                      int enabled, uint8_t* __restrict__ out) {
+                                                                      int r0, int r1, uint8_t* __restrict__ out,
+                                                                      long long out_stride,
+                                                                      unsigned long long* __restrict__ flags,
+                                                                      long long flags_stride) {
   SOSVO_STREAMING_PRIO();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * kThreads + threadIdx.x) >> 6));
@@ -155,43 +226,78 @@ __global__ __launch_bounds__(kThreads) void fast_score_rolling_kernel(const uint
   const bool out_lane = lane >= kFsHalo && lane < 64 - kFsHalo && xc < cols;
   const bool interior_x = xc >= 3 && xc < cols - 3;
   const uint8_t* g = in + (size_t)img * img_stride;
-  uint8_t* o = out + (size_t)img * img_stride;
-  int v[7] = {0, 0, 0, 0, 0, 0, 0};  // rows t-6 .. t of this lane's column, slot = row mod 7 (compile-time after unrolling)
-  const int t_last = rows - 1 + 3;
-  int c_next = (int)g[(uint32_t)xs];
+  uint8_t* o = out + (size_t)img * out_stride;
+  unsigned long long* fo = flags ? flags + (size_t)img * flags_stride : nullptr;
+  // ring slot = (row - t_first) mod 7, compile-time after unrolling; per slot the centre value and its six shifted copies
+  int vc[7], vl1[7], vl2[7], vl3[7], vr1[7], vr2[7], vr3[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) vc[k] = vl1[k] = vl2[k] = vl3[k] = vr1[k] = vr2[k] = vr3[k] = 0;
+  int hm_a = 0, hm_b = 0, s_b = 0, lr_b = 0;  // NMS state: hm = max over (x-1, x, x+1) of rows y-2 / y-1, s / lr of row y-1
+  const int t_first = r0 - 3, t_last = r1 - 1 + 3;
+  auto src_row = [&](int t) { return min(max(t, 0), rows - 1); };  // clamped rows are never used as circle pixels
+  int c_next = (int)g[(uint32_t)(src_row(t_first) * cols) + (uint32_t)xs];
   auto step = [&](auto phase_tag, const int t) __attribute__((always_inline)) {
     constexpr int P = decltype(phase_tag)::value;
     if (t > t_last) return;  // uniform
-    v[P] = c_next;           // row t (rows past the image repeat the last one: they are never used as circle pixels)
-    c_next = (int)g[(uint32_t)(min(t + 1, rows - 1) * cols) + (uint32_t)xs];
+    {
+      const int c = c_next;  // row t
+      c_next = (int)g[(uint32_t)(src_row(t + 1) * cols) + (uint32_t)xs];
+      vc[P] = c;
+      vr1[P] = fs_from_right(c);
+      vr2[P] = fs_from_right(vr1[P]);
+      vr3[P] = fs_from_right(vr2[P]);
+      vl1[P] = fs_from_left(c);
+      vl2[P] = fs_from_left(vl1[P]);
+      vl3[P] = fs_from_left(vl2[P]);
+    }
     const int y = t - 3;
-    if (y < 0) return;  // uniform
+    if (y < r0) return;  // uniform
     int s = 0;
-    if (enabled && y >= 3 && y < rows - 3) {  // uniform
+    if (y >= 3 && y < rows - 3) {  // uniform
       // row y + dy lives in slot (P + 4 + dy) mod 7; circle pixel k = (rx[k], ry[k]) as in OpenCV's table
-      const int c = v[(P + 4) % 7];
-      int d[16];
-      d[0] = v[(P + 7) % 7] - c;                                   // ( 0,  3)
-      d[1] = __shfl(v[(P + 7) % 7], lane + 1) - c;                 // ( 1,  3)
-      d[2] = __shfl(v[(P + 6) % 7], lane + 2) - c;                 // ( 2,  2)
-      d[3] = __shfl(v[(P + 5) % 7], lane + 3) - c;                 // ( 3,  1)
-      d[4] = __shfl(v[(P + 4) % 7], lane + 3) - c;                 // ( 3,  0)
-      d[5] = __shfl(v[(P + 3) % 7], lane + 3) - c;                 // ( 3, -1)
-      d[6] = __shfl(v[(P + 2) % 7], lane + 2) - c;                 // ( 2, -2)
-      d[7] = __shfl(v[(P + 1) % 7], lane + 1) - c;                 // ( 1, -3)
-      d[8] = v[(P + 1) % 7] - c;                                   // ( 0, -3)
-      d[9] = __shfl(v[(P + 1) % 7], lane - 1) - c;                 // (-1, -3)
-      d[10] = __shfl(v[(P + 2) % 7], lane - 2) - c;                // (-2, -2)
-      d[11] = __shfl(v[(P + 3) % 7], lane - 3) - c;                // (-3, -1)
-      d[12] = __shfl(v[(P + 4) % 7], lane - 3) - c;                // (-3,  0)
-      d[13] = __shfl(v[(P + 5) % 7], lane - 3) - c;                // (-3,  1)
-      d[14] = __shfl(v[(P + 6) % 7], lane - 2) - c;                // (-2,  2)
-      d[15] = __shfl(v[(P + 7) % 7], lane - 1) - c;                // (-1,  3)
-      s = interior_x ? fast_score_from_diffs(d, thr) : 0;
+      constexpr int s3 = (P + 7) % 7, s2 = (P + 6) % 7, s1 = (P + 5) % 7, s0 = (P + 4) % 7, m1 = (P + 3) % 7, m2 = (P + 2) % 7,
+                    m3 = (P + 1) % 7;
+      const uint32_t base = 256u - (uint32_t)vc[s0];
+      uint32_t e[16];
+      e[0] = (uint32_t)vc[s3] + base;    // ( 0,  3)
+      e[1] = (uint32_t)vr1[s3] + base;   // ( 1,  3)
+      e[2] = (uint32_t)vr2[s2] + base;   // ( 2,  2)
+      e[3] = (uint32_t)vr3[s1] + base;   // ( 3,  1)
+      e[4] = (uint32_t)vr3[s0] + base;   // ( 3,  0)
+      e[5] = (uint32_t)vr3[m1] + base;   // ( 3, -1)
+      e[6] = (uint32_t)vr2[m2] + base;   // ( 2, -2)
+      e[7] = (uint32_t)vr1[m3] + base;   // ( 1, -3)
+      e[8] = (uint32_t)vc[m3] + base;    // ( 0, -3)
+      e[9] = (uint32_t)vl1[m3] + base;   // (-1, -3)
+      e[10] = (uint32_t)vl2[m2] + base;  // (-2, -2)
+      e[11] = (uint32_t)vl3[m1] + base;  // (-3, -1)
+      e[12] = (uint32_t)vl3[s0] + base;  // (-3,  0)
+      e[13] = (uint32_t)vl3[s1] + base;  // (-3,  1)
+      e[14] = (uint32_t)vl2[s2] + base;  // (-2,  2)
+      e[15] = (uint32_t)vl1[s3] + base;  // (-1,  3)
+      // Any arc of 9 consecutive circle pixels holds at least two of the four compass pixels (0, 4, 8, 12), so a corner
+      // at `thr` needs two of them brighter than centre + thr or two darker than centre - thr.  When no lane of the wave
+      // passes that test (most row segments of a blurred panorama) the min / max network is skipped: all scores are 0.
+      const uint32_t hi_t = 256u + (uint32_t)thr, lo_t = 256u - (uint32_t)thr;
+      const int nb = (int)(e[0] > hi_t) + (int)(e[4] > hi_t) + (int)(e[8] > hi_t) + (int)(e[12] > hi_t);
+      const int nd = (int)(e[0] < lo_t) + (int)(e[4] < lo_t) + (int)(e[8] < lo_t) + (int)(e[12] < lo_t);
+      if (__ballot(interior_x && (nb >= 2 || nd >= 2)) != 0ULL) s = interior_x ? fast_score_from_biased(e, thr) : 0;
     }
     if (out_lane) o[(uint32_t)(y * cols) + (uint32_t)xc] = (uint8_t)s;
+    if (fo) {  // uniform
+      const int lr = max(fs_from_left(s), fs_from_right(s)), hm = max(lr, s);
+      if (y - 1 > r0 && y - 1 < r1 - 1) {  // flag row y - 1 (uniform)
+        const bool is_max = out_lane && s_b > 0 && s_b > lr_b && s_b > hm_a && s_b > hm;
+        const unsigned long long bal = __ballot(is_max);
+        if (lane == 0) fo[(uint32_t)((y - 1) * strips + strip)] = bal;
+      }
+      hm_a = hm_b;
+      hm_b = hm;
+      s_b = s;
+      lr_b = lr;
+    }
   };
-  for (int t = 0; t <= t_last; t += 7) {
+  for (int t = t_first; t <= t_last; t += 7) {
     step(std::integral_constant<int, 0>{}, t);
     step(std::integral_constant<int, 1>{}, t + 1);
     step(std::integral_constant<int, 2>{}, t + 2);
@@ -202,11 +308,13 @@ __global__ __launch_bounds__(kThreads) void fast_score_rolling_kernel(const uint
   }
 }
 
+// rows [r0, r1) of the score map; flags (may be null) for rows (r0, r1 - 1)
 static int32_t launch_fast_score(sosvo_ctx* ctx, const uint8_t* in, long long img_stride, int nimg, int rows, int cols, int thr,
-                                 int enabled, uint8_t* out) {
+                                 int r0, int r1, uint8_t* out, long long out_stride, unsigned long long* flags,
+                                 long long flags_stride) {
   const int strips = cdiv(cols, kFsStripW);
   SOSVO_LAUNCH(ctx, fast_score_rolling_kernel, dim3(cdiv(nimg * strips, kThreads / 64)), dim3(kThreads), 0, ctx->stream, in,
-               img_stride, nimg, rows, cols, strips, thr, enabled, out);
+               img_stride, nimg, rows, cols, strips, thr, r0, r1, out, out_stride, flags, flags_stride);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
 }
@@ -310,19 +418,31 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   return a;
 }
 
-__device__ __forceinline__ float harris_response(const uint8_t* __restrict__ im, int h, int w, int cx, int cy) {
+// Harris response of the 7x7 block around (cx, cy), k = 0.04, by ONE WAVE: lane (dy + 3) * 7 + (dx + 3) < 49 evaluates the
+// 3x3 Sobel pair at its pixel (reflect-101 at the level border), the three sums of products are integer wave reductions
+// (exact, order-free), the float expression keeps the oracle's operation order.  Every lane returns the response.
+__device__ __forceinline__ float harris_response_wave(const uint8_t* __restrict__ im, int h, int w, int cx, int cy, int lane) {
   int a = 0, b = 0, c = 0;
-  for (int dy = -3; dy <= 3; ++dy)
-    for (int dx = -3; dx <= 3; ++dx) {
-      const int y = cy + dy, x = cx + dx;
-#define PX(yy, xx) ((int)im[(size_t)refl101((yy), h) * w + refl101((xx), w)])
-      const int Ix = (PX(y, x + 1) - PX(y, x - 1)) * 2 + (PX(y - 1, x + 1) - PX(y - 1, x - 1)) + (PX(y + 1, x + 1) - PX(y + 1, x - 1));
-      const int Iy = (PX(y + 1, x) - PX(y - 1, x)) * 2 + (PX(y + 1, x - 1) - PX(y - 1, x - 1)) + (PX(y + 1, x + 1) - PX(y - 1, x + 1));
-#undef PX
-      a += Ix * Ix;
-      b += Iy * Iy;
-      c += Ix * Iy;
-    }
+  if (lane < 49) {
+    const int dy = lane / 7 - 3, dx = lane - (lane / 7) * 7 - 3;
+    const int y = cy + dy, x = cx + dx;
+    const int ym = refl101(y - 1, h) * w, y0 = refl101(y, h) * w, yp = refl101(y + 1, h) * w;
+    const int xm = refl101(x - 1, w), x0 = refl101(x, w), xp = refl101(x + 1, w);
+    const int p00 = im[ym + xm], p01 = im[ym + x0], p02 = im[ym + xp];
+    const int p10 = im[y0 + xm], p12 = im[y0 + xp];
+    const int p20 = im[yp + xm], p21 = im[yp + x0], p22 = im[yp + xp];
+    const int Ix = (p12 - p10) * 2 + (p02 - p00) + (p22 - p20);
+    const int Iy = (p21 - p01) * 2 + (p20 - p00) + (p22 - p02);
+    a = Ix * Ix;
+    b = Iy * Iy;
+    c = Ix * Iy;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o);
+    b += __shfl_xor(b, o);
+    c += __shfl_xor(c, o);
+  }
   const float scale = 1.f / (4 * 7 * 255.f);
   const float s4 = (scale * scale) * (scale * scale);
   const float fa = (float)a, fb = (float)b, fc = (float)c;
@@ -366,123 +486,172 @@ __global__ __launch_bounds__(kThreads) void orb_mask_bbox_kernel(const uint32_t*
   }
 }
 
-__global__ __launch_bounds__(kThreads) void orb_select_kernel(const uint8_t* __restrict__ pyr,
-                                                              const uint8_t* __restrict__ score,
+// One workgroup per problem (image, mask) walks the detection levels.  Per level:
+//   1. candidates: the local-maximum flags of the FAST score map (one u64 per row and 56-column strip, written by the
+//      score kernel) inside the mask's bounding box and the 31-px border, mask bit set -> (position, score) in LDS;
+//   2. retainBest(2 quota) by FAST score, ties kept: threshold from a 256-bin histogram, suffix sums by the first wave;
+//   3. Harris response, one wave per candidate -> unique sort keys;  4. bitonic sort (response descending, then y, x);
+//   5. retainBest(quota) by response, ties kept (counted in parallel: the list is sorted);
+//   6. orientation, one wave per keypoint.
+__global__ __launch_bounds__(kThreads) void orb_select_kernel(LevelSrc S, const uint8_t* __restrict__ score,
+                                                              const unsigned long long* __restrict__ flags,
                                                               const uint32_t* __restrict__ mask_pyr,
                                                               const uint32_t* __restrict__ bbox, Pyr P,
                                                               int images_per_maskset, int nmask, int cap,
                                                               float* __restrict__ kp4, float* __restrict__ resp_out,
                                                               int32_t* __restrict__ n_out) {
   SOSVO_LATENCY_BOUND_PRIO();
-  __shared__ uint32_t cxy[kCandMax];            // (y << 16) | x
+  __shared__ uint32_t cxy[kCandMax];            // (y << 16) | x; after the sort: the sorted positions
   __shared__ uint8_t cfast[kCandMax];
   __shared__ unsigned long long ckey[kCandMax];  // ordered(harris) << 32 | (0xFFFFFFFF - linear index)
-  uint32_t* sxy = cxy;  // the sorted positions reuse the candidates' array (dead once the sort keys exist): 35 KB of LDS per
-                        // workgroup instead of 43, i.e. four workgroups per CU instead of three for this latency-bound kernel
-  __shared__ float sresp[kCandMax];
+  __shared__ uint32_t kept[kCandMax];            // candidates that pass the FAST-score threshold (compacted)
   __shared__ int hist[256];
-  __shared__ int s_nc, s_thr, s_keep, s_nout;
-  __shared__ int wave_off[5];
-  __shared__ int s_running;
+  __shared__ int s_nc, s_thr, s_keep, s_nout, s_nk;
   const int tid = threadIdx.x, p = blockIdx.x, lane = tid & 63, wid = tid >> 6;
   const int img = p / nmask, m = p - img * nmask;
   const int kumax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
   if (tid == 0) s_nout = 0;
   __syncthreads();
-  for (int l = 0; l < P.nlev; ++l) {
+  for (int l = 0; l < P.ndet; ++l) {
+    if (!P.det[l]) continue;  // uniform
     const int h = P.h[l], w = P.w[l], quota = P.quota[l];
-    if (quota <= 0 || h <= 2 * kEdge || w <= 2 * kEdge) continue;  // uniform
-    const uint8_t* im = pyr + (size_t)img * P.total + P.off[l];
+    const uint8_t* im = level_image(S, P, img, l);
     const uint8_t* sc = score + (size_t)img * P.total + P.off[l];
     const uint32_t* mk = mask_pyr + (size_t)(img / images_per_maskset) * P.total + P.off[l];
-    if (tid == 0) s_nc = 0;
+    const unsigned long long* fl = flags + (size_t)img * P.ftotal + P.foff[l];
+    const int strips = P.fstrips[l];
+    if (tid == 0) {
+      s_nc = 0;
+      s_nk = 0;
+      s_keep = 0;
+    }
     for (int k = tid; k < 256; k += kThreads) hist[k] = 0;
     __syncthreads();
-    // 1. NMS + border + mask -> candidates (unordered); only the mask's bounding box on this level is scanned (the
-    // azimuthal masks are column bands: a twelfth of the level each)
+    // 1. candidates (unordered): flag words of the rows / strips that meet the mask's bounding box on this level
     const uint32_t* bb = bbox + (((size_t)(img / images_per_maskset) * kLevels + l) * 32 + m) * 4;
     const int bx0 = max(kEdge, (int)(0xFFFFFFFFu - bb[0])), by0 = max(kEdge, (int)(0xFFFFFFFFu - bb[1]));
     const int bx1 = min(w - kEdge, (int)bb[2]), by1 = min(h - kEdge, (int)bb[3]);  // exclusive
     const int rw = bb[2] ? max(0, bx1 - bx0) : 0, rh = bb[2] ? max(0, by1 - by0) : 0;
-    for (int i = tid; i < rw * rh; i += kThreads) {
-      const int y = by0 + i / rw, x = bx0 + i % rw;
-      const int s = sc[(size_t)y * w + x];
-      if (!s || !((mk[(size_t)y * w + x] >> m) & 1u)) continue;
-      bool is_max = true;
-#pragma unroll
-      for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-        for (int dx = -1; dx <= 1; ++dx)
-          if ((dy || dx) && sc[(size_t)(y + dy) * w + x + dx] >= s) is_max = false;
-      if (is_max) {
-        const int slot = atomicAdd(&s_nc, 1);
-        if (slot < kCandMax) {
-          cxy[slot] = ((uint32_t)y << 16) | (uint32_t)x;
-          cfast[slot] = (uint8_t)s;
-          atomicAdd(&hist[s], 1);
+    if (rw > 0 && rh > 0) {
+      const int st0 = bx0 / kFsStripW, ns = (bx1 - 1) / kFsStripW - st0 + 1;
+      for (int i = tid; i < ns * rh; i += kThreads) {
+        const int ry = i / ns, sidx = st0 + (i - ry * ns), y = by0 + ry;
+        const int xbase = sidx * kFsStripW - kFsHalo;  // column of bit 0
+        unsigned long long wd = fl[(size_t)y * strips + sidx];
+        {  // keep the bits whose column lies inside [bx0, bx1)
+          const int l_lo = max(0, bx0 - xbase), l_hi = min(63, bx1 - 1 - xbase);
+          wd = l_hi >= l_lo ? (wd >> l_lo << l_lo) & (~0ULL >> (63 - l_hi)) : 0ULL;
+        }
+        while (wd) {
+          const int x = xbase + __ffsll((long long)wd) - 1;
+          wd &= wd - 1ULL;
+          if (!((mk[(size_t)y * w + x] >> m) & 1u)) continue;
+          const int sv = sc[(size_t)y * w + x];
+          const int slot = atomicAdd(&s_nc, 1);
+          if (slot < kCandMax) {
+            cxy[slot] = ((uint32_t)y << 16) | (uint32_t)x;
+            cfast[slot] = (uint8_t)sv;
+            atomicAdd(&hist[sv], 1);
+          }
         }
       }
     }
     __syncthreads();
     const int nc0 = min(s_nc, kCandMax);
-    // 2. retainBest(2 * quota) by FAST score, ties kept: threshold from the histogram
-    if (tid == 0) {
+    if (nc0 == 0) continue;  // uniform: nothing on this level (s_nc is re-initialised behind the barrier of the next level's step 1)
+    // 2. retainBest(2 * quota) by FAST score, ties kept: the largest score t with #(score >= t) >= 2 quota
+    if (wid == 0) {
       int thr = 0;
-      if (nc0 > 2 * quota) {
-        int acc = 0;
-        for (thr = 255; thr >= 0; --thr) {
-          acc += hist[thr];
-          if (acc >= 2 * quota) break;
+      if (nc0 > 2 * quota) {  // uniform
+        const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+        int suf = h0 + h1 + h2 + h3;  // -> sum over the bins of lanes >= lane
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int v = __shfl_down(suf, o);
+          if (lane + o < 64) suf += v;
         }
+        const int a3 = suf - h0 - h1 - h2, a2 = a3 + h2, a1 = a2 + h1, a0 = suf;  // #(score >= 4 lane + k)
+        int best = -1;
+        if (a0 >= 2 * quota) best = 4 * lane;
+        if (a1 >= 2 * quota) best = 4 * lane + 1;
+        if (a2 >= 2 * quota) best = 4 * lane + 2;
+        if (a3 >= 2 * quota) best = 4 * lane + 3;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best = max(best, __shfl_xor(best, o));
+        thr = best;
       }
-      s_thr = thr;
-      s_running = 0;
+      if (lane == 0) s_thr = thr;
     }
     __syncthreads();
     const int thr = s_thr;
-    // 3. Harris response of the survivors -> sort keys (compacted, order irrelevant: keys are unique)
-    for (int i0 = 0; i0 < nc0; i0 += kThreads) {
-      const int i = i0 + tid;
-      const bool keep = i < nc0 && cfast[i] >= thr;
-      uint32_t xy = 0;
-      float r = 0.f;
-      if (keep) {
-        xy = cxy[i];
-        r = harris_response(im, h, w, (int)(xy & 0xFFFFu), (int)(xy >> 16));
-      }
-      const int pos = sosvo_block_compact_pos(keep, wave_off, &s_running, tid);
-      if (keep) {
+    for (int i = tid; i < nc0; i += kThreads)
+      if (cfast[i] >= thr) kept[atomicAdd(&s_nk, 1)] = cxy[i];  // order irrelevant: the sort keys are unique
+    __syncthreads();
+    const int nc = s_nk;
+    // 3. Harris response of the survivors -> sort keys
+    for (int j = wid; j < nc; j += kThreads / 64) {
+      const uint32_t xy = kept[j];
+      const float r = harris_response_wave(im, h, w, (int)(xy & 0xFFFFu), (int)(xy >> 16), lane);
+      if (lane == 0) {
         const uint32_t lin = (xy >> 16) * (uint32_t)w + (xy & 0xFFFFu);
-        ckey[pos] = ((unsigned long long)sosvo_float_ordered(r) << 32) | (0xFFFFFFFFu - lin);
+        ckey[j] = ((unsigned long long)sosvo_float_ordered(r) << 32) | (0xFFFFFFFFu - lin);
       }
     }
+    // 4. sort, descending: response, then (y, x) ascending (keys are unique; padding sorts last).  Up to 64 keys (the usual
+    // case on a blurred panorama): one wave, in registers, no barriers; more: bitonic sort in LDS by the workgroup.
     __syncthreads();
-    const int nc = s_running;
-    // 4. rank sort: response descending, then (y, x) ascending
-    for (int i = tid; i < nc; i += kThreads) {
-      const unsigned long long mine = ckey[i];
-      int rank = 0;
-      for (int j = 0; j < nc; ++j) rank += ckey[j] > mine;
-      const uint32_t lin = 0xFFFFFFFFu - (uint32_t)mine;
-      sxy[rank] = ((lin / (uint32_t)w) << 16) | (lin % (uint32_t)w);
-      sresp[rank] = sosvo_ordered_float((uint32_t)(mine >> 32));
-    }
-    __syncthreads();
-    // 5. retainBest(quota) by Harris response, ties kept
-    if (tid == 0) {
-      int keep = nc;
-      if (nc > quota) {
-        const float amb = sresp[quota - 1];
-        keep = quota;
-        while (keep < nc && sresp[keep] >= amb) keep++;
+    if (nc <= 64) {
+      if (wid == 0) {
+        unsigned long long key = lane < nc ? ckey[lane] : 0ULL;
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+          for (int j = k >> 1; j > 0; j >>= 1) {
+            const unsigned long long other = __shfl_xor(key, j);
+            const bool desc = (lane & k) == 0, lower = (lane & j) == 0;
+            // descending block: the lower lane keeps the larger key
+            const bool take_max = desc == lower;
+            key = take_max ? (key > other ? key : other) : (key < other ? key : other);
+          }
+        }
+        ckey[lane] = key;
       }
-      s_keep = keep;
+      __syncthreads();
+    } else {
+      int N = 128;
+      while (N < nc) N <<= 1;
+      for (int i = nc + tid; i < N; i += kThreads) ckey[i] = 0ULL;
+      __syncthreads();
+      for (int k = 2; k <= N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          for (int t = tid; t < N / 2; t += kThreads) {
+            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), ixj = i | j;
+            const unsigned long long a = ckey[i], b = ckey[ixj];
+            const bool desc = (i & k) == 0;
+            if ((a < b) == desc) {
+              ckey[i] = b;
+              ckey[ixj] = a;
+            }
+          }
+          __syncthreads();
+        }
+      }
+    }
+    // 5. retainBest(quota) by Harris response, ties kept: quota + the following entries that equal the quota-th response
+    if (nc > quota) {  // uniform
+      const uint32_t amb = (uint32_t)(ckey[quota - 1] >> 32);  // ordered(float): same order as the responses
+      const float amb_f = sosvo_ordered_float(amb);
+      int more = 0;
+      for (int j = quota + tid; j < nc; j += kThreads) more += sosvo_ordered_float((uint32_t)(ckey[j] >> 32)) >= amb_f;
+      if (more) atomicAdd(&s_keep, more);
     }
     __syncthreads();
-    const int keep = s_keep, base_out = s_nout;
+    const int keep = nc > quota ? quota + s_keep : nc, base_out = s_nout;
     // 6. orientation: one wave per keypoint, lanes 0..30 take the patch rows v = -15..15
     for (int j = wid; j < keep && base_out + j < cap; j += kThreads / 64) {
-      const int cx = (int)(sxy[j] & 0xFFFFu), cy = (int)(sxy[j] >> 16);
+      const unsigned long long key = ckey[j];
+      const uint32_t lin = 0xFFFFFFFFu - (uint32_t)key;
+      const int cy = (int)(lin / (uint32_t)w), cx = (int)(lin - (uint32_t)cy * (uint32_t)w);
       int m10 = 0, m01 = 0;
       if (lane < 2 * kHalfPatch + 1) {
         const int v = lane - kHalfPatch, d = kumax[v < 0 ? -v : v];
@@ -505,7 +674,7 @@ __global__ __launch_bounds__(kThreads) void orb_select_kernel(const uint8_t* __r
         kp4[4 * o + 1] = (float)cy * P.scale[l];
         kp4[4 * o + 2] = fast_atan2_deg((float)m01, (float)m10);
         kp4[4 * o + 3] = (float)l;
-        resp_out[o] = sresp[j];
+        resp_out[o] = sosvo_ordered_float((uint32_t)(key >> 32));
       }
     }
     __syncthreads();
@@ -516,8 +685,8 @@ __global__ __launch_bounds__(kThreads) void orb_select_kernel(const uint8_t* __r
 }
 
 // ---- descriptors of oriented multi-level keypoints ------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void orb_describe_levels_kernel(const uint8_t* __restrict__ blur, Pyr P, int rows,
-                                                                       int cols, int nmask, int cap,
+__global__ __launch_bounds__(kThreads) void orb_describe_levels_kernel(const uint8_t* __restrict__ blur, Pyr P, int nlev_have,
+                                                                       int rows, int cols, int nmask, int cap,
                                                                        float* __restrict__ kp4, int32_t* __restrict__ n_io,
                                                                        const int8_t* __restrict__ pattern,
                                                                        uint8_t* __restrict__ desc,
@@ -545,7 +714,7 @@ __global__ __launch_bounds__(kThreads) void orb_describe_levels_kernel(const uin
       k3 = s[3];
       const int l = (int)k3;
       keep = k0 >= (float)kEdge && k0 < (float)(cols - kEdge) && k1 >= (float)kEdge && k1 < (float)(rows - kEdge) &&
-             l >= 0 && l < P.nlev;
+             l >= 0 && l < nlev_have;  // (levels whose blurred image exists)
     }
     const int pos = sosvo_block_compact_pos(keep, wave_off, &s_running, tid);
     if (keep) {
@@ -618,18 +787,109 @@ Pyr make_pyr(int rows, int cols, int nfeatures) {
     nd *= f;
   }
   P.quota[kLevels - 1] = nfeatures - sum > 0 ? nfeatures - sum : 0;
+  long long foff = 0;
+  int toff = 0;
+  for (int l = 0; l < P.nlev; ++l) {
+    P.det[l] = P.quota[l] > 0 && P.h[l] > 2 * kEdge && P.w[l] > 2 * kEdge;
+    if (P.det[l]) P.ndet = l + 1;
+    P.fstrips[l] = cdiv(P.w[l], kFsStripW);
+    P.foff[l] = foff;
+    foff += (long long)P.h[l] * P.fstrips[l];
+    P.toff[l] = toff;
+    if (l >= 1) toff += P.w[l] + P.h[l];
+  }
+  P.ftotal = foff;
+  P.ttotal = toff;
   return P;
 }
 
-int32_t build_pyramid(sosvo_ctx* ctx, const uint8_t* gray, int nimg, int rows, int cols, const Pyr& P, uint8_t* pyr) {
-  SOSVO_LAUNCH(ctx, copy_level0_kernel, dim3(cdiv(rows * cols, kThreads), nimg), dim3(kThreads), 0, ctx->stream, gray,
-               rows * cols, P.total, pyr);
+// levels 1 .. nlev_build - 1 of every image into `pyr` (level 0 is `gray` itself); `taps`: P.ttotal words of scratch
+int32_t build_pyramid(sosvo_ctx* ctx, const uint8_t* gray, int nimg, int rows, int cols, const Pyr& P, int nlev_build,
+                      uint8_t* pyr, uint32_t* taps) {
+  if (nlev_build <= 1) return SOSVO_OK;
+  int tmax = 0;
+  for (int l = 1; l < nlev_build; ++l) tmax = tmax > P.w[l] + P.h[l] ? tmax : P.w[l] + P.h[l];
+  SOSVO_LAUNCH(ctx, resize_taps_kernel, dim3(cdiv(tmax, kThreads), nlev_build - 1), dim3(kThreads), 0, ctx->stream, P, taps);
   SOSVO_LAUNCH_CHECK(ctx);
-  for (int l = 1; l < P.nlev; ++l) {
-    SOSVO_LAUNCH(ctx, resize_level_kernel, dim3(cdiv(P.h[l] * P.w[l], kThreads), nimg), dim3(kThreads), 0, ctx->stream, pyr,
-                 P.total, P.off[l - 1], P.h[l - 1], P.w[l - 1], P.off[l], P.h[l], P.w[l]);
+  for (int l = 1; l < nlev_build; ++l) {
+    const uint8_t* src = l == 1 ? gray : pyr + P.off[l - 1];
+    const long long src_stride = l == 1 ? (long long)rows * cols : P.total;
+    SOSVO_LAUNCH(ctx, resize_level_kernel, dim3(cdiv(P.w[l], 4 * kThreads), P.h[l], nimg), dim3(kThreads), 0, ctx->stream, src,
+                 src_stride, P.h[l - 1], P.w[l - 1], pyr + P.off[l], P.total, P.h[l], P.w[l], taps + P.toff[l]);
     SOSVO_LAUNCH_CHECK(ctx);
   }
+  return SOSVO_OK;
+}
+
+inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// Scratch layout shared by the three ORB entry points: pyramid levels, FAST scores (same layout), blurred levels (same
+// layout), local-maximum flags, mask bounding boxes, resize taps.
+struct OrbScratch {
+  uint8_t *pyr, *score, *blur;
+  unsigned long long* flags;
+  uint32_t *bbox, *taps;
+  size_t bbox_bytes, bytes;
+};
+OrbScratch orb_scratch(const Pyr& P, int nimg, int nsets, bool detect, bool describe, char* base) {
+  OrbScratch o;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += al256(bytes);
+    return p;
+  };
+  const size_t lv = (size_t)nimg * P.total;
+  o.pyr = (uint8_t*)take(lv);
+  o.score = (uint8_t*)take(detect ? lv : 0);
+  o.blur = (uint8_t*)take(describe ? lv : 0);
+  o.flags = (unsigned long long*)take(detect ? sizeof(unsigned long long) * (size_t)nimg * P.ftotal : 0);
+  o.bbox_bytes = detect ? (size_t)nsets * kLevels * 32 * 4 * sizeof(uint32_t) : 0;
+  o.bbox = (uint32_t*)take(o.bbox_bytes);
+  o.taps = (uint32_t*)take(sizeof(uint32_t) * (size_t)(P.ttotal > 0 ? P.ttotal : 1));
+  o.bytes = off;
+  return o;
+}
+
+// detection on a pyramid whose levels < P.ndet exist: mask bounding boxes, FAST scores + flags of the detection levels
+// (only the rows inside the 31-px border matter: candidates in [31, h - 31), their neighbours one row further), selection
+int32_t run_orb_detect(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* mask_pyr, int nimg, int images_per_maskset, int rows,
+                       int cols, int nmask, int cap, const Pyr& P, const OrbScratch& W, float* kp4, float* resp, int32_t* n) {
+  const int nsets = cdiv(nimg, images_per_maskset);
+  SOSVO_HIP(ctx, hipMemsetAsync(W.bbox, 0, W.bbox_bytes, ctx->stream));
+  int total_rows = 0;
+  for (int l = 0; l < P.nlev; ++l) total_rows += P.h[l];
+  SOSVO_LAUNCH(ctx, orb_mask_bbox_kernel, dim3(total_rows, nsets), dim3(kThreads), 0, ctx->stream, mask_pyr, P, nmask, W.bbox);
+  SOSVO_LAUNCH_CHECK(ctx);
+  for (int l = 0; l < P.ndet; ++l) {
+    if (!P.det[l]) continue;
+    const uint8_t* in = l == 0 ? gray : W.pyr + P.off[l];
+    const long long in_stride = l == 0 ? (long long)rows * cols : P.total;
+    const int32_t rc = launch_fast_score(ctx, in, in_stride, nimg, P.h[l], P.w[l], kFastThr, kEdge - 1, P.h[l] - kEdge + 1,
+                                         W.score + P.off[l], P.total, W.flags + P.foff[l], P.ftotal);
+    if (rc != SOSVO_OK) return rc;
+  }
+  LevelSrc S{gray, W.pyr, (long long)rows * cols, P.total};
+  SOSVO_LAUNCH(ctx, orb_select_kernel, dim3((unsigned)((size_t)nimg * nmask)), dim3(kThreads), 0, ctx->stream, S, W.score,
+               W.flags, mask_pyr, W.bbox, P, images_per_maskset, nmask, cap, kp4, resp, n);
+  SOSVO_LAUNCH_CHECK(ctx);
+  return SOSVO_OK;
+}
+
+// descriptors on a pyramid whose levels < nlev_have exist: blur those levels, border rule, rotated pattern
+int32_t run_orb_describe(sosvo_ctx* ctx, const uint8_t* gray, int nimg, int rows, int cols, int nmask, int cap, const Pyr& P,
+                         int nlev_have, const OrbScratch& W, float* kp4, int32_t* n, const int8_t* pattern, uint8_t* desc,
+                         float* kp_xy) {
+  for (int l = 0; l < nlev_have; ++l) {  // the rolling strip kernel of detect.hip, level by level (same integer arithmetic)
+    const int32_t rc = l == 0 ? sosvo_launch_gauss7_to(ctx, gray, (long long)rows * cols, nimg, rows, cols, W.blur, P.total)
+                              : sosvo_launch_gauss7_to(ctx, W.pyr + P.off[l], P.total, nimg, P.h[l], P.w[l], W.blur + P.off[l],
+                                                       P.total);
+    if (rc != SOSVO_OK) return rc;
+  }
+  SOSVO_LAUNCH(ctx, orb_describe_levels_kernel, dim3((unsigned)((size_t)nimg * nmask)), dim3(kThreads),
+               (size_t)cap * 4 * sizeof(float), ctx->stream, W.blur, P, nlev_have, rows, cols, nmask, cap, kp4, n, pattern, desc,
+               kp_xy);
+  SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
 }
 
@@ -658,45 +918,27 @@ int32_t sosvo_orb_mask_pyramid(sosvo_ctx* ctx, const uint32_t* mask_bits, int32_
   return SOSVO_OK;
 }
 
+#define SOSVO_ORB_DETECT_ARGS_OK(ctx)                                                                                       \
+  SOSVO_REQUIRE(ctx, nimg >= 0 && nimg <= 65535 && images_per_maskset > 0, "nimg out of range");                            \
+  SOSVO_REQUIRE(ctx, rows >= 1 && cols >= 1 && cols < 65536 && rows < 65536 && rows * (int64_t)cols < (1 << 28),            \
+                "image sizes out of range");                                                                                \
+  SOSVO_REQUIRE(ctx, nmask >= 1 && nmask <= 32 && nfeatures >= 1 && cap >= 1 && cap <= 4096, "bad detector parameters")
+
 int32_t sosvo_detect_orb(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* mask_pyr, int32_t nimg,
                          int32_t images_per_maskset, int32_t rows, int32_t cols, int32_t nmask, int32_t nfeatures,
                          int32_t cap, float* kp4, float* resp, int32_t* n) {
   SOSVO_ENTER(ctx);
   SOSVO_REQUIRE(ctx, gray && mask_pyr && kp4 && resp && n, "null pointer");
-  SOSVO_REQUIRE(ctx, nimg >= 0 && nimg <= 65535 && images_per_maskset > 0, "nimg out of range");
-  SOSVO_REQUIRE(ctx, rows >= 1 && cols >= 1 && cols < 65536 && rows < 65536 && rows * (int64_t)cols < (1 << 28),
-                "image sizes out of range");
-  SOSVO_REQUIRE(ctx, nmask >= 1 && nmask <= 32 && nfeatures >= 1 && cap >= 1 && cap <= 4096, "bad detector parameters");
+  SOSVO_ORB_DETECT_ARGS_OK(ctx);
   if (nimg == 0) return SOSVO_OK;
   const Pyr P = make_pyr(rows, cols, nfeatures);
-  const size_t bytes = (size_t)nimg * P.total;
   const int nsets = cdiv(nimg, images_per_maskset);
-  const size_t bbox_bytes = ((size_t)nsets * kLevels * 32 * 4 * sizeof(uint32_t) + 255) & ~(size_t)255;
-  int32_t rc = sosvo_ws_reserve(ctx, 2 * ((bytes + 255) & ~(size_t)255) + bbox_bytes);
+  int32_t rc = sosvo_ws_reserve(ctx, orb_scratch(P, nimg, nsets, true, false, nullptr).bytes);
   if (rc != SOSVO_OK) return rc;
-  uint8_t* pyr = (uint8_t*)ctx->ws;
-  uint8_t* score = pyr + ((bytes + 255) & ~(size_t)255);
-  uint32_t* bbox = (uint32_t*)(score + ((bytes + 255) & ~(size_t)255));
-  rc = build_pyramid(ctx, gray, nimg, rows, cols, P, pyr);
+  const OrbScratch W = orb_scratch(P, nimg, nsets, true, false, (char*)ctx->ws);
+  rc = build_pyramid(ctx, gray, nimg, rows, cols, P, P.ndet, W.pyr, W.taps);
   if (rc != SOSVO_OK) return rc;
-  SOSVO_HIP(ctx, hipMemsetAsync(bbox, 0, bbox_bytes, ctx->stream));
-  int total_rows = 0;
-  for (int l = 0; l < P.nlev; ++l) total_rows += P.h[l];
-  SOSVO_LAUNCH(ctx, orb_mask_bbox_kernel, dim3(total_rows, nsets), dim3(kThreads), 0, ctx->stream, mask_pyr, P, nmask, bbox);
-  SOSVO_LAUNCH_CHECK(ctx);
-  for (int l = 0; l < P.nlev; ++l) {  // only levels that can hold a keypoint (31-px border) and have a quota are scored
-    const int enabled = P.quota[l] > 0 && P.h[l] > 2 * kEdge && P.w[l] > 2 * kEdge;
-    rc = launch_fast_score(ctx, pyr + P.off[l], P.total, nimg, P.h[l], P.w[l], kFastThr, enabled, score + P.off[l]);
-    if (rc != SOSVO_OK) return rc;
-  }
-  SOSVO_LAUNCH(ctx, orb_select_kernel, dim3((unsigned)((size_t)nimg * nmask)), dim3(kThreads), 0, ctx->stream, pyr, score,
-               mask_pyr, bbox, P, images_per_maskset, nmask, cap, kp4, resp, n);
-  SOSVO_LAUNCH_CHECK(ctx);
-  ctx->pyr_gray = gray;  // the pyramid stays at the start of the scratch workspace for sosvo_describe_orb_levels
-  ctx->pyr_nimg = nimg;
-  ctx->pyr_rows = rows;
-  ctx->pyr_cols = cols;
-  return SOSVO_OK;
+  return run_orb_detect(ctx, gray, mask_pyr, nimg, images_per_maskset, rows, cols, nmask, cap, P, W, kp4, resp, n);
 }
 
 int32_t sosvo_describe_orb_levels(sosvo_ctx* ctx, const uint8_t* gray, int32_t nimg, int32_t rows, int32_t cols,
@@ -710,26 +952,36 @@ int32_t sosvo_describe_orb_levels(sosvo_ctx* ctx, const uint8_t* gray, int32_t n
   SOSVO_REQUIRE(ctx, ((uintptr_t)desc & 7) == 0, "desc must be 8-byte aligned");
   if (nimg == 0) return SOSVO_OK;
   const Pyr P = make_pyr(rows, cols, 0);
-  const size_t bytes = (size_t)nimg * P.total;
-  // the pyramid sosvo_detect_orb built from the same images, if nothing has used the scratch workspace since
-  const bool have_pyr = ctx->pyr_gray == (const void*)gray && ctx->pyr_nimg == nimg && ctx->pyr_rows == rows && ctx->pyr_cols == cols;
-  const void* ws_before = ctx->ws;
-  int32_t rc = sosvo_ws_reserve(ctx, 2 * ((bytes + 255) & ~(size_t)255));
+  int32_t rc = sosvo_ws_reserve(ctx, orb_scratch(P, nimg, 1, false, true, nullptr).bytes);
   if (rc != SOSVO_OK) return rc;
-  uint8_t* pyr = (uint8_t*)ctx->ws;
-  uint8_t* blur = pyr + ((bytes + 255) & ~(size_t)255);
-  if (!(have_pyr && ctx->ws == ws_before)) {
-    rc = build_pyramid(ctx, gray, nimg, rows, cols, P, pyr);
-    if (rc != SOSVO_OK) return rc;
-  }
-  for (int l = 0; l < P.nlev; ++l) {  // the rolling strip kernel of detect.hip, level by level (same integer arithmetic)
-    rc = sosvo_launch_gauss7(ctx, pyr + P.off[l], P.total, nimg, P.h[l], P.w[l], blur + P.off[l]);
-    if (rc != SOSVO_OK) return rc;
-  }
-  SOSVO_LAUNCH(ctx, orb_describe_levels_kernel, dim3((unsigned)((size_t)nimg * nmask)), dim3(kThreads),
-               (size_t)cap * 4 * sizeof(float), ctx->stream, blur, P, rows, cols, nmask, cap, kp4, n, pattern, desc, kp_xy);
-  SOSVO_LAUNCH_CHECK(ctx);
-  return SOSVO_OK;
+  const OrbScratch W = orb_scratch(P, nimg, 1, false, true, (char*)ctx->ws);
+  rc = build_pyramid(ctx, gray, nimg, rows, cols, P, P.nlev, W.pyr, W.taps);  // keypoints of any level: the whole pyramid
+  if (rc != SOSVO_OK) return rc;
+  return run_orb_describe(ctx, gray, nimg, rows, cols, nmask, cap, P, P.nlev, W, kp4, n, pattern, desc, kp_xy);
+}
+
+int32_t sosvo_detect_describe_orb(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* mask_pyr, int32_t nimg,
+                                  int32_t images_per_maskset, int32_t rows, int32_t cols, int32_t nmask, int32_t nfeatures,
+                                  int32_t cap, float* kp4, float* resp, int32_t* n, const int8_t* pattern, uint8_t* desc,
+                                  float* kp_xy) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, gray && mask_pyr && kp4 && resp && n && pattern && desc, "null pointer");
+  SOSVO_ORB_DETECT_ARGS_OK(ctx);
+  SOSVO_REQUIRE(ctx, cap <= 2048, "cap out of range (descriptors: <= 2048)");
+  SOSVO_REQUIRE(ctx, ((uintptr_t)desc & 7) == 0, "desc must be 8-byte aligned");
+  if (nimg == 0) return SOSVO_OK;
+  const Pyr P = make_pyr(rows, cols, nfeatures);
+  const int nsets = cdiv(nimg, images_per_maskset);
+  int32_t rc = sosvo_ws_reserve(ctx, orb_scratch(P, nimg, nsets, true, true, nullptr).bytes);
+  if (rc != SOSVO_OK) return rc;
+  const OrbScratch W = orb_scratch(P, nimg, nsets, true, true, (char*)ctx->ws);
+  // ONE pyramid for both halves, built only as far as a keypoint can come from (the levels with a quota and more than the
+  // 31-px border): the detector's keypoints all lie on those levels
+  rc = build_pyramid(ctx, gray, nimg, rows, cols, P, P.ndet, W.pyr, W.taps);
+  if (rc != SOSVO_OK) return rc;
+  rc = run_orb_detect(ctx, gray, mask_pyr, nimg, images_per_maskset, rows, cols, nmask, cap, P, W, kp4, resp, n);
+  if (rc != SOSVO_OK) return rc;
+  return run_orb_describe(ctx, gray, nimg, rows, cols, nmask, cap, P, P.ndet, W, kp4, n, pattern, desc, kp_xy);
 }
 
 int32_t sosvo_detect_fast(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* mask_bits, int32_t nimg,
@@ -750,7 +1002,8 @@ int32_t sosvo_detect_fast(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* m
   uint8_t* score = (uint8_t*)ctx->ws;
   unsigned long long* flags = (unsigned long long*)((char*)ctx->ws + score_bytes);
   {
-    const int32_t rc2 = launch_fast_score(ctx, gray, (long long)rows * cols, nimg, rows, cols, threshold, 1, score);
+    const int32_t rc2 = launch_fast_score(ctx, gray, (long long)rows * cols, nimg, rows, cols, threshold, 0, rows, score,
+                                          (long long)rows * cols, nullptr, 0);
     if (rc2 != SOSVO_OK) return rc2;
   }
   SOSVO_LAUNCH(ctx, fast_nms_flags_kernel, dim3(cdiv(rows * words, kThreads / 64), nimg), dim3(kThreads), 0, ctx->stream, score,

@@ -326,6 +326,27 @@ class Context(object):
                    _ptr(pattern), _ptr(desc), _ptr(kp_xy))
         return desc, kp_xy
 
+    def detect_describe_orb(self, gray, mask_pyr, images_per_maskset, nmask, nfeatures, pattern, kp4, resp, n, desc,
+                            kp_xy=None):
+        """ORB detect + compute in one call on ONE shared pyramid (sosvo_detect_describe_orb): the outputs of detect_orb
+        followed by describe_orb_levels (kp4 / n compacted by the border rule), all buffers caller-provided."""
+        _check(gray, torch.uint8, "gray", ndim=3)
+        NI, rows, cols = gray.shape
+        P = NI * nmask
+        _check(mask_pyr, torch.uint32, "mask_pyr", (None, self.orb_pyramid_pixels(rows, cols)))
+        _check(kp4, torch.float32, "kp4", (P, None, 4))
+        cap = kp4.shape[1]
+        _check(resp, torch.float32, "resp", (P, cap))
+        _check(n, torch.int32, "n", (P,))
+        _check(pattern, torch.int8, "pattern", (512, 2))
+        _check(desc, torch.uint8, "desc", (P, cap, 32))
+        if kp_xy is not None:
+            _check(kp_xy, torch.float32, "kp_xy", (P, cap, 2))
+        self._call(self._lib.sosvo_detect_describe_orb, _ptr(gray), _ptr(mask_pyr), NI, int(images_per_maskset), rows, cols,
+                   int(nmask), int(nfeatures), cap, _ptr(kp4), _ptr(resp), _ptr(n), _ptr(pattern), _ptr(desc),
+                   _ptr(kp_xy) if kp_xy is not None else None)
+        return kp4, resp, n, desc, kp_xy
+
     # ---- K7 ----------------------------------------------------------------------------
     def match_hamming(self, q_desc, t_desc, nq, nt, k=1, keys=None, q_slot=None, t_slot=None):
         """q_desc [Bq, Sq, 32] u8, t_desc [Bt, St, 32] u8, nq [Bq] / nt [Bt] i32 -> keys [P, Sq, k] u32.

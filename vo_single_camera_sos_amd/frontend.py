@@ -124,9 +124,8 @@ class ImageFrontEnd(object):
         """K4 / K5 + K6: keypoints and descriptors per azimuthal mask on the gray panoramas."""
         c, m = self.ctx, self.model
         if self.method == "ORB":
-            c.detect_orb(self.gray, m.mask_pyr, self.F, m.nmask, self.num_of_features, self.kp_cap, kp4=self.kp4,
-                         resp=self.resp, n=self.n)                                                # K5
-            c.describe_orb_levels(self.gray, self.kp4, self.n, m.nmask, m.pattern, desc=self.desc, kp_xy=self.kp)  # K6'
+            c.detect_describe_orb(self.gray, m.mask_pyr, self.F, m.nmask, self.num_of_features, m.pattern, self.kp4,
+                                  self.resp, self.n, self.desc, kp_xy=self.kp)                   # K5 + K6' on one pyramid
             return
         if self.method == "FAST":
             c.detect_fast(self.gray, m.mask_bits, self.F, m.nmask, self.kp_cap, threshold=10, kp=self.kp, n=self.n,
