@@ -137,6 +137,27 @@ def epnp(f, p):
     return T if ok else None
 
 
+def symeig12(A):
+    """Eigen-decomposition of a symmetric 12 x 12 matrix by the EPnP restatement's solver (Householder + implicit QL)
+    -> (eigenvalues [12] unordered, eigenvectors as columns [12,12]) or None."""
+    V = np.array(A, dtype=np.float64, order="C").reshape(12, 12).copy()
+    d = np.zeros(12, dtype=np.float64)
+    L = lib()
+    L.orc_symeig12_solve.restype = ctypes.c_int32
+    ok = L.orc_symeig12_solve(_p(V), _p(d))
+    return (d, V) if ok else None
+
+
+def jacobi12(A):
+    """The eigen-solver EPnP uses (round-robin Jacobi) -> (eigenvalues [12] unordered, eigenvectors as columns [12,12])."""
+    W = np.array(A, dtype=np.float64, order="C").reshape(12, 12).copy()
+    d, V = np.zeros(12, dtype=np.float64), np.zeros((12, 12), dtype=np.float64)
+    L = lib()
+    L.orc_jacobi12_solve.restype = ctypes.c_int32
+    L.orc_jacobi12_solve(_p(W), _p(d), _p(V))
+    return d, V
+
+
 def sample_distinct(n, k, seed, it):
     s = np.zeros(k, dtype=np.int32)
     L = lib()

@@ -6,8 +6,8 @@
  * :915).  OpenGV is not in the reference tree: this is a restatement of the published algorithm (four control points
  * from the principal axes of the world points, barycentric coordinates, the null space of M^T M by a symmetric
  * eigen-decomposition, the three beta initialisations with five Gauss-Newton steps each, absolute orientation, the
- * candidate with the smallest reprojection error), with own numerics: cyclic Jacobi for the symmetric
- * eigen-problems, normal equations for the small least-squares fits, and the rotation from the Jacobi SVD of the
+ * candidate with the smallest reprojection error), with own numerics: Jacobi rotations for the symmetric
+ * eigen-problems (row-cyclic order for the 3 x 3 ones, round-robin order for the 12 x 12 one), normal equations for the small least-squares fits, and the rotation from the Jacobi SVD of the
  * 3x3 correlation matrix completed to a proper rotation by cross products.
  * Only + - * / sqrt and comparisons, fully parenthesised, no FMA contraction: the HIP implementation
  * (vo_single_camera_sos_amd/csrc/epnp_core.h) reproduces every bit.
@@ -64,6 +64,194 @@ static inline void orc_jacobi_sym(double* A, int n, double* V) {
           V[k * n + q] = (s * vkp) + (c * vkq);
         }
       }
+  }
+}
+
+/* A second, independent solver for the 12 x 12 symmetric eigen-problem -- used by the TESTS only, to cross-check the
+ * Jacobi solver below (and both against numpy): Householder reduction to tridiagonal form followed by the QL algorithm
+ * with implicit shifts, both accumulating the transformation (the classic EISPACK tred2 / tql2 pair as published in
+ * Numerical Recipes ch. 11.2-11.3, restated).  ~10 k floating-point operations against ~70 k for Jacobi sweeps; on
+ * the GPU it still lost to Jacobi (measured: 2.3 against 1.3 ms per 256 k matrices), see orc_jacobi12_rr.
+ * A: 12 x 12 row-major, symmetric on entry; on success its COLUMNS are the eigenvectors and d the eigenvalues
+ * (unordered).  e: 12 doubles of scratch.  Returns 0 if an eigenvalue needs more than 30 QL iterations.
+ * Only + - * / sqrt, fabs, comparisons and EXPLICIT fused multiply-adds (fma(): one rounding, the same on both sides;
+ * the inner products and the eigenvector updates are written with it, a third fewer operations), fully parenthesised:
+ * the HIP side repeats every operation in this order. */
+#define ORC_EIG_N 12
+/* a sub-diagonal element counts as zero below this fraction of its neighbours' magnitude: QL converges cubically, the
+ * last iteration of an eigenvalue would take it from ~1e-8 to ~1e-24 for nothing a RANSAC hypothesis can use */
+#define ORC_EIG_EPS 1e-12
+static inline int orc_symeig12(double* A, double* d, double* e) {
+  const int n = ORC_EIG_N;
+  /* ---- Householder reduction; A becomes the orthogonal matrix Q of the reduction ---- */
+  for (int i = n - 1; i >= 1; --i) {
+    const int l = i - 1;
+    double h = 0.0, scale = 0.0;
+    if (l > 0) {
+      for (int k = 0; k <= l; ++k) scale = scale + fabs(A[i * n + k]);
+      if (scale == 0.0) {
+        e[i] = A[i * n + l];
+      } else {
+        for (int k = 0; k <= l; ++k) {
+          A[i * n + k] = A[i * n + k] / scale;
+          h = h + (A[i * n + k] * A[i * n + k]);
+        }
+        double f = A[i * n + l];
+        double g = f >= 0.0 ? -sqrt(h) : sqrt(h);
+        e[i] = scale * g;
+        h = h - (f * g);
+        A[i * n + l] = f - g;
+        f = 0.0;
+        for (int j = 0; j <= l; ++j) {
+          A[j * n + i] = A[i * n + j] / h;
+          g = 0.0;
+          for (int k = 0; k <= j; ++k) g = fma(A[j * n + k], A[i * n + k], g);
+          for (int k = j + 1; k <= l; ++k) g = fma(A[k * n + j], A[i * n + k], g);
+          e[j] = g / h;
+          f = f + (e[j] * A[i * n + j]);
+        }
+        const double hh = f / (h + h);
+        for (int j = 0; j <= l; ++j) {
+          f = A[i * n + j];
+          g = e[j] - (hh * f);
+          e[j] = g;
+          for (int k = 0; k <= j; ++k) A[j * n + k] = A[j * n + k] - fma(f, e[k], g * A[i * n + k]);
+        }
+      }
+    } else {
+      e[i] = A[i * n + l];
+    }
+    d[i] = h;
+  }
+  d[0] = 0.0;
+  e[0] = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const int l = i - 1;
+    if (d[i] != 0.0) {
+      for (int j = 0; j <= l; ++j) {
+        double g = 0.0;
+        for (int k = 0; k <= l; ++k) g = fma(A[i * n + k], A[k * n + j], g);
+        for (int k = 0; k <= l; ++k) A[k * n + j] = fma(-g, A[k * n + i], A[k * n + j]);
+      }
+    }
+    d[i] = A[i * n + i];
+    A[i * n + i] = 1.0;
+    for (int j = 0; j <= l; ++j) {
+      A[j * n + i] = 0.0;
+      A[i * n + j] = 0.0;
+    }
+  }
+  /* ---- QL with implicit shifts on (d, e), rotations accumulated into the columns of A ---- */
+  for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+  e[n - 1] = 0.0;
+  for (int l = 0; l < n; ++l) {
+    int iter = 0, m;
+    do {
+      for (m = l; m < n - 1; ++m) {
+        const double dd = fabs(d[m]) + fabs(d[m + 1]);
+        if (fabs(e[m]) <= (ORC_EIG_EPS * dd)) break;
+      }
+      if (m != l) {
+        if (iter++ == 30) return 0;
+        double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+        double r = sqrt((g * g) + 1.0);
+        g = (d[m] - d[l]) + (e[l] / (g + (g >= 0.0 ? r : -r)));
+        double s = 1.0, c = 1.0, p = 0.0;
+        int i;
+        for (i = m - 1; i >= l; --i) {
+          double f = s * e[i];
+          const double b = c * e[i];
+          r = sqrt((f * f) + (g * g));
+          e[i + 1] = r;
+          if (r == 0.0) {
+            d[i + 1] = d[i + 1] - p;
+            e[m] = 0.0;
+            break;
+          }
+          s = f / r;
+          c = g / r;
+          g = d[i + 1] - p;
+          r = ((d[i] - g) * s) + ((2.0 * c) * b);
+          p = s * r;
+          d[i + 1] = g + p;
+          g = (c * r) - b;
+          for (int k = 0; k < n; ++k) {
+            f = A[k * n + i + 1];
+            const double zi = A[k * n + i];
+            A[k * n + i + 1] = fma(s, zi, c * f);
+            A[k * n + i] = fma(c, zi, -(s * f));
+          }
+        }
+        if (r == 0.0 && i >= l) continue;
+        d[l] = d[l] - p;
+        e[l] = g;
+        e[m] = 0.0;
+      }
+    } while (m != l);
+  }
+  return 1;
+}
+
+/* The eigen-solver EPnP actually uses for M^T M: Jacobi rotations in ROUND-ROBIN order (the circle method of a
+ * tournament with 12 players: 11 rounds of 6 pairs whose index sets are disjoint; pair i of round r is (r, 11) for
+ * i = 0 and ((r + i) mod 11, (r - i) mod 11) otherwise, smaller index first).  On a SIMD machine Jacobi beats the QL
+ * solver above although it costs ~7x the arithmetic: every lane of a wave does the same work per sweep (QL's iteration
+ * counts differ from lane to lane and the wave pays for the slowest), and the rotations of a round commute as far as
+ * their angles go -- a rotation in the (p, q) plane leaves app, aqq, apq of a disjoint pair untouched -- so a lane
+ * evaluates the six divide / square-root chains of a round side by side and then applies the rotations one after the
+ * other, with exactly the result of this sequential loop.  A: 12 x 12 row-major symmetric (destroyed: its diagonal
+ * ends as the eigenvalues), V: eigenvectors as columns.  Sweeps stop when the off-diagonal mass is below 1e-26 of the
+ * diagonal's (squared norms): eigenvectors to ~1e-13, far inside what a RANSAC hypothesis needs. */
+#define ORC_JACOBI12_TOL 1e-26
+static inline int orc_rr_first(int idx) {
+  const int r = idx / 6, i = idx % 6;
+  const int a = i == 0 ? r : (r + i) % 11, b = i == 0 ? 11 : (r - i + 11) % 11;
+  return a < b ? a : b;
+}
+static inline int orc_rr_second(int idx) {
+  const int r = idx / 6, i = idx % 6;
+  const int a = i == 0 ? r : (r + i) % 11, b = i == 0 ? 11 : (r - i + 11) % 11;
+  return a < b ? b : a;
+}
+static inline void orc_jacobi12_rr(double* A, double* V) {
+  const int n = 12;
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0, diag = 0.0;
+    for (int p = 0; p < n; ++p) {
+      diag = diag + (A[p * n + p] * A[p * n + p]);
+      for (int q = p + 1; q < n; ++q) off = off + (A[p * n + q] * A[p * n + q]);
+    }
+    if (!(off > (ORC_JACOBI12_TOL * diag))) break;
+    for (int idx = 0; idx < 66; ++idx) {
+      const int p = orc_rr_first(idx), q = orc_rr_second(idx);
+      const double apq = A[p * n + q];
+      if (apq == 0.0) continue;
+      const double app = A[p * n + p], aqq = A[q * n + q];
+      const double theta = (aqq - app) / (2.0 * apq);
+      const double at = theta < 0.0 ? -theta : theta;
+      const double t = (theta < 0.0 ? -1.0 : 1.0) / (at + sqrt((theta * theta) + 1.0));
+      const double c = 1.0 / sqrt((t * t) + 1.0), s = t * c;
+      for (int k = 0; k < n; ++k) {
+        if (k == p || k == q) continue;
+        const double akp = A[k * n + p], akq = A[k * n + q];
+        const double x = (c * akp) - (s * akq), y = (s * akp) + (c * akq);
+        A[k * n + p] = x;
+        A[p * n + k] = x;
+        A[k * n + q] = y;
+        A[q * n + k] = y;
+      }
+      A[p * n + p] = app - (t * apq);
+      A[q * n + q] = aqq + (t * apq);
+      A[p * n + q] = 0.0;
+      A[q * n + p] = 0.0;
+      for (int k = 0; k < n; ++k) {
+        const double vkp = V[k * n + p], vkq = V[k * n + q];
+        V[k * n + p] = (c * vkp) - (s * vkq);
+        V[k * n + q] = (s * vkp) + (c * vkq);
+      }
+    }
   }
 }
 
@@ -236,7 +424,7 @@ static inline int orc_epnp(const double* f, const double* p, int n, double* R, d
     alphas[4 * i] = ((1.0 - alphas[4 * i + 1]) - alphas[4 * i + 2]) - alphas[4 * i + 3];
   }
   /* M^T M (12 x 12): two rows per point, [a_j, 0, -a_j u] and [0, a_j, -a_j v] for j = 0..3 */
-  double MtM[144], Ev[144];
+  double MtM[144];
   for (int k = 0; k < 144; ++k) MtM[k] = 0.0;
   for (int i = 0; i < n; ++i) {
     double r1[12], r2[12];
@@ -252,21 +440,19 @@ static inline int orc_epnp(const double* f, const double* p, int n, double* R, d
     for (int r = 0; r < 12; ++r)
       for (int c = 0; c < 12; ++c) MtM[12 * r + c] = (MtM[12 * r + c] + (r1[r] * r1[c])) + (r2[r] * r2[c]);
   }
-  orc_jacobi_sym(MtM, 12, Ev);
-  /* the four eigenvectors of the smallest eigenvalues: vv[0] smallest */
-  int idx[12];
-  for (int k = 0; k < 12; ++k) idx[k] = k;
-  for (int a = 0; a < 4; ++a) { /* partial selection sort, ties keep the lower index */
-    int m = a;
-    for (int b = a + 1; b < 12; ++b)
-      if (MtM[13 * idx[b]] < MtM[13 * idx[m]]) m = b;
-    const int tmp = idx[a];
-    idx[a] = idx[m];
-    idx[m] = tmp;
-  }
+  double evals[12], Ev[144];
+  orc_jacobi12_rr(MtM, Ev);
+  for (int k = 0; k < 12; ++k) evals[k] = MtM[13 * k];
+  /* the four eigenvectors of the smallest eigenvalues, vv[0] the smallest: eigenvalue k has rank = the number of
+   * eigenvalues below it (equal ones: those with a lower index) */
   double vv[48];
-  for (int a = 0; a < 4; ++a)
-    for (int j = 0; j < 12; ++j) vv[12 * a + j] = Ev[12 * j + idx[a]];
+  for (int k = 0; k < 12; ++k) {
+    int rank = 0;
+    for (int j = 0; j < 12; ++j)
+      if (evals[j] < evals[k] || (evals[j] == evals[k] && j < k)) rank++;
+    if (rank < 4)
+      for (int j = 0; j < 12; ++j) vv[12 * rank + j] = Ev[12 * j + k];
+  }
   /* L (6 x 10) and rho (6) over the control-point pairs */
   const int pa[6] = {0, 0, 0, 1, 1, 2}, pb[6] = {1, 2, 3, 2, 3, 3};
   double L[60], rho[6];
@@ -378,13 +564,18 @@ static inline int orc_sample_distinct(int32_t n, int k, uint64_t seed, uint64_t 
   int32_t taken[8]; /* ascending */
   for (int j = 0; j < k; ++j) {
     int32_t v = (int32_t)orc_below(orc_mix64(seed, it, (uint64_t)j), (uint32_t)(n - j));
-    int pos = 0;
-    while (pos < j && v >= taken[pos]) { /* skip the values already taken */
-      v++;
-      pos++;
+    int skipping = 1;
+    for (int pos = 0; pos < j; ++pos) { /* skip the values already taken */
+      if (skipping && v >= taken[pos]) v++;
+      else skipping = 0;
     }
-    for (int q = j; q > pos; --q) taken[q] = taken[q - 1];
-    taken[pos] = v;
+    taken[j] = v;
+    for (int q = j; q > 0; --q) /* keep `taken` ascending: the new value sinks to its place */
+      if (taken[q - 1] > taken[q]) {
+        const int32_t tmp = taken[q - 1];
+        taken[q - 1] = taken[q];
+        taken[q] = tmp;
+      }
     s[j] = v;
   }
   return 1;

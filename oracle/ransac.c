@@ -317,6 +317,19 @@ int32_t orc_epnp_solve(const double* f, const double* p, int32_t n, double* T_ou
   return ok;
 }
 
+/* The 12 x 12 symmetric eigen-solver of EPnP on its own (unit tests): A [144] in / eigenvectors (columns) out, d [12]. */
+int32_t orc_symeig12_solve(double* A, double* d) {
+  double e[12];
+  return orc_symeig12(A, d, e);
+}
+
+/* ... and the Jacobi solver EPnP uses: A [144] in (destroyed), d [12] eigenvalues, V [144] eigenvectors as columns. */
+int32_t orc_jacobi12_solve(double* A, double* d, double* V) {
+  orc_jacobi12_rr(A, V);
+  for (int k = 0; k < 12; ++k) d[k] = A[13 * k];
+  return 1;
+}
+
 int32_t orc_sample_distinct_once(int32_t n, int32_t k, uint64_t seed, int32_t it, int32_t* s) {
   return orc_sample_distinct(n, k, seed, (uint64_t)it, s);
 }

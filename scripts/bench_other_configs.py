@@ -30,6 +30,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--pairs", type=int, default=128)
+    ap.add_argument("--only", default="", help="C3 or C5: run just that configuration")
     args = ap.parse_args()
     from vo_single_camera_sos_amd import synthetic
     from vo_single_camera_sos_amd.omnistereo.gum import synthetic_gums
@@ -40,9 +41,10 @@ def main():
         m.panorama = Panorama(m, width=2400)
     gs.make_annulus_masks((960, 1280))
     uniq = 4
-    omni3 = np.stack([synthetic.render_omni(gs, synthetic.Room(seed=70 + i, cells=(180.0, 45.0)), np.eye(3), np.zeros(3), 2.0,
+    omni3 = None if args.only == "C5" else np.stack([synthetic.render_omni(gs, synthetic.Room(seed=70 + i, cells=(180.0, 45.0)), np.eye(3), np.zeros(3), 2.0,
                                             np.random.default_rng(70 + i)) for i in range(uniq)])
-    omni3 = np.concatenate([omni3] * (-(-args.frames // uniq)))[: args.frames]
+    if omni3 is not None:
+        omni3 = np.concatenate([omni3] * (-(-args.frames // uniq)))[: args.frames]
     B = args.pairs
     bgr, depth = [], []
     for i in range(min(B, 16)):
@@ -61,32 +63,36 @@ def main():
     from vo_single_camera_sos_amd.frontend import DeviceImageModel, ImageFrontEnd
     from vo_single_camera_sos_amd.pipeline import FramePairPipeline, RGBDCamConfig, RGBDPairBatch, RigConfig
     ctx = Context(0)
-    # ---- C3
-    F = args.frames
-    model = DeviceImageModel(ctx, gs, (960, 1280))
-    fe = ImageFrontEnd(ctx, model, F, num_of_features=1000, kp_cap=1024, keep_panoramas=False)
-    pano = gs.top_model.panorama
-    geo = (pano.cols, pano.rows, pano.pixel_size, pano.cyl_height_max)
-    rig = RigConfig(pano_top=geo, pano_bot=geo, F_top=gs.top_model.F[:3, 0], F_bot=gs.bot_model.F[:3, 0], min_range=500.0,
-                    max_range=7000.0, stereo_min_disp=1.0, stereo_max_hdiff=2.5, f2f_max_hdiff=0.125 * 0.5 * pano.cols,
-                    pct_good_matches=1.0)
-    pipe = FramePairPipeline(ctx, rig, F // 2, frame_cap=8192, max_iter=10, seed=0, front_end=fe)
-    fe.load_frames(omni3)
-    h = F * model.nmask
-    keys2 = torch.zeros((h, fe.kp_cap, 2), dtype=torch.uint32, device=ctx.device)
+    if args.only != "C5":
+        # ---- C3
+        F = args.frames
+        model = DeviceImageModel(ctx, gs, (960, 1280))
+        fe = ImageFrontEnd(ctx, model, F, num_of_features=1000, kp_cap=1024, keep_panoramas=False)
+        pano = gs.top_model.panorama
+        geo = (pano.cols, pano.rows, pano.pixel_size, pano.cyl_height_max)
+        rig = RigConfig(pano_top=geo, pano_bot=geo, F_top=gs.top_model.F[:3, 0], F_bot=gs.bot_model.F[:3, 0], min_range=500.0,
+                        max_range=7000.0, stereo_min_disp=1.0, stereo_max_hdiff=2.5, f2f_max_hdiff=0.125 * 0.5 * pano.cols,
+                        pct_good_matches=1.0)
+        pipe = FramePairPipeline(ctx, rig, F // 2, frame_cap=8192, max_iter=10, seed=0, front_end=fe)
+        fe.load_frames(omni3)
+        h = F * model.nmask
+        keys2 = torch.zeros((h, fe.kp_cap, 2), dtype=torch.uint32, device=ctx.device)
 
-    def c3_step():
-        fe.run()
-        ctx.match_hamming(pipe.desc_bot, pipe.desc_top, pipe.n_bot, pipe.n_top, k=2, keys=keys2)  # the ratio rule's 2-NN
-        pipe.stereo()                                                                           # 1-NN keys, sort, gates, triangulation
-    dt = timed(c3_step, ctx.synchronize)
-    n_view = fe.n.cpu().numpy().reshape(2, F, model.nmask).sum(-1).mean()
-    M = pipe.frames["M"].cpu().numpy().mean()
-    print(json.dumps({"config": "C3", "metric": "frames/s (unwrap + median + GFT + ORB descriptors + 2-NN bucket matching + triangulation), 1280x960 omni",
-                      "value": F / dt, "ms_per_step": 1e3 * dt, "frames_per_step": F, "keypoints_per_view": float(n_view),
-                      "stereo_points_per_frame": float(M), "data": "synthetic (%d distinct frames tiled)" % uniq}))
-    del fe, pipe, keys2
+        def c3_step():
+            fe.run()
+            ctx.match_hamming(pipe.desc_bot, pipe.desc_top, pipe.n_bot, pipe.n_top, k=2, keys=keys2)  # the ratio rule's 2-NN
+            pipe.stereo()                                                                           # 1-NN keys, sort, gates, triangulation
+        dt = timed(c3_step, ctx.synchronize)
+        n_view = fe.n.cpu().numpy().reshape(2, F, model.nmask).sum(-1).mean()
+        M = pipe.frames["M"].cpu().numpy().mean()
+        print(json.dumps({"config": "C3", "metric": "frames/s (unwrap + median + GFT + ORB descriptors + 2-NN bucket matching + triangulation), 1280x960 omni",
+                          "value": F / dt, "ms_per_step": 1e3 * dt, "frames_per_step": F, "keypoints_per_view": float(n_view),
+                          "stereo_points_per_frame": float(M), "data": "synthetic (%d distinct frames tiled)" % uniq}))
+        del fe, pipe, keys2
     # ---- C5
+    if args.only == "C3":
+        ctx.close()
+        return
     cam = RGBDCamConfig(fx=554.256258, fy=554.256258, center_x=319.5, center_y=239.5, depth_is_Z=True, min_range=0.8, max_range=7.0)
     for algo in ("EPNP", "KNEIP"):
         one = RGBDPairBatch(ctx, cam, B, num_of_features=2000, max_iter=2000, seed=1, pose_est_algorithm=algo)

@@ -123,7 +123,7 @@ def test_epnp_recovers_known_poses_and_sampler_is_distinct():
         T = oracle.epnp(f, P)
         assert T is not None
         worst = max(worst, np.abs(T[:, :3] - R).max(), np.abs(T[:, 3] - t).max())
-    assert worst < 1e-9, worst
+    assert worst < 2e-7, worst   # (Jacobi sweeps stop at off / diag < 1e-13, ORC_JACOBI12_TOL: 6e-8 here; 1e-9 with 1e-20)
     assert oracle.epnp(np.ones((4, 3)), np.ones((4, 3))) is None and oracle.sample_distinct(5, 6, 1, 0) is None
     for it in range(50):
         s = oracle.sample_distinct(9, 6, 123, it)
@@ -137,3 +137,33 @@ def test_epnp_recovers_known_poses_and_sampler_is_distinct():
     assert r["status"] == 0 and r["n_inliers"] >= 340 and synth.pose_error(r["T"], pr["R"], pr["t"])[0] < np.deg2rad(3.0)
     ra = oracle.ransac_abs_pose(pr["f"], pr["p"], synth.THR_5DEG, 2000, seed=4, epnp=True, adaptive=True)
     assert ra["iters_used"] < 2000 and ra["n_inliers"] >= 340
+
+
+def test_eigen_solvers_against_numpy_eigh_and_each_other():
+    """The 12 x 12 eigen-solver EPnP uses (round-robin Jacobi) and the independent Householder + implicit-QL solver of
+    the oracle, both against numpy.linalg.eigh and against each other (invariant subspaces of the four smallest
+    eigenvalues).  Random symmetric matrices, Gram matrices with a near-null space like EPnP's M^T M, repeated
+    eigenvalues, a diagonal and the zero matrix."""
+    rng = np.random.default_rng(11)
+    cases = []
+    for _ in range(40):
+        B = rng.normal(size=(12, 12))
+        cases.append(B + B.T)
+    for _ in range(40):                                  # rank-deficient Gram matrices + noise
+        M = rng.normal(size=(12, 12)) * rng.uniform(0.01, 100.0)
+        M[:, 8:] = M[:, :4] @ rng.normal(size=(4, 4)) + 1e-7 * rng.normal(size=(12, 4))
+        cases.append(M.T @ M)
+    Q, _ = np.linalg.qr(rng.normal(size=(12, 12)))
+    cases.append(Q @ np.diag([1, 1, 1, 2, 2, 3, 3, 3, 3, 5, 8, 8.0]) @ Q.T)
+    cases.append(np.diag(np.arange(12.0)))
+    cases.append(np.zeros((12, 12)))
+    for A in cases:
+        A = 0.5 * (A + A.T)
+        got = oracle.symeig12(A)
+        assert got is not None
+        w = np.linalg.eigvalsh(A)
+        scale = max(1.0, np.abs(w).max())
+        for d, V in (got, oracle.jacobi12(A)):
+            assert np.allclose(np.sort(d), w, rtol=0, atol=1e-12 * scale)
+            assert np.allclose(V.T @ V, np.eye(12), atol=1e-12)                 # orthonormal columns
+            assert np.allclose(A @ V, V * d[None, :], atol=1e-11 * scale)       # A v_k = d_k v_k

@@ -248,74 +248,39 @@ __device__ static double sv_epnp_pose_from_betas(const double* betas, const doub
   return (err == err) ? err : -1.0;
 }
 
-/* The four eigenvectors of M^T M with the smallest eigenvalues (vv[0] the smallest), work arrays in memory:
- * MtM, Ev = 144 doubles each at stride S (private arrays or lane-interleaved LDS). */
-template <int S>
-__device__ static void sv_epnp_null4_mem(const double* alphas, const double* uv, int n, double* MtM, double* Ev, double* vv) {
-  /* M^T M (12 x 12): two rows per point, [a_j, 0, -a_j u] and [0, a_j, -a_j v] for j = 0..3 */
-  for (int k = 0; k < 144; ++k) MtM[k * S] = 0.0;
-  for (int i = 0; i < n; ++i) {
-    double r1[12], r2[12];
-    for (int j = 0; j < 4; ++j) {
-      const double a = alphas[4 * i + j];
-      r1[3 * j] = a;
-      r1[3 * j + 1] = 0.0;
-      r1[3 * j + 2] = -(a * uv[2 * i]);
-      r2[3 * j] = 0.0;
-      r2[3 * j + 1] = a;
-      r2[3 * j + 2] = -(a * uv[2 * i + 1]);
-    }
-    for (int r = 0; r < 12; ++r)
-      for (int c = 0; c < 12; ++c) MtM[(12 * r + c) * S] = (MtM[(12 * r + c) * S] + (r1[r] * r1[c])) + (r2[r] * r2[c]);
-  }
-  sv_jacobi_sym_s<S>(MtM, 12, Ev);
-  /* the four eigenvectors of the smallest eigenvalues: vv[0] smallest */
-  int idx[12];
-  for (int k = 0; k < 12; ++k) idx[k] = k;
-  for (int a = 0; a < 4; ++a) { /* partial selection sort, ties keep the lower index */
-    int m = a;
-    for (int b = a + 1; b < 12; ++b)
-      if (MtM[(13 * idx[b]) * S] < MtM[(13 * idx[m]) * S]) m = b;
-    const int tmp = idx[a];
-    idx[a] = idx[m];
-    idx[m] = tmp;
-  }
-  for (int a = 0; a < 4; ++a)
-    for (int j = 0; j < 12; ++j) vv[12 * a + j] = Ev[(12 * j + idx[a]) * S];
+/* The 12 x 12 symmetric eigen-problem of EPnP (M^T M): Jacobi rotations in round-robin order (oracle/epnp_core.h,
+ * orc_jacobi12_rr: the same operations in the same order).  Pair i of round r is (r, 11) for i = 0 and
+ * ((r + i) mod 11, (r - i) mod 11) otherwise, smaller index first. */
+#define SV_JACOBI12_TOL 1e-26
+__device__ constexpr int sv_rr_first(int idx) {
+  const int r = idx / 6, i = idx % 6;
+  const int a = i == 0 ? r : (r + i) % 11, b = i == 0 ? 11 : (r - i + 11) % 11;
+  return a < b ? a : b;
 }
-
-/* The same stage with the symmetric matrix in REGISTERS (upper triangle, 78 doubles) and only the eigenvector matrix
- * in LDS (Vl, 144 doubles at stride S): every index into the matrix is a compile-time constant -- the 66 rotation
- * pairs of a sweep are unrolled by a fold -- so the matrix needs no memory at all, a rotation costs 24 LDS loads + 24
- * stores instead of 64 + 64, and a 64-lane wave needs 72 KB of LDS instead of 144.  Operation for operation the
- * arithmetic of sv_epnp_null4_mem / sv_jacobi_sym_s (mirrored entries are the same value there). */
+__device__ constexpr int sv_rr_second(int idx) {
+  const int r = idx / 6, i = idx % 6;
+  const int a = i == 0 ? r : (r + i) % 11, b = i == 0 ? 11 : (r - i + 11) % 11;
+  return a < b ? b : a;
+}
+/* index of element (i, j) of a symmetric 12 x 12 matrix kept as its upper triangle (78 entries) */
 __device__ constexpr int sv_tri(int i, int j) { return i <= j ? i * 12 - i * (i - 1) / 2 + (j - i) : j * 12 - j * (j - 1) / 2 + (i - j); }
-__device__ constexpr int sv_pair_p(int idx) {
-  int p = 0;
-  while (idx >= 11 - p) {
-    idx -= 11 - p;
-    ++p;
-  }
-  return p;
-}
-__device__ constexpr int sv_pair_q(int idx) {
-  int p = 0;
-  while (idx >= 11 - p) {
-    idx -= 11 - p;
-    ++p;
-  }
-  return p + 1 + idx;
-}
-template <typename F, int... I>
-__device__ __forceinline__ void sv_for_each_pair(F& f, std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, sv_pair_p(I)>{}, std::integral_constant<int, sv_pair_q(I)>{}), ...);
+template <typename F, int... R>
+__device__ __forceinline__ void sv_for_each_round(F& f, std::integer_sequence<int, R...>) {
+  (f(std::integral_constant<int, R>{}), ...);
 }
 
-template <int S>
-__device__ static void sv_epnp_null4_reg(const double* alphas, const double* uv, int n, double* Vl, double* vv) {
-  double a[78];
+/* EVERYTHING IN REGISTERS: the symmetric matrix as its upper triangle (a, 78 doubles; built from the barycentric
+ * coordinates: two rows of M per point, [a_j, 0, -a_j u] and [0, a_j, -a_j v]) and the eigenvector matrix V (144
+ * doubles) -- a wave that has a SIMD to itself owns 512 registers per lane.  Every index is a compile-time constant: the
+ * 11 rounds of a sweep are unrolled by a fold.  The six rotations of a round have disjoint index pairs, so their angles
+ * -- two divisions and two square roots in a chain, the longest dependency of the solver -- are evaluated side by side
+ * before the rotations are applied one after the other.  -> vv: the four eigenvectors of the smallest eigenvalues, vv[0]
+ * the smallest (eigenvalue k has rank = the number of eigenvalues below it; equal ones: those with a lower index). */
+__device__ static void sv_epnp_null4_reg(const double* alphas, const double* uv, int n, double* vv) {
+  double a[78], V[144];
 #pragma unroll
   for (int k = 0; k < 78; ++k) a[k] = 0.0;
+#pragma unroll
   for (int i = 0; i < n; ++i) {
     double r1[12], r2[12];
 #pragma unroll
@@ -336,7 +301,7 @@ __device__ static void sv_epnp_null4_reg(const double* alphas, const double* uv,
 #pragma unroll
   for (int i = 0; i < 12; ++i)
 #pragma unroll
-    for (int j = 0; j < 12; ++j) Vl[(i * 12 + j) * S] = (i == j) ? 1.0 : 0.0;
+    for (int j = 0; j < 12; ++j) V[i * 12 + j] = (i == j) ? 1.0 : 0.0;
   for (int sweep = 0; sweep < 60; ++sweep) {
     double off = 0.0, diag = 0.0;
 #pragma unroll
@@ -345,63 +310,75 @@ __device__ static void sv_epnp_null4_reg(const double* alphas, const double* uv,
 #pragma unroll
       for (int q = p + 1; q < 12; ++q) off = off + (a[sv_tri(p, q)] * a[sv_tri(p, q)]);
     }
-    if (!(off > (1e-40 * diag))) break;
-    auto rotate = [&](auto p_tag, auto q_tag) __attribute__((always_inline)) {
-      constexpr int P = decltype(p_tag)::value, Q = decltype(q_tag)::value;
-      const double apq = a[sv_tri(P, Q)];
-      if (apq == 0.0) return;
-      const double app = a[sv_tri(P, P)], aqq = a[sv_tri(Q, Q)];
-      double yp[12], yq[12];
+    if (!(off > (SV_JACOBI12_TOL * diag))) break;
+    auto round = [&](auto r_tag) __attribute__((always_inline)) {
+      constexpr int R = decltype(r_tag)::value;
+      double tt[6], cc[6], ss[6];
+      bool on[6];
 #pragma unroll
-      for (int k = 0; k < 12; ++k) {
-        yp[k] = Vl[(k * 12 + P) * S];
-        yq[k] = Vl[(k * 12 + Q) * S];
+      for (int i = 0; i < 6; ++i) {  // the six angle chains of the round, independent of each other
+        const int P = sv_rr_first(6 * R + i), Q = sv_rr_second(6 * R + i);
+        const double apq = a[sv_tri(P, Q)], app = a[sv_tri(P, P)], aqq = a[sv_tri(Q, Q)];
+        on[i] = apq != 0.0;
+        const double theta = (aqq - app) / (2.0 * apq);
+        const double at = theta < 0.0 ? -theta : theta;
+        tt[i] = (theta < 0.0 ? -1.0 : 1.0) / (at + sqrt((theta * theta) + 1.0));
+        cc[i] = 1.0 / sqrt((tt[i] * tt[i]) + 1.0);
+        ss[i] = tt[i] * cc[i];
       }
-      const double theta = (aqq - app) / (2.0 * apq);
-      const double at = theta < 0.0 ? -theta : theta;
-      const double t = (theta < 0.0 ? -1.0 : 1.0) / (at + sqrt((theta * theta) + 1.0));
-      const double c = 1.0 / sqrt((t * t) + 1.0), s = t * c;
 #pragma unroll
-      for (int k = 0; k < 12; ++k) {
-        if (k == P || k == Q) continue;
-        const double akp = a[sv_tri(k, P)], akq = a[sv_tri(k, Q)];
-        a[sv_tri(k, P)] = (c * akp) - (s * akq);
-        a[sv_tri(k, Q)] = (s * akp) + (c * akq);
-      }
-      a[sv_tri(P, P)] = app - (t * apq);
-      a[sv_tri(Q, Q)] = aqq + (t * apq);
-      a[sv_tri(P, Q)] = 0.0;
+      for (int i = 0; i < 6; ++i) {  // the rotations, one after the other
+        const int P = sv_rr_first(6 * R + i), Q = sv_rr_second(6 * R + i);
+        if (!on[i]) continue;
+        const double c = cc[i], s = ss[i], t = tt[i];
+        const double apq = a[sv_tri(P, Q)], app = a[sv_tri(P, P)], aqq = a[sv_tri(Q, Q)];
 #pragma unroll
-      for (int k = 0; k < 12; ++k) {
-        Vl[(k * 12 + P) * S] = (c * yp[k]) - (s * yq[k]);
-        Vl[(k * 12 + Q) * S] = (s * yp[k]) + (c * yq[k]);
+        for (int k = 0; k < 12; ++k) {
+          if (k == P || k == Q) continue;
+          const double akp = a[sv_tri(k, P)], akq = a[sv_tri(k, Q)];
+          a[sv_tri(k, P)] = (c * akp) - (s * akq);
+          a[sv_tri(k, Q)] = (s * akp) + (c * akq);
+        }
+        a[sv_tri(P, P)] = app - (t * apq);
+        a[sv_tri(Q, Q)] = aqq + (t * apq);
+        a[sv_tri(P, Q)] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+          const double vkp = V[k * 12 + P], vkq = V[k * 12 + Q];
+          V[k * 12 + P] = (c * vkp) - (s * vkq);
+          V[k * 12 + Q] = (s * vkp) + (c * vkq);
+        }
       }
     };
-    sv_for_each_pair(rotate, std::make_integer_sequence<int, 66>{});
+    sv_for_each_round(round, std::make_integer_sequence<int, 11>{});
   }
-  double ev[12];
+  int rank[12];
 #pragma unroll
-  for (int k = 0; k < 12; ++k) ev[k] = a[sv_tri(k, k)];
-  int idx[12];
-  for (int k = 0; k < 12; ++k) idx[k] = k;
-  for (int a4 = 0; a4 < 4; ++a4) { /* partial selection sort, ties keep the lower index */
-    int m = a4;
-    for (int b = a4 + 1; b < 12; ++b)
-      if (ev[idx[b]] < ev[idx[m]]) m = b;
-    const int tmp = idx[a4];
-    idx[a4] = idx[m];
-    idx[m] = tmp;
+  for (int k = 0; k < 12; ++k) {
+    int rk = 0;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const double ej = a[sv_tri(j, j)], ek = a[sv_tri(k, k)];
+      rk += (ej < ek || (ej == ek && j < k)) ? 1 : 0;
+    }
+    rank[k] = rk;
   }
-  for (int a4 = 0; a4 < 4; ++a4)
-    for (int j = 0; j < 12; ++j) vv[12 * a4 + j] = Vl[(12 * j + idx[a4]) * S];
+#pragma unroll
+  for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) v = rank[k] == r4 ? V[12 * j + k] : v;
+      vv[12 * r4 + j] = v;
+    }
 }
 
-/* f, p: n rows of 3 (bearings in the camera, points in the world), 5 <= n <= SV_EPNP_MAXN.
- * -> R, t: pose of the camera in the world (points map by R^T (p - t)), as pyopengv returns it.  0 on failure. */
-template <int S, bool REG = false>
-__device__ static int sv_epnp_s(const double* f, const double* p, int n, double* R, double* t, double* MtM, double* Ev) {
+/* EPnP, first half: f, p: n rows of 3 (bearings in the camera, points in the world), 5 <= n <= SV_EPNP_MAXN ->
+ * normalised image coordinates uv, control points cw, barycentric coordinates alphas.  0 on failure. */
+__device__ static int sv_epnp_front(const double* f, const double* p, int n, double (&uv)[2 * SV_EPNP_MAXN], double (&cw)[12],
+                                    double (&alphas)[4 * SV_EPNP_MAXN]) {
   if (n < 5 || n > SV_EPNP_MAXN) return 0; /* 4 points leave a 4-dimensional null space: not handled */
-  double uv[2 * SV_EPNP_MAXN];
   #pragma unroll
   for (int i = 0; i < n; ++i) {
     if (!(f[3 * i + 2] != 0.0)) return 0;
@@ -409,7 +386,8 @@ __device__ static int sv_epnp_s(const double* f, const double* p, int n, double*
     uv[2 * i + 1] = f[3 * i + 1] / f[3 * i + 2];
   }
   /* control points: centroid + principal axes scaled by sqrt(eigenvalue / n) */
-  double cw[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 12; ++k) cw[k] = 0.0;
   #pragma unroll
   for (int i = 0; i < n; ++i)
     #pragma unroll
@@ -450,7 +428,6 @@ __device__ static int sv_epnp_s(const double* f, const double* p, int n, double*
   Ci[6] = ((CC[3] * CC[7]) - (CC[4] * CC[6])) / det;
   Ci[7] = ((CC[1] * CC[6]) - (CC[0] * CC[7])) / det;
   Ci[8] = ((CC[0] * CC[4]) - (CC[1] * CC[3])) / det;
-  double alphas[4 * SV_EPNP_MAXN];
   #pragma unroll
   for (int i = 0; i < n; ++i) {
     const double d0 = p[3 * i] - cw[0], d1 = p[3 * i + 1] - cw[1], d2 = p[3 * i + 2] - cw[2];
@@ -458,11 +435,13 @@ __device__ static int sv_epnp_s(const double* f, const double* p, int n, double*
     for (int j = 0; j < 3; ++j) alphas[4 * i + 1 + j] = ((Ci[3 * j] * d0) + (Ci[3 * j + 1] * d1)) + (Ci[3 * j + 2] * d2);
     alphas[4 * i] = ((1.0 - alphas[4 * i + 1]) - alphas[4 * i + 2]) - alphas[4 * i + 3];
   }
-  double vv[48];
-  if (REG)
-    sv_epnp_null4_reg<S>(alphas, uv, n, Ev, vv);
-  else
-    sv_epnp_null4_mem<S>(alphas, uv, n, MtM, Ev, vv);
+  return 1;
+}
+
+/* EPnP, second half: the four null-space vectors vv (vv[0] of the smallest eigenvalue) -> R, t: pose of the camera in
+ * the world (points map by R^T (p - t)), as pyopengv returns it.  0 on failure. */
+__device__ static int sv_epnp_back(const double* p, int n, const double* uv, const double* cw, const double* alphas,
+                                   const double* vv, double* R, double* t) {
   /* L (6 x 10) and rho (6) over the control-point pairs */
   const int pa[6] = {0, 0, 0, 1, 1, 2}, pb[6] = {1, 2, 3, 2, 3, 3};
   double L[60], rho[6];
@@ -584,9 +563,12 @@ __device__ static int sv_epnp_s(const double* f, const double* p, int n, double*
   return 1;
 }
 
+/* The whole solver on one lane. */
 __device__ static int sv_epnp(const double* f, const double* p, int n, double* R, double* t) {
-  double MtM[144], Ev[144];
-  return sv_epnp_s<1>(f, p, n, R, t, MtM, Ev);
+  double uv[2 * SV_EPNP_MAXN], cw[12], alphas[4 * SV_EPNP_MAXN], vv[48];
+  if (!sv_epnp_front(f, p, n, uv, cw, alphas)) return 0;
+  sv_epnp_null4_reg(alphas, uv, n, vv);
+  return sv_epnp_back(p, n, uv, cw, alphas, vv, R, t);
 }
 
 /* k distinct indices below n from the counter-based generator (draw numbers d0, d0 + 1, ...): the j-th draw picks
@@ -594,15 +576,24 @@ __device__ static int sv_epnp(const double* f, const double* p, int n, double* R
 __device__ static int sv_sample_distinct(int32_t n, int k, uint64_t seed, uint64_t it, int32_t* s) {
   if (n < k || k > 8) return 0;
   int32_t taken[8]; /* ascending */
-  for (int j = 0; j < k; ++j) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (j >= k) break;
     int32_t v = (int32_t)sv_below(sv_mix64(seed, it, (uint64_t)j), (uint32_t)(n - j));
-    int pos = 0;
-    while (pos < j && v >= taken[pos]) { /* skip the values already taken */
-      v++;
-      pos++;
+    bool skipping = true;
+#pragma unroll
+    for (int pos = 0; pos < j; ++pos) { /* skip the values already taken */
+      if (skipping && v >= taken[pos]) v++;
+      else skipping = false;
     }
-    for (int q = j; q > pos; --q) taken[q] = taken[q - 1];
-    taken[pos] = v;
+    taken[j] = v;
+#pragma unroll
+    for (int q = j; q > 0; --q) /* keep `taken` ascending: the new value sinks to its place */
+      if (taken[q - 1] > taken[q]) {
+        const int32_t tmp = taken[q - 1];
+        taken[q - 1] = taken[q];
+        taken[q] = tmp;
+      }
     s[j] = v;
   }
   return 1;

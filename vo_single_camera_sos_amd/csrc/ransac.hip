@@ -132,37 +132,74 @@ __global__ __launch_bounds__(64) void ransac_hyp_kernel(const double* __restrict
   counts[(size_t)b * H + it] = ok ? 0 : -1;
 }
 
-// The EPnP hypothesis generator (central problems, SOSVO_FLAG_EPNP): a kernel of its own -- its work arrays (LDS and
-// scratch) would otherwise cost the P3P generator of the hot path its occupancy.
-__global__ __launch_bounds__(64) void ransac_hyp_epnp_kernel(const double* __restrict__ f, const double* __restrict__ p,
-                                                             const int32_t* __restrict__ n_arr, int stride, int H,
-                                                             uint64_t seed, double* __restrict__ hyp,
-                                                             int32_t* __restrict__ counts) {
-  // One hypothesis per lane.  The 12 x 12 symmetric matrix of the eigen-solver lives in registers (rotation pairs
-  // unrolled: sv_epnp_null4_reg), only the eigenvector matrix in LDS, element-major ([element][lane]): 72 KB per wave,
-  // two waves per CU.  The generator is one long dependent chain per hypothesis (Jacobi rotations, square roots,
-  // divisions): what counts is how many hypotheses a CU holds and how few instructions a rotation takes.
-  __shared__ double epnp_lds[144 * 64];
+// The EPnP hypothesis generator (central problems, SOSVO_FLAG_EPNP), one hypothesis per lane, as TWO kernels:
+//   ransac_epnp_eigen_kernel  sample -> control points, barycentric coordinates -> M^T M -> the 12 x 12 eigen-solver
+//       entirely in registers (sv_epnp_null4_reg: round-robin Jacobi, 78 + 144 doubles, one wave per SIMD, no LDS) -> the
+//       four null-space vectors, 48 doubles per hypothesis, to the workspace;
+//   ransac_epnp_pose_kernel   recomputes the (cheap) first half, reads the four vectors, runs the three beta
+//       initialisations + Gauss-Newton + absolute orientation.  On its own this half needs a fraction of the registers, so
+//       several waves per SIMD hide its divide / square-root chains.
+// One monolithic kernel held 512 registers per lane for its whole life and its eigen-solver's arrays in LDS (96 hypotheses
+// per CU in flight, every LDS round trip exposed): 5.5 ms per 128 pairs x 2000 hypotheses.
+__device__ __forceinline__ int epnp_sample_front(const double* __restrict__ f, const double* __restrict__ p, int n, size_t base,
+                                                 uint64_t seed, int it, double (&p6)[18], double (&uv)[2 * SV_EPNP_MAXN],
+                                                 double (&cw)[12], double (&alphas)[4 * SV_EPNP_MAXN]) {
+  int32_t s6[6];
+  if (!sv_sample_distinct(n, 6, seed, (uint64_t)it, s6)) return 0;
+  double f6[18];
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      f6[3 * k + c] = f[3 * (base + s6[k]) + c];
+      p6[3 * k + c] = p[3 * (base + s6[k]) + c];
+    }
+  return sv_epnp_front(f6, p6, 6, uv, cw, alphas);
+}
+
+constexpr int kEpnpVecDoubles = 48;
+__global__ __launch_bounds__(64) void ransac_epnp_eigen_kernel(const double* __restrict__ f, const double* __restrict__ p,
+                                                               const int32_t* __restrict__ n_arr, int stride, int H,
+                                                               uint64_t seed, double* __restrict__ vvbuf,
+                                                               int32_t* __restrict__ counts) {
   const int b = blockIdx.y;
   const int it = blockIdx.x * blockDim.x + threadIdx.x;
   if (it >= H) return;
-  double* lds = epnp_lds + threadIdx.x;
   const int n = min(n_arr[b], stride);
-  const size_t base = (size_t)b * stride;
-  double R[9], t[3];
-  int32_t s6[6];
-  double f6[18], p6[18];
-  int ok = sv_sample_distinct(n, 6, problem_seed(seed, b), (uint64_t)it, s6);
+  double p6[18], uv[2 * SV_EPNP_MAXN], cw[12], alphas[4 * SV_EPNP_MAXN];
+  int ok = epnp_sample_front(f, p, n, (size_t)b * stride, problem_seed(seed, b), it, p6, uv, cw, alphas);
+  double* out = vvbuf + ((size_t)b * H + it) * kEpnpVecDoubles;
   if (ok) {
-    for (int k = 0; k < 6; ++k)
-      for (int c = 0; c < 3; ++c) {
-        f6[3 * k + c] = f[3 * (base + s6[k]) + c];
-        p6[3 * k + c] = p[3 * (base + s6[k]) + c];
-      }
-    ok = sv_epnp_s<64, true>(f6, p6, 6, R, t, nullptr, lds);
+    double vv[48];
+    sv_epnp_null4_reg(alphas, uv, 6, vv);
+#pragma unroll
+    for (int k = 0; k < 48; ++k) out[k] = vv[k];
+  }
+  counts[(size_t)b * H + it] = ok ? 0 : -1;
+}
+
+__global__ __launch_bounds__(64) void ransac_epnp_pose_kernel(const double* __restrict__ f, const double* __restrict__ p,
+                                                              const int32_t* __restrict__ n_arr, int stride, int H,
+                                                              uint64_t seed, const double* __restrict__ vvbuf,
+                                                              double* __restrict__ hyp, int32_t* __restrict__ counts) {
+  SOSVO_LATENCY_BOUND_PRIO();
+  const int b = blockIdx.y;
+  const int it = blockIdx.x * blockDim.x + threadIdx.x;
+  if (it >= H) return;
+  const int n = min(n_arr[b], stride);
+  double R[9], t[3];
+  int ok = counts[(size_t)b * H + it] == 0;
+  if (ok) {
+    double p6[18], uv[2 * SV_EPNP_MAXN], cw[12], alphas[4 * SV_EPNP_MAXN], vv[48];
+    ok = epnp_sample_front(f, p, n, (size_t)b * stride, problem_seed(seed, b), it, p6, uv, cw, alphas);  // (same bits as before)
+    const double* in = vvbuf + ((size_t)b * H + it) * kEpnpVecDoubles;
+#pragma unroll
+    for (int k = 0; k < 48; ++k) vv[k] = in[k];
+    if (ok) ok = sv_epnp_back(p6, 6, uv, cw, alphas, vv, R, t);
   }
   double* h = hyp + ((size_t)b * H + it) * kHypDoubles;
   if (ok) {
+#pragma unroll
     for (int k = 0; k < 9; ++k) h[k] = R[k];
     h[9] = t[0];
     h[10] = t[1];
@@ -682,6 +719,8 @@ int32_t sosvo_ransac_abs_pose(sosvo_ctx* ctx, const double* f, const double* p, 
   const size_t o_cinfo = carve(sizeof(int32_t) * (size_t)nprob * (2 * kMaxCam + 1));
   const size_t o_hyp = carve(sizeof(double) * (size_t)nprob * H * kHypDoubles);
   const size_t o_counts = carve(sizeof(int32_t) * (size_t)nprob * H);
+  const bool epnp_vec = (flags & SOSVO_FLAG_EPNP) != 0;
+  const size_t o_vv = carve(epnp_vec ? sizeof(double) * (size_t)nprob * H * kEpnpVecDoubles : 0);
   int32_t rc = sosvo_ws_reserve(ctx, off);
   if (rc != SOSVO_OK) return rc;
   char* ws = (char*)ctx->ws;
@@ -696,10 +735,13 @@ int32_t sosvo_ransac_abs_pose(sosvo_ctx* ctx, const double* f, const double* p, 
   const int epnp = (flags & SOSVO_FLAG_EPNP) != 0;
   SOSVO_REQUIRE(ctx, !epnp || cam == nullptr, "SOSVO_FLAG_EPNP is for central problems (cam == NULL)");
   if (epnp) adaptive = (adaptive ? 1 : 0) | 2;  // bit 1: the adaptive stop uses 6-point samples
-  if (epnp)
-    SOSVO_LAUNCH(ctx, ransac_hyp_epnp_kernel, dim3(cdiv(H, 64), nprob), dim3(64), 0, ctx->stream, f, p, n, stride, H, seed,
-                 hyp, counts);
-  else
+  if (epnp) {
+    double* vvbuf = (double*)(ws + o_vv);
+    SOSVO_LAUNCH(ctx, ransac_epnp_eigen_kernel, dim3(cdiv(H, 64), nprob), dim3(64), 0, ctx->stream, f, p, n, stride, H, seed,
+                 vvbuf, counts);
+    SOSVO_LAUNCH(ctx, ransac_epnp_pose_kernel, dim3(cdiv(H, 64), nprob), dim3(64), 0, ctx->stream, f, p, n, stride, H, seed,
+                 vvbuf, hyp, counts);
+  } else
     SOSVO_LAUNCH(ctx, ransac_hyp_kernel, dim3(cdiv(H, 64), nprob), dim3(64), 0, ctx->stream, f, p, cam, cam_off, cam_rot, n,
                  stride, H, seed, perm, cinfo, hyp, counts);
   SOSVO_LAUNCH_CHECK(ctx);
