@@ -280,6 +280,12 @@ int32_t sosvo_sort_matches(sosvo_ctx* ctx, const uint32_t* keys, const int32_t* 
  * algorithm "EPNP" (the RGB-D tracker's choice, pose_est_tools.py:697, :915), instead of Kneip P3P + a 4th point;
  * the adaptive stop then uses w^6. */
 #define SOSVO_FLAG_EPNP 2
+/* hypotheses from the GENERALISED P3P: four distinct correspondences out of ALL cameras, the generalised three-point
+ * problem on the first three (up to 8 poses), the fourth picks one -- what OpenGV's non-central problem does ("will
+ * ALWAYS use GP3P", pose_est_tools.py:696, :785).  Without the flag the three solve points of a sample come from ONE
+ * camera (central Kneip P3P moved to the body frame; BASELINE config 2's "P3P RANSAC").  Also valid for central
+ * problems (then a P3P that only returns configurations in front of the camera). */
+#define SOSVO_FLAG_GP3P 4
 int32_t sosvo_ransac_abs_pose(sosvo_ctx* ctx, const double* f, const double* p, const int32_t* cam,
                               const double* cam_off, const double* cam_rot, int32_t ncam, int32_t flags,
                               const int32_t* n, int32_t nprob, int32_t stride, double thr,
@@ -458,6 +464,8 @@ typedef struct sosvo_batch_cfg {
   double ransac_threshold; /* 1 - cos(5 deg) (pose_est_tools.py:675-676) */
   uint64_t seed;           /* pair i samples with seed + i */
   float cos_a, sin_a;      /* descriptor orientation given to the GFT keypoints */
+  int32_t ransac_flags;    /* SOSVO_FLAG_GP3P: generalised-P3P hypotheses (samples across both mirrors); 0: one-mirror P3P */
+  int32_t reserved;        /* 0 */
 } sosvo_batch_cfg;
 
 size_t sosvo_frame_pair_batch_workspace(const sosvo_batch_cfg* cfg);

@@ -39,6 +39,7 @@
 
 #include "ransac_core.h"
 #include "epnp_core.h"
+#include "gp3p_core.h"
 
 /* ---- scoring of all points under one pose --------------------------------------------- */
 void orc_score_points(const double* f, const double* p, const int32_t* cam, const double* cam_off,
@@ -68,6 +69,10 @@ int32_t orc_ransac_abs_pose(const double* f, const double* p, const int32_t* cam
   /* `adaptive` bit 1 selects the EPnP hypothesis generator (central problems only): 6-point samples solved by
    * orc_epnp, as OpenGV's AbsolutePoseSacProblem does for algorithm EPNP (pose_est_tools.py:697, :915). */
   const int use_epnp = ((adaptive >> 1) & 1) && !cam;
+  /* bit 2 selects the generalised P3P generator (oracle/gp3p_core.h): four correspondences out of ALL cameras, as
+   * OpenGV's non-central problem does ("will ALWAYS use GP3P", pose_est_tools.py:696); without it the three solve points
+   * come from one camera (central P3P moved to the body frame). */
+  const int use_gp3p = ((adaptive >> 2) & 1) && !use_epnp;
   adaptive &= 1;
   if (!cam) {
     ncam = 1;
@@ -110,6 +115,8 @@ int32_t orc_ransac_abs_pose(const double* f, const double* p, const int32_t* cam
           }
         ok = orc_epnp(f6, p6, 6, R, t);
       }
+    } else if (use_gp3p) {
+      ok = orc_hypothesis_gp3p(f, p, cam, cam_off, cam_rot, n, seed, (uint64_t)it, R, t);
     } else {
       ok = orc_hypothesis(f, p, cam, cam_off, cam_rot, n, perm, cstart, ccount, seed, (uint64_t)it, R, t);
     }
@@ -321,6 +328,33 @@ int32_t orc_epnp_solve(const double* f, const double* p, int32_t n, double* T_ou
 int32_t orc_symeig12_solve(double* A, double* d) {
   double e[12];
   return orc_symeig12(A, d, e);
+}
+
+/* Generalised P3P on its own (unit tests): fb, o, P [9] -> up to 8 poses T_out [8][12] = [R | t]; returns their number.
+ * oct_out (optional): the 9 coefficients of the octic in the first depth, in units of the largest world side. */
+int32_t orc_gp3p_solve(const double* fb, const double* o, const double* P, double* T_out, double* oct_out) {
+  double Rs[72], ts[24];
+  const int ns = orc_gp3p(fb, o, P, Rs, ts);
+  for (int k = 0; k < ns; ++k) orc_Rt_to_T(Rs + 9 * k, ts + 3 * k, T_out + 12 * k);
+  if (oct_out) {
+    double L = 0.0;
+    for (int i = 0; i < 3; ++i) {
+      const int j = (i + 1) % 3;
+      const double d0 = P[3 * i] - P[3 * j], d1 = P[3 * i + 1] - P[3 * j + 1], d2 = P[3 * i + 2] - P[3 * j + 2];
+      const double d = sqrt(((d0 * d0) + (d1 * d1)) + (d2 * d2));
+      if (d > L) L = d;
+    }
+    double os[9], Ps[9], e12[4], e13[4], e23[4], Ap[4], Bp[5];
+    for (int k = 0; k < 9; ++k) {
+      os[k] = o[k] / L;
+      Ps[k] = P[k] / L;
+    }
+    orc_gp3p_pair(fb, fb + 3, os, os + 3, Ps, Ps + 3, e12);
+    orc_gp3p_pair(fb, fb + 6, os, os + 6, Ps, Ps + 6, e13);
+    orc_gp3p_pair(fb + 3, fb + 6, os + 3, os + 6, Ps + 3, Ps + 6, e23);
+    orc_gp3p_octic(e12, e13, e23, oct_out, Ap, Bp);
+  }
+  return ns;
 }
 
 /* ... and the Jacobi solver EPnP uses: A [144] in (destroyed), d [12] eigenvalues, V [144] eigenvectors as columns. */

@@ -161,13 +161,13 @@ def track_inputs(rig, ref, cur):
                 n_top=len(q_top))
 
 
-def track_pair(rig, ref, cur, thr, max_iter, seed, adaptive=False, lm_iter=30):
+def track_pair(rig, ref, cur, thr, max_iter, seed, adaptive=False, lm_iter=30, gp3p=False):
     """track_frame steps 3-4 (pose_est_tools.py:785, :830) on the oracle: RANSAC + LM on the inliers."""
     c = track_inputs(rig, ref, cur)
     cam_off = np.stack([rig.F_top, rig.F_bot])
     cam_rot = np.stack([np.eye(3), np.eye(3)])
     r = oracle.ransac_abs_pose(c["f"], c["p"], thr, max_iter, seed=seed, adaptive=adaptive, cam=c["cam"],
-                               cam_off=cam_off, cam_rot=cam_rot)
+                               cam_off=cam_off, cam_rot=cam_rot, gp3p=gp3p)
     idx = np.nonzero(r["mask"])[0].astype(np.int32)
     T = r["T"]
     if r["status"] == 0:

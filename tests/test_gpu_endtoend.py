@@ -89,6 +89,28 @@ def test_full_hot_path_from_images(ctx, method, nfeat):
         assert np.allclose(rec[i, :12].reshape(3, 4), w["T"], rtol=1e-6, atol=1e-9)   # north_star's bar for the pose ...
         assert np.array_equal(rec[i, :12].reshape(3, 4), w["T"])                        # ... which is met bit for bit
     assert rec[2, 14] == 1 and rec[2, 13] == 0           # black frame: no correspondences, status "no model"
+    if method == "GFT":
+        # the reference's own choice for the non-central RANSAC, generalised P3P on samples across both mirrors
+        # (pose_est_tools.py:696), on the same keypoints: every record equals the oracle flow with gp3p hypotheses
+        pipe_g = FramePairPipeline(ctx, RigConfig(**rig_kw), B, frame_cap=2048, max_iter=500, seed=5, front_end=fe,
+                                   ransac_solver="GP3P")
+        pipe_g.stereo()
+        pipe_g.track()
+        rec_g = pipe_g.results().cpu().numpy()
+        mask_g = pipe_g.ransac["mask"].cpu().numpy()
+        differs = 0
+        for i in range(B):
+            w = refflow.track_pair(rp, frames[2 * i], frames[2 * i + 1], pipe.thr, 500, seed=5 + i, gp3p=True)
+            n = len(w["corr"]["cam"])
+            assert rec_g[i, 13] == n and rec_g[i, 14] == w["ransac"]["status"] and rec_g[i, 12] == w["ransac"]["n_inliers"]
+            assert rec_g[i, 15] == w["ransac"]["best_iter"]
+            assert np.array_equal(mask_g[i, :n].astype(bool), w["ransac"]["mask"])
+            assert np.array_equal(rec_g[i, :12].reshape(3, 4), w["T"])
+            differs += int(rec_g[i, 15] != rec[i, 15])
+        assert differs > 0                                # a different hypothesis set than the one-mirror mode
+        for i in range(2):
+            R, t = poses[i]
+            assert synth.pose_error(rec_g[i, :12].reshape(3, 4), R, t)[0] < np.deg2rad(2.0)
     for i in range(2 if method == "GFT" else 0):          # the planted motion is recovered (loosely: 5 deg threshold)
         R, t = poses[i]
         ang, _ = synth.pose_error(rec[i, :12].reshape(3, 4), R, t)

@@ -87,7 +87,9 @@ def test_pyopengv_mirror_against_oracle(ctx):
         # (the central case draws 6-point samples for EPnP: a higher inlier fraction keeps 300 iterations enough)
         pr = synth.make_abs_pose_problem(rng, 600, inlier_frac=0.4 if noncentral else 0.7, noise_deg=0.2, noncentral=noncentral)
         kw = dict(cam=pr["cam"], cam_off=pr["cam_off"], cam_rot=pr["cam_rot"])
-        ref = oracle.ransac_abs_pose(pr["f"], pr["p"], thr, 300, seed=77, adaptive=True, epnp=not noncentral, **kw)
+        # the non-central call draws GP3P hypotheses (as OpenGV does), the central "EPNP" call 6-point EPnP ones
+        ref = oracle.ransac_abs_pose(pr["f"], pr["p"], thr, 300, seed=77, adaptive=True, epnp=not noncentral,
+                                     gp3p=noncentral, **kw)
         pyopengv.set_seed(77)
         if noncentral:
             T, inl = pyopengv.absolute_pose_noncentral_ransac(pr["f"], pr["cam"].astype(np.float64)[:, None], pr["p"],
@@ -98,6 +100,10 @@ def test_pyopengv_mirror_against_oracle(ctx):
             Tk, inl_k = pyopengv.absolute_pose_ransac(pr["f"], pr["p"], "KNEIP", thr, 300)  # P3P + 4th point
             ref_k = oracle.ransac_abs_pose(pr["f"], pr["p"], thr, 300, seed=77, adaptive=True)
             assert np.array_equal(Tk, ref_k["T"]) and np.array_equal(inl_k, np.flatnonzero(ref_k["mask"]))
+            pyopengv.set_seed(77)
+            Tg, inl_g = pyopengv.absolute_pose_ransac(pr["f"], pr["p"], "GP3P", thr, 300)   # generalised solver, one camera
+            ref_g = oracle.ransac_abs_pose(pr["f"], pr["p"], thr, 300, seed=77, adaptive=True, gp3p=True)
+            assert np.array_equal(Tg, ref_g["T"]) and np.array_equal(inl_g, np.flatnonzero(ref_g["mask"]))
         assert T.shape == (3, 4) and np.array_equal(T, ref["T"])
         assert inl.dtype == np.int64 and np.array_equal(inl, np.flatnonzero(ref["mask"])) and np.all(np.diff(inl) > 0)
         assert synth.pose_error(T, pr["R"], pr["t"])[0] < np.deg2rad(3.0)
@@ -182,7 +188,7 @@ def test_per_frame_api_tracks_like_the_batched_pipeline(ctx):
     geo = (pano.cols, pano.rows, pano.pixel_size, pano.cyl_height_max)
     pipe = FramePairPipeline(ctx, RigConfig(pano_top=geo, pano_bot=geo, F_top=gs.top_model.F[:3, 0], F_bot=gs.bot_model.F[:3, 0],
                                             min_range=500.0, max_range=7000.0), 1, frame_cap=2048, max_iter=400, adaptive=True,
-                             seed=9, front_end=fe)
+                             seed=9, front_end=fe, ransac_solver="GP3P")   # (what the tracker's pyopengv call draws)
     fe.load_frames(omni)
     pipe.step()
     ctx.synchronize()

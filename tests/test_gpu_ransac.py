@@ -36,7 +36,8 @@ def _to(dev, *arrs):
     return [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in arrs]
 
 
-def _run_batch(ctx, problems, S, noncentral, max_iter, seed, adaptive=False, ident=True, thr=synth.THR_5DEG, epnp=False):
+def _run_batch(ctx, problems, S, noncentral, max_iter, seed, adaptive=False, ident=True, thr=synth.THR_5DEG, epnp=False,
+               gp3p=False):
     f, p, cam, n = _pack(problems, S, noncentral)
     dev = ctx.device
     tf, tp, tcam, tn = _to(dev, f, p, cam, n)
@@ -44,13 +45,14 @@ def _run_batch(ctx, problems, S, noncentral, max_iter, seed, adaptive=False, ide
     if noncentral:
         off, rot = _to(dev, problems[0]["cam_off"], problems[0]["cam_rot"])
         kw = dict(cam=tcam, cam_off=off, cam_rot=rot, cam_rot_identity=ident)
-    out = ctx.ransac_abs_pose(tf, tp, tn, thr, max_iter, seed=seed, adaptive=adaptive, want_counts=True, epnp=epnp, **kw)
+    out = ctx.ransac_abs_pose(tf, tp, tn, thr, max_iter, seed=seed, adaptive=adaptive, want_counts=True, epnp=epnp, gp3p=gp3p,
+                              **kw)
     ctx.synchronize()
     got = {k: v.cpu().numpy() for k, v in out.items()}
     for b, pr in enumerate(problems):
         okw = dict(cam=pr["cam"], cam_off=pr["cam_off"], cam_rot=pr["cam_rot"]) if noncentral else {}
         want = oracle.ransac_abs_pose(pr["f"], pr["p"], thr, max_iter, seed=seed + b, adaptive=adaptive,
-                                      want_counts=True, epnp=epnp, **okw)
+                                      want_counts=True, epnp=epnp, gp3p=gp3p, **okw)
         k = n[b]
         used = want["iters_used"]
         assert got["info"][b, 1] == used, "iterations drawn, problem %d" % b
@@ -189,3 +191,27 @@ def test_central_epnp_hypotheses_bit_exact(ctx):
     with pytest.raises(Exception):                                         # EPnP is for central problems
         pr = synth.make_abs_pose_problem(rng, 50, inlier_frac=1.0, noise_deg=0.0, noncentral=True)
         _run_batch(ctx, [pr], 64, True, 10, 1, epnp=True)
+
+
+def test_gp3p_hypotheses_bit_exact(ctx):
+    """SOSVO_FLAG_GP3P: samples of four correspondences across BOTH mirrors, generalised P3P (up to 8 poses), the fourth
+    point picks one -- per-hypothesis inlier counts, winner, masks and pose bits equal the oracle's; fixed and adaptive
+    iteration budgets; identity and rotated camera frames; the central case through the same solver."""
+    rng = np.random.default_rng(31)
+    probs = [synth.make_abs_pose_problem(rng, n, inlier_frac=fr, noise_deg=0.2, noncentral=True, n_top=nt)
+             for n, nt, fr in [(300, 150, 0.5), (1000, 100, 0.35), (33, 30, 0.9), (700, 699, 0.6), (64, 0, 0.7), (1024, 512, 0.4)]]
+    _, _, got = _run_batch(ctx, probs, 1024, True, 300, seed=11, ident=True, gp3p=True)
+    for b, pr in enumerate(probs):
+        assert got["info"][b, 2] == 0 and got["n_inliers"][b] >= 0.85 * pr["is_inlier"].sum(), b
+    _run_batch(ctx, probs, 1024, True, 300, seed=11, ident=False, gp3p=True)
+    _run_batch(ctx, probs, 1024, True, 2000, seed=12, adaptive=True, gp3p=True)
+    Rc = np.stack([synth.rot_from_axis_angle([0, 0, 1], 0.3), synth.rot_from_axis_angle([1, 1, 0], -0.2)])
+    rot = []
+    for n in (400, 800):
+        pr = synth.make_abs_pose_problem(rng, n, inlier_frac=0.5, noise_deg=0.1, noncentral=True)
+        pr["f"] = np.einsum("nji,nj->ni", Rc[pr["cam"]], pr["f"])
+        pr["cam_rot"] = Rc
+        rot.append(pr)
+    _run_batch(ctx, rot, 800, True, 150, seed=5, ident=False, gp3p=True)
+    cen = [synth.make_abs_pose_problem(rng, n, inlier_frac=0.5, noise_deg=0.1, noncentral=False) for n in (200, 77)]
+    _run_batch(ctx, cen, 256, False, 150, seed=6, gp3p=True)

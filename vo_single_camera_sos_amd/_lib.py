@@ -92,6 +92,7 @@ SIGNATURES = {
 
 FLAG_CAM_ROT_IDENTITY = 1
 FLAG_EPNP = 2
+FLAG_GP3P = 4
 
 
 class Rig(ctypes.Structure):
@@ -113,7 +114,8 @@ class BatchCfg(ctypes.Structure):
     _fields_ = [("n_pairs", c_i32), ("H", c_i32), ("W", c_i32), ("rows", c_i32), ("cols", c_i32), ("nmask", c_i32),
                 ("kp_cap", c_i32), ("frame_cap", c_i32), ("median_ksize", c_i32), ("max_corners", c_i32), ("edge", c_i32),
                 ("ransac_max_iter", c_i32), ("ransac_adaptive", c_i32), ("lm_max_iter", c_i32), ("quality", c_f64),
-                ("min_distance", c_f64), ("ransac_threshold", c_f64), ("seed", c_u64), ("cos_a", c_f32), ("sin_a", c_f32)]
+                ("min_distance", c_f64), ("ransac_threshold", c_f64), ("seed", c_u64), ("cos_a", c_f32), ("sin_a", c_f32),
+                ("ransac_flags", c_i32), ("reserved", c_i32)]
 
 
 class RgbdBatchCfg(ctypes.Structure):

@@ -241,7 +241,8 @@ static int32_t run_frame_pairs(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo
   STAGE(sosvo_f2f_assemble(ctx, rig, b.m_top, b.m_bot, b.X, b.b_top, b.b_bot, b.M, Fc, b.ref_frame, b.cur_frame, b.k_top,
                            b.o_top, b.k_bot, b.o_bot, B, Cc, b.f, b.p, b.cam, b.cq, b.ct, b.cn, b.cn_top));
   // 3D-2D absolute pose: RANSAC, then LM on the inliers
-  STAGE(sosvo_ransac_abs_pose(ctx, b.f, b.p, b.cam, b.cam_off, b.cam_rot, 2, SOSVO_FLAG_CAM_ROT_IDENTITY, b.cn, B, Cc,
+  STAGE(sosvo_ransac_abs_pose(ctx, b.f, b.p, b.cam, b.cam_off, b.cam_rot, 2,
+                              SOSVO_FLAG_CAM_ROT_IDENTITY | (cfg->ransac_flags & SOSVO_FLAG_GP3P), b.cn, B, Cc,
                               cfg->ransac_threshold, cfg->ransac_max_iter, cfg->ransac_adaptive, cfg->seed, b.T_ransac,
                               b.mask, b.idx, b.n_inl, b.info, nullptr));
   SOSVO_HIP(ctx, hipMemcpyAsync(b.T, b.T_ransac, sizeof(double) * 12 * B, hipMemcpyDeviceToDevice, ctx->stream));

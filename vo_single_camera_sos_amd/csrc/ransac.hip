@@ -22,6 +22,7 @@
 #include "common.h"
 #include "ransac_core.h"
 #include "epnp_core.h"
+#include "gp3p_core.h"
 
 namespace {
 
@@ -116,6 +117,42 @@ __global__ __launch_bounds__(64) void ransac_hyp_kernel(const double* __restrict
   double R[9], t[3];
   const int ok = sv_hypothesis(f + 3 * base, p + 3 * base, cam ? cam + base : nullptr, off, rot, n, perm + base, ci,
                                ci + kMaxCam + 1, problem_seed(seed, b), (uint64_t)it, R, t);
+  double* h = hyp + ((size_t)b * H + it) * kHypDoubles;
+  if (ok) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) h[k] = R[k];
+    h[9] = t[0];
+    h[10] = t[1];
+    h[11] = t[2];
+    h[12] = -(((R[0] * t[0]) + (R[3] * t[1])) + (R[6] * t[2]));
+    h[13] = -(((R[1] * t[0]) + (R[4] * t[1])) + (R[7] * t[2]));
+    h[14] = -(((R[2] * t[0]) + (R[5] * t[1])) + (R[8] * t[2]));
+  } else {
+    h[0] = __longlong_as_double(0x7FF8000000000000LL);
+  }
+  counts[(size_t)b * H + it] = ok ? 0 : -1;
+}
+
+// The generalised-P3P hypothesis generator (SOSVO_FLAG_GP3P): one lane per (problem, iteration): four distinct
+// correspondences out of all cameras, sv_hypothesis_gp3p (gp3p_core.h, the oracle's text).
+__global__ __launch_bounds__(64) void ransac_hyp_gp3p_kernel(const double* __restrict__ f, const double* __restrict__ p,
+                                                             const int32_t* __restrict__ cam,
+                                                             const double* __restrict__ cam_off,
+                                                             const double* __restrict__ cam_rot,
+                                                             const int32_t* __restrict__ n_arr, int stride, int H,
+                                                             uint64_t seed, double* __restrict__ hyp,
+                                                             int32_t* __restrict__ counts) {
+  SOSVO_LATENCY_BOUND_PRIO();
+  const int b = blockIdx.y;
+  const int it = blockIdx.x * blockDim.x + threadIdx.x;
+  if (it >= H) return;
+  const int n = min(n_arr[b], stride);
+  const size_t base = (size_t)b * stride;
+  const double* off = cam ? cam_off : kZero3;
+  const double* rot = cam ? cam_rot : kEye9;
+  double R[9], t[3];
+  const int ok = sv_hypothesis_gp3p(f + 3 * base, p + 3 * base, cam ? cam + base : nullptr, off, rot, n, problem_seed(seed, b),
+                                    (uint64_t)it, R, t);
   double* h = hyp + ((size_t)b * H + it) * kHypDoubles;
   if (ok) {
 #pragma unroll
@@ -741,6 +778,9 @@ int32_t sosvo_ransac_abs_pose(sosvo_ctx* ctx, const double* f, const double* p, 
                  vvbuf, counts);
     SOSVO_LAUNCH(ctx, ransac_epnp_pose_kernel, dim3(cdiv(H, 64), nprob), dim3(64), 0, ctx->stream, f, p, n, stride, H, seed,
                  vvbuf, hyp, counts);
+  } else if (flags & SOSVO_FLAG_GP3P) {
+    SOSVO_LAUNCH(ctx, ransac_hyp_gp3p_kernel, dim3(cdiv(H, 64), nprob), dim3(64), 0, ctx->stream, f, p, cam, cam_off, cam_rot, n,
+                 stride, H, seed, hyp, counts);
   } else
     SOSVO_LAUNCH(ctx, ransac_hyp_kernel, dim3(cdiv(H, 64), nprob), dim3(64), 0, ctx->stream, f, p, cam, cam_off, cam_rot, n,
                  stride, H, seed, perm, cinfo, hyp, counts);

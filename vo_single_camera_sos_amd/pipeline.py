@@ -30,9 +30,11 @@ class RigConfig(object):
 
 class FramePairPipeline(object):
     def __init__(self, ctx, rig, n_pairs, nmask=12, bucket_cap=192, frame_cap=2048, thr=None, max_iter=2000,
-                 adaptive=False, seed=0, lm_iter=30, front_end=None):
+                 adaptive=False, seed=0, lm_iter=30, front_end=None, ransac_solver="P3P"):
         """front_end: an ImageFrontEnd over 2 * n_pairs frames; its keypoint/descriptor buffers are used in
-        place (no copy).  Without it, keypoints are loaded with load_keypoints()."""
+        place (no copy).  Without it, keypoints are loaded with load_keypoints().
+        ransac_solver: "GP3P" = generalised P3P on samples across both mirrors (what the reference's non-central RANSAC
+        uses, pose_est_tools.py:696); "P3P" = the three solve points of a sample from one mirror (BASELINE config 2)."""
         assert isinstance(ctx, Context)
         self.ctx, self.rig_cfg, self.rig = ctx, rig, rig.as_struct()
         self.front_end = front_end
@@ -44,6 +46,9 @@ class FramePairPipeline(object):
         # TrackerSE3.set_global_parameters_for_tracking (pose_est_tools.py:675-676)
         self.thr = float(1.0 - np.cos(np.deg2rad(5.0))) if thr is None else float(thr)
         self.max_iter, self.adaptive, self.seed, self.lm_iter = int(max_iter), bool(adaptive), int(seed), int(lm_iter)
+        if str(ransac_solver).upper() not in ("P3P", "GP3P"):
+            raise ValueError("ransac_solver: P3P or GP3P")
+        self.gp3p = str(ransac_solver).upper() == "GP3P"
         dev = ctx.device
         P = self.F * self.NM
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
@@ -110,7 +115,7 @@ class FramePairPipeline(object):
         co = self.corr
         c.ransac_abs_pose(co["f"], co["p"], co["n"], self.thr, self.max_iter, seed=self.seed, adaptive=self.adaptive,
                           cam=co["cam"], cam_off=self.cam_off, cam_rot=self.cam_rot, cam_rot_identity=True,
-                          out=self.ransac)
+                          out=self.ransac, gp3p=self.gp3p)
         self.T.copy_(self.ransac["T"])
         c.refine_abs_pose(co["f"], co["p"], co["n"], self.T, idx=self.ransac["idx"], m=self.ransac["n_inliers"],
                           cam=co["cam"], cam_off=self.cam_off, cam_rot=self.cam_rot, max_lm_iter=self.lm_iter,
@@ -152,7 +157,7 @@ class OverlappedFramePairs(object):
 
     def __init__(self, device, gums, omni_shape, rig, n_pairs, n_streams=2, num_of_features=1000, kp_cap=512,
                  frame_cap=2048, max_iter=2000, adaptive=False, seed=0, detection_method="GFT", lm_iter=30, thr=None,
-                 serialize_medians=True):
+                 serialize_medians=True, ransac_solver="P3P"):
         from .frontend import DeviceImageModel, ImageFrontEnd
         from .parallel import shard_range
         self.main = Context(device)                       # model constants + result collection: torch's current stream
@@ -174,7 +179,8 @@ class OverlappedFramePairs(object):
                 p.fe = ImageFrontEnd(p.ctx, m, 2 * (hi - lo), detection_method=detection_method,
                                      num_of_features=num_of_features, kp_cap=kp_cap, keep_panoramas=False)
                 p.pipe = FramePairPipeline(p.ctx, rig, hi - lo, frame_cap=frame_cap, max_iter=max_iter, adaptive=adaptive,
-                                           seed=seed + lo, front_end=p.fe, lm_iter=lm_iter, thr=thr)
+                                           seed=seed + lo, front_end=p.fe, lm_iter=lm_iter, thr=thr,
+                                           ransac_solver=ransac_solver)
             p.median_done = torch.cuda.Event()
             p.done = torch.cuda.Event()
             self.parts.append(p)
@@ -308,7 +314,7 @@ class FramePairBatch(object):
 
     def __init__(self, ctx, model, rig, n_pairs, num_of_features=1000, kp_cap=None, frame_cap=2048, median_win_size=11,
                  quality=0.01, min_distance=5.0, edge=31, thr=None, max_iter=2000, adaptive=False, seed=0, lm_iter=30,
-                 n_streams=1):
+                 n_streams=1, ransac_solver="P3P"):
         """n_streams > 1: sosvo_frame_pair_batch_streams (the batch split over internal HIP streams of the library)."""
         from . import _lib, orb_pattern
         self.ctx, self.model, self.rig_cfg, self.rig = ctx, model, rig, rig.as_struct()
@@ -324,6 +330,7 @@ class FramePairBatch(object):
         c.quality, c.min_distance = float(quality), float(min_distance)
         c.ransac_threshold = float(1.0 - np.cos(np.deg2rad(5.0))) if thr is None else float(thr)
         c.seed, c.cos_a, c.sin_a = int(seed), float(cos_a), float(sin_a)
+        c.ransac_flags, c.reserved = (_lib.FLAG_GP3P if str(ransac_solver).upper() == "GP3P" else 0), 0
         self.cfg = c
         if getattr(model, "unwrap_table", None) is None:  # once per model
             model.unwrap_table = ctx.unwrap_prepare(model.omni_masks, model.map_x, model.map_y, (model.H, model.W))
