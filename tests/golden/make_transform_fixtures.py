@@ -62,6 +62,26 @@ def main():
                                                   pose_format="tum", zero_up_wrt_origin=zero_up)
             out["file_poses7_%d" % zero_up] = np.array(poses7, dtype=np.float64)
             out["file_mats_%d" % zero_up] = np.stack(mats)
+    # POV-Ray layout (common_tools.py:636-705): "tx, ty, tz, rot_x, rot_y, rot_z" per line, angles in degrees,
+    # static-frame x -> y -> z rotations (quaternion_from_euler(..., 'sxyz'))
+    pov = np.zeros((n, 6))
+    pov[:, :3] = rng.normal(size=(n, 3)) * 2.0
+    pov[:, 3:] = rng.uniform(-180.0, 180.0, size=(n, 3))
+    pov[0, 3:] = 0.0
+    pov[2, 3:] = [90.0, -90.0, 180.0]
+    out["pov_rows"] = pov
+    out["euler_quat_sxyz"] = np.stack([tr.quaternion_from_euler(*np.deg2rad(r[3:]), "sxyz") for r in pov])
+    with tempfile.TemporaryDirectory() as d:
+        fn = os.path.join(d, "gt_povray.txt")
+        with open(fn, "w") as fh:
+            fh.write("# tx, ty, tz, rx, ry, rz\n")
+            for r in pov:
+                fh.write(", ".join(repr(float(v)) for v in r) + "\n")
+        for zero_up in (False, True):
+            poses7, mats = ct.get_poses_from_file(poses_filename=fn, input_units="cm", output_working_units="mm", indices=[],
+                                                  pose_format="povray", zero_up_wrt_origin=zero_up)
+            out["pov_poses7_%d" % zero_up] = np.array(poses7, dtype=np.float64)
+            out["pov_mats_%d" % zero_up] = np.stack(mats)
     out["units_mm_m"] = np.array([ct.get_length_units_conversion_factor("mm", "m"), ct.get_length_units_conversion_factor("m", "mm"),
                                   ct.get_length_units_conversion_factor("cm", "m"), ct.get_length_units_conversion_factor("m", "m")])
     np.savez_compressed(OUT, **out)

@@ -54,8 +54,20 @@ def test_tum_entries_and_pose_file_reader(tmp_path):
         assert np.allclose(np.array(p7), G["file_poses7_%d" % zero_up], rtol=0, atol=1e-12)
         assert np.allclose(np.stack(mats), G["file_mats_%d" % zero_up], rtol=0, atol=1e-12)
     assert np.allclose(ct.get_poses_from_file(fn, zero_up_wrt_origin=True)[1][0], np.identity(4), atol=1e-15)
-    with pytest.raises(NotImplementedError):
-        ct.get_poses_from_file(fn, pose_format="povray")
+    with pytest.raises(ValueError):
+        ct.get_poses_from_file(fn, pose_format="kitti")
+    # the POV-Ray layout (common_tools.py:636-705): translation + static x-y-z Euler angles in degrees, comma-separated
+    assert np.allclose(np.stack([tr.quaternion_from_euler(*np.deg2rad(r[3:]), "sxyz") for r in G["pov_rows"]]),
+                       G["euler_quat_sxyz"], rtol=0, atol=1e-15)
+    fp = str(tmp_path / "gt_povray.txt")
+    with open(fp, "w") as fh:
+        fh.write("# tx, ty, tz, rx, ry, rz\n")
+        for r in G["pov_rows"]:
+            fh.write(", ".join(repr(float(v)) for v in r) + "\n")
+    for zero_up in (0, 1):
+        p7, mats = ct.get_poses_from_file(fp, "cm", "mm", [], "povray", bool(zero_up))
+        assert np.allclose(np.array(p7), G["pov_poses7_%d" % zero_up], rtol=0, atol=1e-12)
+        assert np.allclose(np.stack(mats), G["pov_mats_%d" % zero_up], rtol=0, atol=1e-12)
     units = [ct.get_length_units_conversion_factor(a, b) for a, b in (("mm", "m"), ("m", "mm"), ("cm", "m"), ("m", "m"))]
     assert np.array_equal(units, G["units_mm_m"])
     out = str(tmp_path / "out.txt")

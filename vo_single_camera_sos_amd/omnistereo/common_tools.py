@@ -58,14 +58,18 @@ def save_as_tum_poses_to_file(output_tum_filename, poses_7_list, input_units, in
 
 def get_poses_from_file(poses_filename, input_units="m", output_working_units="m", indices=None, pose_format="tum",
                         zero_up_wrt_origin=False, initial_T=None, delimiter=None):
-    """common_tools.py:623-736 for pose_format "tum" (stamp tx ty tz qx qy qz qw per line, '#' comments):
-    -> (list of [tx, ty, tz, qx, qy, qz, qw] in output units, list of 4x4 matrices).  With zero_up_wrt_origin the
-    first valid pose becomes the identity (every pose is pre-multiplied by its inverse, `initial_T` post-multiplied);
-    rows holding NaN give NaN entries."""
-    if pose_format.lower() != "tum":
-        raise NotImplementedError("pose_format %r: only the TUM layout is built" % pose_format)
-    grid = np.loadtxt(poses_filename, delimiter=delimiter if delimiter else None, usecols=tuple(range(8)), comments="#",
-                      ndmin=2)
+    """common_tools.py:623-736.  pose_format "tum": stamp tx ty tz qx qy qz qw per line, blank-separated; "povray":
+    tx, ty, tz, rot_x, rot_y, rot_z per line, comma-separated, angles in degrees about the static x, y, z axes in that
+    order ('#' comments in both) -> (list of [tx, ty, tz, qx, qy, qz, qw] in output units, list of 4x4 matrices).
+    With zero_up_wrt_origin the first valid pose becomes the identity (every pose is pre-multiplied by its inverse,
+    `initial_T` post-multiplied); rows holding NaN give NaN entries."""
+    fmt = pose_format.lower()
+    if fmt not in ("tum", "povray"):
+        raise ValueError("pose_format %r: 'tum' or 'povray'" % pose_format)
+    if delimiter is None and fmt == "povray":
+        delimiter = ","
+    grid = np.loadtxt(poses_filename, delimiter=delimiter if delimiter and delimiter != " " else None,
+                      usecols=tuple(range(8 if fmt == "tum" else 6)), comments="#", ndmin=2)
     if len(grid) == 0:
         raise ValueError("no poses in %s" % poses_filename)
     k = get_length_units_conversion_factor(input_units, output_working_units)
@@ -81,6 +85,10 @@ def get_poses_from_file(poses_filename, input_units="m", output_working_units="m
         row = grid[pose_number]
         if np.any(np.isnan(row)):
             entry = 7 * [np.nan]
+        elif fmt == "povray":
+            qw, qx, qy, qz = tr.quaternion_from_euler(np.deg2rad(float(row[3])), np.deg2rad(float(row[4])),
+                                                      np.deg2rad(float(row[5])), "sxyz")
+            entry = [k * float(row[0]), k * float(row[1]), k * float(row[2]), qx, qy, qz, qw]
         else:
             entry = [k * float(row[1]), k * float(row[2]), k * float(row[3]), float(row[4]), float(row[5]), float(row[6]),
                      float(row[7])]

@@ -95,6 +95,26 @@ def quaternion_from_matrix(matrix, isprecise=False):
     return -q if q[0] < 0.0 else q
 
 
+def quaternion_multiply(q1, q0):
+    """Hamilton product q1 * q0 of two [w, x, y, z] quaternions (the rotation q0 followed by q1)."""
+    w0, x0, y0, z0 = q0
+    w1, x1, y1, z1 = q1
+    return np.array([w1 * w0 - x1 * x0 - y1 * y0 - z1 * z0, w1 * x0 + x1 * w0 + y1 * z0 - z1 * y0,
+                     w1 * y0 - x1 * z0 + y1 * w0 + z1 * x0, w1 * z0 + x1 * y0 - y1 * x0 + z1 * w0], dtype=np.float64)
+
+
+def quaternion_from_euler(ai, aj, ak, axes="sxyz"):
+    """transformations.py:1146 for the one convention this path uses ("sxyz": rotations about the STATIC x, then y, then z
+    axes, the POV-Ray pose files of common_tools.get_poses_from_file): the product q_z(ak) q_y(aj) q_x(ai),
+    [w, x, y, z], not sign-normalised."""
+    if axes != "sxyz":
+        raise NotImplementedError("quaternion_from_euler: only the static x-y-z convention ('sxyz') is built")
+    qx = np.array([np.cos(ai / 2.0), np.sin(ai / 2.0), 0.0, 0.0])
+    qy = np.array([np.cos(aj / 2.0), 0.0, np.sin(aj / 2.0), 0.0])
+    qz = np.array([np.cos(ak / 2.0), 0.0, 0.0, np.sin(ak / 2.0)])
+    return quaternion_multiply(qz, quaternion_multiply(qy, qx))
+
+
 def pose_matrix_from_quaternion_and_translation(q, t):
     T = quaternion_matrix(q)
     T[:3, 3] = np.asarray(t, dtype=np.float64)[:3]
