@@ -1,15 +1,18 @@
-/*
- * ORACLE -- TEST INFRASTRUCTURE ONLY (see ransac.c for the provenance header).
+/* TEST INFRASTRUCTURE ONLY -- CPU oracle (see ransac.c for the provenance header).
  *
  * Numeric core of the absolute-pose RANSAC restatement: sampler, Kneip P3P, real quartic
  * roots, score, Cayley parametrisation, LM pieces.  Only + - * / sqrt and comparisons are used
  * (no libm transcendental), every expression is fully parenthesised and the build disables FMA
- * contraction, so that the HIP implementation can reproduce every bit.
+ * contraction.  The HIP side is the TEXT of this file: tests/gen_device_headers.py writes
+ * vo_single_camera_sos_amd/csrc/ransac_core.h from it (device prefixes, forced inlining) and tests/test_abi.py checks
+ * that the two stay identical, so both sides evaluate the same operations in the same order.  (`#pragma unroll` lines
+ * are for the device compiler; gcc ignores them.)  What a shared text cannot catch -- an error in the formulas
+ * themselves -- is covered by checks that do not share this code: tests/test_oracle_ransac.py (numpy / scipy
+ * evaluations, planted poses, exhaustive small problems).
  */
-#ifndef ORC_RANSAC_CORE_H
-#define ORC_RANSAC_CORE_H
-
+#pragma once
 #include <math.h>
+#include <stdbool.h>
 #include <stdint.h>
 
 #define ORC_LM_LAMBDA0 1e-3
@@ -121,7 +124,7 @@ static inline double orc_adaptive_base(int32_t best, int32_t n) {
   return pno;
 }
 
-/* the same for 6-point samples (EPnP): 1 - w^6 */
+// the same for 6-point samples (EPnP): 1 - w^6
 static inline double orc_adaptive_base6(int32_t best, int32_t n) {
   const double w = (double)best / (double)n;
   const double w2 = w * w;
@@ -462,20 +465,6 @@ static inline int orc_hypothesis(const double* f, const double* p, const int32_t
   return found;
 }
 
-/* Sum of 256 partials: four groups of 64, each by the binary tree v[l] += v[l + o], o = 32..1,
- * then ((w0 + w1) + w2) + w3. */
-static inline double orc_tree_sum256(const double* part) {
-  double w[4];
-  for (int k = 0; k < 4; ++k) {
-    double v[64];
-    for (int l = 0; l < 64; ++l) v[l] = part[64 * k + l];
-    for (int o = 32; o > 0; o >>= 1)
-      for (int l = 0; l < o; ++l) v[l] = v[l] + v[l + o];
-    w[k] = v[0];
-  }
-  return ((w[0] + w[1]) + w[2]) + w[3];
-}
-
 /* ---- Cayley parametrisation -------------------------------------------------------------- */
 static inline void orc_rot2cayley(const double* R, double* c) {
   const double s = 1.0 + ((R[0] + R[4]) + R[8]);
@@ -571,12 +560,15 @@ static inline void orc_residual_jac(const double* x, const double* f, const doub
    * Gauss-Newton keeps only the first term and crawls (linear convergence); adding r G^T G makes the step a
    * Newton step.  Hq = r G^T G, packed upper triangle like the normal matrix. */
   double V[6][3];
+#pragma unroll
   for (int j = 0; j < 3; ++j)
+#pragma unroll
     for (int i = 0; i < 3; ++i) {
       V[j][i] = -(((Rc[i] * R[3 * j]) + (Rc[3 + i] * R[3 * j + 1])) + (Rc[6 + i] * R[3 * j + 2]));
       V[3 + j][i] = ((Rc[i] * Q[j][0]) + (Rc[3 + i] * Q[j][1])) + (Rc[6 + i] * Q[j][2]);
     }
   double G[6][3];
+#pragma unroll
   for (int j = 0; j < 6; ++j) {
     const double gv = ((g0 * V[j][0]) + (g1 * V[j][1])) + (g2 * V[j][2]);
     G[j][0] = (V[j][0] - (g0 * gv)) / nrm;
@@ -586,7 +578,9 @@ static inline void orc_residual_jac(const double* x, const double* f, const doub
   {
     const double rr = *r;
     int a = 0;
+#pragma unroll
     for (int u = 0; u < 6; ++u)
+#pragma unroll
       for (int v = u; v < 6; ++v) Hq[a++] = rr * (((G[u][0] * G[v][0]) + (G[u][1] * G[v][1])) + (G[u][2] * G[v][2]));
   }
 }
@@ -594,14 +588,21 @@ static inline void orc_residual_jac(const double* x, const double* f, const doub
 /* Solve (A + lambda diag(A)) dx = -g for the packed upper triangle A (21) by LDL^T without
  * pivoting.  Returns 0 if a pivot is not positive. */
 static inline int orc_solve_damped(const double* Apacked, const double* g, double lambda, double* dx) {
+  // Every loop is fully unrolled so that M, L, yv live in registers (runtime-indexed local arrays would go to
+  // scratch memory); a failed pivot only clears `ok`, the arithmetic of the successful case is unchanged.
   double M[36];
-  int a = 0;
-  for (int u = 0; u < 6; ++u)
-    for (int v = u; v < 6; ++v) {
-      M[6 * u + v] = Apacked[a];
-      M[6 * v + u] = Apacked[a];
-      a++;
-    }
+  {
+    int a = 0;
+#pragma unroll
+    for (int u = 0; u < 6; ++u)
+#pragma unroll
+      for (int v = u; v < 6; ++v) {
+        M[6 * u + v] = Apacked[a];
+        M[6 * v + u] = Apacked[a];
+        a++;
+      }
+  }
+#pragma unroll
   for (int u = 0; u < 6; ++u) {
     double dg = M[7 * u];
     if (dg < 1e-30) dg = 1e-30;
@@ -609,33 +610,55 @@ static inline int orc_solve_damped(const double* Apacked, const double* g, doubl
   }
   /* Cholesky M = L L^T */
   double L[36];
+#pragma unroll
   for (int i = 0; i < 36; ++i) L[i] = 0.0;
+  bool ok = true;
+#pragma unroll
   for (int j = 0; j < 6; ++j) {
     double s = M[7 * j];
+#pragma unroll
     for (int k = 0; k < j; ++k) s = s - (L[6 * j + k] * L[6 * j + k]);
-    if (!(s > 0.0)) return 0;
+    ok = ok && (s > 0.0);
     const double ljj = sqrt(s);
     L[7 * j] = ljj;
+#pragma unroll
     for (int i = j + 1; i < 6; ++i) {
       double t = M[6 * i + j];
+#pragma unroll
       for (int k = 0; k < j; ++k) t = t - (L[6 * i + k] * L[6 * j + k]);
       L[6 * i + j] = t / ljj;
     }
   }
   double yv[6];
+#pragma unroll
   for (int i = 0; i < 6; ++i) {
     double t = -g[i];
+#pragma unroll
     for (int k = 0; k < i; ++k) t = t - (L[6 * i + k] * yv[k]);
     yv[i] = t / L[7 * i];
   }
+#pragma unroll
   for (int i = 5; i >= 0; --i) {
     double t = yv[i];
+#pragma unroll
     for (int k = i + 1; k < 6; ++k) t = t - (L[6 * k + i] * dx[k]);
     dx[i] = t / L[7 * i];
   }
-  for (int i = 0; i < 6; ++i)
-    if (!isfinite(dx[i])) return 0;
-  return 1;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) ok = ok && isfinite(dx[i]);
+  return ok ? 1 : 0;
 }
 
-#endif /* ORC_RANSAC_CORE_H */
+/* Sum of 256 partials: four groups of 64, each by the binary tree v[l] += v[l + o], o = 32..1,
+ * then ((w0 + w1) + w2) + w3. */
+static inline double orc_tree_sum256(const double* part) {
+  double w[4];
+  for (int k = 0; k < 4; ++k) {
+    double v[64];
+    for (int l = 0; l < 64; ++l) v[l] = part[64 * k + l];
+    for (int o = 32; o > 0; o >>= 1)
+      for (int l = 0; l < o; ++l) v[l] = v[l] + v[l + o];
+    w[k] = v[0];
+  }
+  return ((w[0] + w[1]) + w[2]) + w[3];
+}

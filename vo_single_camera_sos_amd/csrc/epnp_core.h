@@ -1,61 +1,50 @@
 // Device-side EPnP (Lepetit, Moreno-Noguer, Fua, IJCV 2009) for the central absolute-pose RANSAC with algorithm
-// "EPNP" (omnistereo/pose_est_tools.py:697, :915: OpenGV solves 6-point samples with EPnP): four control points from
-// the principal axes of the world points, barycentric coordinates, the null space of M^T M by a cyclic Jacobi
-// eigen-decomposition, the three beta initialisations with five Gauss-Newton steps each, absolute orientation, the
-// candidate with the smallest reprojection error; plus the sampler of k distinct indices.
-//
-// Only + - * / sqrt and comparisons, every expression fully parenthesised, built with -ffp-contract=off: the
-// hypotheses (hence inlier counts and the selected model) are bit-identical to an IEEE scalar evaluation of the same
-// formulas on the host.  One lane per hypothesis; the two runtime-indexed 12 x 12 work arrays of the eigen-solver are kept in
-// LDS, interleaved over the wave's lanes (sv_epnp_s<64>), the small ones in private memory.
+// "EPNP" (omnistereo/pose_est_tools.py:697, :915: OpenGV solves 6-point samples with EPnP): control points,
+// barycentric coordinates, [the null space of M^T M: epnp_eig12_reg.h], the three beta initialisations with five
+// Gauss-Newton steps each, absolute orientation, the candidate with the smallest reprojection error; plus the sampler
+// of k distinct indices.  One lane per hypothesis, every array index a compile-time constant after unrolling.
+// GENERATED from oracle/epnp_core.h by tests/gen_device_headers.py (the oracle's text minus its "oracle only" section, device
+// prefixes): both sides evaluate the same operations in the same order; tests/test_abi.py checks the two files.
 #pragma once
 #include <hip/hip_runtime.h>
-#include <stdint.h>
-
-#include <type_traits>
-#include <utility>
-
 #include "ransac_core.h"
 
 #define SV_EPNP_MAXN 8
 #define SV_JACOBI_MAXN 12
 
-/* Cyclic Jacobi on a symmetric n x n matrix A (row-major, destroyed: its diagonal ends as the eigenvalues);
- * V (n x n) receives the eigenvectors as columns; the classic symmetric update (see oracle/epnp_core.h).
- * Element i of A and V lives at [i * S]: S = 1 for a private array, S > 1 for a lane-interleaved array in LDS (the
- * 12 x 12 problem of sv_epnp: dynamically indexed private arrays would live in scratch memory, one dependent memory
- * round trip per element).  Same operations in the same order either way.  The iterations of each inner loop touch
- * disjoint elements: all their loads are issued before the stores so that the latencies overlap (with runtime p, q
- * the compiler cannot prove that on its own). */
-template <int S>
-__device__ static void sv_jacobi_sym_s(double* A, int n, double* V) {
+/* Cyclic Jacobi on a symmetric n x n matrix A (row-major, destroyed: its diagonal ends as the eigenvalues), n <=
+ * SV_JACOBI_MAXN; V (n x n) receives the eigenvectors as columns.  The classic symmetric update: a rotation in the
+ * (p, q) plane changes rows / columns p and q only -- a'kp = c akp - s akq, a'kq = s akp + c akq for k != p, q
+ * (mirrored), a'pp = app - t apq, a'qq = aqq + t apq, a'pq = 0 exactly.  The iterations of each inner loop touch
+ * disjoint elements: all their loads come before the stores. */
+__device__ static void sv_jacobi_sym(double* A, int n, double* V) {
   #pragma unroll
   for (int i = 0; i < n; ++i)
     #pragma unroll
-    for (int j = 0; j < n; ++j) V[(i * n + j) * S] = (i == j) ? 1.0 : 0.0;
+    for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
   for (int sweep = 0; sweep < 60; ++sweep) {
     double off = 0.0, diag = 0.0;
     #pragma unroll
     for (int p = 0; p < n; ++p) {
-      diag = diag + (A[(p * n + p) * S] * A[(p * n + p) * S]);
+      diag = diag + (A[p * n + p] * A[p * n + p]);
       #pragma unroll
-      for (int q = p + 1; q < n; ++q) off = off + (A[(p * n + q) * S] * A[(p * n + q) * S]);
+      for (int q = p + 1; q < n; ++q) off = off + (A[p * n + q] * A[p * n + q]);
     }
     if (!(off > (1e-40 * diag))) break;
     #pragma unroll
     for (int p = 0; p < n - 1; ++p)
       #pragma unroll
       for (int q = p + 1; q < n; ++q) {
-        const double apq = A[(p * n + q) * S];
+        const double apq = A[p * n + q];
         if (apq == 0.0) continue;
-        const double app = A[(p * n + p) * S], aqq = A[(q * n + q) * S];
+        const double app = A[p * n + p], aqq = A[q * n + q];
         double xp[SV_JACOBI_MAXN], xq[SV_JACOBI_MAXN], yp[SV_JACOBI_MAXN], yq[SV_JACOBI_MAXN];
         #pragma unroll
         for (int k = 0; k < n; ++k) {  // (rows k of columns p, q: the values of k = p, q are loaded but not used)
-          xp[k] = A[(k * n + p) * S];
-          xq[k] = A[(k * n + q) * S];
-          yp[k] = V[(k * n + p) * S];
-          yq[k] = V[(k * n + q) * S];
+          xp[k] = A[k * n + p];
+          xq[k] = A[k * n + q];
+          yp[k] = V[k * n + p];
+          yq[k] = V[k * n + q];
         }
         const double theta = (aqq - app) / (2.0 * apq);
         const double at = theta < 0.0 ? -theta : theta;
@@ -65,24 +54,23 @@ __device__ static void sv_jacobi_sym_s(double* A, int n, double* V) {
         for (int k = 0; k < n; ++k) {
           if (k == p || k == q) continue;
           const double x = (c * xp[k]) - (s * xq[k]), y = (s * xp[k]) + (c * xq[k]);
-          A[(k * n + p) * S] = x;
-          A[(p * n + k) * S] = x;
-          A[(k * n + q) * S] = y;
-          A[(q * n + k) * S] = y;
+          A[k * n + p] = x;
+          A[p * n + k] = x;
+          A[k * n + q] = y;
+          A[q * n + k] = y;
         }
-        A[(p * n + p) * S] = app - (t * apq);
-        A[(q * n + q) * S] = aqq + (t * apq);
-        A[(p * n + q) * S] = 0.0;
-        A[(q * n + p) * S] = 0.0;
+        A[p * n + p] = app - (t * apq);
+        A[q * n + q] = aqq + (t * apq);
+        A[p * n + q] = 0.0;
+        A[q * n + p] = 0.0;
         #pragma unroll
         for (int k = 0; k < n; ++k) {
-          V[(k * n + p) * S] = (c * yp[k]) - (s * yq[k]);
-          V[(k * n + q) * S] = (s * yp[k]) + (c * yq[k]);
+          V[k * n + p] = (c * yp[k]) - (s * yq[k]);
+          V[k * n + q] = (s * yp[k]) + (c * yq[k]);
         }
       }
   }
 }
-__device__ static void sv_jacobi_sym(double* A, int n, double* V) { sv_jacobi_sym_s<1>(A, n, V); }
 
 /* Least squares min |A x - b| for an m x k system (k <= 5) through the normal equations, Gaussian elimination
  * with partial pivoting.  A row-major with row stride lda.  Returns 0 on a vanishing pivot. */
@@ -248,136 +236,9 @@ __device__ static double sv_epnp_pose_from_betas(const double* betas, const doub
   return (err == err) ? err : -1.0;
 }
 
-/* The 12 x 12 symmetric eigen-problem of EPnP (M^T M): Jacobi rotations in round-robin order (oracle/epnp_core.h,
- * orc_jacobi12_rr: the same operations in the same order).  Pair i of round r is (r, 11) for i = 0 and
- * ((r + i) mod 11, (r - i) mod 11) otherwise, smaller index first. */
-#define SV_JACOBI12_TOL 1e-26
-__device__ constexpr int sv_rr_first(int idx) {
-  const int r = idx / 6, i = idx % 6;
-  const int a = i == 0 ? r : (r + i) % 11, b = i == 0 ? 11 : (r - i + 11) % 11;
-  return a < b ? a : b;
-}
-__device__ constexpr int sv_rr_second(int idx) {
-  const int r = idx / 6, i = idx % 6;
-  const int a = i == 0 ? r : (r + i) % 11, b = i == 0 ? 11 : (r - i + 11) % 11;
-  return a < b ? b : a;
-}
-/* index of element (i, j) of a symmetric 12 x 12 matrix kept as its upper triangle (78 entries) */
-__device__ constexpr int sv_tri(int i, int j) { return i <= j ? i * 12 - i * (i - 1) / 2 + (j - i) : j * 12 - j * (j - 1) / 2 + (i - j); }
-template <typename F, int... R>
-__device__ __forceinline__ void sv_for_each_round(F& f, std::integer_sequence<int, R...>) {
-  (f(std::integral_constant<int, R>{}), ...);
-}
-
-/* EVERYTHING IN REGISTERS: the symmetric matrix as its upper triangle (a, 78 doubles; built from the barycentric
- * coordinates: two rows of M per point, [a_j, 0, -a_j u] and [0, a_j, -a_j v]) and the eigenvector matrix V (144
- * doubles) -- a wave that has a SIMD to itself owns 512 registers per lane.  Every index is a compile-time constant: the
- * 11 rounds of a sweep are unrolled by a fold.  The six rotations of a round have disjoint index pairs, so their angles
- * -- two divisions and two square roots in a chain, the longest dependency of the solver -- are evaluated side by side
- * before the rotations are applied one after the other.  -> vv: the four eigenvectors of the smallest eigenvalues, vv[0]
- * the smallest (eigenvalue k has rank = the number of eigenvalues below it; equal ones: those with a lower index). */
-__device__ static void sv_epnp_null4_reg(const double* alphas, const double* uv, int n, double* vv) {
-  double a[78], V[144];
-#pragma unroll
-  for (int k = 0; k < 78; ++k) a[k] = 0.0;
-#pragma unroll
-  for (int i = 0; i < n; ++i) {
-    double r1[12], r2[12];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const double al = alphas[4 * i + j];
-      r1[3 * j] = al;
-      r1[3 * j + 1] = 0.0;
-      r1[3 * j + 2] = -(al * uv[2 * i]);
-      r2[3 * j] = 0.0;
-      r2[3 * j + 1] = al;
-      r2[3 * j + 2] = -(al * uv[2 * i + 1]);
-    }
-#pragma unroll
-    for (int r = 0; r < 12; ++r)
-#pragma unroll
-      for (int c = r; c < 12; ++c) a[sv_tri(r, c)] = (a[sv_tri(r, c)] + (r1[r] * r1[c])) + (r2[r] * r2[c]);
-  }
-#pragma unroll
-  for (int i = 0; i < 12; ++i)
-#pragma unroll
-    for (int j = 0; j < 12; ++j) V[i * 12 + j] = (i == j) ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < 60; ++sweep) {
-    double off = 0.0, diag = 0.0;
-#pragma unroll
-    for (int p = 0; p < 12; ++p) {
-      diag = diag + (a[sv_tri(p, p)] * a[sv_tri(p, p)]);
-#pragma unroll
-      for (int q = p + 1; q < 12; ++q) off = off + (a[sv_tri(p, q)] * a[sv_tri(p, q)]);
-    }
-    if (!(off > (SV_JACOBI12_TOL * diag))) break;
-    auto round = [&](auto r_tag) __attribute__((always_inline)) {
-      constexpr int R = decltype(r_tag)::value;
-      double tt[6], cc[6], ss[6];
-      bool on[6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {  // the six angle chains of the round, independent of each other
-        const int P = sv_rr_first(6 * R + i), Q = sv_rr_second(6 * R + i);
-        const double apq = a[sv_tri(P, Q)], app = a[sv_tri(P, P)], aqq = a[sv_tri(Q, Q)];
-        on[i] = apq != 0.0;
-        const double theta = (aqq - app) / (2.0 * apq);
-        const double at = theta < 0.0 ? -theta : theta;
-        tt[i] = (theta < 0.0 ? -1.0 : 1.0) / (at + sqrt((theta * theta) + 1.0));
-        cc[i] = 1.0 / sqrt((tt[i] * tt[i]) + 1.0);
-        ss[i] = tt[i] * cc[i];
-      }
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {  // the rotations, one after the other
-        const int P = sv_rr_first(6 * R + i), Q = sv_rr_second(6 * R + i);
-        if (!on[i]) continue;
-        const double c = cc[i], s = ss[i], t = tt[i];
-        const double apq = a[sv_tri(P, Q)], app = a[sv_tri(P, P)], aqq = a[sv_tri(Q, Q)];
-#pragma unroll
-        for (int k = 0; k < 12; ++k) {
-          if (k == P || k == Q) continue;
-          const double akp = a[sv_tri(k, P)], akq = a[sv_tri(k, Q)];
-          a[sv_tri(k, P)] = (c * akp) - (s * akq);
-          a[sv_tri(k, Q)] = (s * akp) + (c * akq);
-        }
-        a[sv_tri(P, P)] = app - (t * apq);
-        a[sv_tri(Q, Q)] = aqq + (t * apq);
-        a[sv_tri(P, Q)] = 0.0;
-#pragma unroll
-        for (int k = 0; k < 12; ++k) {
-          const double vkp = V[k * 12 + P], vkq = V[k * 12 + Q];
-          V[k * 12 + P] = (c * vkp) - (s * vkq);
-          V[k * 12 + Q] = (s * vkp) + (c * vkq);
-        }
-      }
-    };
-    sv_for_each_round(round, std::make_integer_sequence<int, 11>{});
-  }
-  int rank[12];
-#pragma unroll
-  for (int k = 0; k < 12; ++k) {
-    int rk = 0;
-#pragma unroll
-    for (int j = 0; j < 12; ++j) {
-      const double ej = a[sv_tri(j, j)], ek = a[sv_tri(k, k)];
-      rk += (ej < ek || (ej == ek && j < k)) ? 1 : 0;
-    }
-    rank[k] = rk;
-  }
-#pragma unroll
-  for (int r4 = 0; r4 < 4; ++r4)
-#pragma unroll
-    for (int j = 0; j < 12; ++j) {
-      double v = 0.0;
-#pragma unroll
-      for (int k = 0; k < 12; ++k) v = rank[k] == r4 ? V[12 * j + k] : v;
-      vv[12 * r4 + j] = v;
-    }
-}
-
 /* EPnP, first half: f, p: n rows of 3 (bearings in the camera, points in the world), 5 <= n <= SV_EPNP_MAXN ->
  * normalised image coordinates uv, control points cw, barycentric coordinates alphas.  0 on failure. */
-__device__ static int sv_epnp_front(const double* f, const double* p, int n, double (&uv)[2 * SV_EPNP_MAXN], double (&cw)[12],
-                                    double (&alphas)[4 * SV_EPNP_MAXN]) {
+__device__ static int sv_epnp_front(const double* f, const double* p, int n, double* uv, double* cw, double* alphas) {
   if (n < 5 || n > SV_EPNP_MAXN) return 0; /* 4 points leave a 4-dimensional null space: not handled */
   #pragma unroll
   for (int i = 0; i < n; ++i) {
@@ -563,14 +424,6 @@ __device__ static int sv_epnp_back(const double* p, int n, const double* uv, con
   return 1;
 }
 
-/* The whole solver on one lane. */
-__device__ static int sv_epnp(const double* f, const double* p, int n, double* R, double* t) {
-  double uv[2 * SV_EPNP_MAXN], cw[12], alphas[4 * SV_EPNP_MAXN], vv[48];
-  if (!sv_epnp_front(f, p, n, uv, cw, alphas)) return 0;
-  sv_epnp_null4_reg(alphas, uv, n, vv);
-  return sv_epnp_back(p, n, uv, cw, alphas, vv, R, t);
-}
-
 /* k distinct indices below n from the counter-based generator (draw numbers d0, d0 + 1, ...): the j-th draw picks
  * among the n - j values not taken yet (kept sorted).  Returns 0 if n < k. */
 __device__ static int sv_sample_distinct(int32_t n, int k, uint64_t seed, uint64_t it, int32_t* s) {
@@ -599,3 +452,5 @@ __device__ static int sv_sample_distinct(int32_t n, int k, uint64_t seed, uint64
   return 1;
 }
 
+
+#include "epnp_eig12_reg.h"

@@ -1,16 +1,14 @@
-// Device-side numeric core of the absolute-pose RANSAC (K8/K10) and LM refinement (K9):
-// counter-based sampler, Kneip P3P, real quartic roots, score, Cayley parametrisation.
-//
-// Reference call sites replaced: pyopengv.absolute_pose_noncentral_ransac
-// (omnistereo/pose_est_tools.py:785), absolute_pose_ransac (:915), *_optimize_nonlinear
-// (:830, :937); score definition from pose_est_tools.py:150-203 (+ :181-185 non-central).
-//
-// Only + - * / sqrt and comparisons are used, every expression is fully parenthesised and the
-// library is built with -ffp-contract=off: the FP64 results (hence inlier masks and the best
-// hypothesis) are bit-identical to an IEEE scalar evaluation of the same formulas on the host.
+// Device-side numeric core of the absolute-pose RANSAC (K8/K10) and LM refinement (K9): counter-based sampler, Kneip
+// P3P, real quartic roots, score, Cayley parametrisation, LM pieces.  Reference call sites replaced:
+// pyopengv.absolute_pose_noncentral_ransac (omnistereo/pose_est_tools.py:785), absolute_pose_ransac (:915),
+// *_optimize_nonlinear (:830, :937); score definition from pose_est_tools.py:150-203 (+ :181-185 non-central).
+// Only + - * / sqrt and comparisons, fully parenthesised, built with -ffp-contract=off.  GENERATED from oracle/ransac_core.h by
+// tests/gen_device_headers.py (same text, device prefixes): the CPU oracle evaluates the same operations in the same
+// order, tests/test_abi.py checks that the two files stay identical.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdbool.h>
 #include <stdint.h>
 
 #define SV_LM_LAMBDA0 1e-3
@@ -647,3 +645,16 @@ __device__ __forceinline__ static int sv_solve_damped(const double* Apacked, con
   return ok ? 1 : 0;
 }
 
+/* Sum of 256 partials: four groups of 64, each by the binary tree v[l] += v[l + o], o = 32..1,
+ * then ((w0 + w1) + w2) + w3. */
+__device__ __forceinline__ static double sv_tree_sum256(const double* part) {
+  double w[4];
+  for (int k = 0; k < 4; ++k) {
+    double v[64];
+    for (int l = 0; l < 64; ++l) v[l] = part[64 * k + l];
+    for (int o = 32; o > 0; o >>= 1)
+      for (int l = 0; l < o; ++l) v[l] = v[l] + v[l + o];
+    w[k] = v[0];
+  }
+  return ((w[0] + w[1]) + w[2]) + w[3];
+}
