@@ -286,6 +286,9 @@ int32_t sosvo_sort_matches(sosvo_ctx* ctx, const uint32_t* keys, const int32_t* 
  * camera (central Kneip P3P moved to the body frame; BASELINE config 2's "P3P RANSAC").  Also valid for central
  * problems (then a P3P that only returns configurations in front of the camera). */
 #define SOSVO_FLAG_GP3P 4
+/* central problems: "TWOPT" (pose_est_tools.py:95-107) -- 2-point samples, the translation of a camera whose rotation is
+ * known (the identity, as pyopengv's binding leaves OpenGV's rotation prior); the adaptive stop then uses w^2. */
+#define SOSVO_FLAG_TWOPT 8
 int32_t sosvo_ransac_abs_pose(sosvo_ctx* ctx, const double* f, const double* p, const int32_t* cam,
                               const double* cam_off, const double* cam_rot, int32_t ncam, int32_t flags,
                               const int32_t* n, int32_t nprob, int32_t stride, double thr,

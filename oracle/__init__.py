@@ -100,7 +100,7 @@ def score_points(f, p, T, cam=None, cam_off=None, cam_rot=None):
 
 
 def ransac_abs_pose(f, p, thr, max_iter, seed=0, adaptive=False, cam=None, cam_off=None, cam_rot=None,
-                    want_counts=False, epnp=False, gp3p=False):
+                    want_counts=False, epnp=False, gp3p=False, twopt=False):
     """-> dict(T [3,4], mask [n] bool, n_inliers, best_iter, iters_used, status[, counts]).  epnp: central problems
     only, hypotheses from EPnP on 6-point samples instead of Kneip P3P + a 4th point."""
     f = _c(f, np.float64).reshape(-1, 3)
@@ -117,7 +117,7 @@ def ransac_abs_pose(f, p, thr, max_iter, seed=0, adaptive=False, cam=None, cam_o
     L.orc_ransac_abs_pose.restype = ctypes.c_int32
     st = L.orc_ransac_abs_pose(_p(f), _p(p), _pn(cam), _pn(cam_off), _pn(cam_rot), ctypes.c_int32(n),
                                ctypes.c_int32(ncam), ctypes.c_double(thr), ctypes.c_int32(max_iter),
-                               ctypes.c_int32((1 if adaptive else 0) | (2 if epnp else 0) | (4 if gp3p else 0)), ctypes.c_uint64(seed), _p(T), _p(mask),
+                               ctypes.c_int32((1 if adaptive else 0) | (2 if epnp else 0) | (4 if gp3p else 0) | (8 if twopt else 0)), ctypes.c_uint64(seed), _p(T), _p(mask),
                                ctypes.byref(n_inl), ctypes.byref(best_it), ctypes.byref(used), _pn(counts))
     out = dict(T=T, mask=mask[:n].astype(bool), n_inliers=n_inl.value, best_iter=best_it.value,
                iters_used=used.value, status=st)

@@ -380,3 +380,13 @@ static inline int orc_hypothesis_gp3p(const double* f, const double* p, const in
   }
   return found;
 }
+
+/* One RANSAC hypothesis of the central problem with TWOPT (known rotation = identity, the binding's prior): two distinct
+ * correspondences, the translation from orc_twopt. */
+static inline int orc_hypothesis_twopt(const double* f, const double* p, int32_t n, uint64_t seed, uint64_t it, double* R_out,
+                                       double* t_out) {
+  int32_t s[2];
+  if (!orc_sample_distinct(n, 2, seed, it, s)) return 0;
+  for (int i = 0; i < 9; ++i) R_out[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  return orc_twopt(f + 3 * s[0], f + 3 * s[1], p + 3 * s[0], p + 3 * s[1], R_out, t_out);
+}

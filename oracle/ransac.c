@@ -73,6 +73,8 @@ int32_t orc_ransac_abs_pose(const double* f, const double* p, const int32_t* cam
    * OpenGV's non-central problem does ("will ALWAYS use GP3P", pose_est_tools.py:696); without it the three solve points
    * come from one camera (central P3P moved to the body frame). */
   const int use_gp3p = ((adaptive >> 2) & 1) && !use_epnp;
+  /* bit 3: TWOPT (central problems): 2-point samples, translation only, rotation = identity */
+  const int use_twopt = ((adaptive >> 3) & 1) && !cam && !use_epnp && !use_gp3p;
   adaptive &= 1;
   if (!cam) {
     ncam = 1;
@@ -115,6 +117,8 @@ int32_t orc_ransac_abs_pose(const double* f, const double* p, const int32_t* cam
           }
         ok = orc_epnp(f6, p6, 6, R, t);
       }
+    } else if (use_twopt) {
+      ok = orc_hypothesis_twopt(f, p, n, seed, (uint64_t)it, R, t);
     } else if (use_gp3p) {
       ok = orc_hypothesis_gp3p(f, p, cam, cam_off, cam_rot, n, seed, (uint64_t)it, R, t);
     } else {
@@ -133,7 +137,7 @@ int32_t orc_ransac_abs_pose(const double* f, const double* p, const int32_t* cam
       best_it = it;
       memcpy(best_R, R, sizeof(R));
       memcpy(best_t, t, sizeof(t));
-      base = use_epnp ? orc_adaptive_base6(cnt, n) : orc_adaptive_base(cnt, n);
+      base = use_epnp ? orc_adaptive_base6(cnt, n) : (use_twopt ? orc_adaptive_base2(cnt, n) : orc_adaptive_base(cnt, n));
     }
     iterations++;
   }

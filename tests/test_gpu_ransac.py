@@ -37,7 +37,7 @@ def _to(dev, *arrs):
 
 
 def _run_batch(ctx, problems, S, noncentral, max_iter, seed, adaptive=False, ident=True, thr=synth.THR_5DEG, epnp=False,
-               gp3p=False):
+               gp3p=False, twopt=False):
     f, p, cam, n = _pack(problems, S, noncentral)
     dev = ctx.device
     tf, tp, tcam, tn = _to(dev, f, p, cam, n)
@@ -46,13 +46,13 @@ def _run_batch(ctx, problems, S, noncentral, max_iter, seed, adaptive=False, ide
         off, rot = _to(dev, problems[0]["cam_off"], problems[0]["cam_rot"])
         kw = dict(cam=tcam, cam_off=off, cam_rot=rot, cam_rot_identity=ident)
     out = ctx.ransac_abs_pose(tf, tp, tn, thr, max_iter, seed=seed, adaptive=adaptive, want_counts=True, epnp=epnp, gp3p=gp3p,
-                              **kw)
+                              twopt=twopt, **kw)
     ctx.synchronize()
     got = {k: v.cpu().numpy() for k, v in out.items()}
     for b, pr in enumerate(problems):
         okw = dict(cam=pr["cam"], cam_off=pr["cam_off"], cam_rot=pr["cam_rot"]) if noncentral else {}
         want = oracle.ransac_abs_pose(pr["f"], pr["p"], thr, max_iter, seed=seed + b, adaptive=adaptive,
-                                      want_counts=True, epnp=epnp, gp3p=gp3p, **okw)
+                                      want_counts=True, epnp=epnp, gp3p=gp3p, twopt=twopt, **okw)
         k = n[b]
         used = want["iters_used"]
         assert got["info"][b, 1] == used, "iterations drawn, problem %d" % b
@@ -215,3 +215,19 @@ def test_gp3p_hypotheses_bit_exact(ctx):
     _run_batch(ctx, rot, 800, True, 150, seed=5, ident=False, gp3p=True)
     cen = [synth.make_abs_pose_problem(rng, n, inlier_frac=0.5, noise_deg=0.1, noncentral=False) for n in (200, 77)]
     _run_batch(ctx, cen, 256, False, 150, seed=6, gp3p=True)
+
+
+def test_twopt_hypotheses_bit_exact(ctx):
+    """SOSVO_FLAG_TWOPT: 2-point samples, translation from a known (identity) rotation; fixed and adaptive budgets."""
+    rng = np.random.default_rng(41)
+    probs = []
+    for n in (300, 64, 1000):
+        pr = synth.make_abs_pose_problem(rng, n, inlier_frac=0.6, noise_deg=0.1, noncentral=False)
+        v = pr["p"] - pr["t"]                              # bearings of a camera that only translated
+        f = synth.perturb_bearings(rng, v / np.linalg.norm(v, axis=1, keepdims=True), 0.1)
+        pr["f"] = np.ascontiguousarray(np.where(pr["is_inlier"][:, None], f, pr["f"]))
+        probs.append(pr)
+    _, _, got = _run_batch(ctx, probs, 1024, False, 200, seed=3, twopt=True)
+    for b, pr in enumerate(probs):
+        assert np.array_equal(got["T"][b][:, :3], np.eye(3)) and got["n_inliers"][b] >= 0.9 * pr["is_inlier"].sum()
+    _run_batch(ctx, probs, 1024, False, 2000, seed=4, adaptive=True, twopt=True)

@@ -167,3 +167,30 @@ def test_eigen_solvers_against_numpy_eigh_and_each_other():
             assert np.allclose(np.sort(d), w, rtol=0, atol=1e-12 * scale)
             assert np.allclose(V.T @ V, np.eye(12), atol=1e-12)                 # orthonormal columns
             assert np.allclose(A @ V, V * d[None, :], atol=1e-11 * scale)       # A v_k = d_k v_k
+
+
+def test_twopt_translation_from_a_known_rotation():
+    """TWOPT: pure translation (the rotation is the binding's identity prior) from 2-point samples; the planted translation
+    is recovered, RANSAC counts the planted inliers, and a scipy least-squares fit of the same two-ray problem agrees."""
+    from scipy.optimize import least_squares
+    rng = np.random.default_rng(17)
+    n = 400
+    t_true = np.array([120.0, -40.0, 65.0])
+    P = rng.normal(size=(n, 3))
+    P = P / np.linalg.norm(P, axis=1, keepdims=True) * rng.uniform(800, 6000, (n, 1))
+    f = P - t_true
+    f /= np.linalg.norm(f, axis=1, keepdims=True)
+    f = synth.perturb_bearings(rng, f, 0.05)
+    bad = rng.random(n) < 0.4
+    g = rng.normal(size=(n, 3))
+    f[bad] = (g / np.linalg.norm(g, axis=1, keepdims=True))[bad]
+    r = oracle.ransac_abs_pose(f, P, synth.THR_5DEG, 100, seed=2, twopt=True, want_counts=True)
+    assert r["status"] == 0 and np.array_equal(r["T"][:, :3], np.eye(3))
+    assert np.linalg.norm(r["T"][:, 3] - t_true) < 60.0 and r["n_inliers"] >= 0.95 * (~bad).sum()
+    # one clean 2-point sample against an independent solver of the same least-squares problem
+    i, j = np.flatnonzero(~bad)[:2]
+    res = least_squares(lambda t: np.concatenate([(np.eye(3) - np.outer(f[k], f[k])) @ (P[k] - t) for k in (i, j)]), np.zeros(3))
+    one = oracle.ransac_abs_pose(f[[i, j]], P[[i, j]], 1.0, 1, seed=0, twopt=True)
+    assert np.allclose(one["T"][:, 3], res.x, rtol=1e-9, atol=1e-6)
+    ra = oracle.ransac_abs_pose(f, P, synth.THR_5DEG, 2000, seed=2, twopt=True, adaptive=True)
+    assert ra["iters_used"] < 60                             # 1 - w^2 with w = 0.6: a handful of iterations

@@ -93,6 +93,7 @@ SIGNATURES = {
 FLAG_CAM_ROT_IDENTITY = 1
 FLAG_EPNP = 2
 FLAG_GP3P = 4
+FLAG_TWOPT = 8
 
 
 class Rig(ctypes.Structure):

@@ -133,6 +133,34 @@ __global__ __launch_bounds__(64) void ransac_hyp_kernel(const double* __restrict
   counts[(size_t)b * H + it] = ok ? 0 : -1;
 }
 
+// TWOPT (SOSVO_FLAG_TWOPT, central problems): two distinct correspondences, translation only (sv_hypothesis_twopt).
+__global__ __launch_bounds__(64) void ransac_hyp_twopt_kernel(const double* __restrict__ f, const double* __restrict__ p,
+                                                              const int32_t* __restrict__ n_arr, int stride, int H,
+                                                              uint64_t seed, double* __restrict__ hyp,
+                                                              int32_t* __restrict__ counts) {
+  const int b = blockIdx.y;
+  const int it = blockIdx.x * blockDim.x + threadIdx.x;
+  if (it >= H) return;
+  const int n = min(n_arr[b], stride);
+  const size_t base = (size_t)b * stride;
+  double R[9], t[3];
+  const int ok = sv_hypothesis_twopt(f + 3 * base, p + 3 * base, n, problem_seed(seed, b), (uint64_t)it, R, t);
+  double* h = hyp + ((size_t)b * H + it) * kHypDoubles;
+  if (ok) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) h[k] = R[k];
+    h[9] = t[0];
+    h[10] = t[1];
+    h[11] = t[2];
+    h[12] = -(((R[0] * t[0]) + (R[3] * t[1])) + (R[6] * t[2]));
+    h[13] = -(((R[1] * t[0]) + (R[4] * t[1])) + (R[7] * t[2]));
+    h[14] = -(((R[2] * t[0]) + (R[5] * t[1])) + (R[8] * t[2]));
+  } else {
+    h[0] = __longlong_as_double(0x7FF8000000000000LL);
+  }
+  counts[(size_t)b * H + it] = ok ? 0 : -1;
+}
+
 // The generalised-P3P hypothesis generator (SOSVO_FLAG_GP3P): one lane per (problem, iteration): four distinct
 // correspondences out of all cameras, sv_hypothesis_gp3p (gp3p_core.h, the oracle's text).
 __global__ __launch_bounds__(64) void ransac_hyp_gp3p_kernel(const double* __restrict__ f, const double* __restrict__ p,
@@ -491,7 +519,7 @@ __global__ __launch_bounds__(kThreads) void ransac_select_kernel(
         if (c > best_count) {
           best_count = c;
           best_it = it;
-          base = (adaptive & 2) ? sv_adaptive_base6(c, n) : sv_adaptive_base(c, n);
+          base = (adaptive & 2) ? sv_adaptive_base6(c, n) : ((adaptive & 4) ? sv_adaptive_base2(c, n) : sv_adaptive_base(c, n));
         }
         iterations++;
       }
@@ -771,13 +799,19 @@ int32_t sosvo_ransac_abs_pose(sosvo_ctx* ctx, const double* f, const double* p, 
   SOSVO_LAUNCH_CHECK(ctx);
   const int epnp = (flags & SOSVO_FLAG_EPNP) != 0;
   SOSVO_REQUIRE(ctx, !epnp || cam == nullptr, "SOSVO_FLAG_EPNP is for central problems (cam == NULL)");
+  const int twopt = (flags & SOSVO_FLAG_TWOPT) != 0 && !epnp && !(flags & SOSVO_FLAG_GP3P);
+  SOSVO_REQUIRE(ctx, !twopt || cam == nullptr, "SOSVO_FLAG_TWOPT is for central problems (cam == NULL)");
   if (epnp) adaptive = (adaptive ? 1 : 0) | 2;  // bit 1: the adaptive stop uses 6-point samples
+  if (twopt) adaptive = (adaptive ? 1 : 0) | 4;  // bit 2: ... 2-point samples
   if (epnp) {
     double* vvbuf = (double*)(ws + o_vv);
     SOSVO_LAUNCH(ctx, ransac_epnp_eigen_kernel, dim3(cdiv(H, 64), nprob), dim3(64), 0, ctx->stream, f, p, n, stride, H, seed,
                  vvbuf, counts);
     SOSVO_LAUNCH(ctx, ransac_epnp_pose_kernel, dim3(cdiv(H, 64), nprob), dim3(64), 0, ctx->stream, f, p, n, stride, H, seed,
                  vvbuf, hyp, counts);
+  } else if (twopt) {
+    SOSVO_LAUNCH(ctx, ransac_hyp_twopt_kernel, dim3(cdiv(H, 64), nprob), dim3(64), 0, ctx->stream, f, p, n, stride, H, seed, hyp,
+                 counts);
   } else if (flags & SOSVO_FLAG_GP3P) {
     SOSVO_LAUNCH(ctx, ransac_hyp_gp3p_kernel, dim3(cdiv(H, 64), nprob), dim3(64), 0, ctx->stream, f, p, cam, cam_off, cam_rot, n,
                  stride, H, seed, hyp, counts);

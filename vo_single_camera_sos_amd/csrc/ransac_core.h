@@ -131,6 +131,16 @@ __device__ __forceinline__ static double sv_adaptive_base6(int32_t best, int32_t
   return pno;
 }
 
+// ... and for 2-point samples (TWOPT): 1 - w^2
+__device__ __forceinline__ static double sv_adaptive_base2(int32_t best, int32_t n) {
+  const double w = (double)best / (double)n;
+  double pno = 1.0 - (w * w);
+  const double eps = 2.220446049250313e-16;
+  if (pno < eps) pno = eps;
+  if (pno > 1.0 - eps) pno = 1.0 - eps;
+  return pno;
+}
+
 __device__ __forceinline__ static int sv_ransac_continue(double base, int32_t iterations) {
   double result = 1.0, b = base;
   int32_t m = iterations;
@@ -643,6 +653,36 @@ __device__ __forceinline__ static int sv_solve_damped(const double* Apacked, con
 #pragma unroll
   for (int i = 0; i < 6; ++i) ok = ok && isfinite(dx[i]);
   return ok ? 1 : 0;
+}
+
+/* ---- TWOPT: the translation of a camera whose rotation is KNOWN, from two correspondences ---------------
+ * (pyopengv.absolute_pose_ransac(..., "TWOPT", ...), omnistereo/pose_est_tools.py:95-107: OpenGV's twopt takes the
+ * rotation prior of its adapter, which the binding leaves at the identity.)  Restated as the least-squares meeting
+ * point of the two rays through the world points: minimise sum |(I - f_i f_i^T)(p_i - t)|^2, f_i the bearings rotated
+ * into the world frame -- a 3 x 3 linear system, solved by Cramer's rule.  Returns 0 for (nearly) parallel rays. */
+__device__ __forceinline__ static int sv_twopt(const double* f1, const double* f2, const double* p1, const double* p2, const double* R,
+                            double* t) {
+  double A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+  for (int k = 0; k < 2; ++k) {
+    const double* f = k ? f2 : f1;
+    const double* p = k ? p2 : p1;
+    double g[3]; /* bearing in the world frame */
+    for (int i = 0; i < 3; ++i) g[i] = ((R[3 * i] * f[0]) + (R[3 * i + 1] * f[1])) + (R[3 * i + 2] * f[2]);
+    const double gp = ((g[0] * p[0]) + (g[1] * p[1])) + (g[2] * p[2]);
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) A[3 * i + j] = A[3 * i + j] + ((i == j ? 1.0 : 0.0) - (g[i] * g[j]));
+      b[i] = b[i] + (p[i] - (g[i] * gp));
+    }
+  }
+  const double c00 = (A[4] * A[8]) - (A[5] * A[7]), c01 = (A[5] * A[6]) - (A[3] * A[8]), c02 = (A[3] * A[7]) - (A[4] * A[6]);
+  const double det = ((A[0] * c00) + (A[1] * c01)) + (A[2] * c02);
+  if (!(det > 1e-12)) return 0; /* A = 2 I - g1 g1^T - g2 g2^T has determinant sin^2 of the angle between the rays */
+  const double c10 = (A[2] * A[7]) - (A[1] * A[8]), c11 = (A[0] * A[8]) - (A[2] * A[6]), c12 = (A[1] * A[6]) - (A[0] * A[7]);
+  const double c20 = (A[1] * A[5]) - (A[2] * A[4]), c21 = (A[2] * A[3]) - (A[0] * A[5]), c22 = (A[0] * A[4]) - (A[1] * A[3]);
+  t[0] = (((c00 * b[0]) + (c10 * b[1])) + (c20 * b[2])) / det;
+  t[1] = (((c01 * b[0]) + (c11 * b[1])) + (c21 * b[2])) / det;
+  t[2] = (((c02 * b[0]) + (c12 * b[1])) + (c22 * b[2])) / det;
+  return 1;
 }
 
 /* Sum of 256 partials: four groups of 64, each by the binary tree v[l] += v[l + o], o = 32..1,

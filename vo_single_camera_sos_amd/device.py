@@ -428,7 +428,7 @@ class Context(object):
         return _ptr(cam), _ptr(cam_off), _ptr(cam_rot), ncam
 
     def ransac_abs_pose(self, f, p, n, thr, max_iter, seed=0, adaptive=False, cam=None, cam_off=None,
-                        cam_rot=None, cam_rot_identity=False, want_counts=False, out=None, epnp=False, gp3p=False):
+                        cam_rot=None, cam_rot_identity=False, want_counts=False, out=None, epnp=False, gp3p=False, twopt=False):
         """f, p [P, S, 3] f64, n [P] i32 (+ cam [P, S] i32, cam_off [C,3], cam_rot [C,3,3]) ->
         dict(T [P,3,4], mask [P,S] u8, idx [P,S] i32, n_inliers [P] i32, info [P,4] i32[, counts [P,max_iter]]).
         `out` may carry preallocated result tensors (same keys) to avoid allocations in a hot loop."""
@@ -455,7 +455,7 @@ class Context(object):
         if counts is not None:
             _check(counts, torch.int32, "counts", (P, int(max_iter)))
         flags = (_lib.FLAG_CAM_ROT_IDENTITY if cam_rot_identity else 0) | (_lib.FLAG_EPNP if epnp else 0) | \
-            (_lib.FLAG_GP3P if gp3p else 0)
+            (_lib.FLAG_GP3P if gp3p else 0) | (_lib.FLAG_TWOPT if twopt else 0)
         self._call(self._lib.sosvo_ransac_abs_pose, _ptr(f), _ptr(p), cam_p, off_p, rot_p, ncam, flags,
                    _ptr(n), P, S, float(thr), int(max_iter), 1 if adaptive else 0, int(seed) & (2 ** 64 - 1),
                    _ptr(out["T"]), _ptr(out["mask"]), _ptr(out["idx"]), _ptr(out["n_inliers"]), _ptr(out["info"]),

@@ -74,7 +74,8 @@ def _rig(ctx, cam_offsets, cam_rotations):
     return _dev(ctx, off, np.float64), _dev(ctx, rot, np.float64)
 
 
-def _ransac(b, p, threshold, max_iterations, cam_idx=None, cam_offsets=None, cam_rotations=None, epnp=False, gp3p=False):
+def _ransac(b, p, threshold, max_iterations, cam_idx=None, cam_offsets=None, cam_rotations=None, epnp=False, gp3p=False,
+            twopt=False):
     ctx = _ctx()
     f_t, p_t, n_t, cam_t, n = _problem(ctx, b, p, cam_idx)
     kw = {}
@@ -82,7 +83,7 @@ def _ransac(b, p, threshold, max_iterations, cam_idx=None, cam_offsets=None, cam
         off_t, rot_t = _rig(ctx, cam_offsets, cam_rotations)
         kw = dict(cam=cam_t, cam_off=off_t, cam_rot=rot_t)
     out = ctx.ransac_abs_pose(f_t, p_t, n_t, float(threshold), int(max_iterations), seed=_next_seed(), adaptive=True,
-                              epnp=epnp, gp3p=gp3p, **kw)
+                              epnp=epnp, gp3p=gp3p, twopt=twopt, **kw)
     ctx.synchronize()
     k = int(out["n_inliers"][0].item())
     T = out["T"][0].cpu().numpy()
@@ -119,14 +120,14 @@ def absolute_pose_noncentral_optimize_nonlinear(b, cam_idx, p, cam_offsets, cam_
 def absolute_pose_ransac(b, p, algo_name, threshold, max_iterations):
     """-> (T [3,4], inlier indices int64 [k] ascending)."""
     name = str(algo_name).upper()
-    if name == "TWOPT":
-        raise NotImplementedError("TWOPT (translation from a known rotation) is not built")
-    if name not in ("KNEIP", "GAO", "EPNP", "GP3P"):
+    if name not in ("TWOPT", "KNEIP", "GAO", "EPNP", "GP3P"):
         raise ValueError("unknown algorithm %r" % algo_name)
-    # "EPNP": 6-point samples solved by EPnP, as in OpenGV; "GP3P": the generalised three-point solver on a one-camera
-    # rig; "KNEIP" / "GAO": a closed-form central P3P + a 4th point (Gao's and Kneip's solvers return the same poses:
-    # the real solutions of the three-point problem; Kneip's is the one built)
-    return _ransac(b, p, threshold, max_iterations, epnp=(name == "EPNP"), gp3p=(name == "GP3P"))
+    # "EPNP": 6-point samples solved by EPnP, as in OpenGV.  "KNEIP": Kneip's closed-form P3P (camera pose from two
+    # angles) + a 4th point.  "GAO" and "GP3P": the three-point problem posed on the three DEPTHS (the law-of-cosines
+    # system Gao et al. solve), here through the generalised solver on a one-camera rig, + a 4th point.  "TWOPT": 2-point
+    # samples, translation only, rotation = the binding's identity prior.
+    return _ransac(b, p, threshold, max_iterations, epnp=(name == "EPNP"), gp3p=(name in ("GP3P", "GAO")),
+                   twopt=(name == "TWOPT"))
 
 
 def absolute_pose_optimize_nonlinear(b, p, t, R):
