@@ -219,6 +219,16 @@ int32_t sosvo_detect_fast(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* m
                           int32_t images_per_maskset, int32_t rows, int32_t cols, int32_t nmask,
                           int32_t threshold, int32_t cap, float* kp, int32_t* n, int32_t* status);
 
+/* ---- AGAST as a detector (a4, feature_detection_method "AGAST") -------------------------------------------
+ * Replaces cv2.AgastFeatureDetector_create() + setNonmaxSuppression(True) + .detect(image, mask)
+ * (omnistereo/camera_models.py:1670-1671, :1755; pose_est_tools.py:508-509): OAST 9/16 -- the corner set and response of
+ * FAST-9/16 at `threshold` (OpenCV default 10) -- with AGAST's own non-maximum suppression (one maximum per block of
+ * vertically / horizontally touching corners), keypoints where the mask bit is set, raster order.  Same arguments and
+ * outputs as sosvo_detect_fast; status bit 1: more than 16384 corners in an image (the rest is dropped); rows <= 1024. */
+int32_t sosvo_detect_agast(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* mask_bits, int32_t nimg,
+                           int32_t images_per_maskset, int32_t rows, int32_t cols, int32_t nmask,
+                           int32_t threshold, int32_t cap, float* kp, int32_t* n, int32_t* status);
+
 /* ---- K7: brute-force Hamming matching ------------------------------------------------
  * Replaces cv2.BFMatcher(NORM_HAMMING).match / .knnMatch as called from
  * omnistereo/camera_models.py:442 and :420 (FeatureMatcher.match, :404-446).

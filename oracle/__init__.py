@@ -389,6 +389,14 @@ def fast_score_map(img, thr=20):
     return out
 
 
+def agast_nms(score):
+    """AGAST's block-maximum non-maximum suppression on a corner score map -> bool [rows, cols]."""
+    score = _c(score, np.uint8)
+    keep = np.zeros(score.shape, dtype=np.uint8)
+    lib().orc_agast_nms(_p(score), ctypes.c_int32(score.shape[0]), ctypes.c_int32(score.shape[1]), _p(keep))
+    return keep.astype(bool)
+
+
 def orb_quotas(nfeatures):
     q = np.zeros(8, dtype=np.int32)
     lib().orc_orb_quotas(ctypes.c_int32(nfeatures), _p(q))

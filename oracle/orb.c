@@ -97,6 +97,69 @@ void orc_fast_score_map(const uint8_t* img, int32_t rows, int32_t cols, int32_t 
     }
 }
 
+/* ---- AGAST (OAST 9/16) with non-maximum suppression -------------------------------------------------------
+ * cv2.AgastFeatureDetector_create() (threshold 10, nonmaxSuppression, OAST_9_16) + .detect(image, mask)
+ * (omnistereo/camera_models.py:1670-1671, :1755; pose_est_tools.py:508-509).  OpenCV's AGAST is not in the reference
+ * tree; restated from the published method (Mair et al., ECCV 2010) and the recalled structure of its OpenCV port:
+ *   - OAST 9/16 is the 9-of-16 accelerated segment test by an optimal decision tree: the SAME corner criterion as
+ *     FAST-9/16, hence the same corner set (3-px border); the response is the largest threshold at which the pixel is
+ *     still a corner (found by bisection there), i.e. the FAST score of orc_fast_score_map;
+ *   - its non-maximum suppression is NOT a 3x3 test: corners that touch vertically or horizontally form blocks, and a
+ *     raster scan with a union-find-like link table keeps one maximum per block (current corner against the block of
+ *     the corner directly above, then against the block of the corner directly to the left; on equal responses the
+ *     later corner takes over).
+ * keep[rows * cols] receives 1 at the kept corners.  Parity status: UNPINNED against OpenCV binaries. */
+void orc_agast_nms(const uint8_t* score, int32_t rows, int32_t cols, uint8_t* keep) {
+  const int64_t npix = (int64_t)rows * cols;
+  int32_t* idx_of = (int32_t*)malloc(sizeof(int32_t) * (size_t)npix); /* pixel -> corner index, -1 */
+  int64_t n = 0;
+  for (int64_t i = 0; i < npix; ++i) {
+    keep[i] = 0;
+    idx_of[i] = score[i] ? (int32_t)n++ : -1;
+  }
+  int32_t* pix = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+  int32_t* link = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+  for (int64_t i = 0; i < npix; ++i)
+    if (idx_of[i] >= 0) {
+      pix[idx_of[i]] = (int32_t)i;
+      link[idx_of[i]] = -1;
+    }
+  for (int32_t cur = 0; cur < (int32_t)n; ++cur) {
+    const int32_t y = pix[cur] / cols, x = pix[cur] - y * cols;
+    const int resp = score[pix[cur]];
+    if (y > 0 && idx_of[pix[cur] - cols] >= 0) { /* a corner directly above */
+      int32_t w = idx_of[pix[cur] - cols];
+      while (link[w] != -1) w = link[w];
+      if (resp < (int)score[pix[w]]) link[cur] = w;
+      else link[w] = cur;
+    }
+    if (x > 0 && idx_of[pix[cur] - 1] >= 0) { /* a corner directly to the left */
+      int32_t t = idx_of[pix[cur] - 1];
+      const int32_t above = link[cur];
+      while (link[t] != -1) t = link[t];
+      if (above == -1) {
+        if (t != cur) {
+          if (resp < (int)score[pix[t]]) link[cur] = t;
+          else link[t] = cur;
+        }
+      } else if (t != above) {
+        if ((int)score[pix[above]] < (int)score[pix[t]]) {
+          link[above] = t;
+          link[cur] = t;
+        } else {
+          link[t] = above;
+          link[cur] = above;
+        }
+      }
+    }
+  }
+  for (int32_t c = 0; c < (int32_t)n; ++c)
+    if (link[c] == -1) keep[pix[c]] = 1;
+  free(idx_of);
+  free(pix);
+  free(link);
+}
+
 /* ---- orientation and Harris ------------------------------------------------------------------------ */
 static const int kUmax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 

@@ -94,6 +94,14 @@ def fast_keypoints(gray, mask_bits, which, thr=10):
     return np.stack([xs, ys], axis=1).astype(np.float32)
 
 
+def agast_keypoints(gray, mask_bits, which, thr=10):
+    """cv2.AgastFeatureDetector_create() (threshold 10, NMS, OAST_9_16).detect(gray, mask): the FAST-9/16 corner set with
+    AGAST's block-maximum suppression (oracle.agast_nms), mask set; raster order -> [n,2] float32 (x, y)."""
+    keep = oracle.agast_nms(oracle.fast_score_map(gray, thr)) & ((mask_bits >> which) & 1).astype(bool)
+    ys, xs = np.nonzero(keep)
+    return np.stack([xs, ys], axis=1).astype(np.float32)
+
+
 def detect_view(im, omni, view):
     """set_current_omni_image (camera_models.py:3107) + detect_sparse_features_on_panorama with GFT
     (camera_models.py:1708-1797) for one mirror: lists over azimuthal masks of keypoints / descriptors."""
@@ -108,9 +116,10 @@ def detect_view(im, omni, view):
         return kps, descs, pano, gray
     blurred = oracle.gauss7(gray)
     kps, descs = [], []
-    if im.method == "FAST":                                                           # :1664-1666, :1755, :1765
+    if im.method in ("FAST", "AGAST"):                                                # :1664-1671, :1755, :1765
+        detect = fast_keypoints if im.method == "FAST" else agast_keypoints
         for m in range(im.nmask):
-            kp = fast_keypoints(gray, im.mask_bits[view], m)[: im.kp_cap]
+            kp = detect(gray, im.mask_bits[view], m)[: im.kp_cap]
             d, kept = oracle.orb_describe(blurred, kp, im.cos_a, im.sin_a, im.pattern, im.edge)
             kps.append(kp[kept])
             descs.append(d)

@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--workers", type=int, default=16)
     ap.add_argument("--iters", type=int, default=2000)
     ap.add_argument("--pano-width", type=int, default=1440)
-    ap.add_argument("--detector", default="GFT", choices=["GFT", "ORB", "FAST"])
+    ap.add_argument("--detector", default="GFT", choices=["GFT", "ORB", "FAST", "AGAST"])
     ap.add_argument("--kp-cap", type=int, default=512, help="keypoint capacity per (frame, mirror, mask)")
     ap.add_argument("--rgbd", choices=["EPNP", "KNEIP"], default=None,
                     help="soak the RGB-D path (BASELINE config 5: sosvo_rgbd_pair_batch) with this pose algorithm instead")

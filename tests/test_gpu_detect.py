@@ -133,6 +133,34 @@ def test_fast_detector_raster_order_masks_and_cap(ctx):
         assert n[0] >= min(cap, 100) and n[2] == 0 and n[8:].sum() == 0
 
 
+def test_agast_detector_block_maxima_masks_and_cap(ctx):
+    """sosvo_detect_agast: the FAST-9/16 corner set with AGAST's block-maximum suppression (oracle.agast_nms), masks,
+    raster order, cap / status; a larger image with long runs of touching corners."""
+    import refflow
+    rng = np.random.default_rng(78)
+    for rows, cols in ((61, 203), (146, 700)):
+        sigma = 40 if rows < 100 else 9          # (white noise at sigma 40 makes a quarter of the pixels corners)
+        imgs = np.stack([np.clip(rng.normal(120, sigma, (rows, cols)), 0, 255).astype(np.uint8) for _ in range(3)])
+        imgs[1, : rows // 2] = np.clip(imgs[1, : rows // 2].astype(int) // 16 * 16 + 5, 0, 255)   # plateaus: ties in the responses
+        imgs[2] = 90
+        masks = np.zeros((1, rows, cols), np.uint32)
+        masks[0, :, : cols // 2 + 9] |= 1
+        masks[0, 10: rows - 9, cols // 2:] |= 2
+        masks[0, :, :] |= 8
+        t_img, t_mask = torch.from_numpy(imgs).to(ctx.device), torch.from_numpy(masks).to(ctx.device)
+        for cap in (4096, 40):
+            kp, n, status = ctx.detect_agast(t_img, t_mask, 3, 4, cap)
+            ctx.synchronize()
+            kp, n, status = kp.cpu().numpy(), n.cpu().numpy(), status.cpu().numpy()
+            for i in range(3):
+                for m in range(4):
+                    want = refflow.agast_keypoints(imgs[i], masks[0], m)
+                    p = i * 4 + m
+                    assert n[p] == min(len(want), cap) and status[p] == (1 if len(want) > cap else 0), (cap, i, m, n[p], len(want))
+                    assert np.array_equal(kp[p, : n[p]], want[:cap]), (cap, i, m)
+            assert n[0] >= min(cap, 100) and n[2] == 0 and n[8:].sum() == 0
+
+
 def test_detect_gft_reports_candidate_overflow(ctx):
     """More 3x3 local maxima above the threshold than the selection holds (4096 for cap <= 1024): status bit 0 is set
     (include/sosvo.h: "the result then depends on which were kept"); the call still returns cap corners that respect the

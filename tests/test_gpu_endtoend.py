@@ -17,7 +17,7 @@ from vo_single_camera_sos_amd.pipeline import FramePairPipeline, RigConfig
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("method,nfeat", [("GFT", 330), ("ORB", 250), ("FAST", 250)])
+@pytest.mark.parametrize("method,nfeat", [("GFT", 330), ("ORB", 250), ("FAST", 250), ("AGAST", 250)])
 def test_full_hot_path_from_images(ctx, method, nfeat):
     B = 3
     gs = synthetic_gums()

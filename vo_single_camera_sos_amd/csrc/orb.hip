@@ -397,6 +397,119 @@ __global__ __launch_bounds__(64) void fast_collect_kernel(const unsigned long lo
   }
 }
 
+// ---- AGAST (OAST 9/16) as a detector (feature_detection_method "AGAST") ---------------------------------------------
+// cv2.AgastFeatureDetector_create() + setNonmaxSuppression(True) + detect(image, mask) (omnistereo/camera_models.py:
+// 1670-1671, :1755; pose_est_tools.py:508-509): the 9-of-16 segment test by an optimal decision tree -- the corner set and
+// the response of FAST-9/16 (the score map above, threshold 10) -- followed by AGAST's own suppression: corners that touch
+// vertically or horizontally form blocks, a raster scan with a link table keeps one maximum per block (oracle/orb.c,
+// orc_agast_nms, for the exact rule).  That scan is sequential by nature: one workgroup per image builds the corner list
+// in raster order (all lanes), lane 0 walks it with everything in LDS (entry = pixel index | response << 24, link table,
+// row starts: 132 KB), then all lanes compact the survivors per mask.
+constexpr int kAgastCap = 16384, kAgastMaxRows = 1024;
+__global__ __launch_bounds__(64) void agast_nms_collect_kernel(const uint8_t* __restrict__ score,
+                                                               const uint32_t* __restrict__ mask_bits, int images_per_maskset,
+                                                               int nmask, int rows, int cols, int cap, float* __restrict__ kp,
+                                                               int32_t* __restrict__ n_out, int32_t* __restrict__ status) {
+  __shared__ uint32_t ent[kAgastCap];
+  __shared__ int32_t link[kAgastCap];
+  __shared__ int32_t rowptr[kAgastMaxRows + 1];
+  const int lane = threadIdx.x, img = blockIdx.x;
+  const uint8_t* sc = score + (size_t)img * rows * cols;
+  const uint32_t* mb = mask_bits + (size_t)(img / images_per_maskset) * rows * cols;
+  // A. corners (score > 0) in raster order
+  int total = 0;  // wave-uniform
+  bool overflow = false;
+  for (int y = 0; y < rows; ++y) {
+    if (lane == 0) rowptr[y] = min(total, kAgastCap);
+    for (int x0 = 0; x0 < cols; x0 += 64) {
+      const int x = x0 + lane;
+      const int sv = x < cols ? (int)sc[(size_t)y * cols + x] : 0;
+      const unsigned long long bal = __ballot(sv > 0);
+      const int pos = total + __popcll(bal & ((1ULL << lane) - 1ULL));
+      if (sv > 0) {
+        if (pos < kAgastCap) {
+          ent[pos] = (uint32_t)(y * cols + x) | ((uint32_t)sv << 24);
+          link[pos] = -1;
+        } else {
+          overflow = true;
+        }
+      }
+      total += __popcll(bal);
+    }
+  }
+  const int n = min(total, kAgastCap);
+  if (lane == 0) rowptr[rows] = n;
+  __syncthreads();
+  // B. block maxima, sequentially (the pointer `ap` walks the previous row's corners: amortised O(1) per corner)
+  if (lane == 0) {
+    int row = -1, ap = 0, ap_end = 0;
+    for (int cur = 0; cur < n; ++cur) {
+      const uint32_t e = ent[cur];
+      const int pix = (int)(e & 0xFFFFFFu), resp = (int)(e >> 24);
+      const int y = pix / cols, x = pix - y * cols;
+      if (y != row) {
+        row = y;
+        ap = y > 0 ? rowptr[y - 1] : 0;
+        ap_end = y > 0 ? rowptr[y] : 0;
+      }
+      const int above_pix = pix - cols;
+      while (ap < ap_end && (int)(ent[ap] & 0xFFFFFFu) < above_pix) ++ap;
+      if (ap < ap_end && (int)(ent[ap] & 0xFFFFFFu) == above_pix) {
+        int w = ap;
+        while (link[w] != -1) w = link[w];
+        if (resp < (int)(ent[w] >> 24)) link[cur] = w;
+        else link[w] = cur;
+      }
+      if (x > 0 && cur > 0 && (int)(ent[cur - 1] & 0xFFFFFFu) == pix - 1) {
+        int t = cur - 1;
+        const int above = link[cur];
+        while (link[t] != -1) t = link[t];
+        if (above == -1) {
+          if (t != cur) {
+            if (resp < (int)(ent[t] >> 24)) link[cur] = t;
+            else link[t] = cur;
+          }
+        } else if (t != above) {
+          if ((int)(ent[above] >> 24) < (int)(ent[t] >> 24)) {
+            link[above] = t;
+            link[cur] = t;
+          } else {
+            link[t] = above;
+            link[cur] = above;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // C. survivors (link == -1) per mask, raster order
+  for (int m = 0; m < nmask; ++m) {
+    const int p = img * nmask + m;
+    int cnt = 0;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+      const int c = c0 + lane;
+      bool keep = false;
+      int pix = 0;
+      if (c < n && link[c] == -1) {
+        pix = (int)(ent[c] & 0xFFFFFFu);
+        keep = ((mb[pix] >> m) & 1u) != 0u;
+      }
+      const unsigned long long bal = __ballot(keep);
+      const int pos = cnt + __popcll(bal & ((1ULL << lane) - 1ULL));
+      if (keep && pos < cap) {
+        const int y = pix / cols;
+        kp[((size_t)p * cap + pos) * 2] = (float)(pix - y * cols);
+        kp[((size_t)p * cap + pos) * 2 + 1] = (float)y;
+      }
+      cnt += __popcll(bal);
+    }
+    if (lane == 0) {
+      n_out[p] = min(cnt, cap);
+      if (status) status[p] = (cnt > cap ? 1 : 0) | ((__ballot(overflow) != 0ULL || total > kAgastCap) ? 2 : 0);
+    }
+  }
+}
+
 // ---- selection ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   const float scale = (float)(180.0 / 3.14159265358979323846);
@@ -1011,6 +1124,30 @@ int32_t sosvo_detect_fast(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* m
   SOSVO_LAUNCH_CHECK(ctx);
   SOSVO_LAUNCH(ctx, fast_collect_kernel, dim3((unsigned)((size_t)nimg * nmask)), dim3(64), 0, ctx->stream, flags, mask_bits,
                images_per_maskset, nmask, rows, cols, words, cap, kp, n, status);
+  SOSVO_LAUNCH_CHECK(ctx);
+  return SOSVO_OK;
+}
+
+int32_t sosvo_detect_agast(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* mask_bits, int32_t nimg,
+                           int32_t images_per_maskset, int32_t rows, int32_t cols, int32_t nmask, int32_t threshold,
+                           int32_t cap, float* kp, int32_t* n, int32_t* status) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, gray && mask_bits && kp && n, "null pointer");
+  SOSVO_REQUIRE(ctx, nimg >= 0 && nimg <= 65535 && images_per_maskset > 0, "nimg out of range");
+  SOSVO_REQUIRE(ctx, rows >= 7 && rows <= kAgastMaxRows && cols >= 7 && rows * (int64_t)cols < (1 << 24),
+                "image sizes out of range (rows <= 1024, rows * cols < 2^24)");
+  SOSVO_REQUIRE(ctx, nmask >= 1 && nmask <= 32, "nmask out of range (1..32)");
+  SOSVO_REQUIRE(ctx, cap > 0 && cap <= 16384 && threshold >= 0 && threshold <= 254, "bad detector parameters");
+  if (nimg == 0) return SOSVO_OK;
+  const size_t score_bytes = ((size_t)nimg * rows * cols + 255) & ~(size_t)255;
+  int32_t rc = sosvo_ws_reserve(ctx, score_bytes);
+  if (rc != SOSVO_OK) return rc;
+  uint8_t* score = (uint8_t*)ctx->ws;
+  rc = launch_fast_score(ctx, gray, (long long)rows * cols, nimg, rows, cols, threshold, 0, rows, score, (long long)rows * cols,
+                         nullptr, 0);
+  if (rc != SOSVO_OK) return rc;
+  SOSVO_LAUNCH(ctx, agast_nms_collect_kernel, dim3((unsigned)nimg), dim3(64), 0, ctx->stream, score, mask_bits, images_per_maskset,
+               nmask, rows, cols, cap, kp, n, status);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
 }

@@ -208,7 +208,12 @@ class Context(object):
                        _ptr(row_range), _ptr(gray))
         return gray
 
-    def detect_fast(self, gray, mask_bits, images_per_maskset, nmask, cap, threshold=10, kp=None, n=None, status=None):
+    def detect_agast(self, gray, mask_bits, images_per_maskset, nmask, cap, threshold=10, kp=None, n=None, status=None):
+        """AGAST (OAST 9/16) + its block-maximum NMS per azimuthal mask, raster order; arguments as detect_fast."""
+        return self.detect_fast(gray, mask_bits, images_per_maskset, nmask, cap, threshold, kp, n, status, _agast=True)
+
+    def detect_fast(self, gray, mask_bits, images_per_maskset, nmask, cap, threshold=10, kp=None, n=None, status=None,
+                    _agast=False):
         """FAST-9/16 + NMS per azimuthal mask, raster order: gray [NI,rows,cols] u8, mask_bits [nsets,rows,cols] u32
         -> kp [NI*nmask, cap, 2] f32, n [NI*nmask] i32, status [NI*nmask] i32."""
         _check(gray, torch.uint8, "gray", ndim=3)
@@ -226,8 +231,8 @@ class Context(object):
         _check(kp, torch.float32, "kp", (P, cap, 2))
         _check(n, torch.int32, "n", (P,))
         _check(status, torch.int32, "status", (P,))
-        self._call(self._lib.sosvo_detect_fast, _ptr(gray), _ptr(mask_bits), NI, int(images_per_maskset), rows, cols,
-                   int(nmask), int(threshold), int(cap), _ptr(kp), _ptr(n), _ptr(status))
+        self._call(self._lib.sosvo_detect_agast if _agast else self._lib.sosvo_detect_fast, _ptr(gray), _ptr(mask_bits), NI,
+                   int(images_per_maskset), rows, cols, int(nmask), int(threshold), int(cap), _ptr(kp), _ptr(n), _ptr(status))
         return kp, n, status
 
     # ---- K4 / K6 -----------------------------------------------------------------------

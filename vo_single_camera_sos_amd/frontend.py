@@ -55,9 +55,9 @@ class ImageFrontEnd(object):
         """num_of_features: per azimuthal mask (FeatureMatcher.num_of_features, pose_est_tools.py:862).
         keep_panoramas=False: K1 is fused into the median kernel and the colour panoramas are not materialised
         (nothing downstream of K3 reads them); identical gray images."""
-        if detection_method.upper() not in ("GFT", "ORB", "FAST"):
-            raise NotImplementedError("detection method %r: GFT (the reference default, pose_est_tools.py:684), ORB "
-                                      "and FAST are built" % detection_method)
+        if detection_method.upper() not in ("GFT", "ORB", "FAST", "AGAST"):
+            raise NotImplementedError("detection method %r: GFT (the reference default, pose_est_tools.py:684), ORB, "
+                                      "FAST and AGAST are built" % detection_method)
         self.ctx, self.model, self.F = ctx, model, int(nframes)
         self.method = detection_method.upper()
         self.num_of_features, self.median_win_size = int(num_of_features), int(median_win_size)
@@ -65,7 +65,7 @@ class ImageFrontEnd(object):
         self.skip_unreachable_rows = bool(skip_unreachable_rows)
         if kp_cap:
             self.kp_cap = int(kp_cap)
-        elif self.method == "FAST":  # every corner is kept (num_of_features only names the ORB descriptor object)
+        elif self.method in ("FAST", "AGAST"):  # every corner is kept (num_of_features only names the ORB descriptor object)
             self.kp_cap = 2048
         elif self.method == "ORB":  # retainBest keeps ties beyond the quota: leave head room
             self.kp_cap = int(min(2048, max(64, -(-int(self.num_of_features * 1.25) // 64) * 64)))
@@ -127,9 +127,10 @@ class ImageFrontEnd(object):
             c.detect_describe_orb(self.gray, m.mask_pyr, self.F, m.nmask, self.num_of_features, m.pattern, self.kp4,
                                   self.resp, self.n, self.desc, kp_xy=self.kp)                   # K5 + K6' on one pyramid
             return
-        if self.method == "FAST":
-            c.detect_fast(self.gray, m.mask_bits, self.F, m.nmask, self.kp_cap, threshold=10, kp=self.kp, n=self.n,
-                          status=self.status)                                                     # FAST + NMS
+        if self.method in ("FAST", "AGAST"):
+            (c.detect_fast if self.method == "FAST" else c.detect_agast)(
+                self.gray, m.mask_bits, self.F, m.nmask, self.kp_cap, threshold=10, kp=self.kp, n=self.n,
+                status=self.status)                                                               # FAST / AGAST + NMS
             c.describe_orb(self.gray, self.kp, self.n, m.nmask, m.pattern, self.cos_a, self.sin_a, edge=self.edge,
                            desc=self.desc)                                                        # K6
             return
