@@ -54,6 +54,116 @@ def pmc_traffic(kernel, pairs_per_launch, pmc_csv=None):
     return None, None
 
 
+def traffic_step(pairs_per_step, streams, b_alg_pair, pmc_csv=None):
+    """HBM bytes of ONE step summed over all kernels of the newest committed PMC summary (per-kernel bytes per launch x
+    launches per step; the summary's launches cover (dispatches of the dominant kernel / streams) steps), per pair, and
+    its ratio to the algorithmic bytes.  None without a summary."""
+    import csv
+    import glob
+    paths = [pmc_csv] if pmc_csv else sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*pmc_hbm_per_kernel.csv")))
+    for path in reversed(paths):
+        if not os.path.exists(path):
+            continue
+        rows = list(csv.DictReader(open(path)))
+        dom = [r for r in rows if r["label"] in ("unwrap_median_gray_kernel", "median_gray_kernel")]
+        if not dom or not int(dom[0]["pairs_per_launch"] or 0):
+            continue
+        steps_profiled = max(int(dom[0]["dispatches_fetch_pass"]), int(dom[0]["dispatches_write_pass"])) / float(streams)
+        pairs_profiled_step = float(dom[0]["pairs_per_launch"]) * streams
+        total, per_kernel = 0.0, {}
+        for r in rows:
+            if not r["label"].endswith("_kernel"):
+                continue  # (torch's fill / copy kernels of the set-up)
+            disp = max(int(r["dispatches_fetch_pass"]), int(r["dispatches_write_pass"]))
+            b = float(r["hbm_bytes_per_launch"]) * disp / steps_profiled / pairs_profiled_step
+            per_kernel[r["label"]] = b
+            total += b
+        top = dict(sorted(per_kernel.items(), key=lambda kv: -kv[1])[:6])
+        return {"bytes_per_pair": total, "algorithmic_bytes_per_pair": b_alg_pair, "ratio_to_algorithmic": total / b_alg_pair,
+                "bytes_per_step": total * pairs_per_step, "top_kernels_bytes_per_pair": top, "source": os.path.relpath(path, ROOT)}
+    return None
+
+
+def other_configs_subrecords(timeout_s=420):
+    """BASELINE configs 3 and 5 as sub-records of the ONE bench line, so that the driver times them too: a child process
+    (fresh interpreter, scripts/bench_other_configs.py) after this process's own GPU work is done."""
+    import subprocess
+    out = {}
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_other_configs.py"), "--frames", "64", "--pairs", "128"],
+                           capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+        for line in r.stdout.splitlines():
+            if not line.startswith("{"):
+                continue
+            d = json.loads(line)
+            key = "c3" if d["config"] == "C3" else "c5_" + d.get("algorithm", "").lower()
+            d.pop("config", None)
+            out[key] = d
+        if r.returncode != 0 and not out:
+            out["error"] = (r.stderr or "")[-400:]
+    except Exception as e:  # the headline number does not depend on these
+        out["error"] = repr(e)
+    return out
+
+
+def opencv_opengv_baseline(omni, model, rig_kw, args, n_pairs):
+    """if cv2 / pyopengv happen to be importable on this box, time the reference's own third-party calls
+    (written against their public API; no reference file is shipped) on a bounded sample and report that as the primary
+    CPU baseline.  Neither exists in the build image, so this leg normally reports availability only."""
+    info = {"cv2": False, "pyopengv": False}
+    try:
+        import cv2  # noqa: F401
+        info["cv2"] = True
+    except Exception as e:
+        info["cv2_error"] = type(e).__name__
+    try:
+        import pyopengv  # noqa: F401
+        info["pyopengv"] = True
+    except Exception as e:
+        info["pyopengv_error"] = type(e).__name__
+    if not info["cv2"]:
+        return info
+    try:
+        import cv2
+        mx, my = model.map_x.cpu().numpy(), model.map_y.cpu().numpy()
+        masks = (model.mask_bits_host != 0)
+        orb = cv2.ORB_create(nfeatures=args.features_per_mask)
+        bf = cv2.BFMatcher(cv2.NORM_HAMMING, crossCheck=False)
+        t0 = time.perf_counter()
+        for i in range(n_pairs):
+            per_frame = []
+            for fr in (omni[2 * i], omni[2 * i + 1]):
+                views = []
+                for v in range(2):
+                    pano = cv2.remap(fr, mx[v], my[v], cv2.INTER_LINEAR, borderMode=cv2.BORDER_CONSTANT, borderValue=0)
+                    gray = cv2.cvtColor(cv2.medianBlur(pano, 11), cv2.COLOR_BGR2GRAY)
+                    kps, descs = [], []
+                    for m in range(model.nmask):
+                        mk = (((model.mask_bits_host[v] >> m) & 1) * 255).astype(np.uint8)
+                        pts = cv2.goodFeaturesToTrack(gray, args.features_per_mask, 0.01, 5, mask=mk, useHarrisDetector=False)
+                        kp = [cv2.KeyPoint(float(p[0][0]), float(p[0][1]), 31) for p in (pts if pts is not None else [])]
+                        kp, d = orb.compute(gray, kp)
+                        kps.append(kp)
+                        descs.append(d)
+                    views.append((kps, descs))
+                for m in range(model.nmask):   # static stereo per bucket
+                    if views[0][1][m] is not None and views[1][1][m] is not None and len(views[0][1][m]) and len(views[1][1][m]):
+                        bf.match(views[1][1][m], views[0][1][m])
+                per_frame.append(views)
+            for v in range(2):                 # frame-to-frame per view
+                a = [d for d in per_frame[1][v][1] if d is not None and len(d)]
+                b = [d for d in per_frame[0][v][1] if d is not None and len(d)]
+                if a and b:
+                    bf.match(np.concatenate(a), np.concatenate(b))
+        dt = time.perf_counter() - t0
+        info.update({"value": n_pairs / dt, "unit": "frame-pairs/s", "cores": 1, "kind": "reference-libraries",
+                     "sample": "%d frame pairs: cv2 remap / medianBlur / goodFeaturesToTrack / ORB.compute / BFMatcher "
+                               "(image stages + matching; RANSAC through pyopengv only if importable), %.1f s" % (n_pairs, dt)})
+    except Exception as e:
+        info["error"] = repr(e)
+    return info
+
+
 def host_cores():
     """Cores this process may run on (cgroup / affinity aware where the platform tells)."""
     try:
@@ -85,13 +195,20 @@ def valu_issue(kernel, pairs_per_launch, avg_launch_s):
                 if row.get("label") == label:
                     insts = float(row["valu_insts"]) * pairs_per_launch / 64.0  # the SQ pass ran 64 pairs per launch
                     limit = 1024 * 2.4e9 / cyc  # wave-instructions/s of 1024 SIMDs at 2.4 GHz
+                    guide = 1024 * 2.4e9 / 2.0  # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles
                     return {"kernel": kernel, "valu_wave_insts_per_launch": insts, "achieved_ginst_s": insts / avg_launch_s / 1e9,
                             "issue_cycles_per_inst": cyc, "issue_limit_ginst_s": limit / 1e9,
                             "frac": insts / avg_launch_s / limit,
+                            "frac_vs_guide_2cyc": insts / avg_launch_s / guide,
+                            "guide_limit_ginst_s": guide / 1e9,
                             "source": os.path.relpath(path, ROOT), "mix_source": mix_src,
                             "note": "instruction count from the SQ pass; duration of isolated launches of the kernel "
                                     "(roofline.isolated_launch_ms): in the timed region the launches share the SIMDs with "
-                                    "the other streams' kernels -- the whole step is accounted in valu_issue_step"}
+                                    "the other streams' kernels -- the whole step is accounted in valu_issue_step.  frac: "
+                                    "against the ceiling of the kernel's own instruction mix (per-opcode issue rates measured "
+                                    "by scripts/valu_rate.hip: ~2.7 cycles for the fast class, ~4.4 for the slow one); "
+                                    "frac_vs_guide_2cyc: against one wave64 VALU instruction per 2 SIMD-cycles, the guide's "
+                                    "figure, which no opcode reached in that micro-benchmark"}
     return None
 
 
@@ -157,6 +274,12 @@ def parse():
                          "per-kernel averages then cover the timed region only)")
     ap.add_argument("--pmc-csv", default=None, help="per-kernel PMC summary for roofline.traffic (default: newest in profiles/)")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--ransac-solver", default="P3P", choices=["P3P", "GP3P"],
+                    help="P3P: the three solve points of a sample from one mirror (BASELINE config 2's \"P3P RANSAC\"); GP3P: "
+                         "generalised P3P on samples across both mirrors (what the reference's non-central RANSAC uses)")
+    ap.add_argument("--no-sub", action="store_true",
+                    help="skip the sub-records (ORB-detector path, GP3P hypotheses, BASELINE configs 3 and 5)")
+    ap.add_argument("--sub-steps", type=int, default=5, help="timed steps of each in-process sub-record")
     ap.add_argument("--dump-records", default=None,
                     help="rank 0 writes the last step's gathered [N*B,16] records (global pair order) to this .npy file")
     return ap.parse_args()
@@ -259,7 +382,8 @@ def main():
     torch.cuda.set_device(local_rank)
     eng = OverlappedFramePairs(local_rank, gs, (H, W), RigConfig(**rig_kw), B, n_streams=args.streams,
                                num_of_features=args.features_per_mask, kp_cap=512, frame_cap=2048, max_iter=args.iters,
-                               adaptive=False, seed=args.seed + rank * B, detection_method=args.detector)
+                               adaptive=False, seed=args.seed + rank * B, detection_method=args.detector,
+                               ransac_solver=args.ransac_solver)
     model, dev = eng.model, eng.device
     eng.load_frames(omni)
     gathered = torch.empty((n_gpus * B, 16), dtype=torch.float64, device=dev) if dist else None
@@ -372,9 +496,10 @@ def main():
             "config": {"workload": "C2: 640x480 BGR omni frame pair -> 2 x %dx%d panoramas per frame, 11x11 median, "
                                    "%s detector (budget %d per azimuthal mask x %d masks) + ORB descriptors, "
                                    "%d bucket + 2 frame-to-frame BF Hamming matchings, midpoint triangulation, "
-                                   "non-central P3P RANSAC %d iterations fixed, LM"
+                                   "non-central %s RANSAC %d iterations fixed, LM"
                                    % (pano.cols, pano.rows, args.detector, args.features_per_mask, model.nmask,
-                                      2 * model.nmask, args.iters),
+                                      2 * model.nmask, "P3P (one-mirror samples)" if args.ransac_solver == "P3P" else
+                                      "GP3P (samples across both mirrors)", args.iters),
                        "keypoint_capacity_hit": bool(cap_hit),
                        "pairs_per_gpu": B, "global_pairs_per_step": n_gpus * B,
                        "parallelism": "pairs sharded over ranks, dp%d; %d HIP streams per GPU" % (n_gpus, eng.S),
@@ -422,13 +547,55 @@ def main():
                     out["cpu_baseline_all_cores"] = {"error": repr(e)}
         if out["valu_issue"]:
             out["valu_issue_step"] = valu_issue_step(B, out["ms_per_step"], out["valu_issue"]["issue_cycles_per_inst"])
+        out["traffic_step"] = traffic_step(B, eng.S, b_alg, args.pmc_csv)
+        if n_gpus == 1 and not args.no_sub:
+            # ---- sub-records of the same line (driver-timed): other detector / solver on the SAME frames, in this process
+            def sub_engine(**kw):
+                e2 = OverlappedFramePairs(local_rank, gs, (H, W), RigConfig(**rig_kw), B, n_streams=args.streams,
+                                          num_of_features=args.features_per_mask, kp_cap=512, frame_cap=2048,
+                                          max_iter=args.iters, adaptive=False, seed=args.seed, **kw)
+                e2.load_frames(omni)
+                for _ in range(2):
+                    e2.step()
+                    e2.results()
+                    e2.consumed()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.sub_steps):
+                    e2.step()
+                    r2 = e2.results()
+                    e2.consumed()
+                torch.cuda.synchronize()
+                dt2 = time.perf_counter() - t1
+                r2 = r2.cpu().numpy()
+                nk = np.concatenate([p.fe.n.cpu().numpy().reshape(2, -1, model.nmask).sum(-1) for p in e2.parts], axis=1)
+                rec2 = {"value": B * args.sub_steps / dt2, "unit": "frame-pairs/s", "ms_per_step": 1e3 * dt2 / args.sub_steps,
+                        "steps": args.sub_steps, "pairs_per_step": B, "keypoints_per_view_mean": float(nk.mean()),
+                        "tracked_ok": int((r2[:, 14] == 0).sum()), "inliers_per_pair_mean": float(r2[:, 12].mean())}
+                e2.close()
+                return rec2
+            try:
+                if args.detector != "ORB":
+                    out["orb_detector"] = sub_engine(detection_method="ORB", ransac_solver=args.ransac_solver)
+                if args.ransac_solver != "GP3P":
+                    out["gp3p"] = sub_engine(detection_method=args.detector, ransac_solver="GP3P")
+            except Exception as e:
+                out["sub_error"] = repr(e)
         if pcie is not None:
             out["pcie_inclusive"] = pcie
-        print(json.dumps(out))
+        if n_gpus == 1 and not args.no_cpu:
+            out["reference_libraries"] = opencv_opengv_baseline(omni, model, rig_kw, args, min(8, B))
+        sub_other = n_gpus == 1 and not args.no_sub
     if dist:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+    if rank == 0:
+        if sub_other:
+            torch.cuda.synchronize()
+            out.update(other_configs_subrecords())
+        print(json.dumps(out))
+    return
 
 
 if __name__ == "__main__":

@@ -8,7 +8,7 @@
 set -e -o pipefail
 TAG=${1:-run}
 PAIRS_PER_LAUNCH=${2:-256}   # pairs one kernel launch covers = pairs-per-gpu / streams (bench defaults: 768 / 3)
-ARGS="--steps 10 --warmup 2 --no-cpu --no-h2d --no-isolated --render-workers 1"
+ARGS="--steps 10 --warmup 2 --no-cpu --no-h2d --no-isolated --no-sub --render-workers 1"
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$TAG --output-format csv -- python3 bench.py $ARGS > gpurun_out/prof_${TAG}_bench.log 2>&1
@@ -19,7 +19,7 @@ rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_${TAG}_write --output-format csv --
 echo "write pass done"
 if [ "${SQ_PASS:-1}" = "1" ]; then
   # 4. instruction counters (their own pass; one stream, 64 pairs per launch -- bench.py's valu_issue scales from that)
-  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES -d gpurun_out/pmc_${TAG}_sq --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu --no-h2d --no-isolated --render-workers 1 --streams 1 --pairs-per-gpu 64 > gpurun_out/pmc_${TAG}_sq.log 2>&1
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES -d gpurun_out/pmc_${TAG}_sq --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu --no-h2d --no-isolated --no-sub --render-workers 1 --streams 1 --pairs-per-gpu 64 > gpurun_out/pmc_${TAG}_sq.log 2>&1
   echo "sq pass done"
   python3 scripts/summarize_sq.py gpurun_out/pmc_${TAG}_sq > gpurun_out/${TAG}_sq_per_kernel.csv
 fi
