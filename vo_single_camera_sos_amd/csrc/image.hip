@@ -451,11 +451,11 @@ int32_t launch_median(sosvo_ctx* ctx, const uint8_t* img, const uint2* table, in
 //   pattern (radius Rp, computed exactly as orb_describe_kernel does) on the 7x7-blurred image:
 //   gray rows [max(edge, mlo) - Rp - 3, min(rows - edge - 1, mhi) + Rp + 3].
 // One workgroup per set; out[2 * set] = first row, out[2 * set + 1] = last row + 1 (0, 0 for an empty mask set).
-__global__ __launch_bounds__(kThreads) void gray_rows_kernel(const uint32_t* __restrict__ mask_bits, int rows, int cols,
-                                                             int nmask, int edge, const int8_t* __restrict__ pattern,
-                                                             float cos_a, float sin_a, int32_t* __restrict__ out) {
+__global__ __launch_bounds__(1024) void gray_rows_kernel(const uint32_t* __restrict__ mask_bits, int rows, int cols,
+                                                         int nmask, int edge, const int8_t* __restrict__ pattern,
+                                                         float cos_a, float sin_a, int32_t* __restrict__ out) {
   __shared__ int s_lo, s_hi, s_R;
-  const int tid = threadIdx.x, set = blockIdx.x;
+  const int tid = threadIdx.x, set = blockIdx.x, lane = tid & 63, wid = tid >> 6;
   if (tid == 0) {
     s_lo = rows;
     s_hi = -1;
@@ -464,15 +464,15 @@ __global__ __launch_bounds__(kThreads) void gray_rows_kernel(const uint32_t* __r
   __syncthreads();
   const uint32_t mask_all = nmask < 32 ? (1u << nmask) - 1u : 0xFFFFFFFFu;
   const uint32_t* mb = mask_bits + (size_t)set * rows * cols;
-  for (int y = 0; y < rows; ++y) {
-    bool any = false;
-    for (int x = tid; x < cols; x += kThreads) any = any || (mb[(size_t)y * cols + x] & mask_all) != 0u;
-    if (__ballot(any) != 0ULL && (tid & 63) == 0) {
+  for (int y = wid; y < rows; y += 16) {  // one wave per row, 16 rows in flight: the loads of a row are independent
+    uint32_t acc = 0u;
+    for (int x = lane; x < cols; x += 64) acc |= mb[(size_t)y * cols + x];
+    if (__ballot((acc & mask_all) != 0u) != 0ULL && lane == 0) {
       atomicMin(&s_lo, y);
       atomicMax(&s_hi, y);
     }
   }
-  for (int i = tid; i < 512; i += kThreads) {
+  for (int i = tid; i < 512; i += 1024) {
     const float px = (float)pattern[2 * i], py = (float)pattern[2 * i + 1];
     const float xr = (px * cos_a) - (py * sin_a), yr = (px * sin_a) + (py * cos_a);
     atomicMax(&s_R, max(abs(__float2int_rn(xr)), abs(__float2int_rn(yr))));
@@ -568,7 +568,7 @@ int32_t sosvo_gray_rows_needed(sosvo_ctx* ctx, const uint32_t* mask_bits, int32_
   SOSVO_REQUIRE(ctx, mask_bits && pattern && row_range, "null pointer");
   SOSVO_REQUIRE(ctx, nsets >= 1 && nsets <= 65535 && nmask >= 1 && nmask <= 32, "nsets / nmask out of range");
   SOSVO_REQUIRE(ctx, rows > 0 && cols > 0 && rows * (int64_t)cols < (1 << 28) && edge >= 0, "image sizes out of range");
-  SOSVO_LAUNCH(ctx, gray_rows_kernel, dim3((unsigned)nsets), dim3(kThreads), 0, ctx->stream, mask_bits, rows, cols, nmask, edge,
+  SOSVO_LAUNCH(ctx, gray_rows_kernel, dim3((unsigned)nsets), dim3(1024), 0, ctx->stream, mask_bits, rows, cols, nmask, edge,
                pattern, cos_a, sin_a, row_range);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
