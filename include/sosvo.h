@@ -321,6 +321,25 @@ int32_t sosvo_refine_abs_pose(sosvo_ctx* ctx, const double* f, const double* p, 
                               const int32_t* m, int32_t max_lm_iter, double* T_io, double* cost_out,
                               int32_t* iters_out);
 
+/* ---- 2D-2D relative-pose RANSAC ------------------------------------------------
+ * Replaces pyopengv.relative_pose_ransac(b1, b2, algorithm, threshold, max_iterations) as called by
+ * pose_relative_ransac_2D_to_2D (omnistereo/pose_est_tools.py:54-90, call at :78).
+ * f1, f2 [nprob*stride,3] f64: unit bearings of the SAME features seen from viewpoints 1 and 2; n [nprob].
+ * Score of a correspondence under (R, t) -- the reference's own restatement, pose_est_tools.py:150-203: X = the midpoint
+ * triangulation (OpenGV triangulate2) in frame 1, score = (1 - f1 . X/|X|) + (1 - f2 . x2/|x2|), x2 = R^T (X - t); inlier
+ * iff score < thr.  algorithm selects the minimal solver (sample size incl. the disambiguation points in brackets):
+ * SOSVO_REL_FIVEPT (5 + 3; Nister's five-point algorithm, the reference's default "STEWENIUS" and "NISTER"),
+ * SOSVO_REL_SEVENPT (7 + 2), SOSVO_REL_EIGHTPT (8).  Among all decompositions of all essential matrices of a sample the
+ * (R, t) with the smallest summed score over the sample becomes the hypothesis.  Outputs as sosvo_ransac_abs_pose: T_out [nprob,3,4] = [R | t], the pose of viewpoint 2 in
+ * frame 1 (X1 = R X2 + t), |t| = 1 (the scale of a 2D-2D motion is unobservable). */
+#define SOSVO_REL_FIVEPT 5
+#define SOSVO_REL_SEVENPT 7
+#define SOSVO_REL_EIGHTPT 8
+int32_t sosvo_ransac_rel_pose(sosvo_ctx* ctx, const double* f1, const double* f2, const int32_t* n, int32_t nprob,
+                              int32_t stride, int32_t algorithm, double thr, int32_t max_iter, int32_t adaptive,
+                              uint64_t seed, double* T_out, uint8_t* inlier_mask, int32_t* inlier_idx,
+                              int32_t* n_inliers, int32_t* info, int32_t* hyp_counts);
+
 /* ---- geometry: a7-a10, a12 -------------------------------------------------------------------
  * Elementwise restatements of the reference's numpy geometry (FP64; values agree with the
  * reference to rel-tol 1e-12, the transcendental functions come from the device math library).

@@ -148,6 +148,60 @@ def symeig12(A):
     return (d, V) if ok else None
 
 
+def ransac_rel_pose(f1, f2, thr, max_iter, seed=0, adaptive=False, want_counts=False, algorithm=8):
+    """2D-2D relative-pose RANSAC with the eight-point solver -> dict(T [3,4] (pose of view 2 in frame 1, |t| = 1), mask,
+    n_inliers, best_iter, iters_used, status[, counts])."""
+    f1 = _c(f1, np.float64).reshape(-1, 3)
+    f2 = _c(f2, np.float64).reshape(-1, 3)
+    n = f1.shape[0]
+    T = np.zeros((3, 4), dtype=np.float64)
+    mask = np.zeros(max(n, 1), dtype=np.uint8)
+    n_inl, best_it, used = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+    counts = np.zeros(max(max_iter, 1), dtype=np.int32) if want_counts else None
+    L = lib()
+    L.orc_ransac_rel_pose.restype = ctypes.c_int32
+    st = L.orc_ransac_rel_pose(_p(f1), _p(f2), ctypes.c_int32(n), ctypes.c_int32(algorithm), ctypes.c_double(thr), ctypes.c_int32(max_iter),
+                               ctypes.c_int32(1 if adaptive else 0), ctypes.c_uint64(seed), _p(T), _p(mask), ctypes.byref(n_inl),
+                               ctypes.byref(best_it), ctypes.byref(used), _pn(counts))
+    out = dict(T=T, mask=mask[:n].astype(bool), n_inliers=n_inl.value, best_iter=best_it.value, iters_used=used.value, status=st)
+    if want_counts:
+        out["counts"] = counts[:max_iter]
+    return out
+
+
+def rel_score(T, f1, f2):
+    """The reference's relative-pose score (pose_est_tools.py:150-203) of one correspondence."""
+    L = lib()
+    L.orc_rel_score_once.restype = ctypes.c_double
+    return L.orc_rel_score_once(_p(_c(T, np.float64)), _p(_c(f1, np.float64)), _p(_c(f2, np.float64)))
+
+
+def eightpt(f1, f2):
+    T = np.zeros((3, 4), dtype=np.float64)
+    L = lib()
+    L.orc_eightpt_solve.restype = ctypes.c_int32
+    ok = L.orc_eightpt_solve(_p(_c(f1, np.float64).reshape(8, 3)), _p(_c(f2, np.float64).reshape(8, 3)), _p(T))
+    return T if ok else None
+
+
+def fivept(f1, f2):
+    """Nister's five-point algorithm: f1, f2 [5,3] -> E [k,3,3], k <= 10 real solutions (f1^T E f2 = 0)."""
+    E = np.zeros((10, 9), dtype=np.float64)
+    L = lib()
+    L.orc_fivept_solve.restype = ctypes.c_int32
+    k = L.orc_fivept_solve(_p(_c(f1, np.float64).reshape(5, 3)), _p(_c(f2, np.float64).reshape(5, 3)), _p(E))
+    return E[:k].reshape(k, 3, 3)
+
+
+def sevenpt(f1, f2):
+    """Seven-point algorithm: f1, f2 [7,3] -> E [k,3,3], k in (1, 3)."""
+    E = np.zeros((3, 9), dtype=np.float64)
+    L = lib()
+    L.orc_sevenpt_solve.restype = ctypes.c_int32
+    k = L.orc_sevenpt_solve(_p(_c(f1, np.float64).reshape(7, 3)), _p(_c(f2, np.float64).reshape(7, 3)), _p(E))
+    return E[:k].reshape(k, 3, 3)
+
+
 def gp3p(fb, o, P, want_octic=False):
     """Generalised P3P: fb, o, P [3,3] (body-frame unit bearings, their camera offsets, world points) -> list of T [3,4]
     (P = R x_body + t), optionally with the octic's coefficients (lowest first, lengths in units of the largest side)."""

@@ -102,10 +102,10 @@ static inline void orc_laguerre(const orc_cplx* a, int m, orc_cplx* x) {
   }
 }
 
-/* All roots of the real polynomial c[0] + c[1] x + ... + c[m] x^m (m <= 8, c[m] != 0): Laguerre from 0 with deflation,
+/* All roots of the real polynomial c[0] + c[1] x + ... + c[m] x^m (m <= 10, c[m] != 0): Laguerre from 0 with deflation,
  * then each root polished on the undeflated polynomial. */
 static inline void orc_poly_roots(const double* c, int m, orc_cplx* roots) {
-  orc_cplx a[9], ad[9];
+  orc_cplx a[11], ad[11];
   for (int j = 0; j <= m; ++j) {
     a[j] = orc_c(c[j], 0.0);
     ad[j] = a[j];

@@ -40,6 +40,7 @@
 #include "ransac_core.h"
 #include "epnp_core.h"
 #include "gp3p_core.h"
+#include "relpose_core.h"
 
 /* ---- scoring of all points under one pose --------------------------------------------- */
 void orc_score_points(const double* f, const double* p, const int32_t* cam, const double* cam_off,
@@ -332,6 +333,74 @@ int32_t orc_epnp_solve(const double* f, const double* p, int32_t n, double* T_ou
 int32_t orc_symeig12_solve(double* A, double* d) {
   double e[12];
   return orc_symeig12(A, d, e);
+}
+
+/* ---- 2D-2D relative-pose RANSAC (pyopengv.relative_pose_ransac, pose_est_tools.py:78) with the eight-point solver ----
+ * T_out: 3x4 [R|t], pose of viewpoint 2 in frame 1, |t| = 1.  Same sequential semantics as orc_ransac_abs_pose
+ * (strictly-better update, failed solves skipped, adaptive stop of sac::Ransac on 8-point samples). */
+int32_t orc_ransac_rel_pose(const double* f1, const double* f2, int32_t n, int32_t algorithm, double thr, int32_t max_iter, int32_t adaptive,
+                            uint64_t seed, double* T_out, uint8_t* inlier_mask, int32_t* n_inliers, int32_t* best_iter,
+                            int32_t* iters_used, int32_t* counts_out) {
+  int best_count = -1, best_it = -1;
+  double best_R[9], best_t[3];
+  double base = 1.0;
+  int iterations = 0, used = 0;
+  for (int it = 0; it < max_iter; ++it) {
+    if (adaptive && iterations > 0 && !orc_ransac_continue(base, iterations)) break;
+    used = it + 1;
+    double R[9], t[3];
+    const int ok = orc_rel_hypothesis(f1, f2, n, algorithm, seed, (uint64_t)it, R, t);
+    if (counts_out) counts_out[it] = -1;
+    if (!ok) continue;
+    int cnt = 0;
+    for (int i = 0; i < n; ++i)
+      if (orc_rel_score(R, t, f1 + 3 * i, f2 + 3 * i) < thr) cnt++;
+    if (counts_out) counts_out[it] = cnt;
+    if (cnt > best_count) {
+      best_count = cnt;
+      best_it = it;
+      memcpy(best_R, R, sizeof(R));
+      memcpy(best_t, t, sizeof(t));
+      base = orc_adaptive_base_k(cnt, n, algorithm == ORC_REL_SEVENPT ? 9 : 8);
+    }
+    iterations++;
+  }
+  for (int it = used; counts_out && it < max_iter; ++it) counts_out[it] = -2;
+  int status = 0;
+  if (best_it < 0) {
+    status = 1;
+    const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z[3] = {0, 0, 0};
+    memcpy(best_R, eye, sizeof(eye));
+    memcpy(best_t, z, sizeof(z));
+  }
+  orc_Rt_to_T(best_R, best_t, T_out);
+  int cnt = 0;
+  for (int i = 0; i < n; ++i) {
+    const int in = status == 0 && orc_rel_score(best_R, best_t, f1 + 3 * i, f2 + 3 * i) < thr;
+    inlier_mask[i] = (uint8_t)in;
+    cnt += in;
+  }
+  *n_inliers = cnt;
+  *best_iter = best_it;
+  *iters_used = used;
+  return status;
+}
+
+double orc_rel_score_once(const double* T, const double* f1, const double* f2) {
+  double R[9], t[3];
+  orc_T_to_Rt(T, R, t);
+  return orc_rel_score(R, t, f1, f2);
+}
+
+/* the essential matrices of the five- and seven-point solvers on their own (unit tests): E_out [10][9] / [3][9] */
+int32_t orc_fivept_solve(const double* f1, const double* f2, double* E_out) { return orc_fivept(f1, f2, E_out); }
+int32_t orc_sevenpt_solve(const double* f1, const double* f2, double* E_out) { return orc_sevenpt(f1, f2, E_out); }
+
+int32_t orc_eightpt_solve(const double* f1, const double* f2, double* T_out) {
+  double R[9], t[3];
+  const int ok = orc_eightpt(f1, f2, R, t);
+  if (ok) orc_Rt_to_T(R, t, T_out);
+  return ok;
 }
 
 /* Generalised P3P on its own (unit tests): fb, o, P [9] -> up to 8 poses T_out [8][12] = [R | t]; returns their number.

@@ -2,6 +2,7 @@
     oracle/trig_core.h -> vo_single_camera_sos_amd/csrc/trig_core.h
     oracle/gp3p_core.h -> vo_single_camera_sos_amd/csrc/gp3p_core.h
     oracle/ransac_core.h -> vo_single_camera_sos_amd/csrc/ransac_core.h     (forced inlining on the device)
+    oracle/relpose_core.h -> vo_single_camera_sos_amd/csrc/relpose_core.h
     oracle/epnp_core.h -> vo_single_camera_sos_amd/csrc/epnp_core.h         (minus the "@oracle-only" section; the device's
                                                                             register-resident 12 x 12 eigen-solver is the
                                                                             hand-written csrc/epnp_eig12_reg.h)
@@ -14,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PAIRS = [("oracle/trig_core.h", "vo_single_camera_sos_amd/csrc/trig_core.h"),
          ("oracle/gp3p_core.h", "vo_single_camera_sos_amd/csrc/gp3p_core.h"),
          ("oracle/ransac_core.h", "vo_single_camera_sos_amd/csrc/ransac_core.h"),
-         ("oracle/epnp_core.h", "vo_single_camera_sos_amd/csrc/epnp_core.h")]
+         ("oracle/epnp_core.h", "vo_single_camera_sos_amd/csrc/epnp_core.h"),
+         ("oracle/relpose_core.h", "vo_single_camera_sos_amd/csrc/relpose_core.h")]
 # device-only continuation appended to the generated text (hand-written, see the file's header)
 TAIL = {"oracle/epnp_core.h": '\n#include "epnp_eig12_reg.h"\n'}
 FORCE_INLINE = {"oracle/ransac_core.h"}
@@ -40,6 +42,12 @@ NOTICE = {
         "// of k distinct indices.  One lane per hypothesis, every array index a compile-time constant after unrolling.\n"
         "// GENERATED from %s by tests/gen_device_headers.py (the oracle's text minus its \"oracle only\" section, device\n"
         "// prefixes): both sides evaluate the same operations in the same order; tests/test_abi.py checks the two files.",
+    "oracle/relpose_core.h":
+        "// Device-side numeric core of the 2D-2D relative-pose RANSAC (pyopengv.relative_pose_ransac, reference call site\n"
+        "// omnistereo/pose_est_tools.py:78): the reference's own score of a correspondence under a relative pose\n"
+        "// (pose_est_tools.py:150-203), the decomposition of an essential matrix, the minimal solvers, one hypothesis per lane.\n"
+        "// GENERATED from %s by tests/gen_device_headers.py (same text, device prefixes): the CPU oracle evaluates the same\n"
+        "// operations in the same order, tests/test_abi.py checks that the two files stay identical.",
     "oracle/ransac_core.h":
         "// Device-side numeric core of the absolute-pose RANSAC (K8/K10) and LM refinement (K9): counter-based sampler, Kneip\n"
         "// P3P, real quartic roots, score, Cayley parametrisation, LM pieces.  Reference call sites replaced:\n"

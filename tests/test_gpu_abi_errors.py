@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 NOT_COMPUTE = {"sosvo_abi_version", "sosvo_create", "sosvo_destroy", "sosvo_set_stream", "sosvo_synchronize",
                "sosvo_last_error", "sosvo_timer_start", "sosvo_timer_stop", "sosvo_timer_elapsed_ms", "sosvo_profile_enable",
                "sosvo_profile_count", "sosvo_profile_get", "sosvo_orb_pyramid_pixels", "sosvo_frame_pair_batch_workspace",
-               "sosvo_rgbd_pair_batch_workspace", "sosvo_frame_pair_batch_streams_workspace"}
+               "sosvo_rgbd_pair_batch_workspace", "sosvo_frame_pair_batch_streams_workspace", "sosvo_debug_fill_scratch"}
 
 
 def _dummy_args(argtypes, ctx_value):

@@ -125,15 +125,13 @@ def test_pyopengv_mirror_against_oracle(ctx):
     T0, i0 = pyopengv.absolute_pose_ransac(pr["f"][:3], pr["p"][:3], "KNEIP", thr, 50)
     assert len(i0) == 0 and np.array_equal(T0[:, :3], np.eye(3))
     # the helper of pose_est_tools.py:92-129: iteration budget from the outlier fraction (w = 0.5, n = 3: 34 + 3 * 7.48
-    # -> 56 iterations), homogeneous 4x4 result; the 2D-2D relative-pose helper says that it is not built
+    # -> 56 iterations), homogeneous 4x4 result (the 2D-2D relative-pose helper: test_gpu_relpose.py)
     from vo_single_camera_sos_amd.omnistereo import pose_est_tools
     pyopengv.set_seed(9)
     T4, inl4 = pose_est_tools.pose_absolute_ransac_3D_to_2D(pr["f"], pr["p"], thr, "KNEIP", outlier_fraction_known=0.5)
     pyopengv.set_seed(9)
     T3, inl3 = pyopengv.absolute_pose_ransac(pr["f"], pr["p"], "KNEIP", thr, 56)
     assert T4.shape == (4, 4) and np.array_equal(T4[:3], T3) and np.array_equal(T4[3], [0, 0, 0, 1]) and np.array_equal(inl4, inl3)
-    with pytest.raises(NotImplementedError):
-        pose_est_tools.pose_relative_ransac_2D_to_2D(pr["f"], pr["f"])
 
 
 def test_triangulate2_against_oracle_and_geometry(ctx):

@@ -128,8 +128,10 @@ def test_matcher_and_pyopengv_mirror_fail_loudly_without_gpu():
         FeatureMatcher("ORB", "FLANN", 1)
     fm = FeatureMatcher("GFT", "BF", 1, percentage_good_matches=0.5, num_of_features=77)
     assert fm.percentage_good_matches == 0.5 and fm.num_of_features == 77 and fm.use_radius_match is False
-    with pytest.raises(NotImplementedError):
-        pyopengv.absolute_pose_ransac(np.zeros((8, 3)), np.zeros((8, 3)), "TWOPT", 0.01, 10)
+    with pytest.raises(ValueError):
+        pyopengv.absolute_pose_ransac(np.zeros((8, 3)), np.zeros((8, 3)), "UPNP", 0.01, 10)
+    with pytest.raises(ValueError):
+        pyopengv.relative_pose_ransac(np.zeros((8, 3)), np.zeros((8, 3)), "NOPE", 0.01, 10)
     if torch.cuda.is_available():
         return
     d = np.zeros((4, 32), np.uint8)

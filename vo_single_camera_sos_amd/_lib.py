@@ -78,6 +78,8 @@ SIGNATURES = {
     "sosvo_f2f_assemble": (c_i32, [c_p] + [c_p] * 7 + [c_i32] + [c_p] * 6 + [c_i32, c_i32] + [c_p] * 7),
     "sosvo_ransac_abs_pose": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_p, c_i32, c_i32, c_f64,
                                       c_i32, c_i32, c_u64, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "sosvo_ransac_rel_pose": (c_i32, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_f64, c_i32, c_i32, c_u64, c_p, c_p, c_p, c_p,
+                                      c_p, c_p]),
     "sosvo_refine_abs_pose": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_p, c_i32, c_i32, c_p, c_p, c_i32,
                                       c_p, c_p, c_p]),
     "sosvo_rgbd_assemble": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p, c_p]),
@@ -95,6 +97,9 @@ FLAG_CAM_ROT_IDENTITY = 1
 FLAG_EPNP = 2
 FLAG_GP3P = 4
 FLAG_TWOPT = 8
+REL_FIVEPT = 5
+REL_SEVENPT = 7
+REL_EIGHTPT = 8
 
 
 class Rig(ctypes.Structure):

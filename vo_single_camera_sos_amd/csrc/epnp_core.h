@@ -427,10 +427,10 @@ __device__ static int sv_epnp_back(const double* p, int n, const double* uv, con
 /* k distinct indices below n from the counter-based generator (draw numbers d0, d0 + 1, ...): the j-th draw picks
  * among the n - j values not taken yet (kept sorted).  Returns 0 if n < k. */
 __device__ static int sv_sample_distinct(int32_t n, int k, uint64_t seed, uint64_t it, int32_t* s) {
-  if (n < k || k > 8) return 0;
-  int32_t taken[8]; /* ascending */
+  if (n < k || k > 9) return 0;
+  int32_t taken[9]; /* ascending */
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < 9; ++j) {
     if (j >= k) break;
     int32_t v = (int32_t)sv_below(sv_mix64(seed, it, (uint64_t)j), (uint32_t)(n - j));
     bool skipping = true;

@@ -86,10 +86,10 @@ __device__ static void sv_laguerre(const sv_cplx* a, int m, sv_cplx* x) {
   }
 }
 
-/* All roots of the real polynomial c[0] + c[1] x + ... + c[m] x^m (m <= 8, c[m] != 0): Laguerre from 0 with deflation,
+/* All roots of the real polynomial c[0] + c[1] x + ... + c[m] x^m (m <= 10, c[m] != 0): Laguerre from 0 with deflation,
  * then each root polished on the undeflated polynomial. */
 __device__ static void sv_poly_roots(const double* c, int m, sv_cplx* roots) {
-  sv_cplx a[9], ad[9];
+  sv_cplx a[11], ad[11];
   for (int j = 0; j <= m; ++j) {
     a[j] = sv_c(c[j], 0.0);
     ad[j] = a[j];

@@ -467,6 +467,26 @@ class Context(object):
                    _ptr(counts))
         return out
 
+    def ransac_rel_pose(self, f1, f2, n, thr, max_iter, algorithm=_lib.REL_EIGHTPT, seed=0, adaptive=False, want_counts=False):
+        """f1, f2 [P, S, 3] f64 (bearings of the same features from viewpoints 1 and 2), n [P] i32 ->
+        dict(T [P,3,4] (pose of viewpoint 2 in frame 1, |t| = 1), mask, idx, n_inliers, info[, counts])."""
+        _check(f1, torch.float64, "f1", (None, None, 3))
+        P, S = f1.shape[0], f1.shape[1]
+        _check(f2, torch.float64, "f2", (P, S, 3))
+        _check(n, torch.int32, "n", (P,))
+        dev = f1.device
+        out = dict(T=torch.empty((P, 3, 4), dtype=torch.float64, device=dev),
+                   mask=torch.zeros((P, S), dtype=torch.uint8, device=dev),
+                   idx=torch.full((P, S), -1, dtype=torch.int32, device=dev),
+                   n_inliers=torch.empty((P,), dtype=torch.int32, device=dev),
+                   info=torch.empty((P, 4), dtype=torch.int32, device=dev))
+        if want_counts:
+            out["counts"] = torch.empty((P, int(max_iter)), dtype=torch.int32, device=dev)
+        self._call(self._lib.sosvo_ransac_rel_pose, _ptr(f1), _ptr(f2), _ptr(n), P, S, int(algorithm), float(thr), int(max_iter),
+                   1 if adaptive else 0, int(seed) & (2 ** 64 - 1), _ptr(out["T"]), _ptr(out["mask"]), _ptr(out["idx"]),
+                   _ptr(out["n_inliers"]), _ptr(out["info"]), _ptr(out.get("counts")))
+        return out
+
     def refine_abs_pose(self, f, p, n, T, idx=None, m=None, cam=None, cam_off=None, cam_rot=None,
                         max_lm_iter=30, cost=None, iters=None):
         """In-place LM refinement of T [P,3,4]; returns (T, cost [P] f64, iters [P] i32)."""

@@ -38,10 +38,20 @@ def normalized(v):
 
 def pose_relative_ransac_2D_to_2D(bearing_vectors1, bearing_vectors2, model_error_threshold=0.001,
                                   rel_pose_est_algorithm="STEWENIUS", outlier_fraction_known=0.50):
-    """pose_est_tools.py:54-90 (pyopengv.relative_pose_ransac with a 5 / 7 / 8-point solver).  Not reached by the VO
-    drivers and not built: raises instead of answering with something else."""
-    raise NotImplementedError("2D-2D relative-pose RANSAC (%s) is not built; the VO drivers use the 3D-2D absolute pose"
-                              % rel_pose_est_algorithm)
+    """pose_est_tools.py:54-90: 2D-2D relative-pose RANSAC with the iteration budget N = log(0.01) / log(1 - w^n) + 3 std,
+    n = 5 ("NISTER", "STEWENIUS"), 7 ("SEVENPT") or 8 ("EIGHTPT") -> (T 4x4 with |t| = 1, inlier indices).  Not reached
+    by the VO drivers."""
+    from math import log10, sqrt
+    n_points_for_model = {"NISTER": 5, "STEWENIUS": 5, "SEVENPT": 7, "EIGHTPT": 8}.get(rel_pose_est_algorithm, -1)
+    w = 1.0 - outlier_fraction_known
+    num_of_iters = log10(1.0 - 0.99) / log10(1.0 - w ** n_points_for_model)
+    std_of_k = sqrt(1.0 - w ** n_points_for_model) / (w ** n_points_for_model)
+    max_iterations = int(num_of_iters + 3 * std_of_k)
+    T, inliers = pyopengv.relative_pose_ransac(bearing_vectors1[..., :3], bearing_vectors2[..., :3], rel_pose_est_algorithm,
+                                               model_error_threshold, max_iterations)
+    T_homo = np.identity(4)
+    T_homo[:3] = T
+    return T_homo, inliers
 
 
 def pose_absolute_ransac_3D_to_2D(bearing_vectors, points3D, model_error_threshold=0.001, pose_est_algorithm="EPNP",

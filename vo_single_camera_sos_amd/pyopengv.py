@@ -6,6 +6,7 @@ libsosvo on the GPU (no CPU fallback: importing works anywhere, calling needs th
     absolute_pose_ransac                         omnistereo/pose_est_tools.py:116, :915
     absolute_pose_optimize_nonlinear             omnistereo/pose_est_tools.py:937
     triangulation_triangulate2                   omnistereo/pose_est_tools.py:359, :163
+    relative_pose_ransac                         omnistereo/pose_est_tools.py:78  (2D-2D; not reached by the VO drivers)
 
 Conventions are OpenGV's as the reference uses them: T = [R | t] (3x4) is the pose of the current viewpoint in
 the frame the points are given in (points map by R^T (p - t), pose_est_tools.py:155-160, :177); `threshold`
@@ -133,6 +134,23 @@ def absolute_pose_ransac(b, p, algo_name, threshold, max_iterations):
 def absolute_pose_optimize_nonlinear(b, p, t, R):
     """-> T [3,4]."""
     return _refine(b, p, t, R)
+
+
+REL_ALGORITHMS = {"STEWENIUS": 5, "NISTER": 5, "SEVENPT": 7, "EIGHTPT": 8}   # both five-point names: Nister's algorithm
+
+
+def relative_pose_ransac(b1, b2, algo_name, threshold, max_iterations):
+    """-> (T [3,4] = [R | t], the pose of viewpoint 2 in frame 1 with |t| = 1, inlier indices int64 [k] ascending)."""
+    name = str(algo_name).upper()
+    if name not in REL_ALGORITHMS:
+        raise ValueError("unknown relative-pose algorithm %r (have: %s)" % (algo_name, ", ".join(sorted(REL_ALGORITHMS))))
+    ctx = _ctx()
+    f1_t, f2_t, n_t, _, n = _problem(ctx, b1, b2)
+    out = ctx.ransac_rel_pose(f1_t, f2_t, n_t, float(threshold), int(max_iterations), algorithm=REL_ALGORITHMS[name],
+                              seed=_next_seed(), adaptive=True)
+    ctx.synchronize()
+    k = int(out["n_inliers"][0].item())
+    return out["T"][0].cpu().numpy(), out["idx"][0, :k].cpu().numpy().astype(np.int64)
 
 
 def triangulation_triangulate2(b1, b2, t12, R12):
