@@ -5,10 +5,12 @@
 //   ORB_create(nfeatures=N).compute(pano, keypoints)     camera_models.py:1765, :1785, pose_est_tools.py:553
 //
 // Batched over images (view-major) and azimuthal masks; problem p = image * nmask + mask.
-//   eig      min-eigenvalue map in float32 with a fixed operation order (identical to the oracle's), the
-//            per-mask maximum folded in through an order-preserving atomicMax;
-//   select   one workgroup per problem: 3x3 non-maximum suppression of the thresholded map inside the mask's
-//            bounding box -> sort keys (ordered(value) << 32 | pixel index) in LDS, rank sort (descending value,
+//   eig      min-eigenvalue response in float32 with a fixed operation order (identical to the oracle's), the
+//            per-mask maximum folded in through an order-preserving atomicMax; the response never goes to memory as a
+//            map: the kernel keeps three rows in registers, tests the 3x3 local maximum there and emits the positive
+//            local maxima as compact records (value, pixel, mask bits) into a region of its own per wave;
+//   select   one workgroup per problem: the records of the waves that cover the mask's bounding box, thresholded ->
+//            sort keys (ordered(value) << 32 | pixel index) in LDS, rank sort (descending value,
 //            higher address first), then the greedy minimum-distance pass on an LDS cell grid by the first wave,
 //            64 candidates per step with an exact replay of the sequential acceptance rule;
 //   blur     7x7 sigma=2 Gaussian in 8.8 fixed point (separable, LDS tile);
@@ -61,12 +63,18 @@ static inline unsigned xcd_grid(int nimg, int nmask) { return (unsigned)(8 * cdi
 // One wave owns a 64-column strip (3 halo columns each side, 58 output columns) of one image and walks down a
 // chunk of rows; everything a 3x3 Sobel + 3x3 box sum + 3x3 local-maximum test needs from neighbouring columns
 // comes from neighbouring LANES (ds_bpermute), everything from neighbouring rows from three-deep register rings.
-// Per row and lane: one byte load, ten lane exchanges, ~70 VALU ops, one float store; no LDS, no barriers.
+// Per row and lane: one byte load, ten lane exchanges, ~70 VALU ops; no LDS, no barriers.  Output: per-mask maxima and
+// the candidate records -- a candidate of goodFeaturesToTrack is a pixel whose thresholded response is non-zero and
+// equals its 3x3 dilation; with 0 < quality < 1 the threshold quality * max is positive wherever a candidate exists (a
+// mask whose maximum is <= 0 has none: c > max * q >= max is impossible for c <= max < 0), so exactly the POSITIVE 3x3
+// local maxima of the raw response qualify, whatever the threshold turns out to be.  Each wave appends those of its
+// (strip, row chunk) to its own region (running position in an SGPR, no atomics, deterministic order); the selection
+// kernel applies the threshold once the per-mask maxima are complete.
 //   gray row t  -> hd = g[x+1] - g[x-1], hs = g[x-1] + 2 g[x] + g[x+1]                  (integers, exact)
 //   P row v=t-1 -> dx = hd(v-1) + 2 hd(v) + hd(v+1), dy = hs(v+1) - hs(v-1), products dx*dx, dx*dy, dy*dy (f32)
 //                  and their horizontal 3-sums (a + b) + c in the oracle's order
 //   e row y=v-1 -> vertical sums (ha + hc) + hb, min eigenvalue, per-mask maximum, hm = max(e[x-1], e[x], e[x+1])
-//   flag row y-1-> e == max(hm(y-2), hm(y-1), hm(y)): 3x3 local maximum, one ballot (u64) per wave and row
+//   flag row y-1-> e == max(hm(y-2), hm(y-1), hm(y)): 3x3 local maximum; e > 0 and inside some mask -> one record
 // Border rules (identical to the tile version it replaces): reflect-101 on the gray image, and a covariance
 // product outside the image is the product AT the reflected position.  In x both are "take the mirrored
 // lane".  In y a rolling reflect-101 of the gray rows evaluates the Sobel pair of the mirrored row with the
@@ -85,9 +93,8 @@ __device__ __forceinline__ void eig_flush(uint32_t* __restrict__ mstat_img, uint
 __global__ __launch_bounds__(kThreads) void min_eigen_kernel(const uint8_t* __restrict__ gray,
                                                              const uint32_t* __restrict__ mask_bits, int nimg,
                                                              int images_per_maskset, int rows, int cols, int nmask,
-                                                             int strips, int nchunks, int chunk_rows,
-                                                             float* __restrict__ eig,
-                                                             unsigned long long* __restrict__ flags,
+                                                             int strips, int nchunks, int chunk_rows, int wcap,
+                                                             uint4* __restrict__ cand, uint32_t* __restrict__ wcnt,
                                                              uint32_t* __restrict__ mstat) {
   SOSVO_STREAMING_PRIO();
   const int lane = threadIdx.x & 63;
@@ -106,8 +113,9 @@ __global__ __launch_bounds__(kThreads) void min_eigen_kernel(const uint8_t* __re
   const int e_lo = max(ys - 1, 0), e_hi = min(ye, rows - 1);  // e rows this chunk evaluates
   const int f_lo = max(ys, 1), f_hi = min(ye, rows - 1) - 1;   // flag rows this chunk owns
   const uint8_t* g = gray + (size_t)img * rows * cols;
-  float* eo = eig + (size_t)img * rows * cols;
-  unsigned long long* fo = flags + (size_t)img * rows * strips;
+  uint4* region = cand + (size_t)wave * wcap;  // this wave's candidate records
+  int wpos = 0;                                // records emitted so far (wave-uniform)
+  uint32_t mb_prev = 0u;                       // mask word of the row the flag stage looks at (the previous e row)
   const uint32_t* mb = mask_bits + (size_t)(img / images_per_maskset) * rows * cols;
   const uint32_t mask_all = nmask < 32 ? (1u << nmask) - 1u : 0xFFFFFFFFu;
   uint32_t* mstat_img = mstat + (size_t)img * nmask * 5;
@@ -161,7 +169,6 @@ __global__ __launch_bounds__(kThreads) void min_eigen_kernel(const uint8_t* __re
       const float c = ((pyy[i0] + pyy[i1]) + pyy[i2]) * 0.5f;
       const float e = (a + c) - sqrtf(((a - c) * (a - c)) + (b * b));
       if (y_out) {
-        eo[o_pre] = e;
         const uint32_t bits = mb_pre & mask_all;
         if (bits != cur_bits) {
           eig_flush(mstat_img, cur_bits, cur_max);
@@ -175,11 +182,19 @@ __global__ __launch_bounds__(kThreads) void min_eigen_kernel(const uint8_t* __re
       ec[i2] = e;
     }
     const int f = y - 1;
+    const uint32_t mb_f = mb_prev & mask_all;  // row f was the e row of the previous step
+    mb_prev = mb_pre;
     if (f < f_lo || f > f_hi) return;  // uniform
     {
-      const bool is_max = out_lane && xc >= 1 && xc <= cols - 2 && ec[i1] == fmaxf(fmaxf(hm[i0], hm[i1]), hm[i2]);
-      const unsigned long long bal = __ballot(is_max);
-      if (lane == 0) fo[(uint32_t)(f * strips + strip)] = bal;
+      const float ev = ec[i1];
+      const bool is_cand = out_lane && xc >= 1 && xc <= cols - 2 && ev == fmaxf(fmaxf(hm[i0], hm[i1]), hm[i2]) && ev > 0.0f &&
+                           mb_f != 0u;
+      const unsigned long long bal = __ballot(is_cand);
+      if (bal) {  // uniform
+        const int pos = wpos + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (is_cand && pos < wcap) region[pos] = make_uint4(__float_as_uint(ev), (uint32_t)(f * cols + xc), mb_f, 0u);
+        wpos += __popcll(bal);
+      }
     }
   };
   auto run = [&](auto edge_tag) __attribute__((always_inline)) {
@@ -190,6 +205,7 @@ __global__ __launch_bounds__(kThreads) void min_eigen_kernel(const uint8_t* __re
     }
   };
   if (edge_strip) run(std::true_type{}); else run(std::false_type{});
+  if (lane == 0) wcnt[wave] = (uint32_t)wpos;  // may exceed wcap: the selection kernel reports the overflow
   // per-mask maxima: one set of atomics per wave when all its output lanes saw a single mask word
   const unsigned long long act = __ballot(out_lane && cur_bits != 0u);
   if (act) {
@@ -234,17 +250,18 @@ __global__ __launch_bounds__(kThreads) void mask_bbox_kernel(const uint32_t* __r
   }
 }
 
-// One workgroup per problem (image, mask).  Phase 1 scans the mask's bounding box for 3x3 maxima of the
-// thresholded response and builds the sort keys in LDS; phase 2 rank-sorts them (descending value, higher
+// One workgroup per problem (image, mask).  Phase 1 walks the candidate records of the waves of min_eigen_kernel whose
+// (strip, row chunk) meets the mask's bounding box, keeps those of this mask above the threshold and builds the sort
+// keys in LDS; phase 2 rank-sorts them (descending value, higher
 // address first) into global memory; phase 3 -- the keys are dead, the 32 KB of LDS become the cell grid --
 // is the greedy minimum-distance pass by the first wave, 64 candidates at a time: every lane tests its
 // candidate against the grid of already accepted points (9 cells x 2 slots) and against the earlier lanes
 // of its batch (64 shuffles -> a 64-bit conflict mask); a short scalar pass over the batch then replays the
 // sequential acceptance rule exactly (accept iff no conflict with anything accepted before).
 template <int CAND>
-__global__ __launch_bounds__(kThreads) void gft_select_kernel(const float* __restrict__ eig,
-                                                              const unsigned long long* __restrict__ flags, int strips,
-                                                              const uint32_t* __restrict__ mask_bits,
+__global__ __launch_bounds__(kThreads) void gft_select_kernel(const uint4* __restrict__ cand,
+                                                              const uint32_t* __restrict__ wcnt, int strips, int nchunks,
+                                                              int chunk_rows, int wcap,
                                                               const uint32_t* __restrict__ mstat, int images_per_maskset,
                                                               int nmask, int rows, int cols, double quality,
                                                               float min_distance, int cell, int max_corners, int cap,
@@ -261,7 +278,7 @@ __global__ __launch_bounds__(kThreads) void gft_select_kernel(const float* __res
   if (p < 0) return;  // uniform (padding workgroup)
   if (redo && redo_pass == 1 && redo[p] == 0) return;  // uniform
   __shared__ unsigned long long lds_u64[CAND];
-  __shared__ int s_count, s_accepted;
+  __shared__ int s_count, s_accepted, s_overflow;
   unsigned long long* keys = lds_u64;
   uint32_t* grid = reinterpret_cast<uint32_t*>(lds_u64);  // phase 3: 2 slots per cell, pixel index + 1 (0 = empty)
   uint32_t* acc_list = grid + 2 * kSelGridCells;          // phase 3 fallback: accepted pixel indices (<= 1024)
@@ -273,6 +290,7 @@ __global__ __launch_bounds__(kThreads) void gft_select_kernel(const float* __res
   if (tid == 0) {
     s_count = 0;
     s_accepted = 0;
+    s_overflow = 0;
   }
   __syncthreads();
   // ---- phase 1: candidates ------------------------------------------------------------------------------
@@ -282,64 +300,22 @@ __global__ __launch_bounds__(kThreads) void gft_select_kernel(const float* __res
   const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
   if (any && bw > 0 && bh > 0) {
     const float thr = (float)((double)sosvo_ordered_float(st[0]) * quality);
-    const float* e = eig + (size_t)img * rows * cols;
-    const uint32_t* mb = mask_bits + (size_t)(img / images_per_maskset) * rows * cols;
-    // the local-maximum flags come from min_eigen_kernel: one u64 per (row, 58-column strip), bit = lane
-    const unsigned long long* fl = flags + (size_t)img * rows * strips;
-    const int s0 = bx0 / kEigStripW, ns = bx1 / kEigStripW - s0 + 1;
-    for (int i = tid; i < ns * bh; i += kThreads) {
-      const int ry = i / ns, sidx = s0 + (i - ry * ns);
-      const int y = by0 + ry;
-      const int xbase = sidx * kEigStripW - kEigHalo;  // column of bit 0
-      unsigned long long w = fl[(size_t)y * strips + sidx];
-      {  // keep the bits whose column lies inside [bx0, bx1]
-        const int l_lo = max(0, bx0 - xbase), l_hi = min(63, bx1 - xbase);
-        w = l_hi >= l_lo ? (w >> l_lo << l_lo) & (~0ULL >> (63 - l_hi)) : 0ULL;
-      }
-      const int rowpix = y * cols + xbase;
-      while (w) {
-        // four flagged pixels per round: their mask and response loads are issued together
-        int l[4];
-        bool ok[4];
-        uint32_t mbv[4];
-        float ev[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          ok[q] = w != 0ULL;
-          l[q] = ok[q] ? __ffsll((long long)w) - 1 : (q ? l[q - 1] : 0);
-          w &= w - 1ULL;  // 0 stays 0
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          mbv[q] = mb[rowpix + l[q]];
-          ev[q] = e[rowpix + l[q]];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (!ok[q] || !((mbv[q] >> m) & 1u)) continue;
-          const int pix = rowpix + l[q];
-          const float c = ev[q];
-          const float v = c > thr ? c : 0.0f;
-          if (v == 0.0f) continue;
-          if (v < 0.0f) {
-            // negative response above a negative threshold (all-negative mask): the thresholded neighbours
-            // (zeros) matter, evaluate the dilation as written
-            float dil = v;
-#pragma unroll
-            for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-              for (int dx = -1; dx <= 1; ++dx) {
-                const float qv = e[pix + dy * cols + dx];
-                const float t = qv > thr ? qv : 0.0f;
-                dil = t > dil ? t : dil;
-              }
-            if (v != dil) continue;
-          }
+    const int s0 = bx0 / kEigStripW, s1 = bx1 / kEigStripW;
+    const int c0 = by0 / chunk_rows, c1 = by1 / chunk_rows;
+    for (int c = c0; c <= c1; ++c)
+      for (int sidx = s0; sidx <= s1; ++sidx) {
+        const int w = (img * nchunks + c) * strips + sidx;  // the wave numbering of min_eigen_kernel
+        const int have = (int)wcnt[w];
+        if (have > wcap && tid == 0) s_overflow = 1;
+        const uint4* region = cand + (size_t)w * wcap;
+        for (int i = tid; i < min(have, wcap); i += kThreads) {
+          const uint4 r = region[i];
+          const float v = __uint_as_float(r.x);
+          if (!((r.z >> m) & 1u) || !(v > thr)) continue;
           const int slot = atomicAdd(&s_count, 1);
-          if (slot < CAND) keys[slot] = ((unsigned long long)sosvo_float_ordered(v) << 32) | (uint32_t)pix;
+          if (slot < CAND) keys[slot] = ((unsigned long long)sosvo_float_ordered(v) << 32) | r.y;
         }
       }
-    }
   }
   __syncthreads();
   const int total = s_count;
@@ -376,7 +352,7 @@ __global__ __launch_bounds__(kThreads) void gft_select_kernel(const float* __res
     const uint32_t y = pix / (uint32_t)cols;
     sorted[i] = (y << 16) | (pix - y * (uint32_t)cols);
   }
-  int stt = total > CAND ? 1 : 0;
+  int stt = (total > CAND || s_overflow) ? 1 : 0;
   const int cx0 = bx0 / cell, cy0 = by0 / cell;
   const int gw = bw > 0 ? bx1 / cell - cx0 + 1 : 0, gh = bh > 0 ? by1 / cell - cy0 + 1 : 0;
   const bool use_grid = gw * gh <= kSelGridCells;
@@ -703,7 +679,8 @@ int32_t sosvo_detect_gft(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* ma
   SOSVO_REQUIRE(ctx, nimg >= 0 && nimg <= 65535 && images_per_maskset > 0, "nimg out of range");
   SOSVO_REQUIRE(ctx, rows >= 3 && cols >= 3 && rows * (int64_t)cols < (1 << 28), "image sizes out of range");
   SOSVO_REQUIRE(ctx, nmask >= 1 && nmask <= kMaxMasks, "nmask out of range (1..32)");
-  SOSVO_REQUIRE(ctx, cap > 0 && cap <= 4096 && quality > 0 && min_distance >= 0, "bad detector parameters");
+  SOSVO_REQUIRE(ctx, cap > 0 && cap <= 4096 && quality > 0 && quality < 1 && min_distance >= 0,
+                "bad detector parameters (0 < quality < 1)");
   if (nimg == 0) return SOSVO_OK;
   const size_t P = (size_t)nimg * nmask;
   size_t off = 0;
@@ -715,8 +692,12 @@ int32_t sosvo_detect_gft(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* ma
   const int strips = cdiv(cols, kEigStripW);
   int nchunks, chunk_rows;
   rolling_chunks(nimg, rows, strips, &nchunks, &chunk_rows);
-  const size_t o_eig = carve(sizeof(float) * (size_t)nimg * rows * cols);
-  const size_t o_flags = carve(sizeof(unsigned long long) * (size_t)nimg * rows * strips);
+  // candidate records: a region per wave of min_eigen_kernel, room for a quarter of its pixels (3x3 maxima of distinct
+  // values are at most that dense; plateaus of equal positive responses could exceed it: status bit 0)
+  const int wcap = (chunk_rows * kEigStripW / 4 + 63) & ~63;
+  const size_t n_waves = (size_t)nimg * strips * nchunks;
+  const size_t o_cand = carve(sizeof(uint4) * n_waves * wcap);
+  const size_t o_wcnt = carve(sizeof(uint32_t) * n_waves);
   const size_t o_stat = carve(sizeof(uint32_t) * P * 5);
   const bool large = cap > 1024;  // whole-image masks (RGB-D frames): 16384 candidates, 15872 grid cells
   const int sorted_stride = large ? kCandCapLarge : kCandCap;
@@ -725,8 +706,8 @@ int32_t sosvo_detect_gft(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* ma
   int32_t rc = sosvo_ws_reserve(ctx, off);
   if (rc != SOSVO_OK) return rc;
   char* ws = (char*)ctx->ws;
-  float* eig = (float*)(ws + o_eig);
-  unsigned long long* flags = (unsigned long long*)(ws + o_flags);
+  uint4* cand = (uint4*)(ws + o_cand);
+  uint32_t* wcnt = (uint32_t*)(ws + o_wcnt);
   uint32_t* mstat = (uint32_t*)(ws + o_stat);
   uint32_t* sorted_g = (uint32_t*)(ws + o_sorted);
   SOSVO_HIP(ctx, hipMemsetAsync(mstat, 0, sizeof(uint32_t) * P * 5, ctx->stream));
@@ -737,22 +718,22 @@ int32_t sosvo_detect_gft(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* ma
   SOSVO_LAUNCH_CHECK(ctx);
   const int waves = nimg * strips * nchunks;
   SOSVO_LAUNCH(ctx, min_eigen_kernel, dim3(cdiv(waves, kThreads / 64)), dim3(kThreads), 0, ctx->stream, gray, mask_bits, nimg,
-               images_per_maskset, rows, cols, nmask, strips, nchunks, chunk_rows, eig, flags, mstat);
+               images_per_maskset, rows, cols, nmask, strips, nchunks, chunk_rows, wcap, cand, wcnt, mstat);
   SOSVO_LAUNCH_CHECK(ctx);
   const int cell = min_distance >= 1 ? (int)lrint(min_distance) : 1;
   int32_t* redo = (int32_t*)(ws + o_redo);
   if (large) {
     SOSVO_PROFILE(ctx, "gft_select_kernel");
-    hipLaunchKernelGGL(gft_select_kernel<kCandCapLarge>, dim3(xcd_grid(nimg, nmask)), dim3(kThreads), 0, ctx->stream, eig, flags,
-                       strips, mask_bits, mstat, images_per_maskset, nmask, rows, cols, quality, (float)min_distance, cell,
+    hipLaunchKernelGGL(gft_select_kernel<kCandCapLarge>, dim3(xcd_grid(nimg, nmask)), dim3(kThreads), 0, ctx->stream, cand, wcnt,
+                       strips, nchunks, chunk_rows, wcap, mstat, images_per_maskset, nmask, rows, cols, quality, (float)min_distance, cell,
                        max_corners, cap, sorted_g, sorted_stride, kp, n, status, nullptr, 0, nimg);
   } else {
     SOSVO_PROFILE(ctx, "gft_select_kernel");
-    hipLaunchKernelGGL(gft_select_kernel<kCandCapSmall>, dim3(xcd_grid(nimg, nmask)), dim3(kThreads), 0, ctx->stream, eig, flags,
-                       strips, mask_bits, mstat, images_per_maskset, nmask, rows, cols, quality, (float)min_distance, cell,
+    hipLaunchKernelGGL(gft_select_kernel<kCandCapSmall>, dim3(xcd_grid(nimg, nmask)), dim3(kThreads), 0, ctx->stream, cand, wcnt,
+                       strips, nchunks, chunk_rows, wcap, mstat, images_per_maskset, nmask, rows, cols, quality, (float)min_distance, cell,
                        max_corners, cap, sorted_g, sorted_stride, kp, n, status, redo, 0, nimg);
-    hipLaunchKernelGGL(gft_select_kernel<kCandCap>, dim3(xcd_grid(nimg, nmask)), dim3(kThreads), 0, ctx->stream, eig, flags,
-                       strips, mask_bits, mstat, images_per_maskset, nmask, rows, cols, quality, (float)min_distance, cell,
+    hipLaunchKernelGGL(gft_select_kernel<kCandCap>, dim3(xcd_grid(nimg, nmask)), dim3(kThreads), 0, ctx->stream, cand, wcnt,
+                       strips, nchunks, chunk_rows, wcap, mstat, images_per_maskset, nmask, rows, cols, quality, (float)min_distance, cell,
                        max_corners, cap, sorted_g, sorted_stride, kp, n, status, redo, 1, nimg);
   }
   SOSVO_LAUNCH_CHECK(ctx);
