@@ -97,68 +97,85 @@ __global__ __launch_bounds__(kThreads) void ransac_prepare_kernel(const int32_t*
 }
 
 // ---- 2. hypotheses --------------------------------------------------------------------------
+// Workgroup -> (problem, hypothesis chunk) for the hypothesis generators: workgroups are dealt round-robin over the 8
+// XCDs by linear id, so with the chunk as the fastest index the ~30 workgroups of one problem land on all eight L2s and
+// every one of them fetches the problem's correspondences (measured: 0.54 MB of HBM fetches per pair for 37 KB of
+// bearings and points).  Here XCD x takes the problems x, x + 8, ... with all their chunks (1-D grid of
+// 8 * ceil(nprob / 8) * chunks workgroups; the padding ones exit).
+__device__ __forceinline__ bool hyp_block(int nprob, int chunks, int* b, int* chunk) {
+  const int xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3);
+  *b = (slot / chunks) * 8 + xcd;
+  *chunk = slot - (slot / chunks) * chunks;
+  return *b < nprob;
+}
+static inline unsigned hyp_grid(int nprob, int chunks) { return (unsigned)(8 * cdiv(nprob, 8) * chunks); }
+
+// The 64 hypothesis records of a wave (R[9], t[3], -R^T t[3], pad: 128 B each) leave through LDS: a lane storing its own
+// record issues 15 eight-byte stores 128 B apart from its neighbours' (partial sectors: 2.6 x the bytes at the memory
+// interface); transposed, every store instruction of the wave writes 512 contiguous bytes.  One-wave workgroups; all 64
+// lanes call (ok = false for a failed solve or a lane beyond H: NaN in R[0], the rest zero).
+__device__ __forceinline__ void hyp_store_wave(double* __restrict__ hyp_b, int it0, int H, bool ok, const double* R,
+                                               const double* t) {
+  __shared__ double sh[64 * 17];
+  const int lane = threadIdx.x;
+  double* row = sh + lane * 17;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) row[k] = ok ? R[k] : (k == 0 ? __longlong_as_double(0x7FF8000000000000LL) : 0.0);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) row[9 + k] = ok ? t[k] : 0.0;
+  row[12] = ok ? -(((R[0] * t[0]) + (R[3] * t[1])) + (R[6] * t[2])) : 0.0;
+  row[13] = ok ? -(((R[1] * t[0]) + (R[4] * t[1])) + (R[7] * t[2])) : 0.0;
+  row[14] = ok ? -(((R[2] * t[0]) + (R[5] * t[1])) + (R[8] * t[2])) : 0.0;
+  row[15] = 0.0;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int idx = j * 64 + lane, rec = idx >> 4, e = idx & 15;
+    if (it0 + rec < H) hyp_b[(size_t)(it0 + rec) * kHypDoubles + e] = sh[rec * 17 + e];
+  }
+}
+
 __global__ __launch_bounds__(64) void ransac_hyp_kernel(const double* __restrict__ f, const double* __restrict__ p,
                                                         const int32_t* __restrict__ cam,
                                                         const double* __restrict__ cam_off,
                                                         const double* __restrict__ cam_rot,
-                                                        const int32_t* __restrict__ n_arr, int stride, int H,
+                                                        const int32_t* __restrict__ n_arr, int nprob, int stride, int H,
                                                         uint64_t seed, const int32_t* __restrict__ perm,
                                                         const int32_t* __restrict__ cinfo, double* __restrict__ hyp,
                                                         int32_t* __restrict__ counts) {
   SOSVO_LATENCY_BOUND_PRIO();
-  const int b = blockIdx.y;
-  const int it = blockIdx.x * blockDim.x + threadIdx.x;
-  if (it >= H) return;
+  int b, chunk;
+  if (!hyp_block(nprob, (H + 63) >> 6, &b, &chunk)) return;  // uniform
+  const int it = chunk * 64 + threadIdx.x;
   const int n = min(n_arr[b], stride);
   const size_t base = (size_t)b * stride;
   const int32_t* ci = cinfo + (size_t)b * (2 * kMaxCam + 1);
   const double* off = cam ? cam_off : kZero3;
   const double* rot = cam ? cam_rot : kEye9;
   double R[9], t[3];
-  const int ok = sv_hypothesis(f + 3 * base, p + 3 * base, cam ? cam + base : nullptr, off, rot, n, perm + base, ci,
-                               ci + kMaxCam + 1, problem_seed(seed, b), (uint64_t)it, R, t);
-  double* h = hyp + ((size_t)b * H + it) * kHypDoubles;
-  if (ok) {
-#pragma unroll
-    for (int k = 0; k < 9; ++k) h[k] = R[k];
-    h[9] = t[0];
-    h[10] = t[1];
-    h[11] = t[2];
-    h[12] = -(((R[0] * t[0]) + (R[3] * t[1])) + (R[6] * t[2]));
-    h[13] = -(((R[1] * t[0]) + (R[4] * t[1])) + (R[7] * t[2]));
-    h[14] = -(((R[2] * t[0]) + (R[5] * t[1])) + (R[8] * t[2]));
-  } else {
-    h[0] = __longlong_as_double(0x7FF8000000000000LL);
-  }
-  counts[(size_t)b * H + it] = ok ? 0 : -1;
+  int ok = 0;
+  if (it < H)
+    ok = sv_hypothesis(f + 3 * base, p + 3 * base, cam ? cam + base : nullptr, off, rot, n, perm + base, ci, ci + kMaxCam + 1,
+                       problem_seed(seed, b), (uint64_t)it, R, t);
+  hyp_store_wave(hyp + (size_t)b * H * kHypDoubles, chunk * 64, H, ok != 0, R, t);
+  if (it < H) counts[(size_t)b * H + it] = ok ? 0 : -1;
 }
 
 // TWOPT (SOSVO_FLAG_TWOPT, central problems): two distinct correspondences, translation only (sv_hypothesis_twopt).
 __global__ __launch_bounds__(64) void ransac_hyp_twopt_kernel(const double* __restrict__ f, const double* __restrict__ p,
-                                                              const int32_t* __restrict__ n_arr, int stride, int H,
-                                                              uint64_t seed, double* __restrict__ hyp,
+                                                              const int32_t* __restrict__ n_arr, int nprob, int stride,
+                                                              int H, uint64_t seed, double* __restrict__ hyp,
                                                               int32_t* __restrict__ counts) {
-  const int b = blockIdx.y;
-  const int it = blockIdx.x * blockDim.x + threadIdx.x;
-  if (it >= H) return;
+  int b, chunk;
+  if (!hyp_block(nprob, (H + 63) >> 6, &b, &chunk)) return;  // uniform
+  const int it = chunk * 64 + threadIdx.x;
   const int n = min(n_arr[b], stride);
   const size_t base = (size_t)b * stride;
   double R[9], t[3];
-  const int ok = sv_hypothesis_twopt(f + 3 * base, p + 3 * base, n, problem_seed(seed, b), (uint64_t)it, R, t);
-  double* h = hyp + ((size_t)b * H + it) * kHypDoubles;
-  if (ok) {
-#pragma unroll
-    for (int k = 0; k < 9; ++k) h[k] = R[k];
-    h[9] = t[0];
-    h[10] = t[1];
-    h[11] = t[2];
-    h[12] = -(((R[0] * t[0]) + (R[3] * t[1])) + (R[6] * t[2]));
-    h[13] = -(((R[1] * t[0]) + (R[4] * t[1])) + (R[7] * t[2]));
-    h[14] = -(((R[2] * t[0]) + (R[5] * t[1])) + (R[8] * t[2]));
-  } else {
-    h[0] = __longlong_as_double(0x7FF8000000000000LL);
-  }
-  counts[(size_t)b * H + it] = ok ? 0 : -1;
+  int ok = 0;
+  if (it < H) ok = sv_hypothesis_twopt(f + 3 * base, p + 3 * base, n, problem_seed(seed, b), (uint64_t)it, R, t);
+  hyp_store_wave(hyp + (size_t)b * H * kHypDoubles, chunk * 64, H, ok != 0, R, t);
+  if (it < H) counts[(size_t)b * H + it] = ok ? 0 : -1;
 }
 
 // The generalised-P3P hypothesis generator (SOSVO_FLAG_GP3P): one lane per (problem, iteration): four distinct
@@ -167,34 +184,24 @@ __global__ __launch_bounds__(64) void ransac_hyp_gp3p_kernel(const double* __res
                                                              const int32_t* __restrict__ cam,
                                                              const double* __restrict__ cam_off,
                                                              const double* __restrict__ cam_rot,
-                                                             const int32_t* __restrict__ n_arr, int stride, int H,
-                                                             uint64_t seed, double* __restrict__ hyp,
+                                                             const int32_t* __restrict__ n_arr, int nprob, int stride,
+                                                             int H, uint64_t seed, double* __restrict__ hyp,
                                                              int32_t* __restrict__ counts) {
   SOSVO_LATENCY_BOUND_PRIO();
-  const int b = blockIdx.y;
-  const int it = blockIdx.x * blockDim.x + threadIdx.x;
-  if (it >= H) return;
+  int b, chunk;
+  if (!hyp_block(nprob, (H + 63) >> 6, &b, &chunk)) return;  // uniform
+  const int it = chunk * 64 + threadIdx.x;
   const int n = min(n_arr[b], stride);
   const size_t base = (size_t)b * stride;
   const double* off = cam ? cam_off : kZero3;
   const double* rot = cam ? cam_rot : kEye9;
   double R[9], t[3];
-  const int ok = sv_hypothesis_gp3p(f + 3 * base, p + 3 * base, cam ? cam + base : nullptr, off, rot, n, problem_seed(seed, b),
-                                    (uint64_t)it, R, t);
-  double* h = hyp + ((size_t)b * H + it) * kHypDoubles;
-  if (ok) {
-#pragma unroll
-    for (int k = 0; k < 9; ++k) h[k] = R[k];
-    h[9] = t[0];
-    h[10] = t[1];
-    h[11] = t[2];
-    h[12] = -(((R[0] * t[0]) + (R[3] * t[1])) + (R[6] * t[2]));
-    h[13] = -(((R[1] * t[0]) + (R[4] * t[1])) + (R[7] * t[2]));
-    h[14] = -(((R[2] * t[0]) + (R[5] * t[1])) + (R[8] * t[2]));
-  } else {
-    h[0] = __longlong_as_double(0x7FF8000000000000LL);
-  }
-  counts[(size_t)b * H + it] = ok ? 0 : -1;
+  int ok = 0;
+  if (it < H)
+    ok = sv_hypothesis_gp3p(f + 3 * base, p + 3 * base, cam ? cam + base : nullptr, off, rot, n, problem_seed(seed, b),
+                            (uint64_t)it, R, t);
+  hyp_store_wave(hyp + (size_t)b * H * kHypDoubles, chunk * 64, H, ok != 0, R, t);
+  if (it < H) counts[(size_t)b * H + it] = ok ? 0 : -1;
 }
 
 // The EPnP hypothesis generator (central problems, SOSVO_FLAG_EPNP), one hypothesis per lane, as TWO kernels:
@@ -224,11 +231,12 @@ __device__ __forceinline__ int epnp_sample_front(const double* __restrict__ f, c
 
 constexpr int kEpnpVecDoubles = 48;
 __global__ __launch_bounds__(64) void ransac_epnp_eigen_kernel(const double* __restrict__ f, const double* __restrict__ p,
-                                                               const int32_t* __restrict__ n_arr, int stride, int H,
-                                                               uint64_t seed, double* __restrict__ vvbuf,
+                                                               const int32_t* __restrict__ n_arr, int nprob, int stride,
+                                                               int H, uint64_t seed, double* __restrict__ vvbuf,
                                                                int32_t* __restrict__ counts) {
-  const int b = blockIdx.y;
-  const int it = blockIdx.x * blockDim.x + threadIdx.x;
+  int b, chunk;
+  if (!hyp_block(nprob, (H + 63) >> 6, &b, &chunk)) return;  // uniform
+  const int it = chunk * 64 + threadIdx.x;
   if (it >= H) return;
   const int n = min(n_arr[b], stride);
   double p6[18], uv[2 * SV_EPNP_MAXN], cw[12], alphas[4 * SV_EPNP_MAXN];
@@ -244,16 +252,16 @@ __global__ __launch_bounds__(64) void ransac_epnp_eigen_kernel(const double* __r
 }
 
 __global__ __launch_bounds__(64) void ransac_epnp_pose_kernel(const double* __restrict__ f, const double* __restrict__ p,
-                                                              const int32_t* __restrict__ n_arr, int stride, int H,
-                                                              uint64_t seed, const double* __restrict__ vvbuf,
+                                                              const int32_t* __restrict__ n_arr, int nprob, int stride,
+                                                              int H, uint64_t seed, const double* __restrict__ vvbuf,
                                                               double* __restrict__ hyp, int32_t* __restrict__ counts) {
   SOSVO_LATENCY_BOUND_PRIO();
-  const int b = blockIdx.y;
-  const int it = blockIdx.x * blockDim.x + threadIdx.x;
-  if (it >= H) return;
+  int b, chunk;
+  if (!hyp_block(nprob, (H + 63) >> 6, &b, &chunk)) return;  // uniform
+  const int it = chunk * 64 + threadIdx.x;
   const int n = min(n_arr[b], stride);
   double R[9], t[3];
-  int ok = counts[(size_t)b * H + it] == 0;
+  int ok = it < H && counts[(size_t)b * H + it] == 0;
   if (ok) {
     double p6[18], uv[2 * SV_EPNP_MAXN], cw[12], alphas[4 * SV_EPNP_MAXN], vv[48];
     ok = epnp_sample_front(f, p, n, (size_t)b * stride, problem_seed(seed, b), it, p6, uv, cw, alphas);  // (same bits as before)
@@ -262,20 +270,8 @@ __global__ __launch_bounds__(64) void ransac_epnp_pose_kernel(const double* __re
     for (int k = 0; k < 48; ++k) vv[k] = in[k];
     if (ok) ok = sv_epnp_back(p6, 6, uv, cw, alphas, vv, R, t);
   }
-  double* h = hyp + ((size_t)b * H + it) * kHypDoubles;
-  if (ok) {
-#pragma unroll
-    for (int k = 0; k < 9; ++k) h[k] = R[k];
-    h[9] = t[0];
-    h[10] = t[1];
-    h[11] = t[2];
-    h[12] = -(((R[0] * t[0]) + (R[3] * t[1])) + (R[6] * t[2]));
-    h[13] = -(((R[1] * t[0]) + (R[4] * t[1])) + (R[7] * t[2]));
-    h[14] = -(((R[2] * t[0]) + (R[5] * t[1])) + (R[8] * t[2]));
-  } else {
-    h[0] = __longlong_as_double(0x7FF8000000000000LL);
-  }
-  counts[(size_t)b * H + it] = ok ? 0 : -1;
+  hyp_store_wave(hyp + (size_t)b * H * kHypDoubles, chunk * 64, H, ok != 0, R, t);
+  if (it < H) counts[(size_t)b * H + it] = ok ? 0 : -1;
 }
 
 // ---- 3. score -------------------------------------------------------------------------------
@@ -805,19 +801,19 @@ int32_t sosvo_ransac_abs_pose(sosvo_ctx* ctx, const double* f, const double* p, 
   if (twopt) adaptive = (adaptive ? 1 : 0) | 4;  // bit 2: ... 2-point samples
   if (epnp) {
     double* vvbuf = (double*)(ws + o_vv);
-    SOSVO_LAUNCH(ctx, ransac_epnp_eigen_kernel, dim3(cdiv(H, 64), nprob), dim3(64), 0, ctx->stream, f, p, n, stride, H, seed,
-                 vvbuf, counts);
-    SOSVO_LAUNCH(ctx, ransac_epnp_pose_kernel, dim3(cdiv(H, 64), nprob), dim3(64), 0, ctx->stream, f, p, n, stride, H, seed,
-                 vvbuf, hyp, counts);
+    SOSVO_LAUNCH(ctx, ransac_epnp_eigen_kernel, dim3(hyp_grid(nprob, cdiv(H, 64))), dim3(64), 0, ctx->stream, f, p, n, nprob, stride, H,
+                 seed, vvbuf, counts);
+    SOSVO_LAUNCH(ctx, ransac_epnp_pose_kernel, dim3(hyp_grid(nprob, cdiv(H, 64))), dim3(64), 0, ctx->stream, f, p, n, nprob, stride, H,
+                 seed, vvbuf, hyp, counts);
   } else if (twopt) {
-    SOSVO_LAUNCH(ctx, ransac_hyp_twopt_kernel, dim3(cdiv(H, 64), nprob), dim3(64), 0, ctx->stream, f, p, n, stride, H, seed, hyp,
-                 counts);
+    SOSVO_LAUNCH(ctx, ransac_hyp_twopt_kernel, dim3(hyp_grid(nprob, cdiv(H, 64))), dim3(64), 0, ctx->stream, f, p, n, nprob, stride, H, seed,
+                 hyp, counts);
   } else if (flags & SOSVO_FLAG_GP3P) {
-    SOSVO_LAUNCH(ctx, ransac_hyp_gp3p_kernel, dim3(cdiv(H, 64), nprob), dim3(64), 0, ctx->stream, f, p, cam, cam_off, cam_rot, n,
-                 stride, H, seed, hyp, counts);
+    SOSVO_LAUNCH(ctx, ransac_hyp_gp3p_kernel, dim3(hyp_grid(nprob, cdiv(H, 64))), dim3(64), 0, ctx->stream, f, p, cam, cam_off, cam_rot,
+                 n, nprob, stride, H, seed, hyp, counts);
   } else
-    SOSVO_LAUNCH(ctx, ransac_hyp_kernel, dim3(cdiv(H, 64), nprob), dim3(64), 0, ctx->stream, f, p, cam, cam_off, cam_rot, n,
-                 stride, H, seed, perm, cinfo, hyp, counts);
+    SOSVO_LAUNCH(ctx, ransac_hyp_kernel, dim3(hyp_grid(nprob, cdiv(H, 64))), dim3(64), 0, ctx->stream, f, p, cam, cam_off, cam_rot, n,
+                 nprob, stride, H, seed, perm, cinfo, hyp, counts);
   SOSVO_LAUNCH_CHECK(ctx);
 
   const bool ident = (flags & SOSVO_FLAG_CAM_ROT_IDENTITY) != 0 || cam == nullptr;
