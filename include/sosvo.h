@@ -246,6 +246,17 @@ int32_t sosvo_match_hamming(sosvo_ctx* ctx, const uint8_t* q_desc, const uint8_t
                             const int32_t* t_slot, int32_t nprob, int32_t q_stride,
                             int32_t t_stride, int32_t k, uint32_t* keys);
 
+/* Float descriptors (SIFT / SURF / KAZE ...; feature_detection_method "SIFT" / "SURF" makes FeatureMatcher build
+ * cv2.BFMatcher() with its default NORM_L2, omnistereo/camera_models.py:394-396): brute-force L2 matching.
+ * q_desc [nprob, q_stride, dim] f32, t_desc [nprob, t_stride, dim] f32, dim <= 128, finite values.  distance = sqrt of the
+ * float32 sum of squared differences, four terms per step in index order (OpenCV's scalar normL2Sqr_).
+ *   keys[(p*q_stride + i)*k + r] = (bits of the float32 distance << 32) | train index of the r-th neighbour (r < k,
+ *   k = 1 or 2; smallest distance, first train index on ties), all ones if absent.
+ * The reference's FLANN matcher (camera_models.py:384-393: KD-trees for float, LSH for binary descriptors, randomised,
+ * approximate) has no counterpart: matcher_type "FLANN" is served by the exact searches (sosvo_match_hamming / this). */
+int32_t sosvo_match_l2(sosvo_ctx* ctx, const float* q_desc, const float* t_desc, const int32_t* nq, const int32_t* nt,
+                       int32_t nprob, int32_t q_stride, int32_t t_stride, int32_t dim, int32_t k, uint64_t* keys);
+
 /* Radius match: cv2.BFMatcher.radiusMatch(query, train, maxDistance) as called from FeatureMatcher.match when
  * use_radius_match is set (omnistereo/camera_models.py:412-415).  For each query row i < nq[qs] ALL train rows j
  * with hamming(q_i, t_j) <= max_distance, as packed keys in ascending order (distance, then train index):

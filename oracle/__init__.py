@@ -55,6 +55,16 @@ def match_hamming(q, t, k=1):
     return keys
 
 
+def match_l2(q, t, k=1):
+    """q [nq,dim] f32, t [nt,dim] f32 -> keys [nq,k] u64 = (float32 distance bits << 32 | train idx)."""
+    q = _c(q, np.float32)
+    t = _c(t, np.float32)
+    keys = np.empty((q.shape[0], k), dtype=np.uint64)
+    lib().orc_match_l2(_p(q), _p(t), ctypes.c_int32(q.shape[0]), ctypes.c_int32(t.shape[0]), ctypes.c_int32(q.shape[1]),
+                       ctypes.c_int32(k), _p(keys))
+    return keys
+
+
 def match_radius(q, t, max_distance, cap):
     """q [nq,32] u8, t [nt,32] u8 -> (keys [nq,cap] u32 ascending, KEY_NONE padded; counts [nq] i32)."""
     q = _c(q, np.uint8).reshape(-1, 32)

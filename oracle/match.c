@@ -118,3 +118,47 @@ void orc_match_radius(const uint8_t* q, const uint8_t* t, int32_t nq, int32_t nt
   }
   free(all);
 }
+
+/* Float descriptors (SIFT / SURF / KAZE ...): cv2.BFMatcher() with its default NORM_L2 (camera_models.py:396) --
+ * distance = sqrt of the sum of squared differences accumulated in float32, four terms per step in index order
+ * (OpenCV's scalar normL2Sqr_: s += v0*v0 + v1*v1 + v2*v2 + v3*v3, then the tail one by one), k smallest per query, a
+ * later train row replaces an earlier one only when strictly smaller.  keys[i*k + r] = (bits of the float32 distance
+ * << 32) | train index (non-negative floats order like their bit patterns), all ones if absent. */
+#include <math.h>
+static float l2_distance(const float* a, const float* b, int dim) {
+  float s = 0.0f;
+  int i = 0;
+  for (; i <= dim - 4; i += 4) {
+    const float v0 = a[i] - b[i], v1 = a[i + 1] - b[i + 1], v2 = a[i + 2] - b[i + 2], v3 = a[i + 3] - b[i + 3];
+    s += (((v0 * v0) + (v1 * v1)) + (v2 * v2)) + (v3 * v3);
+  }
+  for (; i < dim; ++i) {
+    const float v = a[i] - b[i];
+    s += v * v;
+  }
+  return sqrtf(s);
+}
+
+void orc_match_l2(const float* q, const float* t, int32_t nq, int32_t nt, int32_t dim, int32_t k, uint64_t* keys) {
+  for (int i = 0; i < nq; ++i) {
+    float bd[2] = {INFINITY, INFINITY};
+    int bi[2] = {-1, -1};
+    for (int j = 0; j < nt; ++j) {
+      const float d = l2_distance(q + (size_t)dim * i, t + (size_t)dim * j, dim);
+      if (d < bd[0] || bi[0] < 0) {
+        bd[1] = bd[0];
+        bi[1] = bi[0];
+        bd[0] = d;
+        bi[0] = j;
+      } else if (k > 1 && (d < bd[1] || bi[1] < 0)) {
+        bd[1] = d;
+        bi[1] = j;
+      }
+    }
+    for (int r = 0; r < k; ++r) {
+      uint32_t bits;
+      memcpy(&bits, &bd[r], 4);
+      keys[(size_t)i * k + r] = bi[r] < 0 ? ~(uint64_t)0 : ((uint64_t)bits << 32) | (uint32_t)bi[r];
+    }
+  }
+}

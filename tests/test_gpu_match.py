@@ -133,3 +133,48 @@ def test_radius_match_ragged_batch_with_slots_and_truncation(ctx):
             assert np.array_equal(keys[p, :nq], wk), (radius, p)
     with pytest.raises(Exception):
         ctx.match_radius(tb, tb, tn, tn, 10, 513)
+
+
+def test_l2_float_descriptors_match_the_oracle_bit_for_bit(ctx):
+    """sosvo_match_l2 (BFMatcher() with NORM_L2, the reference's matcher for "SIFT" / "SURF" descriptors) against the
+    oracle: keys (float32 distance bits, train index) identical, ragged problems, k = 1 and 2, odd dimensions."""
+    rng = np.random.default_rng(21)
+    for dim, k in ((128, 2), (64, 1), (61, 2), (5, 1)):
+        nq = np.array([300, 1, 0, 77], dtype=np.int32)
+        nt = np.array([257, 40, 9, 1], dtype=np.int32)
+        q = rng.normal(size=(4, 300, dim)).astype(np.float32)
+        t = rng.normal(size=(4, 260, dim)).astype(np.float32)
+        t[0, 100] = t[0, 3]
+        q[0, 5] = t[0, 3]
+        dev = ctx.device
+        keys = ctx.match_l2(torch.from_numpy(q).to(dev), torch.from_numpy(t).to(dev), torch.from_numpy(nq).to(dev),
+                            torch.from_numpy(nt).to(dev), k=k)
+        ctx.synchronize()
+        got = keys.cpu().numpy().view(np.uint64)
+        for p in range(4):
+            want = oracle.match_l2(q[p, :nq[p]], t[p, :nt[p]], k=k)
+            assert np.array_equal(got[p, :nq[p]], want), (dim, k, p)
+
+
+def test_feature_matcher_mirror_on_float_descriptors_and_flann(ctx):
+    """FeatureMatcher("SIFT", ...) on float32 descriptors: best match, the k = 2 ratio rule (:421-423), the flattened
+    2-NN lists; matcher_type "FLANN" answers with the exact neighbours."""
+    from vo_single_camera_sos_amd.omnistereo.camera_models import FeatureMatcher
+    rng = np.random.default_rng(22)
+    t = rng.normal(size=(120, 128)).astype(np.float32)
+    q = (t[rng.permutation(120)[:80]] + 0.05 * rng.normal(size=(80, 128))).astype(np.float32)
+    keys = oracle.match_l2(q, t, k=2)
+    d = (keys >> 32).astype(np.uint32).view(np.float32)
+    i = (keys & 0xFFFFFFFF).astype(np.int64)
+    qi, ti, di = FeatureMatcher("SIFT", "BF", 1, context=ctx).match_arrays(q, t)
+    o = np.argsort(d[:, 0], kind="stable")
+    assert np.array_equal(qi, o) and np.array_equal(ti, i[o, 0]) and np.array_equal(di, d[o, 0])
+    qi, ti, di = FeatureMatcher("SIFT", "FLANN", 2, context=ctx).match_arrays(q, t)
+    keep = d[o, 0] < d[o, 1] * np.float32(0.75)
+    assert np.array_equal(qi, o[keep]) and np.array_equal(ti, i[o, 0][keep]) and len(qi) > 40
+    qi, ti, di = FeatureMatcher("SURF", "BF", 2, context=ctx).match_arrays(q, t)
+    o2 = np.argsort(d.reshape(-1), kind="stable")
+    assert np.array_equal(qi, o2 // 2) and np.array_equal(ti, i.reshape(-1)[o2])
+    ml = FeatureMatcher("ORB", "FLANN", 1, context=ctx).match(rng.integers(0, 256, (30, 32), dtype=np.uint8),
+                                                               rng.integers(0, 256, (40, 32), dtype=np.uint8))
+    assert len(ml) == 30

@@ -124,8 +124,9 @@ def test_matcher_and_pyopengv_mirror_fail_loudly_without_gpu():
     from vo_single_camera_sos_amd import pyopengv
     from vo_single_camera_sos_amd._lib import SosvoError
     from vo_single_camera_sos_amd.omnistereo.camera_models import FeatureMatcher
-    with pytest.raises(NotImplementedError):
-        FeatureMatcher("ORB", "FLANN", 1)
+    assert FeatureMatcher("ORB", "FLANN", 1).matcher_type == "FLANN"        # served by the exact search
+    with pytest.raises(ValueError):
+        FeatureMatcher("ORB", "ANNOY", 1)
     fm = FeatureMatcher("GFT", "BF", 1, percentage_good_matches=0.5, num_of_features=77)
     assert fm.percentage_good_matches == 0.5 and fm.num_of_features == 77 and fm.use_radius_match is False
     with pytest.raises(ValueError):

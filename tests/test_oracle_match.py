@@ -78,3 +78,22 @@ def test_radius_match_against_numpy_and_truncation():
     assert k2[0].tolist() == sorted((int(d[0, j]) << 20) | j for j in range(150))[:5]
     k0, c0 = oracle.match_radius(q, t[:0], 10, 4)
     assert (c0 == 0).all() and (k0 == oracle.KEY_NONE).all()
+
+
+def test_l2_matching_of_float_descriptors_against_numpy():
+    """BFMatcher() with NORM_L2 on float descriptors: the nearest two train rows per query, ties to the lower index; the
+    distances agree with a float64 evaluation to float32 rounding, and the first-index rule is exercised by duplicates."""
+    rng = np.random.default_rng(8)
+    for dim in (128, 64, 61, 3):
+        q = rng.normal(size=(40, dim)).astype(np.float32)
+        t = rng.normal(size=(55, dim)).astype(np.float32)
+        t[20] = t[7]                                               # a duplicate train row: index 7 must win
+        q[0] = t[7]
+        keys = oracle.match_l2(q, t, k=2)
+        d = np.sqrt(((q[:, None, :].astype(np.float64) - t[None].astype(np.float64)) ** 2).sum(-1))
+        idx = np.argsort(d, axis=1, kind="stable")[:, :2]
+        assert np.array_equal((keys & 0xFFFFFFFF).astype(np.int64), idx)
+        got = (keys >> 32).astype(np.uint32).view(np.float32)
+        assert np.abs(got - np.take_along_axis(d, idx, 1)).max() < 1e-5
+        assert got[0, 0] == 0.0 and (keys[0] & 0xFFFFFFFF).tolist() == [7, 20]
+    assert np.array_equal(oracle.match_l2(q[:2], t[:1], k=2)[:, 1], np.full(2, 2 ** 64 - 1, dtype=np.uint64))   # no second row

@@ -78,6 +78,7 @@ SIGNATURES = {
     "sosvo_f2f_assemble": (c_i32, [c_p] + [c_p] * 7 + [c_i32] + [c_p] * 6 + [c_i32, c_i32] + [c_p] * 7),
     "sosvo_ransac_abs_pose": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_p, c_i32, c_i32, c_f64,
                                       c_i32, c_i32, c_u64, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "sosvo_match_l2": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]),
     "sosvo_ransac_rel_pose": (c_i32, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_f64, c_i32, c_i32, c_u64, c_p, c_p, c_p, c_p,
                                       c_p, c_p]),
     "sosvo_refine_abs_pose": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_p, c_i32, c_i32, c_p, c_p, c_i32,

@@ -111,6 +111,68 @@ __global__ __launch_bounds__(kThreads) void match_hamming_kernel(
   }
 }
 
+// ---- float descriptors (SIFT / SURF / KAZE ...): brute-force L2, cv2.BFMatcher() with its default norm
+// (omnistereo/camera_models.py:396).  Not on the VO drivers' path (they use binary descriptors): one wave per 64
+// queries, the query rows transposed in LDS (lane-contiguous: conflict-free), the train rows in an LDS tile read as
+// broadcasts; the squared differences accumulate in float32 four at a time in index order, as OpenCV's scalar
+// normL2Sqr_ does (no contraction), distance = sqrt.  Key = (distance bits << 32 | train index): non-negative floats
+// order like their bit patterns, so an unsigned min is "smallest distance, first train index".
+constexpr int kL2MaxDim = 128, kL2Tile = 32;
+template <int K>
+__global__ __launch_bounds__(64) void match_l2_kernel(const float* __restrict__ q, const float* __restrict__ t,
+                                                      const int32_t* __restrict__ nq, const int32_t* __restrict__ nt,
+                                                      int q_stride, int t_stride, int dim,
+                                                      unsigned long long* __restrict__ keys) {
+  __shared__ float qs[kL2MaxDim * 64];
+  __shared__ __attribute__((aligned(16))) float tile[kL2Tile * kL2MaxDim];
+  const int lane = threadIdx.x, p = blockIdx.x;
+  const int nqp = min(nq[p], q_stride), ntp = min(nt[p], t_stride);
+  const int q0 = blockIdx.y * 64;
+  if (q0 >= nqp) return;  // uniform
+  const int dimp = (dim + 3) & ~3;  // row pitch in the tile
+  const float* qsrc = q + ((size_t)p * q_stride + q0) * dim;
+  const int rows = min(64, nqp - q0);
+  for (int i = lane; i < rows * dim; i += 64) {  // coalesced read, transposed store
+    const int r = i / dim, d = i - r * dim;
+    qs[d * 64 + r] = qsrc[i];
+  }
+  unsigned long long best = ~0ULL, second = ~0ULL;
+  const float* tsrc = t + (size_t)p * t_stride * dim;
+  for (int t0 = 0; t0 < ntp; t0 += kL2Tile) {
+    const int lim = min(kL2Tile, ntp - t0);
+    __syncthreads();
+    for (int i = lane; i < lim * dim; i += 64) {
+      const int r = i / dim, d = i - r * dim;
+      tile[r * dimp + d] = tsrc[(size_t)t0 * dim + i];
+    }
+    __syncthreads();
+    if (lane >= rows) continue;  // (the barriers above are reached by every lane)
+    for (int j = 0; j < lim; ++j) {
+      const float* tr = tile + j * dimp;
+      float s = 0.0f;
+      int i = 0;
+      for (; i <= dim - 4; i += 4) {
+        const float4 tv = *reinterpret_cast<const float4*>(tr + i);
+        const float v0 = qs[i * 64 + lane] - tv.x, v1 = qs[(i + 1) * 64 + lane] - tv.y;
+        const float v2 = qs[(i + 2) * 64 + lane] - tv.z, v3 = qs[(i + 3) * 64 + lane] - tv.w;
+        s += (((v0 * v0) + (v1 * v1)) + (v2 * v2)) + (v3 * v3);
+      }
+      for (; i < dim; ++i) {
+        const float v = qs[i * 64 + lane] - tr[i];
+        s += v * v;
+      }
+      const unsigned long long key = ((unsigned long long)__float_as_uint(sqrtf(s)) << 32) | (uint32_t)(t0 + j);
+      if (K == 2) second = min(second, max(best, key));
+      best = min(best, key);
+    }
+  }
+  if (lane < rows) {
+    unsigned long long* out = keys + ((size_t)p * q_stride + q0 + lane) * K;
+    out[0] = best;
+    if (K == 2) out[1] = second;
+  }
+}
+
 // Rank sort: the sort key of query i is (distance << 20 | i); its rank is the number of
 // smaller sort keys.  Keys are unique, so ranks are a permutation and ties on distance
 // keep query order (stable), as Python's sorted() does at camera_models.py:444.
@@ -313,6 +375,25 @@ int32_t sosvo_match_radius(sosvo_ctx* ctx, const uint8_t* q_desc, const uint8_t*
   SOSVO_LAUNCH(ctx, match_radius_kernel, dim3(nprob, cdiv(q_stride, kThreads / 64)), dim3(kThreads), 0, ctx->stream,
                reinterpret_cast<const uint4*>(q_desc), reinterpret_cast<const uint4*>(t_desc), nq, nt, q_slot, t_slot,
                q_stride, t_stride, (uint32_t)max_distance, cap, keys, counts);
+  SOSVO_LAUNCH_CHECK(ctx);
+  return SOSVO_OK;
+}
+
+int32_t sosvo_match_l2(sosvo_ctx* ctx, const float* q_desc, const float* t_desc, const int32_t* nq, const int32_t* nt,
+                       int32_t nprob, int32_t q_stride, int32_t t_stride, int32_t dim, int32_t k, uint64_t* keys) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, q_desc && t_desc && nq && nt && keys, "null pointer");
+  SOSVO_REQUIRE(ctx, nprob >= 0 && nprob <= 65535, "nprob out of range");
+  SOSVO_REQUIRE(ctx, q_stride > 0 && q_stride <= (1 << 20) && t_stride > 0 && t_stride <= (1 << 20), "strides out of range");
+  SOSVO_REQUIRE(ctx, dim >= 1 && dim <= kL2MaxDim, "dim out of range (1..128)");
+  SOSVO_REQUIRE(ctx, k == 1 || k == 2, "k must be 1 or 2");
+  if (nprob == 0) return SOSVO_OK;
+  if (k == 1)
+    SOSVO_LAUNCH(ctx, match_l2_kernel<1>, dim3(nprob, cdiv(q_stride, 64)), dim3(64), 0, ctx->stream, q_desc, t_desc, nq, nt,
+                 q_stride, t_stride, dim, reinterpret_cast<unsigned long long*>(keys));
+  else
+    SOSVO_LAUNCH(ctx, match_l2_kernel<2>, dim3(nprob, cdiv(q_stride, 64)), dim3(64), 0, ctx->stream, q_desc, t_desc, nq, nt,
+                 q_stride, t_stride, dim, reinterpret_cast<unsigned long long*>(keys));
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
 }

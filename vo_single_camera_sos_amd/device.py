@@ -379,6 +379,20 @@ class Context(object):
                    _ptr(t_slot), P, Sq, St, int(k), _ptr(keys))
         return keys
 
+    def match_l2(self, q_desc, t_desc, nq, nt, k=1):
+        """Float descriptors: q_desc [P, Sq, dim] f32, t_desc [P, St, dim] f32 -> keys [P, Sq, k] int64 holding the u64
+        (float32 distance bits << 32 | train index); all ones (-1) if absent."""
+        _check(q_desc, torch.float32, "q_desc", (None, None, None))
+        P, Sq, dim = q_desc.shape
+        _check(t_desc, torch.float32, "t_desc", (P, None, dim))
+        St = t_desc.shape[1]
+        _check(nq, torch.int32, "nq", (P,))
+        _check(nt, torch.int32, "nt", (P,))
+        keys = torch.empty((P, Sq, int(k)), dtype=torch.int64, device=q_desc.device)
+        self._call(self._lib.sosvo_match_l2, _ptr(q_desc), _ptr(t_desc), _ptr(nq), _ptr(nt), P, Sq, St, int(dim), int(k),
+                   _ptr(keys))
+        return keys
+
     def match_radius(self, q_desc, t_desc, nq, nt, max_distance, cap, q_slot=None, t_slot=None):
         """radiusMatch: q_desc [Bq, Sq, 32] u8, t_desc [Bt, St, 32] u8 -> (keys [P, Sq, cap] u32 ascending,
         KEY_NONE padded; counts [P, Sq] i32 = matches within max_distance, may exceed cap)."""

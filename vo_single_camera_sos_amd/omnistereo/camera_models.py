@@ -128,11 +128,12 @@ class PanoramicCorrespondences(object):
 
 
 class FeatureMatcher(object):
-    """camera_models.py:364-446.  Brute-force Hamming matching of 32-byte binary descriptors on the GPU.
-    Built: matcher_type "BF", k_best 1 (the trackers' setting, pose_est_tools.py:686) and 2, the "SIFT"
-    k_best == 2 ratio rule applied to whatever distances the descriptors give, radius match
-    (use_radius_match, at most 512 matches per query).  Not built (raises): "FLANN", float (L2) descriptors,
-    k_best > 2."""
+    """camera_models.py:364-446.  Brute-force matching on the GPU: Hamming distance for 32-byte binary descriptors
+    (uint8), L2 for float32 descriptors of up to 128 dimensions (what the reference's BFMatcher() does for "SIFT" /
+    "SURF", :394-396).  k_best 1 (the trackers' setting, pose_est_tools.py:686) and 2, the "SIFT" k_best == 2 ratio
+    rule, radius match for binary descriptors (use_radius_match, at most 512 matches per query).
+    matcher_type "FLANN" (:384-393: randomised KD-trees / LSH tables, approximate) is served by the same EXACT searches:
+    the neighbours FLANN approximates.  Not built (raises): k_best > 2, radius match on float descriptors."""
 
     def __init__(self, method, matcher_type, k_best, *args, **kwargs):
         self.feature_detection_method = method
@@ -144,8 +145,8 @@ class FeatureMatcher(object):
         self.percentage_good_matches = kwargs.get("percentage_good_matches", 1.0)
         self.num_of_features = kwargs.get("num_of_features", 100)
         self.use_radius_match = kwargs.get("use_radius_match", False)
-        if str(matcher_type).upper() != "BF":
-            raise NotImplementedError("matcher_type %r: only the brute-force matcher is built" % matcher_type)
+        if str(matcher_type).upper() not in ("BF", "FLANN"):
+            raise ValueError("matcher_type %r: \"BF\" or \"FLANN\"" % matcher_type)
         self._ctx = kwargs.get("context", None)
 
     def _context(self):
@@ -177,7 +178,7 @@ class FeatureMatcher(object):
         every pair, but as ONE batched launch + one copy back when the matcher is in its best-match mode (the per-bucket
         loop of match_features_panoramic_top_bottom costs a dozen launch / synchronise round trips per frame otherwise)."""
         import torch
-        if self.use_radius_match or self.k_best != 1 or len(pairs) == 0:
+        if self.use_radius_match or self.k_best != 1 or len(pairs) == 0 or any(self._is_float(q) for q, _ in pairs):
             return [self.match_arrays(q, t) for q, t in pairs]
         ctx = self._context()
         qs = [np.ascontiguousarray(np.asarray(q)) for q, _ in pairs]
@@ -211,9 +212,55 @@ class FeatureMatcher(object):
             out.append((o, k & KEY_IDX_MASK, (k >> KEY_SHIFT).astype(np.float32)))
         return out
 
+    @staticmethod
+    def _is_float(d):
+        import torch
+        return (d.dtype in (torch.float32, torch.float64)) if isinstance(d, torch.Tensor) else np.asarray(d).dtype.kind == "f"
+
+    def _l2_arrays(self, query_descriptors, train_descriptors):
+        """Float descriptors: (query_idx, train_idx, distance) as match_arrays gives them for binary ones."""
+        import torch
+        if self.use_radius_match:
+            raise NotImplementedError("radius match on float descriptors is not built")
+        if self.k_best > 2:
+            raise NotImplementedError("k_best > 2 is not built")
+        ctx = self._context()
+        q = np.ascontiguousarray(np.asarray(query_descriptors.cpu() if isinstance(query_descriptors, torch.Tensor) else
+                                            query_descriptors), dtype=np.float32)
+        t = np.ascontiguousarray(np.asarray(train_descriptors.cpu() if isinstance(train_descriptors, torch.Tensor) else
+                                            train_descriptors), dtype=np.float32)
+        if q.ndim != 2 or t.ndim != 2 or q.shape[1] != t.shape[1] or not 1 <= q.shape[1] <= 128:
+            raise ValueError("float descriptors must be [n, dim] with the same dim <= 128; got %s and %s" % (q.shape, t.shape))
+        nq, nt = q.shape[0], t.shape[0]
+        if nq == 0 or nt == 0:
+            return (np.empty(0, np.int64),) * 2 + (np.empty(0, np.float32),)
+        dev = ctx.device
+        k = 2 if self.k_best == 2 else 1
+        keys = ctx.match_l2(torch.from_numpy(q[None]).to(dev), torch.from_numpy(t[None]).to(dev),
+                            torch.tensor([nq], dtype=torch.int32, device=dev), torch.tensor([nt], dtype=torch.int32, device=dev), k=k)
+        ctx.synchronize()
+        kh = keys[0].cpu().numpy()                                     # [nq, k] int64 (u64 bit patterns)
+        dist = (kh >> 32).astype(np.uint32).view(np.float32)
+        idx = kh & 0xFFFFFFFF
+        none = kh == -1
+        ratio_rule = k == 2 and str(self.feature_detection_method).upper() == "SIFT"
+        if k == 1 or ratio_rule:
+            order = np.argsort(dist[:, 0], kind="stable")            # sorted(matches, key=distance), ties in query order
+            qi, ti, di = order, idx[order, 0], dist[order, 0]
+            if ratio_rule:
+                keep = ~none[order, 1] & (di < dist[order, 1] * np.float32(0.75))
+                qi, ti, di = qi[keep], ti[keep], di[keep]
+            return qi.astype(np.int64), ti.astype(np.int64), di
+        flat_d, flat_i, flat_none = dist.reshape(-1), idx.reshape(-1), none.reshape(-1)   # [q0 best, q0 second, q1 best, ...]
+        order = np.argsort(flat_d, kind="stable")
+        order = order[~flat_none[order]]
+        return (order // 2).astype(np.int64), flat_i[order].astype(np.int64), flat_d[order]
+
     def match_arrays(self, query_descriptors, train_descriptors, max_descriptor_distance_radius=-1):
         """-> (query_idx, train_idx, distance) numpy arrays in the order of match()."""
         import torch
+        if self._is_float(query_descriptors) or self._is_float(train_descriptors):
+            return self._l2_arrays(query_descriptors, train_descriptors)
         if self.use_radius_match:
             return self._radius_arrays(query_descriptors, train_descriptors, max_descriptor_distance_radius)
         if self.k_best > 2:
