@@ -652,9 +652,9 @@ static inline void orc_jacobi12_rr(double* A, double* V) {
 
 /* M^T M -> the four eigenvectors of the smallest eigenvalues, vv[0] the smallest (eigenvalue k has rank = the number of
  * eigenvalues below it; equal ones: those with a lower index). */
-static inline void orc_epnp_null4(const double* alphas, const double* uv, int n, double* vv) {
+static inline int orc_epnp_null4(const double* alphas, const double* uv, int n, double* vv) {
   /* M^T M (12 x 12): two rows per point, [a_j, 0, -a_j u] and [0, a_j, -a_j v] for j = 0..3 */
-  double MtM[144], Ev[144], evals[12];
+  double MtM[144], evals[12], esub[12];
   for (int k = 0; k < 144; ++k) MtM[k] = 0.0;
   for (int i = 0; i < n; ++i) {
     double r1[12], r2[12];
@@ -670,15 +670,15 @@ static inline void orc_epnp_null4(const double* alphas, const double* uv, int n,
     for (int r = 0; r < 12; ++r)
       for (int c = 0; c < 12; ++c) MtM[12 * r + c] = (MtM[12 * r + c] + (r1[r] * r1[c])) + (r2[r] * r2[c]);
   }
-  orc_jacobi12_rr(MtM, Ev);
-  for (int k = 0; k < 12; ++k) evals[k] = MtM[13 * k];
+  if (!orc_symeig12(MtM, evals, esub)) return 0; /* the columns of MtM are the eigenvectors now */
   for (int k = 0; k < 12; ++k) {
     int rank = 0;
     for (int j = 0; j < 12; ++j)
       if (evals[j] < evals[k] || (evals[j] == evals[k] && j < k)) rank++;
     if (rank < 4)
-      for (int j = 0; j < 12; ++j) vv[12 * rank + j] = Ev[12 * j + k];
+      for (int j = 0; j < 12; ++j) vv[12 * rank + j] = MtM[12 * j + k];
   }
+  return 1;
 }
 
 /* f, p: n rows of 3 (bearings in the camera, points in the world), 5 <= n <= ORC_EPNP_MAXN.
@@ -686,7 +686,7 @@ static inline void orc_epnp_null4(const double* alphas, const double* uv, int n,
 static inline int orc_epnp(const double* f, const double* p, int n, double* R, double* t) {
   double uv[2 * ORC_EPNP_MAXN], cw[12], alphas[4 * ORC_EPNP_MAXN], vv[48];
   if (!orc_epnp_front(f, p, n, uv, cw, alphas)) return 0;
-  orc_epnp_null4(alphas, uv, n, vv);
+  if (!orc_epnp_null4(alphas, uv, n, vv)) return 0;
   return orc_epnp_back(p, n, uv, cw, alphas, vv, R, t);
 }
 /* @oracle-only: end */

@@ -1,6 +1,7 @@
-"""Per-kernel times (library HIP-event profile) of one RGB-D batch step (BASELINE config 5):
-    python scripts/profile_c5.py [--pairs 128] [--algo EPNP]"""
+"""Per-kernel milliseconds of one step of config 5 (RGB-D pairs through sosvo_rgbd_pair_batch), from the library's own
+HIP-event profile:   python scripts/profile_c5.py [--pairs 128] [--algo EPNP]"""
 import argparse
+import collections
 import os
 import sys
 
@@ -37,17 +38,17 @@ def main():
         one.step()
     ctx.synchronize()
     ctx.profile_enable(True)
-    steps = 4
+    steps = 5
     for _ in range(steps):
         one.step()
     ctx.synchronize()
-    acc = {}
+    acc = collections.OrderedDict()
     for name, ms in ctx.profile_read():
         acc[name] = acc.get(name, 0.0) + ms / steps
-    for k, v in sorted(acc.items(), key=lambda kv: -kv[1]):
-        print("%-40s %8.3f ms" % (k, v))
-    print("total %.3f ms per step of %d pairs" % (sum(acc.values()), B))
-    ctx.close()
+    tot = sum(acc.values())
+    for name, ms in sorted(acc.items(), key=lambda kv: -kv[1]):
+        print("%-44s %8.3f ms" % (name, ms))
+    print("total %.3f ms per step of %d pairs -> %.0f pairs/s if back to back" % (tot, B, B / tot * 1e3))
 
 
 if __name__ == "__main__":

@@ -1,44 +1,203 @@
 // The 12 x 12 eigen-solver of EPnP on the device and the solver's driver: the ONE part of the EPnP restatement that is
 // not the oracle's text (csrc/epnp_core.h is generated from oracle/epnp_core.h; this file is hand-written and included at its
-// end).  Same operations in the same order as orc_jacobi12_rr / orc_epnp_null4 -- the GPU parity tests compare every
-// hypothesis bit for bit -- but worded for registers: upper triangle + eigenvector matrix in 78 + 144 doubles, the eleven
-// rounds of a sweep unrolled by a fold so that every index is a compile-time constant.
+// end).  Same operations in the same order as orc_symeig12 / orc_epnp_null4 -- the GPU parity tests compare every
+// hypothesis bit for bit -- but worded for registers: the 12 x 12 matrix (which becomes the eigenvector matrix), the
+// diagonal and the sub-diagonal in 144 + 24 doubles, every loop unrolled so that every index is a compile-time constant.
+// (Until round 2 this was a round-robin Jacobi solver, ~7 x the arithmetic: 1.52 ms per 128 pairs x 2000 hypotheses
+// against the figure in DESIGN.md section 10 now; the oracle keeps its loop form, orc_jacobi12_rr, as a cross-check.)
 #pragma once
 #include <type_traits>
 #include <utility>
-
-/* The 12 x 12 symmetric eigen-problem of EPnP (M^T M): Jacobi rotations in round-robin order (oracle/epnp_core.h,
- * orc_jacobi12_rr: the same operations in the same order).  Pair i of round r is (r, 11) for i = 0 and
- * ((r + i) mod 11, (r - i) mod 11) otherwise, smaller index first. */
-#define SV_JACOBI12_TOL 1e-26
-__device__ constexpr int sv_rr_first(int idx) {
-  const int r = idx / 6, i = idx % 6;
-  const int a = i == 0 ? r : (r + i) % 11, b = i == 0 ? 11 : (r - i + 11) % 11;
-  return a < b ? a : b;
-}
-__device__ constexpr int sv_rr_second(int idx) {
-  const int r = idx / 6, i = idx % 6;
-  const int a = i == 0 ? r : (r + i) % 11, b = i == 0 ? 11 : (r - i + 11) % 11;
-  return a < b ? b : a;
-}
-/* index of element (i, j) of a symmetric 12 x 12 matrix kept as its upper triangle (78 entries) */
-__device__ constexpr int sv_tri(int i, int j) { return i <= j ? i * 12 - i * (i - 1) / 2 + (j - i) : j * 12 - j * (j - 1) / 2 + (i - j); }
 template <typename F, int... R>
-__device__ __forceinline__ void sv_for_each_round(F& f, std::integer_sequence<int, R...>) {
+__device__ __forceinline__ void sv_for_each_const(F& f, std::integer_sequence<int, R...>) {
   (f(std::integral_constant<int, R>{}), ...);
 }
 
-/* EVERYTHING IN REGISTERS: the symmetric matrix as its upper triangle (a, 78 doubles; built from the barycentric
- * coordinates: two rows of M per point, [a_j, 0, -a_j u] and [0, a_j, -a_j v]) and the eigenvector matrix V (144
- * doubles) -- a wave that has a SIMD to itself owns 512 registers per lane.  Every index is a compile-time constant: the
- * 11 rounds of a sweep are unrolled by a fold.  The six rotations of a round have disjoint index pairs, so their angles
- * -- two divisions and two square roots in a chain, the longest dependency of the solver -- are evaluated side by side
- * before the rotations are applied one after the other.  -> vv: the four eigenvectors of the smallest eigenvalues, vv[0]
- * the smallest (eigenvalue k has rank = the number of eigenvalues below it; equal ones: those with a lower index). */
-__device__ static void sv_epnp_null4_reg(const double* alphas, const double* uv, int n, double* vv) {
-  double a[78], V[144];
+/* ---- Householder tridiagonalisation + QL with implicit shifts, register-resident --------------------------------------
+ * The same operations in the same order as orc_symeig12 (oracle/epnp_core.h: the EISPACK tred2 / tql2 pair restated;
+ * explicit fused multiply-adds where the oracle writes fma()), worded so that every array index is a compile-time
+ * constant after unrolling: the loops of the reduction have static bounds; in the QL part the two data-dependent indices
+ * -- m, where the matrix splits, and the start of the rotation chain -- become per-lane predicates over static ranges
+ * ("rotation i runs if i < m"), and d[m] / e[m] are read and written through select chains.  ~1/7 of the arithmetic of
+ * the Jacobi sweeps; lanes of a wave converge after different numbers of QL iterations and the wave pays for the
+ * slowest, which still leaves it several times ahead.  A: symmetric on entry, its COLUMNS are the eigenvectors on exit,
+ * d the eigenvalues (unordered).  Returns 0 if an eigenvalue needs more than 30 iterations. */
+#define SV_EIG_EPS 1e-12
+__device__ __forceinline__ static int sv_symeig12_reg(double (&A)[144], double (&d)[12], double (&e)[12]) {
+  constexpr int n = 12;
+  // (the outer loops are unrolled by a fold: a constexpr index makes the triangular inner loops' bounds constants at once)
+  auto reduce_step = [&](auto i_tag) __attribute__((always_inline)) {
+    constexpr int i = n - 1 - decltype(i_tag)::value;
+    constexpr int l = i - 1;
+    double h = 0.0, scale = 0.0;
+    if (l > 0) {
 #pragma unroll
-  for (int k = 0; k < 78; ++k) a[k] = 0.0;
+      for (int k = 0; k <= l; ++k) scale = scale + fabs(A[i * n + k]);
+      if (scale == 0.0) {
+        e[i] = A[i * n + l];
+      } else {
+#pragma unroll
+        for (int k = 0; k <= l; ++k) {
+          A[i * n + k] = A[i * n + k] / scale;
+          h = h + (A[i * n + k] * A[i * n + k]);
+        }
+        double f = A[i * n + l];
+        double g = f >= 0.0 ? -sqrt(h) : sqrt(h);
+        e[i] = scale * g;
+        h = h - (f * g);
+        A[i * n + l] = f - g;
+        f = 0.0;
+#pragma unroll
+        for (int j = 0; j <= l; ++j) {
+          A[j * n + i] = A[i * n + j] / h;
+          g = 0.0;
+#pragma unroll
+          for (int k = 0; k <= j; ++k) g = fma(A[j * n + k], A[i * n + k], g);
+#pragma unroll
+          for (int k = j + 1; k <= l; ++k) g = fma(A[k * n + j], A[i * n + k], g);
+          e[j] = g / h;
+          f = f + (e[j] * A[i * n + j]);
+        }
+        const double hh = f / (h + h);
+#pragma unroll
+        for (int j = 0; j <= l; ++j) {
+          f = A[i * n + j];
+          g = e[j] - (hh * f);
+          e[j] = g;
+#pragma unroll
+          for (int k = 0; k <= j; ++k) A[j * n + k] = A[j * n + k] - fma(f, e[k], g * A[i * n + k]);
+        }
+      }
+    } else {
+      e[i] = A[i * n + l];
+    }
+    d[i] = h;
+  };
+  sv_for_each_const(reduce_step, std::make_integer_sequence<int, n - 1>{});
+  d[0] = 0.0;
+  e[0] = 0.0;
+  auto accumulate_step = [&](auto i_tag) __attribute__((always_inline)) {
+    constexpr int i = decltype(i_tag)::value;
+    constexpr int l = i - 1;
+    if (d[i] != 0.0) {
+#pragma unroll
+      for (int j = 0; j <= l; ++j) {
+        double g = 0.0;
+#pragma unroll
+        for (int k = 0; k <= l; ++k) g = fma(A[i * n + k], A[k * n + j], g);
+#pragma unroll
+        for (int k = 0; k <= l; ++k) A[k * n + j] = fma(-g, A[k * n + i], A[k * n + j]);
+      }
+    }
+    d[i] = A[i * n + i];
+    A[i * n + i] = 1.0;
+#pragma unroll
+    for (int j = 0; j <= l; ++j) {
+      A[j * n + i] = 0.0;
+      A[i * n + j] = 0.0;
+    }
+  };
+  sv_for_each_const(accumulate_step, std::make_integer_sequence<int, n>{});
+#pragma unroll
+  for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+  e[n - 1] = 0.0;
+  /* QL: eigenvalue after eigenvalue.  Written once, for "l = 0": after each eigenvalue the arrays d, e and the columns
+   * of A are shifted one place to the left (cyclically), so that the active block always starts at position 0 and ends at
+   * len - 1; after the twelfth shift everything is back in its original place.  Same arithmetic as the oracle's loop over
+   * l -- only the place of the operands moves -- and one copy of the rotation chain (~20 KB of code) that every wave of
+   * the chip runs, instead of twelve specialised ones (the waves drift apart with their iteration counts and would evict
+   * each other's part of the instruction cache: measured 5.1 against 1.5 ms). */
+  int ok = 1;
+  for (int len = n; len >= 1; --len) {
+    int iter = 0;
+    while (ok) {
+      /* m = the first position whose sub-diagonal element is negligible (len - 1 if none) */
+      int m = len - 1;
+#pragma unroll
+      for (int mm = n - 2; mm >= 0; --mm) {
+        const double dd = fabs(d[mm]) + fabs(d[mm + 1]);
+        if (mm <= len - 2 && fabs(e[mm]) <= (SV_EIG_EPS * dd)) m = mm;
+      }
+      if (m == 0) break;
+      if (iter++ == 30) {
+        ok = 0;
+        break;
+      }
+      double dm = d[n - 1];  // d[m]
+#pragma unroll
+      for (int mm = n - 2; mm > 0; --mm) dm = (m == mm) ? d[mm] : dm;
+      double g = (d[1] - d[0]) / (2.0 * e[0]);
+      double r = sqrt((g * g) + 1.0);
+      g = (dm - d[0]) + (e[0] / (g + (g >= 0.0 ? r : -r)));
+      double s = 1.0, c = 1.0, p = 0.0;
+      bool broke = false;
+#pragma unroll
+      for (int i = n - 2; i >= 0; --i) {
+        if (i < m && !broke) {
+          double f = s * e[i];
+          const double b = c * e[i];
+          r = sqrt((f * f) + (g * g));
+          e[i + 1] = r;
+          if (r == 0.0) {
+            d[i + 1] = d[i + 1] - p;
+#pragma unroll
+            for (int mm = 0; mm < n; ++mm)
+              if (m == mm) e[mm] = 0.0;
+            broke = true;
+          } else {
+            s = f / r;
+            c = g / r;
+            g = d[i + 1] - p;
+            r = ((d[i] - g) * s) + ((2.0 * c) * b);
+            p = s * r;
+            d[i + 1] = g + p;
+            g = (c * r) - b;
+#pragma unroll
+            for (int k = 0; k < n; ++k) {
+              f = A[k * n + i + 1];
+              const double zi = A[k * n + i];
+              A[k * n + i + 1] = fma(s, zi, c * f);
+              A[k * n + i] = fma(c, zi, -(s * f));
+            }
+          }
+        }
+      }
+      if (!broke) {
+        d[0] = d[0] - p;
+        e[0] = g;
+#pragma unroll
+        for (int mm = 0; mm < n; ++mm)
+          if (m == mm) e[mm] = 0.0;
+      }
+    }
+    { /* position 0 is done: everything one place to the left, position 0 to the end */
+      const double d0 = d[0], e0 = e[0];
+#pragma unroll
+      for (int q = 0; q < n - 1; ++q) {
+        d[q] = d[q + 1];
+        e[q] = e[q + 1];
+      }
+      d[n - 1] = d0;
+      e[n - 1] = e0;
+#pragma unroll
+      for (int k = 0; k < n; ++k) {
+        const double a0 = A[k * n];
+#pragma unroll
+        for (int q = 0; q < n - 1; ++q) A[k * n + q] = A[k * n + q + 1];
+        A[k * n + n - 1] = a0;
+      }
+    }
+  }
+  return ok;
+}
+
+/* M^T M of the sample (two rows of M per point, [a_j, 0, -a_j u] and [0, a_j, -a_j v]) -> the four eigenvectors of the
+ * smallest eigenvalues, vv[0] the smallest (eigenvalue k has rank = the number of eigenvalues below it; equal ones:
+ * those with a lower index); orc_epnp_null4's operations.  Returns 0 if the eigen-solver gives up. */
+__device__ static int sv_epnp_null4_ql(const double* alphas, const double* uv, int n, double* vv) {
+  double A[144], d[12], e[12];
+#pragma unroll
+  for (int k = 0; k < 144; ++k) A[k] = 0.0;
 #pragma unroll
   for (int i = 0; i < n; ++i) {
     double r1[12], r2[12];
@@ -55,71 +214,15 @@ __device__ static void sv_epnp_null4_reg(const double* alphas, const double* uv,
 #pragma unroll
     for (int r = 0; r < 12; ++r)
 #pragma unroll
-      for (int c = r; c < 12; ++c) a[sv_tri(r, c)] = (a[sv_tri(r, c)] + (r1[r] * r1[c])) + (r2[r] * r2[c]);
+      for (int c = 0; c < 12; ++c) A[12 * r + c] = (A[12 * r + c] + (r1[r] * r1[c])) + (r2[r] * r2[c]);
   }
-#pragma unroll
-  for (int i = 0; i < 12; ++i)
-#pragma unroll
-    for (int j = 0; j < 12; ++j) V[i * 12 + j] = (i == j) ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < 60; ++sweep) {
-    double off = 0.0, diag = 0.0;
-#pragma unroll
-    for (int p = 0; p < 12; ++p) {
-      diag = diag + (a[sv_tri(p, p)] * a[sv_tri(p, p)]);
-#pragma unroll
-      for (int q = p + 1; q < 12; ++q) off = off + (a[sv_tri(p, q)] * a[sv_tri(p, q)]);
-    }
-    if (!(off > (SV_JACOBI12_TOL * diag))) break;
-    auto round = [&](auto r_tag) __attribute__((always_inline)) {
-      constexpr int R = decltype(r_tag)::value;
-      double tt[6], cc[6], ss[6];
-      bool on[6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {  // the six angle chains of the round, independent of each other
-        const int P = sv_rr_first(6 * R + i), Q = sv_rr_second(6 * R + i);
-        const double apq = a[sv_tri(P, Q)], app = a[sv_tri(P, P)], aqq = a[sv_tri(Q, Q)];
-        on[i] = apq != 0.0;
-        const double theta = (aqq - app) / (2.0 * apq);
-        const double at = theta < 0.0 ? -theta : theta;
-        tt[i] = (theta < 0.0 ? -1.0 : 1.0) / (at + sqrt((theta * theta) + 1.0));
-        cc[i] = 1.0 / sqrt((tt[i] * tt[i]) + 1.0);
-        ss[i] = tt[i] * cc[i];
-      }
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {  // the rotations, one after the other
-        const int P = sv_rr_first(6 * R + i), Q = sv_rr_second(6 * R + i);
-        if (!on[i]) continue;
-        const double c = cc[i], s = ss[i], t = tt[i];
-        const double apq = a[sv_tri(P, Q)], app = a[sv_tri(P, P)], aqq = a[sv_tri(Q, Q)];
-#pragma unroll
-        for (int k = 0; k < 12; ++k) {
-          if (k == P || k == Q) continue;
-          const double akp = a[sv_tri(k, P)], akq = a[sv_tri(k, Q)];
-          a[sv_tri(k, P)] = (c * akp) - (s * akq);
-          a[sv_tri(k, Q)] = (s * akp) + (c * akq);
-        }
-        a[sv_tri(P, P)] = app - (t * apq);
-        a[sv_tri(Q, Q)] = aqq + (t * apq);
-        a[sv_tri(P, Q)] = 0.0;
-#pragma unroll
-        for (int k = 0; k < 12; ++k) {
-          const double vkp = V[k * 12 + P], vkq = V[k * 12 + Q];
-          V[k * 12 + P] = (c * vkp) - (s * vkq);
-          V[k * 12 + Q] = (s * vkp) + (c * vkq);
-        }
-      }
-    };
-    sv_for_each_round(round, std::make_integer_sequence<int, 11>{});
-  }
+  if (!sv_symeig12_reg(A, d, e)) return 0;
   int rank[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) {
     int rk = 0;
 #pragma unroll
-    for (int j = 0; j < 12; ++j) {
-      const double ej = a[sv_tri(j, j)], ek = a[sv_tri(k, k)];
-      rk += (ej < ek || (ej == ek && j < k)) ? 1 : 0;
-    }
+    for (int j = 0; j < 12; ++j) rk += (d[j] < d[k] || (d[j] == d[k] && j < k)) ? 1 : 0;
     rank[k] = rk;
   }
 #pragma unroll
@@ -128,16 +231,16 @@ __device__ static void sv_epnp_null4_reg(const double* alphas, const double* uv,
     for (int j = 0; j < 12; ++j) {
       double v = 0.0;
 #pragma unroll
-      for (int k = 0; k < 12; ++k) v = rank[k] == r4 ? V[12 * j + k] : v;
+      for (int k = 0; k < 12; ++k) v = rank[k] == r4 ? A[12 * j + k] : v;
       vv[12 * r4 + j] = v;
     }
+  return 1;
 }
 
 /* The whole solver on one lane. */
 __device__ static int sv_epnp(const double* f, const double* p, int n, double* R, double* t) {
   double uv[2 * SV_EPNP_MAXN], cw[12], alphas[4 * SV_EPNP_MAXN], vv[48];
   if (!sv_epnp_front(f, p, n, uv, cw, alphas)) return 0;
-  sv_epnp_null4_reg(alphas, uv, n, vv);
+  if (!sv_epnp_null4_ql(alphas, uv, n, vv)) return 0;
   return sv_epnp_back(p, n, uv, cw, alphas, vv, R, t);
 }
-

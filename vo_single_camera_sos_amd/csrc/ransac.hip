@@ -206,8 +206,8 @@ __global__ __launch_bounds__(64) void ransac_hyp_gp3p_kernel(const double* __res
 
 // The EPnP hypothesis generator (central problems, SOSVO_FLAG_EPNP), one hypothesis per lane, as TWO kernels:
 //   ransac_epnp_eigen_kernel  sample -> control points, barycentric coordinates -> M^T M -> the 12 x 12 eigen-solver
-//       entirely in registers (sv_epnp_null4_reg: round-robin Jacobi, 78 + 144 doubles, one wave per SIMD, no LDS) -> the
-//       four null-space vectors, 48 doubles per hypothesis, to the workspace;
+//       entirely in registers (sv_epnp_null4_ql: Householder tridiagonalisation + implicit QL, 144 + 24 doubles, one wave
+//       per SIMD, no LDS) -> the four null-space vectors, 48 doubles per hypothesis, to the workspace;
 //   ransac_epnp_pose_kernel   recomputes the (cheap) first half, reads the four vectors, runs the three beta
 //       initialisations + Gauss-Newton + absolute orientation.  On its own this half needs a fraction of the registers, so
 //       several waves per SIMD hide its divide / square-root chains.
@@ -244,9 +244,11 @@ __global__ __launch_bounds__(64) void ransac_epnp_eigen_kernel(const double* __r
   double* out = vvbuf + ((size_t)b * H + it) * kEpnpVecDoubles;
   if (ok) {
     double vv[48];
-    sv_epnp_null4_reg(alphas, uv, 6, vv);
+    ok = sv_epnp_null4_ql(alphas, uv, 6, vv);
+    if (ok) {
 #pragma unroll
-    for (int k = 0; k < 48; ++k) out[k] = vv[k];
+      for (int k = 0; k < 48; ++k) out[k] = vv[k];
+    }
   }
   counts[(size_t)b * H + it] = ok ? 0 : -1;
 }
