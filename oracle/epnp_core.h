@@ -339,7 +339,10 @@ static inline int orc_epnp_back(const double* p, int n, const double* uv, const 
     rho[j] = ((e0 * e0) + (e1 * e1)) + (e2 * e2);
   }
   double best_err = -1.0, Rb[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tb[3] = {0, 0, 0};
-  #pragma unroll
+  /* (a real loop on the device: the three initialisations share ONE copy of the Gauss-Newton steps and of the absolute
+   * orientation -- a third of the code and of the registers of the unrolled form, so that two waves fit a SIMD and the
+   * divisions / square roots of one hide behind the other's arithmetic) */
+  #pragma unroll 1
   for (int variant = 0; variant < 3; ++variant) {
     double betas[4] = {0, 0, 0, 0}, A[6 * 5], x[5];
     int ok;
@@ -366,12 +369,14 @@ static inline int orc_epnp_back(const double* p, int n, const double* uv, const 
         }
       }
     } else { /* [B11 B12 B22] and [B11 B12 B22 B13 B23] */
-      const int k = variant == 1 ? 3 : 5;
       #pragma unroll
       for (int j = 0; j < 6; ++j)
         #pragma unroll
-        for (int c = 0; c < k; ++c) A[5 * j + c] = L[10 * j + c];
-      ok = orc_lsq_small(A, 5, rho, 6, k, x);
+        for (int c = 0; c < 5; ++c) A[5 * j + c] = L[10 * j + c];
+      x[3] = 0.0;
+      x[4] = 0.0;
+      if (variant == 1) ok = orc_lsq_small(A, 5, rho, 6, 3, x); /* (the system size stays a constant at each call) */
+      else ok = orc_lsq_small(A, 5, rho, 6, 5, x);
       if (ok) {
         if (x[0] < 0.0) {
           betas[0] = sqrt(-x[0]);
@@ -386,7 +391,7 @@ static inline int orc_epnp_back(const double* p, int n, const double* uv, const 
       }
     }
     if (!ok) continue;
-    #pragma unroll
+    #pragma unroll 1
     for (int itn = 0; itn < 5; ++itn) { /* Gauss-Newton on the six distance constraints */
       double J[6 * 5], r[6], dx[4];
       #pragma unroll
