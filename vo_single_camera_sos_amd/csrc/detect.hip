@@ -258,8 +258,10 @@ __global__ __launch_bounds__(kThreads) void mask_bbox_kernel(const uint32_t* __r
 // candidate against the grid of already accepted points (9 cells x 2 slots) and against the earlier lanes
 // of its batch (64 shuffles -> a 64-bit conflict mask); a short scalar pass over the batch then replays the
 // sequential acceptance rule exactly (accept iff no conflict with anything accepted before).
-template <int CAND>
-__global__ __launch_bounds__(kThreads) void gft_select_kernel(const uint4* __restrict__ cand,
+// (NT threads per workgroup: 256, or 1024 for the whole-image variant whose 128 KB of LDS allow one workgroup per CU anyway --
+// sixteen waves share the sort passes instead of four)
+template <int CAND, int NT>
+__global__ __launch_bounds__(NT) void gft_select_kernel(const uint4* __restrict__ cand,
                                                               const uint32_t* __restrict__ wcnt, int strips, int nchunks,
                                                               int chunk_rows, int wcap,
                                                               const uint32_t* __restrict__ mstat, int images_per_maskset,
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(kThreads) void gft_select_kernel(const uint4* __res
         const int have = (int)wcnt[w];
         if (have > wcap && tid == 0) s_overflow = 1;
         const uint4* region = cand + (size_t)w * wcap;
-        for (int i = tid; i < min(have, wcap); i += kThreads) {
+        for (int i = tid; i < min(have, wcap); i += NT) {
           const uint4 r = region[i];
           const float v = __uint_as_float(r.x);
           if (!((r.z >> m) & 1u) || !(v > thr)) continue;
@@ -330,11 +332,11 @@ __global__ __launch_bounds__(kThreads) void gft_select_kernel(const uint4* __res
   // ---- phase 2: bitonic sort, descending (keys are unique: value, then higher address first) ---------------
   int N = 64;
   while (N < n) N <<= 1;
-  for (int i = n + tid; i < N; i += kThreads) keys[i] = 0ULL;  // padding sorts last
+  for (int i = n + tid; i < N; i += NT) keys[i] = 0ULL;  // padding sorts last
   __syncthreads();
   for (int k = 2; k <= N; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < N / 2; t += kThreads) {
+      for (int t = tid; t < N / 2; t += NT) {
         const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), ixj = i | j;
         const unsigned long long a = keys[i], b = keys[ixj];
         const bool desc = (i & k) == 0;
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(kThreads) void gft_select_kernel(const uint4* __res
     }
   }
   // candidates leave as packed (y << 16 | x), in order
-  for (int i = tid; i < n; i += kThreads) {
+  for (int i = tid; i < n; i += NT) {
     const uint32_t pix = (uint32_t)keys[i];
     const uint32_t y = pix / (uint32_t)cols;
     sorted[i] = (y << 16) | (pix - y * (uint32_t)cols);
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(kThreads) void gft_select_kernel(const uint4* __res
   const bool use_grid = gw * gh <= kSelGridCells;
   const int limit_list = 1024;
   __syncthreads();  // keys are dead from here on; sorted[] is visible to the whole workgroup
-  for (int i = tid; i < (use_grid ? gw * gh * 2 : 0); i += kThreads) grid[i] = 0u;
+  for (int i = tid; i < (use_grid ? gw * gh * 2 : 0); i += NT) grid[i] = 0u;
   __syncthreads();
   // ---- phase 3: greedy minimum-distance pass, first wave ----------------------------------------------------
   // 64 candidates per round.  Every lane tests its candidate against the points accepted in earlier rounds
@@ -724,15 +726,15 @@ int32_t sosvo_detect_gft(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* ma
   int32_t* redo = (int32_t*)(ws + o_redo);
   if (large) {
     SOSVO_PROFILE(ctx, "gft_select_kernel");
-    hipLaunchKernelGGL(gft_select_kernel<kCandCapLarge>, dim3(xcd_grid(nimg, nmask)), dim3(kThreads), 0, ctx->stream, cand, wcnt,
+    hipLaunchKernelGGL((gft_select_kernel<kCandCapLarge, 1024>), dim3(xcd_grid(nimg, nmask)), dim3(1024), 0, ctx->stream, cand, wcnt,
                        strips, nchunks, chunk_rows, wcap, mstat, images_per_maskset, nmask, rows, cols, quality, (float)min_distance, cell,
                        max_corners, cap, sorted_g, sorted_stride, kp, n, status, nullptr, 0, nimg);
   } else {
     SOSVO_PROFILE(ctx, "gft_select_kernel");
-    hipLaunchKernelGGL(gft_select_kernel<kCandCapSmall>, dim3(xcd_grid(nimg, nmask)), dim3(kThreads), 0, ctx->stream, cand, wcnt,
+    hipLaunchKernelGGL((gft_select_kernel<kCandCapSmall, kThreads>), dim3(xcd_grid(nimg, nmask)), dim3(kThreads), 0, ctx->stream, cand, wcnt,
                        strips, nchunks, chunk_rows, wcap, mstat, images_per_maskset, nmask, rows, cols, quality, (float)min_distance, cell,
                        max_corners, cap, sorted_g, sorted_stride, kp, n, status, redo, 0, nimg);
-    hipLaunchKernelGGL(gft_select_kernel<kCandCap>, dim3(xcd_grid(nimg, nmask)), dim3(kThreads), 0, ctx->stream, cand, wcnt,
+    hipLaunchKernelGGL((gft_select_kernel<kCandCap, kThreads>), dim3(xcd_grid(nimg, nmask)), dim3(kThreads), 0, ctx->stream, cand, wcnt,
                        strips, nchunks, chunk_rows, wcap, mstat, images_per_maskset, nmask, rows, cols, quality, (float)min_distance, cell,
                        max_corners, cap, sorted_g, sorted_stride, kp, n, status, redo, 1, nimg);
   }
