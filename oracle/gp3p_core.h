@@ -67,18 +67,19 @@ static inline orc_cplx orc_csqrt(orc_cplx z) { /* principal square root from rea
   return orc_c(z.im / (2.0 * im), im);
 }
 
-/* Laguerre's iteration on a polynomial of degree m with complex coefficients a[0..m] (a[m] leading), from *x; the
- * classic formulation with a fractional step every tenth iteration to break limit cycles. */
-static inline void orc_laguerre(const orc_cplx* a, int m, orc_cplx* x) {
+/* Laguerre's iteration on a polynomial of degree m with REAL coefficients a[0..m] (a[m] leading), from *x; the classic
+ * formulation with a fractional step every tenth iteration to break limit cycles. */
+static inline void orc_laguerre(const double* a, int m, orc_cplx* x) {
   const double frac[9] = {0.0, 0.5, 0.25, 0.75, 0.13, 0.38, 0.62, 0.88, 1.0};
   for (int iter = 1; iter <= 80; ++iter) {
-    orc_cplx b = a[m], d = orc_c(0.0, 0.0), f = orc_c(0.0, 0.0);
+    orc_cplx b = orc_c(a[m], 0.0), d = orc_c(0.0, 0.0), f = orc_c(0.0, 0.0);
     double err = orc_cabs(b);
     const double abx = orc_cabs(*x);
     for (int j = m - 1; j >= 0; --j) {
       f = orc_cadd(orc_cmul(*x, f), d);
       d = orc_cadd(orc_cmul(*x, d), b);
-      b = orc_cadd(orc_cmul(*x, b), a[j]);
+      b = orc_cmul(*x, b);
+      b.re = b.re + a[j];
       err = orc_cabs(b) + (abx * err);
     }
     err = err * 1e-15;
@@ -102,27 +103,45 @@ static inline void orc_laguerre(const orc_cplx* a, int m, orc_cplx* x) {
   }
 }
 
-/* All roots of the real polynomial c[0] + c[1] x + ... + c[m] x^m (m <= 10, c[m] != 0): Laguerre from 0 with deflation,
- * then each root polished on the undeflated polynomial. */
+/* All roots of the real polynomial c[0] + c[1] x + ... + c[m] x^m (m <= 10, c[m] != 0): Laguerre from 0 on the
+ * deflated polynomial, which stays REAL -- a real root is divided out as (x - r), a complex one together with its
+ * conjugate as the real quadratic x^2 - 2 Re(z) x + |z|^2 (one iteration run finds both: conjugate roots of a real
+ * polynomial need not be searched twice).  Then the roots that can still turn out real (|Im| <= 1e-3 (1 + |Re|): every
+ * caller discards the others) are polished on the undeflated polynomial. */
 static inline void orc_poly_roots(const double* c, int m, orc_cplx* roots) {
-  orc_cplx a[11], ad[11];
-  for (int j = 0; j <= m; ++j) {
-    a[j] = orc_c(c[j], 0.0);
-    ad[j] = a[j];
-  }
-  for (int j = m; j >= 1; --j) {
+  double ad[11];
+  for (int j = 0; j <= m; ++j) ad[j] = c[j];
+  int deg = m, nr = 0;
+  while (deg >= 1) {
     orc_cplx x = orc_c(0.0, 0.0);
-    orc_laguerre(ad, j, &x);
-    if (fabs(x.im) <= (4e-16 * fabs(x.re))) x.im = 0.0;
-    roots[j - 1] = x;
-    orc_cplx b = ad[j];
-    for (int jj = j - 1; jj >= 0; --jj) { /* deflate by (x - root) */
-      const orc_cplx t = ad[jj];
-      ad[jj] = b;
-      b = orc_cadd(orc_cmul(x, b), t);
+    orc_laguerre(ad, deg, &x);
+    if (deg == 1 || fabs(x.im) <= (1e-14 * (1.0 + fabs(x.re)))) {
+      x.im = 0.0;
+      roots[nr++] = x;
+      double b = ad[deg];
+      for (int jj = deg - 1; jj >= 0; --jj) { /* deflate by (x - r) */
+        const double t = ad[jj];
+        ad[jj] = b;
+        b = (x.re * b) + t;
+      }
+      deg = deg - 1;
+    } else {
+      roots[nr++] = x;
+      roots[nr++] = orc_c(x.re, -x.im);
+      const double p2 = 2.0 * x.re, q = (x.re * x.re) + (x.im * x.im); /* divide by x^2 - p2 x + q */
+      double b1 = 0.0, b0 = 0.0; /* quotient coefficients of the two degrees above the current one */
+      for (int jj = deg; jj >= 2; --jj) {
+        const double t = (ad[jj] + (p2 * b0)) - (q * b1);
+        b1 = b0;
+        b0 = t;
+        ad[jj] = t; /* quotient coefficient of x^(jj - 2), stored two places up for now */
+      }
+      for (int jj = 0; jj <= deg - 2; ++jj) ad[jj] = ad[jj + 2];
+      deg = deg - 2;
     }
   }
-  for (int j = 0; j < m; ++j) orc_laguerre(a, m, &roots[j]);
+  for (int j = 0; j < m; ++j)
+    if (fabs(roots[j].im) <= (1e-3 * (1.0 + fabs(roots[j].re)))) orc_laguerre(c, m, &roots[j]);
 }
 
 /* small real-polynomial helpers: p (degree dp) times q (degree dq) accumulated into out with weight w */

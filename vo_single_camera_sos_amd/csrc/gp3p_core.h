@@ -51,18 +51,19 @@ __device__ static sv_cplx sv_csqrt(sv_cplx z) { /* principal square root from re
   return sv_c(z.im / (2.0 * im), im);
 }
 
-/* Laguerre's iteration on a polynomial of degree m with complex coefficients a[0..m] (a[m] leading), from *x; the
- * classic formulation with a fractional step every tenth iteration to break limit cycles. */
-__device__ static void sv_laguerre(const sv_cplx* a, int m, sv_cplx* x) {
+/* Laguerre's iteration on a polynomial of degree m with REAL coefficients a[0..m] (a[m] leading), from *x; the classic
+ * formulation with a fractional step every tenth iteration to break limit cycles. */
+__device__ static void sv_laguerre(const double* a, int m, sv_cplx* x) {
   const double frac[9] = {0.0, 0.5, 0.25, 0.75, 0.13, 0.38, 0.62, 0.88, 1.0};
   for (int iter = 1; iter <= 80; ++iter) {
-    sv_cplx b = a[m], d = sv_c(0.0, 0.0), f = sv_c(0.0, 0.0);
+    sv_cplx b = sv_c(a[m], 0.0), d = sv_c(0.0, 0.0), f = sv_c(0.0, 0.0);
     double err = sv_cabs(b);
     const double abx = sv_cabs(*x);
     for (int j = m - 1; j >= 0; --j) {
       f = sv_cadd(sv_cmul(*x, f), d);
       d = sv_cadd(sv_cmul(*x, d), b);
-      b = sv_cadd(sv_cmul(*x, b), a[j]);
+      b = sv_cmul(*x, b);
+      b.re = b.re + a[j];
       err = sv_cabs(b) + (abx * err);
     }
     err = err * 1e-15;
@@ -86,27 +87,45 @@ __device__ static void sv_laguerre(const sv_cplx* a, int m, sv_cplx* x) {
   }
 }
 
-/* All roots of the real polynomial c[0] + c[1] x + ... + c[m] x^m (m <= 10, c[m] != 0): Laguerre from 0 with deflation,
- * then each root polished on the undeflated polynomial. */
+/* All roots of the real polynomial c[0] + c[1] x + ... + c[m] x^m (m <= 10, c[m] != 0): Laguerre from 0 on the
+ * deflated polynomial, which stays REAL -- a real root is divided out as (x - r), a complex one together with its
+ * conjugate as the real quadratic x^2 - 2 Re(z) x + |z|^2 (one iteration run finds both: conjugate roots of a real
+ * polynomial need not be searched twice).  Then the roots that can still turn out real (|Im| <= 1e-3 (1 + |Re|): every
+ * caller discards the others) are polished on the undeflated polynomial. */
 __device__ static void sv_poly_roots(const double* c, int m, sv_cplx* roots) {
-  sv_cplx a[11], ad[11];
-  for (int j = 0; j <= m; ++j) {
-    a[j] = sv_c(c[j], 0.0);
-    ad[j] = a[j];
-  }
-  for (int j = m; j >= 1; --j) {
+  double ad[11];
+  for (int j = 0; j <= m; ++j) ad[j] = c[j];
+  int deg = m, nr = 0;
+  while (deg >= 1) {
     sv_cplx x = sv_c(0.0, 0.0);
-    sv_laguerre(ad, j, &x);
-    if (fabs(x.im) <= (4e-16 * fabs(x.re))) x.im = 0.0;
-    roots[j - 1] = x;
-    sv_cplx b = ad[j];
-    for (int jj = j - 1; jj >= 0; --jj) { /* deflate by (x - root) */
-      const sv_cplx t = ad[jj];
-      ad[jj] = b;
-      b = sv_cadd(sv_cmul(x, b), t);
+    sv_laguerre(ad, deg, &x);
+    if (deg == 1 || fabs(x.im) <= (1e-14 * (1.0 + fabs(x.re)))) {
+      x.im = 0.0;
+      roots[nr++] = x;
+      double b = ad[deg];
+      for (int jj = deg - 1; jj >= 0; --jj) { /* deflate by (x - r) */
+        const double t = ad[jj];
+        ad[jj] = b;
+        b = (x.re * b) + t;
+      }
+      deg = deg - 1;
+    } else {
+      roots[nr++] = x;
+      roots[nr++] = sv_c(x.re, -x.im);
+      const double p2 = 2.0 * x.re, q = (x.re * x.re) + (x.im * x.im); /* divide by x^2 - p2 x + q */
+      double b1 = 0.0, b0 = 0.0; /* quotient coefficients of the two degrees above the current one */
+      for (int jj = deg; jj >= 2; --jj) {
+        const double t = (ad[jj] + (p2 * b0)) - (q * b1);
+        b1 = b0;
+        b0 = t;
+        ad[jj] = t; /* quotient coefficient of x^(jj - 2), stored two places up for now */
+      }
+      for (int jj = 0; jj <= deg - 2; ++jj) ad[jj] = ad[jj + 2];
+      deg = deg - 2;
     }
   }
-  for (int j = 0; j < m; ++j) sv_laguerre(a, m, &roots[j]);
+  for (int j = 0; j < m; ++j)
+    if (fabs(roots[j].im) <= (1e-3 * (1.0 + fabs(roots[j].re)))) sv_laguerre(c, m, &roots[j]);
 }
 
 /* small real-polynomial helpers: p (degree dp) times q (degree dq) accumulated into out with weight w */
