@@ -68,29 +68,32 @@ static inline orc_cplx orc_csqrt(orc_cplx z) { /* principal square root from rea
 }
 
 /* Laguerre's iteration on a polynomial of degree m with REAL coefficients a[0..m] (a[m] leading), from *x; the classic
- * formulation with a fractional step every tenth iteration to break limit cycles. */
+ * formulation with a fractional step every tenth iteration to break limit cycles.  Magnitudes that only feed the
+ * rounding-error bound of the evaluation (Adams' running bound) or a comparison are taken in the 1-norm / squared:
+ * a square root per coefficient and three per iteration were more than half of the instructions of an iteration. */
+static inline double orc_cabs1(orc_cplx a) { return fabs(a.re) + fabs(a.im); }
 static inline void orc_laguerre(const double* a, int m, orc_cplx* x) {
   const double frac[9] = {0.0, 0.5, 0.25, 0.75, 0.13, 0.38, 0.62, 0.88, 1.0};
   for (int iter = 1; iter <= 80; ++iter) {
     orc_cplx b = orc_c(a[m], 0.0), d = orc_c(0.0, 0.0), f = orc_c(0.0, 0.0);
-    double err = orc_cabs(b);
-    const double abx = orc_cabs(*x);
+    double err = orc_cabs1(b);
+    const double abx = orc_cabs1(*x);
     for (int j = m - 1; j >= 0; --j) {
       f = orc_cadd(orc_cmul(*x, f), d);
       d = orc_cadd(orc_cmul(*x, d), b);
       b = orc_cmul(*x, b);
       b.re = b.re + a[j];
-      err = orc_cabs(b) + (abx * err);
+      err = orc_cabs1(b) + (abx * err);
     }
     err = err * 1e-15;
-    if (orc_cabs(b) <= err) return; /* on a root */
+    if (orc_cabs1(b) <= err) return; /* on a root */
     const orc_cplx g = orc_cdiv(d, b), g2 = orc_cmul(g, g);
     const orc_cplx h = orc_csub(g2, orc_cscale(orc_cdiv(f, b), 2.0));
     const orc_cplx sq = orc_csqrt(orc_cscale(orc_csub(orc_cscale(h, (double)m), g2), (double)(m - 1)));
     orc_cplx gp = orc_cadd(g, sq);
     const orc_cplx gm = orc_csub(g, sq);
-    double abp = orc_cabs(gp);
-    const double abm = orc_cabs(gm);
+    double abp = (gp.re * gp.re) + (gp.im * gp.im);
+    const double abm = (gm.re * gm.re) + (gm.im * gm.im);
     if (abp < abm) {
       gp = gm;
       abp = abm;

@@ -52,29 +52,32 @@ __device__ static sv_cplx sv_csqrt(sv_cplx z) { /* principal square root from re
 }
 
 /* Laguerre's iteration on a polynomial of degree m with REAL coefficients a[0..m] (a[m] leading), from *x; the classic
- * formulation with a fractional step every tenth iteration to break limit cycles. */
+ * formulation with a fractional step every tenth iteration to break limit cycles.  Magnitudes that only feed the
+ * rounding-error bound of the evaluation (Adams' running bound) or a comparison are taken in the 1-norm / squared:
+ * a square root per coefficient and three per iteration were more than half of the instructions of an iteration. */
+__device__ static double sv_cabs1(sv_cplx a) { return fabs(a.re) + fabs(a.im); }
 __device__ static void sv_laguerre(const double* a, int m, sv_cplx* x) {
   const double frac[9] = {0.0, 0.5, 0.25, 0.75, 0.13, 0.38, 0.62, 0.88, 1.0};
   for (int iter = 1; iter <= 80; ++iter) {
     sv_cplx b = sv_c(a[m], 0.0), d = sv_c(0.0, 0.0), f = sv_c(0.0, 0.0);
-    double err = sv_cabs(b);
-    const double abx = sv_cabs(*x);
+    double err = sv_cabs1(b);
+    const double abx = sv_cabs1(*x);
     for (int j = m - 1; j >= 0; --j) {
       f = sv_cadd(sv_cmul(*x, f), d);
       d = sv_cadd(sv_cmul(*x, d), b);
       b = sv_cmul(*x, b);
       b.re = b.re + a[j];
-      err = sv_cabs(b) + (abx * err);
+      err = sv_cabs1(b) + (abx * err);
     }
     err = err * 1e-15;
-    if (sv_cabs(b) <= err) return; /* on a root */
+    if (sv_cabs1(b) <= err) return; /* on a root */
     const sv_cplx g = sv_cdiv(d, b), g2 = sv_cmul(g, g);
     const sv_cplx h = sv_csub(g2, sv_cscale(sv_cdiv(f, b), 2.0));
     const sv_cplx sq = sv_csqrt(sv_cscale(sv_csub(sv_cscale(h, (double)m), g2), (double)(m - 1)));
     sv_cplx gp = sv_cadd(g, sq);
     const sv_cplx gm = sv_csub(g, sq);
-    double abp = sv_cabs(gp);
-    const double abm = sv_cabs(gm);
+    double abp = (gp.re * gp.re) + (gp.im * gp.im);
+    const double abm = (gm.re * gm.re) + (gm.im * gm.im);
     if (abp < abm) {
       gp = gm;
       abp = abm;
