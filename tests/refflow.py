@@ -249,14 +249,15 @@ def pairs_worker(job):
 def pairs_records_worker(job):
     """As pairs_worker, but returns the [n,16] result records (3x4 refined pose, inliers, correspondences, status,
     winning iteration) -- tests/soak_parity.py compares them with the GPU's."""
-    rig_kw, im_kw, omni, thr, iters, seed0 = job
+    rig_kw, im_kw, omni, thr, iters, seed0 = job[:6]
+    gp3p = bool(job[6]) if len(job) > 6 else False
     rp = RigParams(**rig_kw)
     im = ImageModel(**im_kw)
     out = np.zeros((omni.shape[0] // 2, 16))
     for i in range(omni.shape[0] // 2):
         ref = frame_from_image(rp, im, omni[2 * i])
         cur = frame_from_image(rp, im, omni[2 * i + 1])
-        w = track_pair(rp, ref, cur, thr, iters, seed=seed0 + i)
+        w = track_pair(rp, ref, cur, thr, iters, seed=seed0 + i, gp3p=gp3p)
         out[i, :12] = np.asarray(w["T"]).reshape(12)
         out[i, 12], out[i, 13] = w["ransac"]["n_inliers"], len(w["corr"]["cam"])
         out[i, 14], out[i, 15] = w["ransac"]["status"], w["ransac"]["best_iter"]

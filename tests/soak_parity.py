@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--pano-width", type=int, default=1440)
     ap.add_argument("--detector", default="GFT", choices=["GFT", "ORB", "FAST", "AGAST"])
     ap.add_argument("--kp-cap", type=int, default=512, help="keypoint capacity per (frame, mirror, mask)")
+    ap.add_argument("--solver", default="P3P", choices=["P3P", "GP3P"],
+                    help="hypothesis generator of the non-central RANSAC: one-mirror P3P (bench default) or the generalised P3P")
     ap.add_argument("--rgbd", choices=["EPNP", "KNEIP"], default=None,
                     help="soak the RGB-D path (BASELINE config 5: sosvo_rgbd_pair_batch) with this pose algorithm instead")
     args = ap.parse_args()
@@ -50,7 +52,8 @@ def main():
     import torch
     from vo_single_camera_sos_amd.pipeline import OverlappedFramePairs, RigConfig
     eng = OverlappedFramePairs(0, gs, (480, 640), RigConfig(**rig_kw), B, n_streams=2, num_of_features=1000, kp_cap=args.kp_cap,
-                               frame_cap=2048, max_iter=args.iters, adaptive=False, seed=args.seed, detection_method=args.detector)
+                               frame_cap=2048, max_iter=args.iters, adaptive=False, seed=args.seed, detection_method=args.detector,
+                               ransac_solver=args.solver)
     assert not any(int(p.fe.status.max().item()) for p in eng.parts) or args.detector != "GFT"
     eng.load_frames(omni)
     eng.step()
@@ -62,7 +65,8 @@ def main():
                  mask_bits=model.mask_bits_host, nmask=model.nmask, max_corners=1000, pattern=model.pattern_host, cos_a=ca,
                  sin_a=sa, kp_cap=args.kp_cap, method=args.detector)
     per = -(-B // args.workers)
-    jobs = [(rig_kw, im_kw, omni[2 * lo: 2 * min(B, lo + per)], eng.thr, args.iters, args.seed + lo) for lo in range(0, B, per)]
+    jobs = [(rig_kw, im_kw, omni[2 * lo: 2 * min(B, lo + per)], eng.thr, args.iters, args.seed + lo, args.solver == "GP3P")
+            for lo in range(0, B, per)]
     t0 = time.perf_counter()
     with multiprocessing.get_context("spawn").Pool(len(jobs)) as pool:
         outs = pool.map(refflow.pairs_records_worker, jobs)
@@ -76,7 +80,7 @@ def main():
         if not (exact and close):
             bad += 1
             print("pair %d differs: gpu %s\n               cpu %s" % (i, rec[i], want[i]))
-    print("detector %s:" % args.detector, end=" ")
+    print("detector %s, solver %s:" % (args.detector, args.solver), end=" ")
     print("soak: %d / %d pairs identical (counts, status, winning iteration exact; pose rel-tol 1e-6); %d / %d refined poses "
           "bit-identical; inliers %.0f mean" % (B - bad, B, exact_pose, B, rec[:, 12].mean()))
     eng.close()

@@ -1,6 +1,7 @@
 """GPU: tests/soak_parity.py at a small size -- the bench configuration itself (1440 x 146 panoramas, ~2000 keypoints
 per view, 2000 RANSAC iterations) through the GPU engine and through the oracle flow on host processes, every record
-compared (the tool exits non-zero on any difference); likewise the RGB-D path with the reference's default "EPNP"."""
+compared (the tool exits non-zero on any difference); likewise the RGB-D path with the reference's default "EPNP", the
+generalised-P3P hypothesis generator, and the ORB and FAST detectors."""
 import os
 import subprocess
 import sys
@@ -11,7 +12,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("extra", [[], ["--rgbd", "EPNP"]])
+@pytest.mark.parametrize("extra", [[], ["--rgbd", "EPNP"], ["--solver", "GP3P"], ["--detector", "ORB", "--kp-cap", "1280"],
+                                   ["--detector", "FAST", "--kp-cap", "2048"]])
 def test_soak_parity_small(extra):
     cmd = [sys.executable, os.path.join(ROOT, "tests", "soak_parity.py"), "--pairs", "16", "--workers", "4", "--seed", "12321"] + extra
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
