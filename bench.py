@@ -468,9 +468,10 @@ def main():
         cap_hit = any(int(p.fe.n.max().item()) >= p.fe.kp_cap for p in eng.parts)
         per_kernel = {}
         for name, ms in prof:
-            s = per_kernel.setdefault(name, [0, 0.0])
+            s = per_kernel.setdefault(name, [0, 0.0, float("inf")])
             s[0] += 1
             s[1] += ms
+            s[2] = min(s[2], ms)
         dom = max(per_kernel.items(), key=lambda kv: kv[1][1])
         dom_avg_s = dom[1][1] / dom[1][0] / 1e3
         dom_pairs = B / float(eng.S)  # one launch of the dominant kernel covers one stream's share of the batch
@@ -521,6 +522,10 @@ def main():
             "streams": eng.S,
             "kernels_ms_per_step": {k: v[1] / args.steps for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])},
             "kernel_ms_per_step_total": sum(v[1] for v in per_kernel.values()) / args.steps,
+            # the same sum with every launch at its kernel's SHORTEST duration in the timed region (~ the kernel with the
+            # chip to itself): what the step's kernels cost back to back; the difference to the line above is time launches
+            # spend sharing SIMDs / waiting for slots next to the other streams' kernels, not work
+            "kernel_ms_per_step_min_total": sum(v[2] * v[0] for v in per_kernel.values()) / args.steps,
         }
         if n_gpus == 1 and not args.no_cpu:
             import refflow
