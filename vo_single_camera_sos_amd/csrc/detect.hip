@@ -447,6 +447,15 @@ __global__ __launch_bounds__(NT) void gft_select_kernel(const uint4* __restrict_
   }
 }
 
+// a * b + c with 24-bit operands as ONE v_mad_u32_u24 (the compiler multiplies 32-bit values with v_mul_lo_u32 and adds
+// separately; __umul24 does not survive its constant folding either).  Integer arithmetic: the order of the additions
+// does not matter.
+__device__ __forceinline__ uint32_t mad24(uint32_t k, uint32_t x, uint32_t acc) {
+  uint32_t r;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(k), "v"(acc));
+  return r;
+}
+
 // ---- K6a: 7x7 Gaussian, 8.8 fixed point ------------------------------------------------------------------
 // Same rolling layout as min_eigen_kernel: a wave owns a 64-column strip (58 output columns) and walks down a
 // chunk of rows; the six horizontal neighbours come from neighbouring lanes (mirrored lanes at the image
@@ -490,12 +499,14 @@ __global__ __launch_bounds__(kThreads) void gauss7_kernel(const uint8_t* __restr
       l1 = lane_from_left(c); l2 = lane_from_left(l1); l3 = lane_from_left(l2);
       r1 = lane_from_right(c); r2 = lane_from_right(r1); r3 = lane_from_right(r2);
     }
-    h[P] = 18u * (uint32_t)(l3 + r3) + 34u * (uint32_t)(l2 + r2) + 49u * (uint32_t)(l1 + r1) + 54u * (uint32_t)c;
+    // (24-bit multiplies -- every operand is below 2^18, every sum below 2^24 -- so that each tap is ONE v_mad_u32_u24
+    // instead of a 32-bit multiply plus an add)
+    h[P] = mad24(18u, (uint32_t)(l3 + r3), mad24(34u, (uint32_t)(l2 + r2), mad24(49u, (uint32_t)(l1 + r1), 54u * (uint32_t)c)));
     const int y = t - 3;
     if (y < ys) return;  // uniform
     // rows y-3 .. y+3 = t-6 .. t live in slots P+1 .. P+7 (mod 7)
-    const uint32_t vsum = 18u * (h[(P + 1) % 7] + h[P]) + 34u * (h[(P + 2) % 7] + h[(P + 6) % 7]) +
-                          49u * (h[(P + 3) % 7] + h[(P + 5) % 7]) + 54u * h[(P + 4) % 7];
+    const uint32_t vsum = mad24(18u, h[(P + 1) % 7] + h[P], mad24(34u, h[(P + 2) % 7] + h[(P + 6) % 7],
+                                mad24(49u, h[(P + 3) % 7] + h[(P + 5) % 7], 54u * h[(P + 4) % 7])));
     if (out_lane) o[(uint32_t)(y * cols) + (uint32_t)xc] = (uint8_t)((vsum + 32768u) >> 16);
   };
   auto run = [&](auto edge_tag) __attribute__((always_inline)) {
