@@ -555,8 +555,8 @@ def main():
         out["traffic_step"] = traffic_step(B, eng.S, b_alg, args.pmc_csv)
         if n_gpus == 1 and not args.no_sub:
             # ---- sub-records of the same line (driver-timed): other detector / solver on the SAME frames, in this process
-            def sub_engine(**kw):
-                e2 = OverlappedFramePairs(local_rank, gs, (H, W), RigConfig(**rig_kw), B, n_streams=args.streams,
+            def sub_engine(gs_=None, rig_kw_=None, **kw):
+                e2 = OverlappedFramePairs(local_rank, gs_ or gs, (H, W), RigConfig(**(rig_kw_ or rig_kw)), B, n_streams=args.streams,
                                           num_of_features=args.features_per_mask, kp_cap=512, frame_cap=2048,
                                           max_iter=args.iters, adaptive=False, seed=args.seed, **kw)
                 e2.load_frames(omni)
@@ -584,6 +584,19 @@ def main():
                     out["orb_detector"] = sub_engine(detection_method="ORB", ransac_solver=args.ransac_solver)
                 if args.ransac_solver != "GP3P":
                     out["gp3p"] = sub_engine(detection_method=args.detector, ransac_solver="GP3P")
+                if args.pano_width != 1200:
+                    # the reference's default panorama width (demo_vo_sos.py: 1200 columns -> 1200 x 122 panoramas, fewer
+                    # keypoints per view than the 2000 BASELINE's metric names) on the same omni frames
+                    gs12 = synthetic_gums()
+                    for m in (gs12.top_model, gs12.bot_model):
+                        m.panorama = Panorama(m, width=1200)
+                    gs12.make_annulus_masks((H, W))
+                    p12 = gs12.top_model.panorama
+                    geo12 = (p12.cols, p12.rows, p12.pixel_size, p12.cyl_height_max)
+                    rig12 = dict(rig_kw, pano_top=geo12, pano_bot=geo12, f2f_max_hdiff=0.125 * 0.5 * p12.cols)
+                    out["pano_1200"] = sub_engine(gs_=gs12, rig_kw_=rig12, detection_method=args.detector,
+                                                  ransac_solver=args.ransac_solver)
+                    out["pano_1200"]["panorama"] = "%d x %d" % (p12.cols, p12.rows)
             except Exception as e:
                 out["sub_error"] = repr(e)
         if pcie is not None:
