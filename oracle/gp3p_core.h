@@ -109,13 +109,23 @@ static inline void orc_laguerre(const double* a, int m, orc_cplx* x) {
 /* All roots of the real polynomial c[0] + c[1] x + ... + c[m] x^m (m <= 10, c[m] != 0): Laguerre from 0 on the
  * deflated polynomial, which stays REAL -- a real root is divided out as (x - r), a complex one together with its
  * conjugate as the real quadratic x^2 - 2 Re(z) x + |z|^2 (one iteration run finds both: conjugate roots of a real
- * polynomial need not be searched twice).  Then the roots that can still turn out real (|Im| <= 1e-3 (1 + |Re|): every
+ * polynomial need not be searched twice); once four roots are left, the real ones among them come from the closed-form
+ * quartic solver.  Then the roots that can still turn out real (|Im| <= 1e-3 (1 + |Re|): every
  * caller discards the others) are polished on the undeflated polynomial. */
 static inline void orc_poly_roots(const double* c, int m, orc_cplx* roots) {
   double ad[11];
   for (int j = 0; j <= m; ++j) ad[j] = c[j];
   int deg = m, nr = 0;
   while (deg >= 1) {
+    if (deg == 4) { /* the last four in closed form -- every caller wants the REAL roots only (orc_quartic: Ferrari) */
+      const double q4[5] = {ad[4], ad[3], ad[2], ad[1], ad[0]};
+      double rr[4];
+      const int k4 = orc_quartic(q4, rr);
+      for (int k = 0; k < 4; ++k)
+        if (k < k4) roots[nr++] = orc_c(rr[k], 0.0);
+      while (nr < m) roots[nr++] = orc_c(0.0, 1.0); /* stand-ins for the complex ones: skipped by every caller */
+      break;
+    }
     orc_cplx x = orc_c(0.0, 0.0);
     orc_laguerre(ad, deg, &x);
     if (deg == 1 || fabs(x.im) <= (1e-14 * (1.0 + fabs(x.re)))) {
