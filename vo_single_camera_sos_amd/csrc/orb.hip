@@ -96,32 +96,38 @@ __global__ __launch_bounds__(kThreads) void resize_taps_kernel(Pyr P, uint32_t* 
   taps[P.toff[l] + i] = (uint32_t)t.i0 | ((uint32_t)t.w1 << 16);
 }
 
-// level l from level l - 1: a thread produces FOUR neighbouring output pixels of one row (grid: 1024 output columns x
-// output row x image; the row's y tap is scalar).  Their eight source columns span at most 7 bytes (scale 1.2), so each
-// of the two source rows is ONE unaligned 8-byte load (clamped to stay inside the row) and the result ONE dword store
-// -- against 16 byte loads and 4 byte stores; rows narrower than 8 pixels and a row's ragged tail go pixel by pixel.
+// level l from level l - 1: a thread produces FOUR neighbouring output pixels of one row (grid: output row x image, one
+// workgroup of up to 1024 threads per row, sized to the row: level 1 of a 1440-wide panorama is 300 quads = 5 waves, not
+// two workgroups of 256 threads with the second one 83 % idle; the row's y tap is scalar).  The quads are laid out from the
+// first DWORD-ALIGNED byte of the output row (level widths are rarely multiples of four, so most rows do not start on
+// one): every interior quad is ONE dword store; its eight source columns span at most 7 bytes (scale 1.2), so each of
+// the two source rows is ONE unaligned 8-byte load (clamped to stay inside the row) -- against 16 byte loads and 4 byte
+// stores; rows narrower than 8 pixels and the (up to three) pixels before / after the aligned quads go pixel by pixel.
 typedef unsigned long long __attribute__((aligned(1))) orb_u64_unaligned;
-__global__ __launch_bounds__(kThreads) void resize_level_kernel(const uint8_t* __restrict__ src, long long src_stride,
-                                                                int h0, int w0, uint8_t* __restrict__ dst,
-                                                                long long dst_stride, int h1, int w1,
-                                                                const uint32_t* __restrict__ taps) {
+__global__ __launch_bounds__(1024) void resize_level_kernel(const uint8_t* __restrict__ src, long long src_stride, int h0,
+                                                            int w0, uint8_t* __restrict__ dst, long long dst_stride, int h1,
+                                                            int w1, const uint32_t* __restrict__ taps) {
   SOSVO_STREAMING_PRIO();
-  const int dx4 = 4 * (blockIdx.x * kThreads + threadIdx.x), dy = blockIdx.y, img = blockIdx.z;
-  if (dx4 >= w1) return;
+  const int dy = blockIdx.y, img = blockIdx.z;
+  uint8_t* row_out = dst + (size_t)img * dst_stride + (size_t)dy * w1;
+  const int lead = (int)((4 - ((uintptr_t)row_out & 3)) & 3);  // pixels before the first aligned dword of this row (uniform)
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;         // quad 0 = the leading pixels, quad k >= 1 starts at lead + 4 (k - 1)
+  const int dx4 = q == 0 ? 0 : lead + 4 * (q - 1);
+  const int cnt = q == 0 ? lead : 4;                           // pixels of this thread
+  if (dx4 >= w1 || cnt == 0) return;
   const uint32_t ty = taps[w1 + dy];
   const int y0 = (int)(ty & 0xFFFFu), y1 = y0 + 1 < h0 ? y0 + 1 : h0 - 1;
   const uint32_t wy1 = ty >> 16, wy0 = 2048u - wy1;
   const uint8_t* s = src + (size_t)img * src_stride;
   const uint8_t* r0 = s + (size_t)y0 * w0;
   const uint8_t* r1 = s + (size_t)y1 * w0;
-  uint8_t* out = dst + (size_t)img * dst_stride + (size_t)dy * w1 + dx4;
+  uint8_t* out = row_out + dx4;
   // (wy0 * top + wy1 * bot + 2^21) >> 22 with top, bot <= 2048 * 255: 32-bit arithmetic is exact
   auto blend = [&](uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, uint32_t wx1) {
     const uint32_t wx0 = 2048u - wx1;
     return ((wy0 * (wx0 * a0 + wx1 * a1) + wy1 * (wx0 * b0 + wx1 * b1)) + (1u << 21)) >> 22;
   };
-  const bool dword_ok = ((uintptr_t)out & 3) == 0;
-  if (w0 >= 8 && dx4 + 3 < w1 && dword_ok) {
+  if (w0 >= 8 && q > 0 && dx4 + 3 < w1) {
     uint32_t t[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) t[k] = taps[dx4 + k];
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(kThreads) void resize_level_kernel(const uint8_t* _
     *reinterpret_cast<uint32_t*>(out) = res;
     return;
   }
-  for (int k = 0; k < 4 && dx4 + k < w1; ++k) {
+  for (int k = 0; k < cnt && dx4 + k < w1; ++k) {
     const uint32_t tx = taps[dx4 + k];
     const int x0 = (int)(tx & 0xFFFFu), x1 = x0 + 1 < w0 ? x0 + 1 : w0 - 1;
     out[k] = (uint8_t)blend(r0[x0], r0[x1], r1[x0], r1[x1], tx >> 16);
@@ -927,8 +933,10 @@ int32_t build_pyramid(sosvo_ctx* ctx, const uint8_t* gray, int nimg, int rows, i
   for (int l = 1; l < nlev_build; ++l) {
     const uint8_t* src = l == 1 ? gray : pyr + P.off[l - 1];
     const long long src_stride = l == 1 ? (long long)rows * cols : P.total;
-    SOSVO_LAUNCH(ctx, resize_level_kernel, dim3(cdiv(P.w[l], 4 * kThreads), P.h[l], nimg), dim3(kThreads), 0, ctx->stream, src,
-                 src_stride, P.h[l - 1], P.w[l - 1], pyr + P.off[l], P.total, P.h[l], P.w[l], taps + P.toff[l]);
+    const int quads = cdiv(P.w[l], 4) + 2;  // + the leading pixels' thread, + one quad the alignment may add at the end
+    const int nthr = quads < 1024 ? (quads + 63) & ~63 : 1024;
+    SOSVO_LAUNCH(ctx, resize_level_kernel, dim3(cdiv(quads, nthr), P.h[l], nimg), dim3(nthr), 0, ctx->stream, src, src_stride,
+                 P.h[l - 1], P.w[l - 1], pyr + P.off[l], P.total, P.h[l], P.w[l], taps + P.toff[l]);
     SOSVO_LAUNCH_CHECK(ctx);
   }
   return SOSVO_OK;
