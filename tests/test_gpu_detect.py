@@ -183,3 +183,30 @@ def test_detect_gft_reports_candidate_overflow(ctx):
     want, _ = oracle.gft_select(oracle.min_eigen(img[0]), bits[0], 0, 1e-4, 5.0, 0)
     m = min(2048, len(want))
     assert n2.cpu().numpy()[0] == m and np.array_equal(kp2.cpu().numpy()[0, :m], want[:m])
+
+
+def test_detect_gft_on_a_patch_where_every_pixel_is_a_maximum(ctx):
+    """An exactly periodic texture gives a plateau of EQUAL positive responses: every pixel of the patch equals its 3x3
+    dilation and is a candidate (four times the density distinct values allow).  A 40 x 60 patch (2400 candidates inside one
+    58-column strip) must still come out exactly as the oracle's goodFeaturesToTrack (the candidate records of a wave have
+    room for all of its pixels).  A frame covered by the texture has more candidates than the selection sorts (4096):
+    status bit 0, call still well-formed."""
+    tile = np.array([[255, 0, 0, 0], [255, 0, 0, 0], [255, 255, 0, 255]], dtype=np.uint8)
+    rows, cols = 120, 256
+    rng = np.random.default_rng(5)
+    img = np.full((2, rows, cols), 90, dtype=np.uint8)
+    img[0, 30:70, 66:126] = np.tile(tile, (14, 15))[:40, :60]
+    img[0, 80:110, 150:240] = rng.integers(0, 256, (30, 90), dtype=np.uint8)      # ordinary texture next to it
+    img[1] = np.tile(tile, (rows // 3 + 1, cols // 4 + 1))[:rows, :cols]
+    bits = np.ones((1, rows, cols), dtype=np.uint32)
+    e = oracle.min_eigen(img[0])
+    assert (e[35:65, 72:120] == e[40, 80]).all() and e[40, 80] > 0                # the plateau the test is about
+    t_img, t_bits = _to(ctx.device, img, bits)
+    kp, n, status = ctx.detect_gft(t_img, t_bits, 2, 1, 1024, quality=0.01, max_corners=0)
+    ctx.synchronize()
+    kp, n, status = kp.cpu().numpy(), n.cpu().numpy(), status.cpu().numpy()
+    want, _ = oracle.gft_select(e, bits[0], 0, 0.01, 5.0, 0)
+    assert status[0] == 0 and n[0] == len(want) and np.array_equal(kp[0, : n[0]], want)
+    assert status[1] & 1 and 0 < n[1] <= 1024
+    d = np.linalg.norm(kp[1, : n[1], None, :] - kp[1, None, : n[1], :], axis=-1) + 1e9 * np.eye(n[1])
+    assert d.min() >= 5.0

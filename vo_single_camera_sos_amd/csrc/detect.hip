@@ -8,7 +8,7 @@
 //   eig      min-eigenvalue response in float32 with a fixed operation order (identical to the oracle's), the
 //            per-mask maximum folded in through an order-preserving atomicMax; the response never goes to memory as a
 //            map: the kernel keeps three rows in registers, tests the 3x3 local maximum there and emits the positive
-//            local maxima as compact records (value, pixel, mask bits) into a region of its own per wave;
+//            local maxima as compact records (value, pixel) into a region of its own per wave;
 //   select   one workgroup per problem: the records of the waves that cover the mask's bounding box, thresholded ->
 //            sort keys (ordered(value) << 32 | pixel index) in LDS, rank sort (descending value,
 //            higher address first), then the greedy minimum-distance pass on an LDS cell grid by the first wave,
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kThreads) void min_eigen_kernel(const uint8_t* __re
                                                              const uint32_t* __restrict__ mask_bits, int nimg,
                                                              int images_per_maskset, int rows, int cols, int nmask,
                                                              int strips, int nchunks, int chunk_rows, int wcap,
-                                                             uint4* __restrict__ cand, uint32_t* __restrict__ wcnt,
+                                                             uint2* __restrict__ cand, uint32_t* __restrict__ wcnt,
                                                              uint32_t* __restrict__ mstat) {
   SOSVO_STREAMING_PRIO();
   const int lane = threadIdx.x & 63;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kThreads) void min_eigen_kernel(const uint8_t* __re
   const int e_lo = max(ys - 1, 0), e_hi = min(ye, rows - 1);  // e rows this chunk evaluates
   const int f_lo = max(ys, 1), f_hi = min(ye, rows - 1) - 1;   // flag rows this chunk owns
   const uint8_t* g = gray + (size_t)img * rows * cols;
-  uint4* region = cand + (size_t)wave * wcap;  // this wave's candidate records
+  uint2* region = cand + (size_t)wave * wcap;  // this wave's candidate records (response, pixel)
   int wpos = 0;                                // records emitted so far (wave-uniform)
   uint32_t mb_prev = 0u;                       // mask word of the row the flag stage looks at (the previous e row)
   const uint32_t* mb = mask_bits + (size_t)(img / images_per_maskset) * rows * cols;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(kThreads) void min_eigen_kernel(const uint8_t* __re
       const unsigned long long bal = __ballot(is_cand);
       if (bal) {  // uniform
         const int pos = wpos + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-        if (is_cand && pos < wcap) region[pos] = make_uint4(__float_as_uint(ev), (uint32_t)(f * cols + xc), mb_f, 0u);
+        if (is_cand && pos < wcap) region[pos] = make_uint2(__float_as_uint(ev), (uint32_t)(f * cols + xc));
         wpos += __popcll(bal);
       }
     }
@@ -261,9 +261,9 @@ __global__ __launch_bounds__(kThreads) void mask_bbox_kernel(const uint32_t* __r
 // (NT threads per workgroup: 256, or 1024 for the whole-image variant whose 128 KB of LDS allow one workgroup per CU anyway --
 // sixteen waves share the sort passes instead of four)
 template <int CAND, int NT>
-__global__ __launch_bounds__(NT) void gft_select_kernel(const uint4* __restrict__ cand,
+__global__ __launch_bounds__(NT) void gft_select_kernel(const uint2* __restrict__ cand,
                                                               const uint32_t* __restrict__ wcnt, int strips, int nchunks,
-                                                              int chunk_rows, int wcap,
+                                                              int chunk_rows, int wcap, const uint32_t* __restrict__ mask_bits,
                                                               const uint32_t* __restrict__ mstat, int images_per_maskset,
                                                               int nmask, int rows, int cols, double quality,
                                                               float min_distance, int cell, int max_corners, int cap,
@@ -302,6 +302,7 @@ __global__ __launch_bounds__(NT) void gft_select_kernel(const uint4* __restrict_
   const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
   if (any && bw > 0 && bh > 0) {
     const float thr = (float)((double)sosvo_ordered_float(st[0]) * quality);
+    const uint32_t* mb = mask_bits + (size_t)(img / images_per_maskset) * rows * cols;
     const int s0 = bx0 / kEigStripW, s1 = bx1 / kEigStripW;
     const int c0 = by0 / chunk_rows, c1 = by1 / chunk_rows;
     for (int c = c0; c <= c1; ++c)
@@ -309,11 +310,11 @@ __global__ __launch_bounds__(NT) void gft_select_kernel(const uint4* __restrict_
         const int w = (img * nchunks + c) * strips + sidx;  // the wave numbering of min_eigen_kernel
         const int have = (int)wcnt[w];
         if (have > wcap && tid == 0) s_overflow = 1;
-        const uint4* region = cand + (size_t)w * wcap;
+        const uint2* region = cand + (size_t)w * wcap;
         for (int i = tid; i < min(have, wcap); i += NT) {
-          const uint4 r = region[i];
+          const uint2 r = region[i];
           const float v = __uint_as_float(r.x);
-          if (!((r.z >> m) & 1u) || !(v > thr)) continue;
+          if (!(v > thr) || !((mb[r.y] >> m) & 1u)) continue;
           const int slot = atomicAdd(&s_count, 1);
           if (slot < CAND) keys[slot] = ((unsigned long long)sosvo_float_ordered(v) << 32) | r.y;
         }
@@ -705,11 +706,13 @@ int32_t sosvo_detect_gft(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* ma
   const int strips = cdiv(cols, kEigStripW);
   int nchunks, chunk_rows;
   rolling_chunks(nimg, rows, strips, &nchunks, &chunk_rows);
-  // candidate records: a region per wave of min_eigen_kernel, room for a quarter of its pixels (3x3 maxima of distinct
-  // values are at most that dense; plateaus of equal positive responses could exceed it: status bit 0)
-  const int wcap = (chunk_rows * kEigStripW / 4 + 63) & ~63;
+  // candidate records (8 bytes: response, pixel): a region per wave of min_eigen_kernel with room for EVERY pixel of its
+  // (strip, row chunk) -- 3x3 maxima of distinct values fill at most a quarter of it, but an exactly periodic texture
+  // gives a plateau of equal positive responses on which every pixel is a candidate, and goodFeaturesToTrack handles
+  // that; only what is written costs traffic
+  const int wcap = (chunk_rows * kEigStripW + 63) & ~63;
   const size_t n_waves = (size_t)nimg * strips * nchunks;
-  const size_t o_cand = carve(sizeof(uint4) * n_waves * wcap);
+  const size_t o_cand = carve(sizeof(uint2) * n_waves * wcap);
   const size_t o_wcnt = carve(sizeof(uint32_t) * n_waves);
   const size_t o_stat = carve(sizeof(uint32_t) * P * 5);
   const bool large = cap > 1024;  // whole-image masks (RGB-D frames): 16384 candidates, 15872 grid cells
@@ -719,7 +722,7 @@ int32_t sosvo_detect_gft(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* ma
   int32_t rc = sosvo_ws_reserve(ctx, off);
   if (rc != SOSVO_OK) return rc;
   char* ws = (char*)ctx->ws;
-  uint4* cand = (uint4*)(ws + o_cand);
+  uint2* cand = (uint2*)(ws + o_cand);
   uint32_t* wcnt = (uint32_t*)(ws + o_wcnt);
   uint32_t* mstat = (uint32_t*)(ws + o_stat);
   uint32_t* sorted_g = (uint32_t*)(ws + o_sorted);
@@ -738,15 +741,15 @@ int32_t sosvo_detect_gft(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* ma
   if (large) {
     SOSVO_PROFILE(ctx, "gft_select_kernel");
     hipLaunchKernelGGL((gft_select_kernel<kCandCapLarge, 1024>), dim3(xcd_grid(nimg, nmask)), dim3(1024), 0, ctx->stream, cand, wcnt,
-                       strips, nchunks, chunk_rows, wcap, mstat, images_per_maskset, nmask, rows, cols, quality, (float)min_distance, cell,
+                       strips, nchunks, chunk_rows, wcap, mask_bits, mstat, images_per_maskset, nmask, rows, cols, quality, (float)min_distance, cell,
                        max_corners, cap, sorted_g, sorted_stride, kp, n, status, nullptr, 0, nimg);
   } else {
     SOSVO_PROFILE(ctx, "gft_select_kernel");
     hipLaunchKernelGGL((gft_select_kernel<kCandCapSmall, kThreads>), dim3(xcd_grid(nimg, nmask)), dim3(kThreads), 0, ctx->stream, cand, wcnt,
-                       strips, nchunks, chunk_rows, wcap, mstat, images_per_maskset, nmask, rows, cols, quality, (float)min_distance, cell,
+                       strips, nchunks, chunk_rows, wcap, mask_bits, mstat, images_per_maskset, nmask, rows, cols, quality, (float)min_distance, cell,
                        max_corners, cap, sorted_g, sorted_stride, kp, n, status, redo, 0, nimg);
     hipLaunchKernelGGL((gft_select_kernel<kCandCap, kThreads>), dim3(xcd_grid(nimg, nmask)), dim3(kThreads), 0, ctx->stream, cand, wcnt,
-                       strips, nchunks, chunk_rows, wcap, mstat, images_per_maskset, nmask, rows, cols, quality, (float)min_distance, cell,
+                       strips, nchunks, chunk_rows, wcap, mask_bits, mstat, images_per_maskset, nmask, rows, cols, quality, (float)min_distance, cell,
                        max_corners, cap, sorted_g, sorted_stride, kp, n, status, redo, 1, nimg);
   }
   SOSVO_LAUNCH_CHECK(ctx);
