@@ -1,4 +1,4 @@
-"""Drop-in for the five `pyopengv` functions the reference's VO path calls, numpy in / numpy out, computed by
+"""Drop-in for the `pyopengv` functions the reference calls, numpy in / numpy out, computed by
 libsosvo on the GPU (no CPU fallback: importing works anywhere, calling needs the MI355X library).
 
     absolute_pose_noncentral_ransac              omnistereo/pose_est_tools.py:785
@@ -12,11 +12,12 @@ Conventions are OpenGV's as the reference uses them: T = [R | t] (3x4) is the po
 the frame the points are given in (points map by R^T (p - t), pose_est_tools.py:155-160, :177); `threshold`
 is 1 - cos(angle); inlier indices come back ascending (relied on at pose_est_tools.py:787-806).
 
-Differences from OpenGV, by design (DESIGN.md "RANSAC"):
-  * hypotheses come from Kneip's P3P on three correspondences of one camera plus a fourth point for
-    disambiguation -- for the non-central call (OpenGV: GP3P) and for the central names "KNEIP", "GAO", "GP3P";
-    the central "EPNP" draws 6-point samples and solves them with EPnP, as OpenGV does ("TWOPT" needs a known
-    rotation and is not built);
+Differences from OpenGV, by design (deviation table):
+  * minimal solvers are restatements of the published algorithms with own numerics: the non-central call draws 4
+    correspondences across all cameras and solves the generalised P3P (as OpenGV does), the central names map to
+    Kneip's P3P ("KNEIP"), the depth formulation through the generalised solver ("GAO", "GP3P"), EPnP on 6-point samples
+    ("EPNP"), the 2-point translation solver with the binding's identity rotation prior ("TWOPT"); the relative pose
+    offers the five-point ("STEWENIUS", "NISTER": Nister's algorithm), seven-point and eight-point solvers;
   * sampling is a counter-based generator: results are a pure function of (inputs, seed).  `set_seed` fixes the
     seed of the next call; every call advances it by one (OpenGV seeds from the clock)."""
 import numpy as np
