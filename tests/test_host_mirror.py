@@ -142,3 +142,17 @@ def test_matcher_and_pyopengv_mirror_fail_loudly_without_gpu():
         pyopengv.absolute_pose_ransac(np.eye(3).repeat(3, 0), np.ones((9, 3)), "KNEIP", 0.01, 10)
     with pytest.raises(SosvoError):
         pyopengv.triangulation_triangulate2(np.ones((2, 3)), np.ones((2, 3)), np.zeros(3), np.eye(3))
+
+
+def test_reference_module_paths_resolve_to_the_mirror():
+    """`omnistereo.*` (the reference's module paths, BASELINE north_star: "entry points intact") are the mirror's modules."""
+    import importlib
+    import omnistereo
+    from omnistereo.camera_models import FeatureMatcher
+    import omnistereo.pose_est_tools as pet
+    import vo_single_camera_sos_amd.omnistereo.pose_est_tools as mirror
+    assert pet is mirror and FeatureMatcher is importlib.import_module("vo_single_camera_sos_amd.omnistereo.camera_models").FeatureMatcher
+    for name in ("TrackerStereoSE3", "TrackerRGBDSE3", "StereoPanoramicFrame", "RGBDFrame", "run_VO", "driver_VO",
+                 "pose_relative_ransac_2D_to_2D", "pose_absolute_ransac_3D_to_2D"):
+        assert hasattr(pet, name), name
+    assert hasattr(omnistereo.panorama, "Panorama") and hasattr(omnistereo.gum, "GUM")
