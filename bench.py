@@ -90,7 +90,7 @@ def other_configs_subrecords(timeout_s=420):
     import subprocess
     out = {}
     try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_other_configs.py"), "--frames", "64", "--pairs", "128"],
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_other_configs.py"), "--frames", "192", "--pairs", "128"],
                            capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
         for line in r.stdout.splitlines():
             if not line.startswith("{"):
