@@ -89,3 +89,17 @@ def test_pyopengv_face_and_the_reference_wrapper(ctx):
     assert np.arccos(np.clip((np.trace(T5[:3, :3].T @ R) - 1) / 2, -1, 1)) < np.deg2rad(1.0)
     with pytest.raises(ValueError):
         pyopengv.relative_pose_ransac(f1, f2, "NOPE", THR, 10)
+
+
+@pytest.mark.parametrize("algorithm", [5, 7, 8])
+def test_degenerate_inputs_agree_with_the_oracle(ctx, algorithm):
+    """No motion at all (f2 = f1: the essential matrix is undefined), all bearings equal, points on a plane seen under a
+    pure rotation: whatever the solvers make of it, the device makes the same of it, bit for bit, and nothing hangs."""
+    rng = np.random.default_rng(40 + algorithm)
+    a, c, R, t, _ = _two_views(rng, 60)
+    same = (a.copy(), a.copy())
+    one = (np.tile(a[:1], (40, 1)), np.tile(a[:1], (40, 1)))
+    rot_only = (a.copy(), np.ascontiguousarray(a @ R))                 # X2 = R^T X1: zero baseline
+    got = _compare(ctx, [same, one, rot_only, (a, c)], 64, 120, seed=77, adaptive=False, algorithm=algorithm)
+    assert np.isfinite(got["T"]).all()
+    assert got["info"][3, 2] == 0 and got["n_inliers"][3] >= 50            # the proper problem next to them is solved
