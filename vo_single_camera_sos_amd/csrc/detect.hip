@@ -109,7 +109,27 @@ __global__ __launch_bounds__(kThreads) void min_eigen_kernel(const uint8_t* __re
   const int ll = clampi(refl101(xs - 1, cols) - xb, 0, 63);  // lane holding column x-1 (mirrored at the border)
   const int lr = clampi(refl101(xs + 1, cols) - xb, 0, 63);
   const bool out_lane = lane >= kEigHalo && lane < 64 - kEigHalo && xc < cols;  // xc >= 0 follows
-  const int ys = chunk * chunk_rows, ye = min(rows, ys + chunk_rows);
+  // Rows that hold a pixel of some mask of this image's mask set (mask_bbox_kernel, earlier on the stream): only they can
+  // own a candidate or feed a per-mask maximum, so the chunk shrinks to them -- their 3x3 neighbourhoods still get the
+  // response rows above and below (e_lo / e_hi), which need the gray rows two further out.  With the SOS panoramas the
+  // azimuthal masks leave out the elevation padding: about a quarter of the rows.  (wave-uniform, scalar loads)
+  uint32_t* mstat_img = mstat + (size_t)img * nmask * 5;
+  int r_lo = rows, r_hi = 0;
+  {
+    const uint32_t* sbb = mstat + (size_t)(img / images_per_maskset) * images_per_maskset * nmask * 5;  // first image of the set
+    for (int m = 0; m < nmask; ++m) {
+      const uint32_t y1 = sbb[m * 5 + 4];
+      if (y1) {
+        r_lo = min(r_lo, (int)(0xFFFFFFFFu - sbb[m * 5 + 2]));
+        r_hi = max(r_hi, (int)y1);
+      }
+    }
+  }
+  const int ys = max(chunk * chunk_rows, r_lo), ye = min(min(rows, chunk * chunk_rows + chunk_rows), r_hi);
+  if (ys >= ye) {  // no mask pixel in this chunk: nothing to emit, no maximum to update
+    if (lane == 0) wcnt[wave] = 0u;
+    return;
+  }
   const int e_lo = max(ys - 1, 0), e_hi = min(ye, rows - 1);  // e rows this chunk evaluates
   const int f_lo = max(ys, 1), f_hi = min(ye, rows - 1) - 1;   // flag rows this chunk owns
   const uint8_t* g = gray + (size_t)img * rows * cols;
@@ -118,7 +138,6 @@ __global__ __launch_bounds__(kThreads) void min_eigen_kernel(const uint8_t* __re
   uint32_t mb_prev = 0u;                       // mask word of the row the flag stage looks at (the previous e row)
   const uint32_t* mb = mask_bits + (size_t)(img / images_per_maskset) * rows * cols;
   const uint32_t mask_all = nmask < 32 ? (1u << nmask) - 1u : 0xFFFFFFFFu;
-  uint32_t* mstat_img = mstat + (size_t)img * nmask * 5;
   const float scale = (float)(1.0 / 3060.0);
 
   // Three-deep register rings indexed by (row mod 3): the row loop is unrolled three times by a fold so that the
