@@ -79,6 +79,20 @@ static inline unsigned xcd_grid(int nimg, int nmask) { return (unsigned)(8 * cdi
 // product outside the image is the product AT the reflected position.  In x both are "take the mirrored
 // lane".  In y a rolling reflect-101 of the gray rows evaluates the Sobel pair of the mirrored row with the
 // row order reversed, i.e. dx unchanged and dy negated -- the dx*dy product is negated back (exact).
+// Correctly rounded square root of a float that is ZERO OR NORMAL (the sum of two squares of image gradients products: zero
+// or above 1e-30, far from the denormal range and from infinity): v_sqrt_f32 is good to one ulp; the result is moved down /
+// up by one ulp where the residual says so -- exactly the correction the compiler emits for sqrtf, without its scaling of
+// denormal inputs and its class test (7 of its 16 instructions, a seventh of this kernel).  Bit-identical to the host's
+// sqrtf on these inputs; the parity tests compare every keypoint.
+__device__ __forceinline__ float sqrt_rn_normal(float x) {
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float s_dn = __int_as_float(__float_as_int(s) - 1), s_up = __int_as_float(__float_as_int(s) + 1);
+  const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
+  float r = (r_dn <= 0.0f) ? s_dn : s;
+  r = (r_up > 0.0f) ? s_up : r;
+  return r;
+}
+
 constexpr int kEigHalo = 3;
 constexpr int kEigStripW = 64 - 2 * kEigHalo;  // 58
 
@@ -186,7 +200,7 @@ __global__ __launch_bounds__(kThreads) void min_eigen_kernel(const uint8_t* __re
     {
       const float a = ((pxx[i0] + pxx[i1]) + pxx[i2]) * 0.5f, b = (pxy[i0] + pxy[i1]) + pxy[i2];
       const float c = ((pyy[i0] + pyy[i1]) + pyy[i2]) * 0.5f;
-      const float e = (a + c) - sqrtf(((a - c) * (a - c)) + (b * b));
+      const float e = (a + c) - sqrt_rn_normal(((a - c) * (a - c)) + (b * b));
       if (y_out) {
         const uint32_t bits = mb_pre & mask_all;
         if (bits != cur_bits) {
