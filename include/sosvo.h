@@ -172,6 +172,13 @@ int32_t sosvo_describe_orb(sosvo_ctx* ctx, const uint8_t* gray, int32_t nimg, in
                            int32_t nmask, int32_t cap, float* kp, int32_t* n, float cos_a, float sin_a,
                            const int8_t* pattern, int32_t edge, uint8_t* desc);
 
+/* The same with the blur restricted to the rows a descriptor can read: row_range = int32 [2][2] in DEVICE memory as written
+ * by sosvo_gray_rows_needed for the same masks / edge / pattern (view-major: first row, last row + 1; image i belongs to
+ * view i / (nimg / 2)); NULL = all rows (sosvo_describe_orb).  Descriptors are sosvo_describe_orb's bit for bit. */
+int32_t sosvo_describe_orb_rows(sosvo_ctx* ctx, const uint8_t* gray, int32_t nimg, int32_t rows, int32_t cols,
+                                int32_t nmask, int32_t cap, float* kp, int32_t* n, float cos_a, float sin_a,
+                                const int8_t* pattern, int32_t edge, const int32_t* row_range, uint8_t* desc);
+
 /* ---- K5: ORB keypoint detection per azimuthal mask (a4, feature_detection_method "ORB") ----------
  * Replaces cv2.ORB_create(nfeatures=N).detect(image, mask) (omnistereo/camera_models.py:1640, :1755;
  * pose_est_tools.py:478, :547) for all azimuthal masks of all images at once: 8 levels x 1.2, per-level

@@ -57,6 +57,8 @@ SIGNATURES = {
                                  c_p, c_p]),
     "sosvo_describe_orb": (c_i32, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_f32, c_f32, c_p, c_i32,
                                    c_p]),
+    "sosvo_describe_orb_rows": (c_i32, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_f32, c_f32, c_p, c_i32,
+                                        c_p, c_p]),
     "sosvo_orb_pyramid_pixels": (ctypes.c_int64, [c_i32, c_i32]),
     "sosvo_orb_mask_pyramid": (c_i32, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p]),
     "sosvo_detect_orb": (c_i32, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p]),

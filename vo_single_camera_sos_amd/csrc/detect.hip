@@ -496,7 +496,8 @@ __device__ __forceinline__ uint32_t mad24(uint32_t k, uint32_t x, uint32_t acc) 
 // border = reflect-101), the seven rows of horizontal sums live in a register ring.
 __global__ __launch_bounds__(kThreads) void gauss7_kernel(const uint8_t* __restrict__ gray, long long img_stride, int nimg,
                                                           int rows, int cols, int strips, int nchunks, int chunk_rows,
-                                                          uint8_t* __restrict__ out, long long out_stride) {
+                                                          uint8_t* __restrict__ out, long long out_stride,
+                                                          const int32_t* __restrict__ row_range, int imgs_per_range) {
   SOSVO_STREAMING_PRIO();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * kThreads + threadIdx.x) >> 6));  // in an SGPR: per-image bases become scalar
@@ -511,7 +512,13 @@ __global__ __launch_bounds__(kThreads) void gauss7_kernel(const uint8_t* __restr
 #pragma unroll
   for (int k = 0; k < 7; ++k) src[k] = clampi(refl101(xs + k - 3, cols) - xb, 0, 63);
   const bool out_lane = lane >= kEigHalo && lane < 64 - kEigHalo && xc < cols;
-  const int ys = chunk * chunk_rows, ye = min(rows, ys + chunk_rows);
+  int ys = chunk * chunk_rows, ye = min(rows, ys + chunk_rows);
+  if (row_range) {  // only the rows a reader of the blurred image can reach (see sosvo_describe_orb_rows); wave-uniform
+    const int v = img / imgs_per_range;
+    ys = max(ys, row_range[2 * v]);
+    ye = min(ye, row_range[2 * v + 1]);
+    if (ys >= ye) return;
+  }
   const uint8_t* g = gray + (size_t)img * img_stride;  // (img_stride = rows * cols for a dense batch; a pyramid level of
   uint8_t* o = out + (size_t)img * out_stride;        //  the ORB detector sits at a fixed offset of a larger per-image block)
   // seven-deep ring of horizontal sums indexed by (row mod 7): the row loop is unrolled seven times by a fold
@@ -700,15 +707,19 @@ static void rolling_chunks(int nimg, int rows, int strips, int* nchunks, int* ch
 }  // namespace
 
 // 7x7 sigma-2 blur (8.8 fixed point) of nimg images that lie img_stride bytes apart (shared with the ORB pyramid levels)
-int32_t sosvo_launch_gauss7_to(sosvo_ctx* ctx, const uint8_t* in, long long in_stride, int nimg, int rows, int cols,
-                               uint8_t* out, long long out_stride) {
+static int32_t launch_gauss7_rows(sosvo_ctx* ctx, const uint8_t* in, long long in_stride, int nimg, int rows, int cols,
+                                  uint8_t* out, long long out_stride, const int32_t* row_range, int imgs_per_range) {
   const int strips = cdiv(cols, kEigStripW);
   int nchunks, chunk_rows;
   rolling_chunks(nimg, rows, strips, &nchunks, &chunk_rows);
   SOSVO_LAUNCH(ctx, gauss7_kernel, dim3(cdiv(nimg * strips * nchunks, kThreads / 64)), dim3(kThreads), 0, ctx->stream, in,
-               in_stride, nimg, rows, cols, strips, nchunks, chunk_rows, out, out_stride);
+               in_stride, nimg, rows, cols, strips, nchunks, chunk_rows, out, out_stride, row_range, imgs_per_range);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
+}
+int32_t sosvo_launch_gauss7_to(sosvo_ctx* ctx, const uint8_t* in, long long in_stride, int nimg, int rows, int cols,
+                               uint8_t* out, long long out_stride) {
+  return launch_gauss7_rows(ctx, in, in_stride, nimg, rows, cols, out, out_stride, nullptr, 1);
 }
 int32_t sosvo_launch_gauss7(sosvo_ctx* ctx, const uint8_t* in, long long img_stride, int nimg, int rows, int cols,
                             uint8_t* out) {
@@ -792,7 +803,14 @@ int32_t sosvo_detect_gft(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* ma
 int32_t sosvo_describe_orb(sosvo_ctx* ctx, const uint8_t* gray, int32_t nimg, int32_t rows, int32_t cols,
                            int32_t nmask, int32_t cap, float* kp, int32_t* n, float cos_a, float sin_a,
                            const int8_t* pattern, int32_t edge, uint8_t* desc) {
+  return sosvo_describe_orb_rows(ctx, gray, nimg, rows, cols, nmask, cap, kp, n, cos_a, sin_a, pattern, edge, nullptr, desc);
+}
+
+int32_t sosvo_describe_orb_rows(sosvo_ctx* ctx, const uint8_t* gray, int32_t nimg, int32_t rows, int32_t cols,
+                                int32_t nmask, int32_t cap, float* kp, int32_t* n, float cos_a, float sin_a,
+                                const int8_t* pattern, int32_t edge, const int32_t* row_range, uint8_t* desc) {
   SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, row_range == nullptr || nimg % 2 == 0, "row_range needs the two views' images (nimg even, view-major)");
   SOSVO_REQUIRE(ctx, gray && kp && n && pattern && desc, "null pointer");
   SOSVO_REQUIRE(ctx, nimg >= 0 && nimg <= 65535 && nmask >= 1, "nimg / nmask out of range");
   SOSVO_REQUIRE(ctx, rows >= 1 && cols >= 1 && rows * (int64_t)cols < (1 << 28), "image sizes out of range");
@@ -804,7 +822,8 @@ int32_t sosvo_describe_orb(sosvo_ctx* ctx, const uint8_t* gray, int32_t nimg, in
   int32_t rc = sosvo_ws_reserve(ctx, bytes);
   if (rc != SOSVO_OK) return rc;
   uint8_t* blurred = (uint8_t*)ctx->ws;
-  rc = sosvo_launch_gauss7(ctx, gray, (long long)rows * cols, nimg, rows, cols, blurred);
+  rc = launch_gauss7_rows(ctx, gray, (long long)rows * cols, nimg, rows, cols, blurred, (long long)rows * cols, row_range,
+                          nimg > 1 ? nimg / 2 : 1);
   if (rc != SOSVO_OK) return rc;
   SOSVO_LAUNCH(ctx, orb_describe_kernel, dim3(xcd_grid(nimg, nmask)), dim3(kThreads), (size_t)cap * 2 * sizeof(float),
                ctx->stream, blurred, rows, cols, nmask, cap, kp, n, cos_a, sin_a, pattern, edge, desc, nimg);

@@ -209,7 +209,8 @@ static int32_t run_frame_pairs(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo
   SOSVO_LAUNCH_CHECK(ctx);
   // image front end: K1, K2 + K3, K4, K6 over all 2 * F panoramas
   if (median_wait) SOSVO_HIP(ctx, hipStreamWaitEvent(ctx->stream, median_wait, 0));
-  if (cfg->median_ksize == 3 || cfg->median_ksize == 5 || cfg->median_ksize == 11) {
+  const bool rows_known = cfg->median_ksize == 3 || cfg->median_ksize == 5 || cfg->median_ksize == 11;
+  if (rows_known) {
     // rows beyond the reach of GFT on the masks and of ORB.compute on its keypoints are not computed (the range is a
     // model constant; a 2-workgroup kernel per call keeps this entry point free of caller-side state)
     STAGE(sosvo_gray_rows_needed(ctx, mask_bits, 2, cfg->rows, cfg->cols, NM, cfg->edge, pattern, cfg->cos_a, cfg->sin_a,
@@ -223,8 +224,8 @@ static int32_t run_frame_pairs(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo
   if (median_done) SOSVO_HIP(ctx, hipEventRecord(median_done, ctx->stream));
   STAGE(sosvo_detect_gft(ctx, b.gray, mask_bits, NI, F, cfg->rows, cfg->cols, NM, cfg->quality, cfg->min_distance,
                          cfg->max_corners, cap, b.kp, b.n, b.status));
-  STAGE(sosvo_describe_orb(ctx, b.gray, NI, cfg->rows, cfg->cols, NM, cap, b.kp, b.n, cfg->cos_a, cfg->sin_a, pattern,
-                           cfg->edge, b.desc));
+  STAGE(sosvo_describe_orb_rows(ctx, b.gray, NI, cfg->rows, cfg->cols, NM, cap, b.kp, b.n, cfg->cos_a, cfg->sin_a, pattern,
+                                cfg->edge, rows_known ? b.gray_rows : nullptr, b.desc));
   // static stereo per frame: query = bottom view, train = top view, bucket by bucket
   const float *kp_top = b.kp, *kp_bot = b.kp + (size_t)h * cap * 2;
   const uint8_t *desc_top = b.desc, *desc_bot = b.desc + (size_t)h * cap * 32;

@@ -261,8 +261,9 @@ class Context(object):
                    _ptr(status))
         return kp, n, status
 
-    def describe_orb(self, gray, kp, n, nmask, pattern, cos_a, sin_a, edge=31, desc=None):
-        """Compacts kp/n in place (border rule) and returns desc [NI*nmask, cap, 32] u8."""
+    def describe_orb(self, gray, kp, n, nmask, pattern, cos_a, sin_a, edge=31, desc=None, row_range=None):
+        """Compacts kp/n in place (border rule) and returns desc [NI*nmask, cap, 32] u8.  row_range (int32 [2,2] on the
+        device, from gray_rows_needed): blur only the rows a descriptor can read."""
         _check(gray, torch.uint8, "gray", ndim=3)
         NI, rows, cols = gray.shape
         P = NI * nmask
@@ -273,8 +274,10 @@ class Context(object):
         if desc is None:
             desc = torch.zeros((P, cap, 32), dtype=torch.uint8, device=gray.device)
         _check(desc, torch.uint8, "desc", (P, cap, 32))
-        self._call(self._lib.sosvo_describe_orb, _ptr(gray), NI, rows, cols, int(nmask), cap, _ptr(kp), _ptr(n),
-                   float(cos_a), float(sin_a), _ptr(pattern), int(edge), _ptr(desc))
+        if row_range is not None:
+            _check(row_range, torch.int32, "row_range", (2, 2))
+        self._call(self._lib.sosvo_describe_orb_rows, _ptr(gray), NI, rows, cols, int(nmask), cap, _ptr(kp), _ptr(n),
+                   float(cos_a), float(sin_a), _ptr(pattern), int(edge), _ptr(row_range), _ptr(desc))
         return desc
 
     # ---- K5 / K6' ----------------------------------------------------------------------

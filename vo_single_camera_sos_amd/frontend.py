@@ -138,7 +138,7 @@ class ImageFrontEnd(object):
                      min_distance=self.min_distance, max_corners=self.num_of_features, kp=self.kp, n=self.n,
                      status=self.status)                                                          # K4
         c.describe_orb(self.gray, self.kp, self.n, m.nmask, m.pattern, self.cos_a, self.sin_a, edge=self.edge,
-                       desc=self.desc)                                                            # K6
+                       desc=self.desc, row_range=None if self.keep_panoramas else self.gray_rows)  # K6
 
     # views in the layout the matching stages expect: problem = frame * nmask + mask
     def view_arrays(self):
