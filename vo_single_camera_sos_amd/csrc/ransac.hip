@@ -179,8 +179,10 @@ __global__ __launch_bounds__(64) void ransac_hyp_twopt_kernel(const double* __re
 }
 
 // The generalised-P3P hypothesis generator (SOSVO_FLAG_GP3P): one lane per (problem, iteration): four distinct
-// correspondences out of all cameras, sv_hypothesis_gp3p (gp3p_core.h, the oracle's text).
-__global__ __launch_bounds__(64) void ransac_hyp_gp3p_kernel(const double* __restrict__ f, const double* __restrict__ p,
+// correspondences out of all cameras, sv_hypothesis_gp3p (gp3p_core.h, the oracle's text).  Latency-bound (SQ counters:
+// 32.5 k VALU instructions per wave at 7.2 SIMD-cycles each: chains of FP64 divisions and square roots), so the register
+// budget is capped for three waves per SIMD (measured 2 / 3 / 4 / 5 / 6 waves: 0.785 / 0.700 / 0.715 / 0.806 / 0.781 ms).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void ransac_hyp_gp3p_kernel(const double* __restrict__ f, const double* __restrict__ p,
                                                              const int32_t* __restrict__ cam,
                                                              const double* __restrict__ cam_off,
                                                              const double* __restrict__ cam_rot,
