@@ -75,6 +75,31 @@ def test_demo_vo_rgbd_end_to_end(ctx, tmp_path):
         assert tr.rpe_rotation_metric(E) < np.deg2rad(10.0) and tr.rpe_translation_metric(E) < 0.6, (i, E)
 
 
+def test_demo_vo_rgbd_accuracy_with_a_tight_ransac_threshold(ctx, tmp_path, monkeypatch):
+    """The same entry point with the trackers' RANSAC threshold at 0.5 degrees instead of the reference's 5
+    (pose_est_tools.py:675: at 5 degrees a narrow-field-of-view pose is only constrained to a few degrees, which is all
+    the test above can assert): now the estimated trajectory has to FOLLOW the planted one -- every frame within 0.5
+    degrees and 2.5 cm per elapsed frame of its ground-truth pose."""
+    import demo_vo_rgbd
+    from vo_single_camera_sos_amd.omnistereo import pose_est_tools
+    original = pose_est_tools.TrackerSE3.set_global_parameters_for_tracking
+
+    def tight(self):
+        original(self)
+        self.backprojection_score_threshold_3D_to_2D_in_degrees = 0.5
+        self.backprojection_score_threshold_3D_to_2D = 1.0 - np.cos(np.deg2rad(0.5))
+    monkeypatch.setattr(pose_est_tools.TrackerSE3, "set_global_parameters_for_tracking", tight)
+    n = 5
+    seq = str(tmp_path / "seq_rgbd_tight")
+    synthetic.write_rgbd_sequence(seq, n_frames=n, seed=33, max_t=40.0, max_deg=2.0, depth_is_Z=False)
+    out = demo_vo_rgbd.main_rgbd_vo([seq, "--is_synthetic", "true"])
+    assert out["tracked"] == n - 1
+    est, gt, kf = _check_files(os.path.join(seq, "results-rgbd"), n)
+    for i in range(1, n):
+        E = tr.rpe(gt[i], est[i])
+        assert tr.rpe_rotation_metric(E) < np.deg2rad(0.5) and tr.rpe_translation_metric(E) < 0.025 * i, (i, E)
+
+
 def test_live_vo_driver_on_a_replayed_camera(ctx, tmp_path):
     """driver_VO_live / run_VO_live (pose_est_tools.py:960-1262, :1743-1797) on a camera thread that replays a rendered
     sequence frame by frame (lock-step, so that the run is reproducible): result files, one pose per frame, the
