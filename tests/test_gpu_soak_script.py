@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("extra", [[], ["--rgbd", "EPNP"], ["--solver", "GP3P"], ["--detector", "ORB", "--kp-cap", "1280"],
+@pytest.mark.parametrize("extra", [[], ["--rgbd", "EPNP"], ["--rgbd", "KNEIP"], ["--solver", "GP3P"], ["--detector", "ORB", "--kp-cap", "1280"],
                                    ["--detector", "FAST", "--kp-cap", "2048"]])
 def test_soak_parity_small(extra):
     cmd = [sys.executable, os.path.join(ROOT, "tests", "soak_parity.py"), "--pairs", "16", "--workers", "4", "--seed", "12321"] + extra
