@@ -150,7 +150,9 @@ int32_t sosvo_gray_rows_needed(sosvo_ctx* ctx, const uint32_t* mask_bits, int32_
  * Problem p = image * nmask + mask.  Per problem: min-eigenvalue map (Sobel 3, block 3, reflect-101,
  * float32), maxVal over the mask, threshold quality * maxVal, 3x3 dilation NMS excluding the 1-px
  * image border, descending sort (ties: higher address first), greedy min-distance on a cell grid,
- * stop at max_corners (<= 0: no limit) or at the output capacity `cap`.
+ * stop at max_corners (<= 0: no limit) or at the output capacity `cap`.  quality > 0; quality >= 1 is accepted as by
+ * OpenCV and yields no corners (threshold >= maximum).  Only positive responses can become corners (with 0 < quality
+ * the threshold is positive wherever the mask's maximum is; a mask whose maximum is <= 0 has no corners).
  *   kp [nimg*nmask, cap, 2] f32 (x, y) in acceptance order, n [nimg*nmask] i32,
  *   status [nimg*nmask] i32 (optional): bit 0 = more candidates than the selection keeps (4096; 16384 when
  *   cap > 1024: the large-mask variant for whole-image detection, e.g. the RGB-D frames) -- the result then
@@ -174,7 +176,11 @@ int32_t sosvo_describe_orb(sosvo_ctx* ctx, const uint8_t* gray, int32_t nimg, in
 
 /* The same with the blur restricted to the rows a descriptor can read: row_range = int32 [2][2] in DEVICE memory as written
  * by sosvo_gray_rows_needed for the same masks / edge / pattern (view-major: first row, last row + 1; image i belongs to
- * view i / (nimg / 2)); NULL = all rows (sosvo_describe_orb).  Descriptors are sosvo_describe_orb's bit for bit. */
+ * view i / (nimg / 2)); NULL = all rows (sosvo_describe_orb).  Descriptors are sosvo_describe_orb's bit for bit.
+ * Precondition made safe: a keypoint whose patch rows y - R .. y + R (R = the rotated pattern's radius) leave the rows
+ * [first + 3, last + 1 - 3) of its view's range (inner ends only; an end at the image border does not count) would read
+ * rows that were never blurred -- it is REMOVED like a keypoint within `edge` of the border.  Keypoints inside the masks
+ * the range was derived from are never affected. */
 int32_t sosvo_describe_orb_rows(sosvo_ctx* ctx, const uint8_t* gray, int32_t nimg, int32_t rows, int32_t cols,
                                 int32_t nmask, int32_t cap, float* kp, int32_t* n, float cos_a, float sin_a,
                                 const int8_t* pattern, int32_t edge, const int32_t* row_range, uint8_t* desc);
@@ -557,7 +563,8 @@ typedef struct sosvo_rgbd_batch_cfg {
   int32_t ransac_max_iter;
   int32_t ransac_adaptive;
   int32_t lm_max_iter;
-  int32_t flags;           /* SOSVO_FLAG_EPNP: "EPNP" (6-point samples); 0: "KNEIP" (P3P + 4th point) */
+  int32_t flags;           /* SOSVO_FLAG_EPNP: "EPNP" (6-point samples); 0: "KNEIP" (P3P + 4th point); SOSVO_FLAG_GP3P: "GAO" / "GP3P";
+                              SOSVO_FLAG_TWOPT: "TWOPT" -- passed through to sosvo_ransac_abs_pose */
   double quality, min_distance;        /* 0.01, 5 */
   double ransac_threshold;             /* 1 - cos(5 deg) */
   double pct_good_matches;             /* 1.0 (pose_est_tools.py:225) */

@@ -218,12 +218,12 @@ def rgbd_frame(cam, bgr, depth, max_corners, pattern, cos_a, sin_a, median_ksize
     return dict(m=kp[valid], d=d[valid], X=xyz[valid], b=b[valid], n_kp=len(kp))
 
 
-def track_pair_rgbd(cam, ref, cur, thr, max_iter, seed, adaptive=False, lm_iter=30, epnp=True):
+def track_pair_rgbd(cam, ref, cur, thr, max_iter, seed, adaptive=False, lm_iter=30, epnp=True, gp3p=False, twopt=False):
     """TrackerRGBDSE3.track_frame (pose_est_tools.py:896-954) on the oracle: frame-to-frame matches, central
     RANSAC (:915), LM on the inliers (:937)."""
     t, q = f2f_view(cam, ref["m"], ref["d"], cur["m"], cur["d"])
     f, p = cur["b"][q], ref["X"][t]
-    r = oracle.ransac_abs_pose(f, p, thr, max_iter, seed=seed, adaptive=adaptive, epnp=epnp)
+    r = oracle.ransac_abs_pose(f, p, thr, max_iter, seed=seed, adaptive=adaptive, epnp=epnp, gp3p=gp3p, twopt=twopt)
     idx = np.nonzero(r["mask"])[0].astype(np.int32)
     T = r["T"]
     if r["status"] == 0:

@@ -36,3 +36,22 @@ def test_two_self_launched_ranks_equal_one_process(tmp_path):
     assert rec2.shape == rec1.shape == (12, 16)
     assert (rec1[:, 14] == 0).sum() >= 10, rec1[:, 12:16]   # the pairs are tracked, not merely equal
     assert np.array_equal(rec2, rec1), np.argwhere(rec2 != rec1)[:8]
+
+
+def _visible_gpus():
+    """Device count WITHOUT initialising the GPU in the pytest process (torch.cuda.device_count() does not, on this image)."""
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif(_visible_gpus() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_two_rccl_ranks_equal_one_process(tmp_path):
+    """The first time a box with two (or more) MI355X runs this suite, RCCL itself carries the N > 1 gather: two ranks on
+    two GPUs, backend nccl (= RCCL over xGMI), and the gathered records must equal one process over the same 16 pairs bit
+    for bit.  Skipped on the one-GPU boxes (there the same flow runs on gloo, above)."""
+    d2, rec2 = _bench(["--gpus", "2", "--dist-backend", "nccl", "--pairs-per-gpu", "8"], str(tmp_path / "two_rccl.npy"))
+    d1, rec1 = _bench(["--gpus", "1", "--pairs-per-gpu", "16"], str(tmp_path / "one16.npy"))
+    assert d2["n_gpus"] == 2 and d2["config"]["global_pairs_per_step"] == 16 and d2["scaling"] == "weak"
+    assert rec2.shape == rec1.shape == (16, 16)
+    assert (rec1[:, 14] == 0).sum() >= 13, rec1[:, 12:16]
+    assert np.array_equal(rec2, rec1), np.argwhere(rec2 != rec1)[:8]

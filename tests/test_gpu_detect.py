@@ -106,6 +106,47 @@ def test_describe_orb_matches_oracle(ctx, angle):
     assert kept_total > 100
 
 
+def test_describe_orb_rows_removes_keypoints_whose_patch_leaves_the_blurred_rows(ctx):
+    """sosvo_describe_orb_rows blurs only the rows of row_range; a keypoint whose patch reaches outside the trustworthy part
+    (e.g. a FAST / AGAST corner of another mask set) must not read stale scratch: it is REMOVED like a keypoint within
+    `edge` of the border, and every other keypoint's descriptor equals the all-rows call bit for bit.  The scratch is
+    poisoned with 0xFF first, so a read of a row that was not blurred in this call would show."""
+    rng = np.random.default_rng(404)
+    NI, nmask, cap, rows, cols = 2, 2, 96, 146, 300
+    imgs = np.stack([oracle.median_gray(_textured(rng, (rows, cols, 3)), 0) for _ in range(NI)])
+    pat = orb_pattern.orb_pattern()
+    ca, sa = orb_pattern.angle_cos_sin(orb_pattern.GFT_KEYPOINT_ANGLE)
+    R = int(max(np.abs(np.rint(pat[:, 0] * ca - pat[:, 1] * sa)).max(), np.abs(np.rint(pat[:, 0] * sa + pat[:, 1] * ca)).max()))
+    rr = np.array([[40, 120], [0, rows]], dtype=np.int32)          # view 0: an inner range; view 1: all rows
+    kp = np.zeros((NI * nmask, cap, 2), np.float32)
+    n = np.full(NI * nmask, cap, dtype=np.int32)
+    for p in range(NI * nmask):
+        kp[p, :, 0] = rng.integers(31, cols - 31, cap)
+        kp[p, :, 1] = rng.integers(31, rows - 31, cap)
+    kp[0, :6, 1] = [40 + 3 + R, 40 + 3 + R - 1, 120 - 3 - 1 - R, 120 - 3 - R, 35, 130]   # edge cases of view 0
+    t_img, t_pat, t_rr = _to(ctx.device, imgs, pat, rr)
+    t_kp_all, t_n_all = _to(ctx.device, kp.copy(), n.copy())
+    d_all = ctx.describe_orb(t_img, t_kp_all, t_n_all, nmask, t_pat, ca, sa)
+    ctx.synchronize()
+    d_all, kp_all, n_all = d_all.cpu().numpy(), t_kp_all.cpu().numpy(), t_n_all.cpu().numpy()
+    ctx.debug_fill_scratch(0xFF)
+    t_kp, t_n = _to(ctx.device, kp.copy(), n.copy())
+    d = ctx.describe_orb(t_img, t_kp, t_n, nmask, t_pat, ca, sa, row_range=t_rr)
+    ctx.synchronize()
+    d, kp_o, n_o = d.cpu().numpy(), t_kp.cpu().numpy(), t_n.cpu().numpy()
+    for p in range(NI * nmask):
+        view = p // nmask   # NI = 2: image i is view i
+        lo, hi = rr[view]
+        y = kp_all[p, : n_all[p], 1].astype(int)
+        ok = (y - R >= (0 if lo == 0 else lo + 3)) & (y + R < (rows if hi == rows else hi - 3))
+        assert n_o[p] == ok.sum(), (p, n_o[p], ok.sum())
+        assert np.array_equal(kp_o[p, : n_o[p]], kp_all[p, : n_all[p]][ok])
+        assert np.array_equal(d[p, : n_o[p]], d_all[p, : n_all[p]][ok])
+    assert n_o[0] < n_all[0] and (n_o[2:] == n_all[2:]).all()
+    ys = kp_o[0, : n_o[0], 1]
+    assert (40 + 3 + R) in ys and (120 - 3 - 1 - R) in ys and (40 + 3 + R - 1) not in ys and (120 - 3 - R) not in ys
+
+
 def test_fast_detector_raster_order_masks_and_cap(ctx):
     """sosvo_detect_fast against the oracle's FAST score map + numpy NMS / mask / raster order; overlapping masks, an
     empty mask, a cap smaller than the corner count (first `cap` in raster order, status 1)."""
@@ -210,3 +251,21 @@ def test_detect_gft_on_a_patch_where_every_pixel_is_a_maximum(ctx):
     assert status[1] & 1 and 0 < n[1] <= 1024
     d = np.linalg.norm(kp[1, : n[1], None, :] - kp[1, None, : n[1], :], axis=-1) + 1e9 * np.eye(n[1])
     assert d.min() >= 5.0
+
+
+def test_detect_gft_accepts_quality_levels_of_one_and_more(ctx):
+    """cv2.goodFeaturesToTrack takes any positive qualityLevel; at >= 1 the threshold reaches the maximum and no corner is
+    left (oracle: same).  The C ABI must not refuse the call (the reference passes the parameter through)."""
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (1, 96, 160), dtype=np.uint8)
+    bits = np.ones((1, 96, 160), dtype=np.uint32)
+    t_img, t_bits = _to(ctx.device, img, bits)
+    for q in (1.0, 1.5):
+        kp, n, status = ctx.detect_gft(t_img, t_bits, 1, 1, 256, quality=q, max_corners=0)
+        ctx.synchronize()
+        want, _ = oracle.gft_select(oracle.min_eigen(img[0]), bits[0], 0, q, 5.0, 0)
+        assert len(want) == 0 and n.cpu().numpy()[0] == 0 and status.cpu().numpy()[0] == 0
+    kp, n, status = ctx.detect_gft(t_img, t_bits, 1, 1, 256, quality=0.999, max_corners=0)
+    ctx.synchronize()
+    want, _ = oracle.gft_select(oracle.min_eigen(img[0]), bits[0], 0, 0.999, 5.0, 0)
+    assert n.cpu().numpy()[0] == len(want) == 1 and np.array_equal(kp.cpu().numpy()[0, :1], want)

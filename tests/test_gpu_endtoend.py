@@ -115,3 +115,36 @@ def test_full_hot_path_from_images(ctx, method, nfeat):
         R, t = poses[i]
         ang, _ = synth.pose_error(rec[i, :12].reshape(3, 4), R, t)
         assert ang < np.deg2rad(2.0)
+
+
+@pytest.mark.parametrize("solver", ["P3P", "GP3P"])
+def test_full_hot_path_accuracy_with_a_tight_ransac_threshold(ctx, solver):
+    """Outside evidence for the absolute-pose solvers (their arithmetic is unpinned by the reference): the same hot path
+    with the RANSAC threshold at 0.5 degrees instead of the reference's 5 (pose_est_tools.py:675-676 -- at 5 degrees the
+    LM set keeps correspondences with degrees of back-projection error and the pose is only good to ~0.7 degrees / 4 cm,
+    profiles/round3/accuracy_sos.json) must RECOVER the planted motion: every pair within 0.3 degrees and 1 cm, for the
+    one-mirror P3P and for the generalised P3P hypotheses.  A wrong-but-self-consistent solver cannot pass this."""
+    B = 6
+    gs = synthetic_gums()
+    for m in (gs.top_model, gs.bot_model):
+        m.panorama = Panorama(m, width=1200)
+    gs.make_annulus_masks((480, 640))
+    omni, poses = synthetic.make_frame_pairs(gs, B, seed=4100)
+    model = DeviceImageModel(ctx, gs, (480, 640))
+    fe = ImageFrontEnd(ctx, model, 2 * B, detection_method="GFT", num_of_features=1000, kp_cap=512)
+    pano = gs.top_model.panorama
+    geo = (pano.cols, pano.rows, pano.pixel_size, pano.cyl_height_max)
+    rig_kw = dict(pano_top=geo, pano_bot=geo, F_top=gs.top_model.F[:3, 0], F_bot=gs.bot_model.F[:3, 0], min_range=500.0,
+                  max_range=7000.0, stereo_min_disp=1.0, stereo_max_hdiff=2.5, f2f_max_hdiff=0.125 * 0.5 * pano.cols,
+                  pct_good_matches=1.0)
+    pipe = FramePairPipeline(ctx, RigConfig(**rig_kw), B, frame_cap=2048, max_iter=2000, seed=11, front_end=fe,
+                             thr=1.0 - np.cos(np.deg2rad(0.5)), ransac_solver=solver)
+    fe.load_frames(omni)
+    pipe.step()
+    rec = pipe.results().cpu().numpy()
+    assert (rec[:, 14] == 0).all() and (rec[:, 12] >= 150).all(), rec[:, 12:15]
+    for i, (R, t) in enumerate(poses):
+        T = rec[i, :12].reshape(3, 4)
+        ang, _ = synth.pose_error(T, R, t)
+        assert np.degrees(ang) < 0.3, (i, np.degrees(ang))
+        assert np.linalg.norm(T[:, 3] - t) < 10.0, (i, np.linalg.norm(T[:, 3] - t))   # model units: mm

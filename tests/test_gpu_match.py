@@ -154,6 +154,8 @@ def test_l2_float_descriptors_match_the_oracle_bit_for_bit(ctx):
         for p in range(4):
             want = oracle.match_l2(q[p, :nq[p]], t[p, :nt[p]], k=k)
             assert np.array_equal(got[p, :nq[p]], want), (dim, k, p)
+            # rows past the query count read "absent" (all ones), whatever the buffer held before the call
+            assert (got[p, nq[p]:] == np.uint64(2 ** 64 - 1)).all(), (dim, k, p)
 
 
 def test_feature_matcher_mirror_on_float_descriptors_and_flann(ctx):

@@ -60,6 +60,42 @@ def test_demo_vo_sos_end_to_end(ctx, tmp_path):
     assert any(f.startswith("estimated_frame_poses_TUM-") for f in os.listdir(os.path.join(seq, "results-omni")))
 
 
+@pytest.mark.parametrize("solver", ["GP3P", "P3P"])
+def test_demo_vo_sos_accuracy_with_a_tight_ransac_threshold(ctx, tmp_path, monkeypatch, solver):
+    """demo_vo_sos.main_sos_vo with the tracker's RANSAC threshold at 0.5 degrees instead of the reference's 5
+    (pose_est_tools.py:675-676): the estimated trajectory has to FOLLOW the planted one -- every frame within 0.3 degrees
+    and 1 cm per elapsed frame of its ground-truth pose -- with the reference's generalised-P3P hypotheses ("GP3P", the
+    tracker's default, :696) and with the one-mirror P3P (BASELINE config 2).  With the solvers' arithmetic unpinned by
+    the reference, this is the outside evidence that they solve the right problem on the SOS path."""
+    import demo_vo_sos
+    from vo_single_camera_sos_amd.omnistereo import pose_est_tools
+    original = pose_est_tools.TrackerSE3.set_global_parameters_for_tracking
+
+    def tight(self):
+        original(self)
+        self.backprojection_score_threshold_3D_to_2D_in_degrees = 0.5
+        self.backprojection_score_threshold_3D_to_2D = 1.0 - np.cos(np.deg2rad(0.5))
+    monkeypatch.setattr(pose_est_tools.TrackerSE3, "set_global_parameters_for_tracking", tight)
+    if solver == "P3P":   # the library's one-mirror generator behind the same pyopengv entry point
+        from vo_single_camera_sos_amd import pyopengv
+        monkeypatch.setattr(pyopengv, "absolute_pose_noncentral_ransac",
+                            lambda b, cam_idx, p, offs, rots, thr, it: pyopengv._ransac(b, p, thr, it, cam_idx, offs, rots, gp3p=False))
+    gs = synthetic_gums()
+    for m in (gs.top_model, gs.bot_model):
+        m.panorama = Panorama(m, width=1200)
+    gs.make_annulus_masks((480, 640))
+    n = 6
+    seq = str(tmp_path / "seq_sos_tight")
+    synthetic.write_sos_sequence(seq, gs, n_frames=n, seed=21, max_t=40.0, max_deg=2.0)
+    out = demo_vo_sos.main_sos_vo([seq, "--calibrated_gums_file", os.path.join(seq, "gums-calibrated.json")])
+    assert out["tracked"] == n - 1
+    est, gt, kf = _check_files(os.path.join(seq, "results-omni"), n)
+    for i in range(1, n):
+        E = tr.rpe(gt[i], est[i])
+        assert tr.rpe_rotation_metric(E) < np.deg2rad(0.3), (i, np.degrees(tr.rpe_rotation_metric(E)))
+        assert tr.rpe_translation_metric(E) < 0.01 * i, (i, tr.rpe_translation_metric(E))
+
+
 def test_demo_vo_rgbd_end_to_end(ctx, tmp_path):
     import demo_vo_rgbd
     n = 5
@@ -128,3 +164,31 @@ def test_live_vo_driver_on_a_replayed_camera(ctx, tmp_path):
         T_gt[:3, :3], T_gt[:3, 3] = R, t * 1e-3
         E = tr.rpe(T_gt, out["poses"][i][1])
         assert tr.rpe_rotation_metric(E) < np.deg2rad(3.0) and tr.rpe_translation_metric(E) < 0.05 * (i + 1), (i, E)
+
+
+def test_demo_vo_sos_live_entry_point(ctx, tmp_path):
+    """demo_vo_sos_live.main_sos_vo_live (the reference's live entry point, demo_vo_sos_live.py:63-109) over replayed
+    frames: same result files as the live driver test above, poses identical to the offline demo on the same frames."""
+    import demo_vo_sos
+    import demo_vo_sos_live
+    gs = synthetic_gums()
+    for m in (gs.top_model, gs.bot_model):
+        m.panorama = Panorama(m, width=1200)
+    gs.make_annulus_masks((480, 640))
+    n = 4
+    seq = str(tmp_path / "seq_live_demo")
+    synthetic.write_sos_sequence(seq, gs, n_frames=n, seed=29, max_t=40.0, max_deg=2.0)
+    gums = os.path.join(seq, "gums-calibrated.json")
+    live_dir = str(tmp_path / "live_out")
+    from vo_single_camera_sos_amd import pyopengv
+    pyopengv.set_seed(0)                    # (the sampler's seed advances with every call: same seeds for both runs)
+    out = demo_vo_sos_live.main_sos_vo_live([live_dir, "--calibrated_gums_file", gums, "--frames", os.path.join(seq, "omni", "image-*.png")])
+    assert out["tracked"] == n - 1 and [p[0] for p in out["poses"]] == list(range(n))
+    for name in ("estimated_frame_poses_TUM.txt", "keyframe_ids.txt", "printed_messages.log"):
+        assert os.path.exists(os.path.join(live_dir, "results-omni", name)), name
+    pyopengv.set_seed(0)
+    off = demo_vo_sos.main_sos_vo([seq, "--calibrated_gums_file", gums])
+    for (i, T_live), (j, T_off) in zip(out["poses"], off["poses"]):
+        assert i == j and np.allclose(T_live, T_off, rtol=1e-9, atol=1e-12), (i, T_live, T_off)
+    with pytest.raises(SystemExit):          # no frame source at all: a usage error, not a silent no-op
+        demo_vo_sos_live.main_sos_vo_live([live_dir, "--calibrated_gums_file", gums])

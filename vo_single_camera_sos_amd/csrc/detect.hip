@@ -571,7 +571,8 @@ __global__ __launch_bounds__(kThreads) void orb_describe_kernel(const uint8_t* _
                                                                 int nmask, int cap, float* __restrict__ kp,
                                                                 int32_t* __restrict__ n_io, float cos_a, float sin_a,
                                                                 const int8_t* __restrict__ pattern, int edge,
-                                                                uint8_t* __restrict__ desc, int nimg_total) {
+                                                                uint8_t* __restrict__ desc, int nimg_total,
+                                                                const int32_t* __restrict__ row_range, int imgs_per_range) {
   SOSVO_LATENCY_BOUND_PRIO();
   extern __shared__ float lds_kp[];  // [cap][2] compacted keypoints
   __shared__ int off[512];
@@ -605,6 +606,16 @@ __global__ __launch_bounds__(kThreads) void orb_describe_kernel(const uint8_t* _
   // (<= 3 bytes) stays inside the image as long as the border rule keeps R + 1 px.
   const bool patch_ok = R <= kPatchMaxR && edge >= R + 1;
   const int PR = 2 * R + 1;
+  // With a row range only the blurred rows [rr_lo, rr_hi) exist, and those within 3 rows of an inner end were blurred
+  // from gray rows outside the range: a keypoint whose patch rows leave the trustworthy part is REMOVED, like one too
+  // close to the image border (callers that derive the range from the keypoints' masks never lose one this way).
+  int y_first = 0, y_last = rows - 1;
+  if (row_range) {
+    const int v = img / imgs_per_range;
+    const int rr_lo = row_range[2 * v], rr_hi = row_range[2 * v + 1];
+    y_first = (rr_lo <= 0 ? 0 : rr_lo + 3) + R;
+    y_last = (rr_hi >= rows ? rows : rr_hi - 3) - 1 - R;
+  }
   const int pdw = (PR + 3) >> 2;      // dwords per patch row
   const int pstride = pdw | 1;        // row pitch in dwords
   if (patch_ok)
@@ -621,6 +632,8 @@ __global__ __launch_bounds__(kThreads) void orb_describe_kernel(const uint8_t* _
       x = kp[((size_t)p * cap + i) * 2];
       y = kp[((size_t)p * cap + i) * 2 + 1];
       keep = x >= (float)edge && x < (float)(cols - edge) && y >= (float)edge && y < (float)(rows - edge);
+      const int yi = __float2int_rn(y);
+      keep = keep && yi >= y_first && yi <= y_last;
     }
     const int pos = sosvo_block_compact_pos(keep, wave_off, &s_running, tid);
     if (keep) {
@@ -737,8 +750,9 @@ int32_t sosvo_detect_gft(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* ma
   SOSVO_REQUIRE(ctx, nimg >= 0 && nimg <= 65535 && images_per_maskset > 0, "nimg out of range");
   SOSVO_REQUIRE(ctx, rows >= 3 && cols >= 3 && rows * (int64_t)cols < (1 << 28), "image sizes out of range");
   SOSVO_REQUIRE(ctx, nmask >= 1 && nmask <= kMaxMasks, "nmask out of range (1..32)");
-  SOSVO_REQUIRE(ctx, cap > 0 && cap <= 4096 && quality > 0 && quality < 1 && min_distance >= 0,
-                "bad detector parameters (0 < quality < 1)");
+  // quality >= 1 is legal as in cv2.goodFeaturesToTrack: the threshold quality * max is then >= every response (the
+  // candidate records hold the POSITIVE local maxima only), so no corner passes `v > thr` and every count comes back 0
+  SOSVO_REQUIRE(ctx, cap > 0 && cap <= 4096 && quality > 0 && min_distance >= 0, "bad detector parameters (quality > 0)");
   if (nimg == 0) return SOSVO_OK;
   const size_t P = (size_t)nimg * nmask;
   size_t off = 0;
@@ -826,7 +840,8 @@ int32_t sosvo_describe_orb_rows(sosvo_ctx* ctx, const uint8_t* gray, int32_t nim
                           nimg > 1 ? nimg / 2 : 1);
   if (rc != SOSVO_OK) return rc;
   SOSVO_LAUNCH(ctx, orb_describe_kernel, dim3(xcd_grid(nimg, nmask)), dim3(kThreads), (size_t)cap * 2 * sizeof(float),
-               ctx->stream, blurred, rows, cols, nmask, cap, kp, n, cos_a, sin_a, pattern, edge, desc, nimg);
+               ctx->stream, blurred, rows, cols, nmask, cap, kp, n, cos_a, sin_a, pattern, edge, desc, nimg, row_range,
+               nimg > 1 ? nimg / 2 : 1);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
 }

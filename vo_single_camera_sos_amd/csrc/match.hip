@@ -128,7 +128,11 @@ __global__ __launch_bounds__(64) void match_l2_kernel(const float* __restrict__ 
   const int lane = threadIdx.x, p = blockIdx.x;
   const int nqp = min(nq[p], q_stride), ntp = min(nt[p], t_stride);
   const int q0 = blockIdx.y * 64;
-  if (q0 >= nqp) return;  // uniform
+  if (q0 >= nqp) {  // uniform: padding rows only -- "absent" is all ones, as include/sosvo.h says
+    if (q0 + lane < q_stride)
+      for (int j = 0; j < K; ++j) keys[((size_t)p * q_stride + q0 + lane) * K + j] = ~0ULL;
+    return;
+  }
   const int dimp = (dim + 3) & ~3;  // row pitch in the tile
   const float* qsrc = q + ((size_t)p * q_stride + q0) * dim;
   const int rows = min(64, nqp - q0);
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(64) void match_l2_kernel(const float* __restrict__ 
       best = min(best, key);
     }
   }
-  if (lane < rows) {
+  if (lane < rows || q0 + lane < q_stride) {  // (rows past the query count keep best = second = all ones)
     unsigned long long* out = keys + ((size_t)p * q_stride + q0 + lane) * K;
     out[0] = best;
     if (K == 2) out[1] = second;

@@ -381,7 +381,7 @@ int32_t sosvo_rgbd_pair_batch(sosvo_ctx* ctx, const sosvo_rgbd_cam* cam, const s
   STAGE(sosvo_sort_matches(ctx, b.keys, b.M, b.cur_frame, B, Fc, b.order));
   STAGE(sosvo_f2f_assemble_central(ctx, cfg->pct_good_matches, cfg->f2f_max_hdiff, b.m, b.X, b.b, b.M, Fc, b.ref_frame,
                                    b.cur_frame, b.keys, b.order, B, Fc, b.f, b.p, b.cq, b.ct, b.cn));
-  STAGE(sosvo_ransac_abs_pose(ctx, b.f, b.p, nullptr, nullptr, nullptr, 1, cfg->flags & SOSVO_FLAG_EPNP, b.cn, B, Fc,
+  STAGE(sosvo_ransac_abs_pose(ctx, b.f, b.p, nullptr, nullptr, nullptr, 1, cfg->flags & (SOSVO_FLAG_EPNP | SOSVO_FLAG_GP3P | SOSVO_FLAG_TWOPT), b.cn, B, Fc,
                               cfg->ransac_threshold, cfg->ransac_max_iter, cfg->ransac_adaptive, cfg->seed, b.T_ransac,
                               b.mask, b.idx, b.n_inl, b.info, nullptr));
   SOSVO_HIP(ctx, hipMemcpyAsync(b.T, b.T_ransac, sizeof(double) * 12 * B, hipMemcpyDeviceToDevice, ctx->stream));

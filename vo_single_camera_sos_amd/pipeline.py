@@ -355,6 +355,18 @@ class FramePairBatch(object):
         return self.out
 
 
+def rgbd_solver_flags(pose_est_algorithm):
+    """TrackerSE3.pose_est_algorithm (pose_est_tools.py:697; the names pyopengv.absolute_pose_ransac accepts, :89-107)
+    -> the SOSVO_FLAG_* bits of the central RANSAC.  Unknown names raise, so that a batched engine can never silently run
+    a different solver from the mirror tracker."""
+    from . import _lib
+    name = str(pose_est_algorithm).upper()
+    table = {"EPNP": _lib.FLAG_EPNP, "KNEIP": 0, "GAO": _lib.FLAG_GP3P, "GP3P": _lib.FLAG_GP3P, "TWOPT": _lib.FLAG_TWOPT}
+    if name not in table:
+        raise ValueError("unknown pose_est_algorithm %r (have: %s)" % (pose_est_algorithm, ", ".join(sorted(table))))
+    return table[name]
+
+
 class RGBDCamConfig(object):
     """What the RGB-D hot path needs to know about the camera (host numbers): RGBDCamModel
     (omnistereo/camera_models.py:756-779), the RGBDFrame ranges (pose_est_tools.py:428-430, depth units) and
@@ -437,9 +449,12 @@ class RGBDPairPipeline(object):
                  median_win_size=0, quality=0.01, min_distance=5.0, edge=31, thr=None, max_iter=2000, adaptive=False,
                  seed=0, lm_iter=30, mask=None, pose_est_algorithm="EPNP"):
         """pose_est_algorithm: TrackerSE3.pose_est_algorithm (pose_est_tools.py:697): "EPNP" = 6-point samples solved by
-        EPnP; "KNEIP" = P3P on 3 points + a 4th for disambiguation."""
+        EPnP; "KNEIP" = P3P on 3 points + a 4th for disambiguation; "GAO" / "GP3P" = the depth formulation through the
+        generalised solver; "TWOPT" = translation from 2 points.  Anything else raises ValueError."""
+        from . import _lib
         self.ctx, self.cam_cfg = ctx, cam
-        self.epnp = str(pose_est_algorithm).upper() == "EPNP"
+        self.solver_flags = rgbd_solver_flags(pose_est_algorithm)
+        self.epnp = bool(self.solver_flags & _lib.FLAG_EPNP)
         self.B, self.F = int(n_pairs), 2 * int(n_pairs)
         fe = RGBDFrontEnd(ctx, cam, self.F, image_shape, num_of_features, kp_cap, frame_cap, median_win_size, quality,
                           min_distance, edge, mask)
@@ -473,8 +488,10 @@ class RGBDPairPipeline(object):
         c.f2f_assemble_central(fr, self.ref_frame, self.cur_frame, self.keys, self.order, self.frame_cap,
                                pct_good_matches=cfg.pct_good_matches, max_hdiff=cfg.f2f_max_hdiff, out=self.corr)
         co = self.corr
+        from . import _lib
         c.ransac_abs_pose(co["f"], co["p"], co["n"], self.thr, self.max_iter, seed=self.seed, adaptive=self.adaptive,
-                          out=self.ransac, epnp=self.epnp)                                          # :915 (central)
+                          out=self.ransac, epnp=self.epnp, gp3p=bool(self.solver_flags & _lib.FLAG_GP3P),
+                          twopt=bool(self.solver_flags & _lib.FLAG_TWOPT))                          # :915 (central)
         self.T.copy_(self.ransac["T"])
         c.refine_abs_pose(co["f"], co["p"], co["n"], self.T, idx=self.ransac["idx"], m=self.ransac["n_inliers"],
                           max_lm_iter=self.lm_iter, cost=self.lm_cost, iters=self.lm_iters)          # :937
@@ -512,7 +529,7 @@ class RGBDPairBatch(object):
         c.n_pairs, c.rows, c.cols, c.kp_cap, c.frame_cap = self.B, rows, cols, kp_cap, int(frame_cap) if frame_cap else kp_cap
         c.median_ksize, c.max_corners, c.edge = int(median_win_size), int(num_of_features), int(edge)
         c.ransac_max_iter, c.ransac_adaptive, c.lm_max_iter = int(max_iter), 1 if adaptive else 0, int(lm_iter)
-        c.flags = _lib.FLAG_EPNP if str(pose_est_algorithm).upper() == "EPNP" else 0
+        c.flags = rgbd_solver_flags(pose_est_algorithm)
         c.quality, c.min_distance = float(quality), float(min_distance)
         c.ransac_threshold = float(1.0 - np.cos(np.deg2rad(5.0))) if thr is None else float(thr)
         c.pct_good_matches, c.f2f_max_hdiff = float(cam.pct_good_matches), float(cam.f2f_max_hdiff)
