@@ -32,6 +32,8 @@ def main_sos_vo_live(argv=None, frame_source=None):
     parser.add_argument("--lockstep", default=True, type="bool",
                         help="deliver every frame exactly once (reproducible runs); false = newest frame wins, as a camera")
     parser.add_argument("--use_multithreads_for_VO", default=True, type="bool")
+    parser.add_argument("--frame_window", default=-1, type=int,
+                        help="frames per batched front-end pass (-1 = 1 for a live source; 0 = the per-frame mirror path)")
     args = parser.parse_args(argv)
 
     from vo_single_camera_sos_amd.omnistereo.gum import load_gums_json
@@ -47,7 +49,8 @@ def main_sos_vo_live(argv=None, frame_source=None):
     cam_working_thread = FrameSourceThread(frame_source, lockstep=args.lockstep)
     gums_calibrated = load_gums_json(osp.realpath(osp.expanduser(args.calibrated_gums_file)))
     out = driver_VO_live(gums_calibrated, results, cam_working_thread, visualize_VO=args.visualize_VO,
-                         use_multithreads_for_VO=args.use_multithreads_for_VO, thread_name="LIVE-SOS")
+                         use_multithreads_for_VO=args.use_multithreads_for_VO, thread_name="LIVE-SOS",
+                         frame_window=None if args.frame_window < 0 else args.frame_window)
     print("GOODBYE!")
     return out
 

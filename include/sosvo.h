@@ -542,6 +542,40 @@ int32_t sosvo_frame_pair_batch_streams(sosvo_ctx* ctx, const sosvo_rig* rig_host
                                        const uint32_t* mask_bits, const int8_t* pattern, void* workspace,
                                        size_t workspace_bytes, double* results);
 
+/* ---- Sequence mode: every frame's front end ONCE, tracking against keyframes -----------------------------
+ * The reference's VO loop (run_VO, omnistereo/pose_est_tools.py:1416-1628) builds ONE StereoPanoramicFrame per image
+ * (:1447-1463: unwrap, median, detection, static stereo, triangulation) and tracks it against the current KEYFRAME
+ * (:1478, TrackerStereoSE3.track_frame :736-847); the keyframe policy (:1509-1565) depends on each tracked pose, so the
+ * tracking is a serial chain while the front ends are independent.  These entry points split the batch path the same
+ * way around a FRAME STORE in the caller's workspace: `slots` frame records (the frame's PanoramicCorrespondences as
+ * SoA: pixels, descriptors, 3-D points, bearings, count), filled `window` frames at a time, tracked by slot numbers.
+ *   cfg: sosvo_batch_cfg as for sosvo_frame_pair_batch; n_pairs = slot pairs one sosvo_sequence_track call may hold.
+ *   workspace: sosvo_sequence_workspace(cfg, window, slots) bytes, 256-aligned, caller-owned; the SAME (cfg, window,
+ *   slots) on every call.
+ * sosvo_sequence_front_end: the front end of n_frames <= window omni frames [n_frames, H, W, 3] u8 (device) -> store
+ *   slots first_slot .. first_slot + n_frames - 1.  Asynchronous.
+ * sosvo_sequence_track: TrackerStereoSE3.track_frame for n_pairs (reference slot, current slot) pairs given as HOST
+ *   arrays; pair i samples with seed + i -> results [n_pairs, 16] f64 (device) as sosvo_frame_pair_batch.  A pair's
+ *   record depends only on its two slots' frames and its seed, so speculative tracking (every frame against its
+ *   predecessor, in one call, before the keyframe decisions are known) gives exactly the records of the serial loop
+ *   wherever the guess was right.  Asynchronous (up to 16 pairs travel as kernel arguments).
+ * sosvo_sequence_copy_slot: store slot src -> dst (a frame promoted to keyframe outlives its window).  Asynchronous.
+ * sosvo_sequence_frame_counts: the valid-correspondence counts (StereoPanoramicFrame.num_valid_keypoints, :372) of n
+ *   slots -> HOST int32 array; SYNCHRONISES the context's stream (the one blocking call of the group).             */
+size_t sosvo_sequence_workspace(const sosvo_batch_cfg* cfg, int32_t window, int32_t slots);
+int32_t sosvo_sequence_front_end(sosvo_ctx* ctx, const sosvo_rig* rig_host, const sosvo_batch_cfg* cfg_host, int32_t window,
+                                 int32_t slots, const uint8_t* omni, int32_t n_frames, int32_t first_slot,
+                                 const uint32_t* unwrap_table, const uint32_t* mask_bits, const int8_t* pattern,
+                                 void* workspace, size_t workspace_bytes);
+int32_t sosvo_sequence_track(sosvo_ctx* ctx, const sosvo_rig* rig_host, const sosvo_batch_cfg* cfg_host, int32_t window,
+                             int32_t slots, const int32_t* ref_slot_host, const int32_t* cur_slot_host, int32_t n_pairs,
+                             uint64_t seed, void* workspace, size_t workspace_bytes, double* results);
+int32_t sosvo_sequence_copy_slot(sosvo_ctx* ctx, const sosvo_batch_cfg* cfg_host, int32_t window, int32_t slots,
+                                 int32_t src_slot, int32_t dst_slot, void* workspace, size_t workspace_bytes);
+int32_t sosvo_sequence_frame_counts(sosvo_ctx* ctx, const sosvo_batch_cfg* cfg_host, int32_t window, int32_t slots,
+                                    int32_t first_slot, int32_t n, void* workspace, size_t workspace_bytes,
+                                    int32_t* counts_host);
+
 /* ---- The RGB-D path for B independent frame pairs behind ONE call (BASELINE config 5) ------------------
  * RGBDFrame.establish_keypoints (omnistereo/pose_est_tools.py:600-623: [median,] gray, goodFeaturesToTrack on the
  * whole image or on RGBDFrame.mask, ORB descriptors, depth back-projection, NaN / range filter, bearings) for the

@@ -112,6 +112,119 @@ __global__ void batch_results_kernel(int npairs, const double* __restrict__ T, c
   out[16 * i + 15] = (double)info[4 * i + 0];
 }
 
+// ---- sequence mode: a frame STORE of `slots` frame records, a front end over a WINDOW of frames, tracking of slot pairs ----
+struct SeqBuffers {
+  // front-end temporaries of one window
+  uint8_t *pano, *gray, *desc;
+  float* kp;
+  int32_t *n, *status, *s_order, *n_cand, *gray_rows;
+  uint32_t* s_keys;
+  // the frame store (PanoramicCorrespondences as SoA, slot-major)
+  uint8_t *d_top, *d_bot;
+  float *m_top, *m_bot;
+  double *X, *b_top, *b_bot;
+  int32_t* M;
+  // tracking of up to cfg.n_pairs slot pairs per call
+  uint8_t* mask;
+  int32_t *ref_frame, *cur_frame, *o_top, *o_bot, *cam, *cq, *ct, *cn, *cn_top, *idx, *n_inl, *info, *lm_iters;
+  uint32_t *k_top, *k_bot;
+  double *f, *p, *T_ransac, *T, *cam_off, *cam_rot, *lm_cost;
+  size_t bytes;
+};
+
+SeqBuffers carve_seq(const sosvo_batch_cfg& c, int window, int slots, void* ws) {
+  Carver cv{reinterpret_cast<char*>(ws)};
+  SeqBuffers b;
+  const size_t B = c.n_pairs, F = window, NI = 2 * F, P = NI * c.nmask, cap = c.kp_cap, Fc = c.frame_cap, Cc = 2 * Fc, S = slots;
+  const size_t npx = (size_t)c.rows * c.cols;
+  const bool fused = c.median_ksize == 3 || c.median_ksize == 5 || c.median_ksize == 11;
+  b.pano = fused ? nullptr : cv.take<uint8_t>(NI * npx * 3);
+  b.gray = cv.take<uint8_t>(NI * npx);
+  b.kp = cv.take<float>(P * cap * 2);
+  b.n = cv.take<int32_t>(P);
+  b.status = cv.take<int32_t>(P);
+  b.desc = cv.take<uint8_t>(P * cap * 32);
+  b.s_keys = cv.take<uint32_t>(P / 2 * cap);
+  b.s_order = cv.take<int32_t>(P / 2 * cap);
+  b.n_cand = cv.take<int32_t>(F);
+  b.gray_rows = cv.take<int32_t>(4);
+  b.m_top = cv.take<float>(S * Fc * 2);
+  b.m_bot = cv.take<float>(S * Fc * 2);
+  b.d_top = cv.take<uint8_t>(S * Fc * 32);
+  b.d_bot = cv.take<uint8_t>(S * Fc * 32);
+  b.X = cv.take<double>(S * Fc * 3);
+  b.b_top = cv.take<double>(S * Fc * 3);
+  b.b_bot = cv.take<double>(S * Fc * 3);
+  b.M = cv.take<int32_t>(S);
+  b.ref_frame = cv.take<int32_t>(B);
+  b.cur_frame = cv.take<int32_t>(B);
+  b.k_top = cv.take<uint32_t>(B * Fc);
+  b.k_bot = cv.take<uint32_t>(B * Fc);
+  b.o_top = cv.take<int32_t>(B * Fc);
+  b.o_bot = cv.take<int32_t>(B * Fc);
+  b.f = cv.take<double>(B * Cc * 3);
+  b.p = cv.take<double>(B * Cc * 3);
+  b.cam = cv.take<int32_t>(B * Cc);
+  b.cq = cv.take<int32_t>(B * Cc);
+  b.ct = cv.take<int32_t>(B * Cc);
+  b.cn = cv.take<int32_t>(B);
+  b.cn_top = cv.take<int32_t>(B);
+  b.T_ransac = cv.take<double>(B * 12);
+  b.mask = cv.take<uint8_t>(B * Cc);
+  b.idx = cv.take<int32_t>(B * Cc);
+  b.n_inl = cv.take<int32_t>(B);
+  b.info = cv.take<int32_t>(B * 4);
+  b.T = cv.take<double>(B * 12);
+  b.cam_off = cv.take<double>(2 * 3);
+  b.cam_rot = cv.take<double>(2 * 9);
+  b.lm_cost = cv.take<double>(B);
+  b.lm_iters = cv.take<int32_t>(B);
+  b.bytes = cv.off;
+  return b;
+}
+
+constexpr int kSeqArgPairs = 16;  // slot pairs that travel as kernel arguments (no host-to-device copy per call)
+struct SlotPairs {
+  int32_t ref[kSeqArgPairs], cur[kSeqArgPairs];
+};
+__global__ void seq_setup_kernel(int npairs, SlotPairs sp, Foci foci, int32_t* __restrict__ ref_frame,
+                                 int32_t* __restrict__ cur_frame, double* __restrict__ cam_off, double* __restrict__ cam_rot) {
+  const int i = threadIdx.x;
+  if (i < npairs && i < kSeqArgPairs) {
+    ref_frame[i] = sp.ref[i];
+    cur_frame[i] = sp.cur[i];
+  }
+  if (i < 3) {
+    cam_off[i] = foci.top[i];
+    cam_off[3 + i] = foci.bot[i];
+  }
+  if (i < 18) cam_rot[i] = (i % 9) % 4 == 0 ? 1.0 : 0.0;
+}
+
+// one frame record of the store -> another slot (a frame promoted to keyframe outlives its window)
+__global__ void seq_copy_slot_kernel(int src, int dst, int Fc, float* m_top, float* m_bot, uint4* d_top, uint4* d_bot,
+                                     double* X, double* b_top, double* b_bot, int32_t* M) {
+  const int n = M[src];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const size_t s = (size_t)src * Fc + i, d = (size_t)dst * Fc + i;
+    m_top[2 * d] = m_top[2 * s];
+    m_top[2 * d + 1] = m_top[2 * s + 1];
+    m_bot[2 * d] = m_bot[2 * s];
+    m_bot[2 * d + 1] = m_bot[2 * s + 1];
+    d_top[2 * d] = d_top[2 * s];
+    d_top[2 * d + 1] = d_top[2 * s + 1];
+    d_bot[2 * d] = d_bot[2 * s];
+    d_bot[2 * d + 1] = d_bot[2 * s + 1];
+    for (int k = 0; k < 3; ++k) {
+      X[3 * d + k] = X[3 * s + k];
+      b_top[3 * d + k] = b_top[3 * s + k];
+      b_bot[3 * d + k] = b_bot[3 * s + k];
+    }
+  }
+  __syncthreads();  // (every thread has read M[src] before it may be overwritten when src == dst is excluded by the caller)
+  if (blockIdx.x == 0 && threadIdx.x == 0) M[dst] = n;
+}
+
 // ---- RGB-D variant (BASELINE config 5) ------------------------------------------------------------------
 struct RgbdBuffers {
   uint8_t *gray, *desc, *d, *mask;
@@ -176,6 +289,95 @@ size_t sosvo_frame_pair_batch_workspace(const sosvo_batch_cfg* cfg) {
   return carve(*cfg, nullptr).bytes;
 }
 
+#define STAGE(call)              \
+  do {                           \
+    rc = (call);                 \
+    if (rc != SOSVO_OK) return rc; \
+  } while (0)
+
+// The image front end + static stereo of F frames (OmniStereoModel.set_current_omni_image + StereoPanoramicFrame.__init__,
+// camera_models.py:3107-3120, pose_est_tools.py:271-402): K1, K2 + K3, K4, K6 over all 2 F panoramas, per-bucket top/bottom
+// matching, gates, bearings, midpoint triangulation, range filter -> F frame records written at out_* (frame-major).
+struct FrontEndTmp {
+  uint8_t *pano, *gray, *desc;
+  float* kp;
+  int32_t *n, *status, *s_order, *n_cand, *gray_rows;
+  uint32_t* s_keys;
+};
+struct FrameStore {
+  float *m_top, *m_bot;
+  uint8_t *d_top, *d_bot;
+  double *X, *b_top, *b_bot;
+  int32_t* M;
+};
+static int32_t run_front_end(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo_batch_cfg* cfg, int F, const uint8_t* omni,
+                             const uint32_t* unwrap_table, const uint32_t* mask_bits, const int8_t* pattern,
+                             const FrontEndTmp& t, const FrameStore& o, hipEvent_t median_wait, hipEvent_t median_done) {
+  const int NI = 2 * F, NM = cfg->nmask, cap = cfg->kp_cap, Fc = cfg->frame_cap;
+  const int h = F * NM;  // problems of one view: (frame, mask); the top view's come first (view-major images)
+  int32_t rc;
+  if (median_wait) SOSVO_HIP(ctx, hipStreamWaitEvent(ctx->stream, median_wait, 0));
+  const bool rows_known = cfg->median_ksize == 3 || cfg->median_ksize == 5 || cfg->median_ksize == 11;
+  if (rows_known) {
+    // rows beyond the reach of GFT on the masks and of ORB.compute on its keypoints are not computed (the range is a
+    // model constant; a 2-workgroup kernel per call keeps this entry point free of caller-side state)
+    STAGE(sosvo_gray_rows_needed(ctx, mask_bits, 2, cfg->rows, cfg->cols, NM, cfg->edge, pattern, cfg->cos_a, cfg->sin_a,
+                                 t.gray_rows));
+    STAGE(sosvo_unwrap_median_gray_rows(ctx, omni, unwrap_table, F, cfg->H, cfg->W, cfg->rows, cfg->cols, cfg->median_ksize,
+                                        t.gray_rows, t.gray));
+  } else {
+    STAGE(sosvo_unwrap_table(ctx, omni, unwrap_table, F, cfg->H, cfg->W, cfg->rows, cfg->cols, t.pano));
+    STAGE(sosvo_median_gray(ctx, t.pano, NI, cfg->rows, cfg->cols, cfg->median_ksize, t.gray));
+  }
+  if (median_done) SOSVO_HIP(ctx, hipEventRecord(median_done, ctx->stream));
+  STAGE(sosvo_detect_gft(ctx, t.gray, mask_bits, NI, F, cfg->rows, cfg->cols, NM, cfg->quality, cfg->min_distance,
+                         cfg->max_corners, cap, t.kp, t.n, t.status));
+  STAGE(sosvo_describe_orb_rows(ctx, t.gray, NI, cfg->rows, cfg->cols, NM, cap, t.kp, t.n, cfg->cos_a, cfg->sin_a, pattern,
+                                cfg->edge, rows_known ? t.gray_rows : nullptr, t.desc));
+  // static stereo per frame: query = bottom view, train = top view, bucket by bucket
+  const float *kp_top = t.kp, *kp_bot = t.kp + (size_t)h * cap * 2;
+  const uint8_t *desc_top = t.desc, *desc_bot = t.desc + (size_t)h * cap * 32;
+  const int32_t *n_top = t.n, *n_bot = t.n + h;
+  STAGE(sosvo_match_hamming(ctx, desc_bot, desc_top, n_bot, n_top, nullptr, nullptr, h, cap, cap, 1, t.s_keys));
+  STAGE(sosvo_sort_matches(ctx, t.s_keys, n_bot, nullptr, h, cap, t.s_order));
+  STAGE(sosvo_stereo_assemble(ctx, rig, kp_top, kp_bot, desc_top, desc_bot, n_top, n_bot, t.s_keys, t.s_order, F, NM, cap,
+                              Fc, o.m_top, o.m_bot, o.d_top, o.d_bot, o.X, o.b_top, o.b_bot, o.M, t.n_cand));
+  return SOSVO_OK;
+}
+
+// TrackerStereoSE3.track_frame (pose_est_tools.py:736-847) for B (reference slot, current slot) pairs of a frame store:
+// frame-to-frame matching per view (query = current frame, train = reference frame), |du| gate, stacking, non-central
+// RANSAC (problem i samples with seed + i), LM on the inliers, [B,16] records.
+struct TrackTmp {
+  int32_t *ref_frame, *cur_frame, *o_top, *o_bot, *cam, *cq, *ct, *cn, *cn_top, *idx, *n_inl, *info, *lm_iters;
+  uint32_t *k_top, *k_bot;
+  uint8_t* mask;
+  double *f, *p, *T_ransac, *T, *cam_off, *cam_rot, *lm_cost;
+};
+static int32_t run_tracking(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo_batch_cfg* cfg, int B, uint64_t seed,
+                            const FrameStore& s, const TrackTmp& b, double* results) {
+  const int Fc = cfg->frame_cap, Cc = 2 * Fc;
+  int32_t rc;
+  STAGE(sosvo_match_hamming(ctx, s.d_top, s.d_top, s.M, s.M, b.cur_frame, b.ref_frame, B, Fc, Fc, 1, b.k_top));
+  STAGE(sosvo_sort_matches(ctx, b.k_top, s.M, b.cur_frame, B, Fc, b.o_top));
+  STAGE(sosvo_match_hamming(ctx, s.d_bot, s.d_bot, s.M, s.M, b.cur_frame, b.ref_frame, B, Fc, Fc, 1, b.k_bot));
+  STAGE(sosvo_sort_matches(ctx, b.k_bot, s.M, b.cur_frame, B, Fc, b.o_bot));
+  STAGE(sosvo_f2f_assemble(ctx, rig, s.m_top, s.m_bot, s.X, s.b_top, s.b_bot, s.M, Fc, b.ref_frame, b.cur_frame, b.k_top,
+                           b.o_top, b.k_bot, b.o_bot, B, Cc, b.f, b.p, b.cam, b.cq, b.ct, b.cn, b.cn_top));
+  // 3D-2D absolute pose: RANSAC, then LM on the inliers
+  STAGE(sosvo_ransac_abs_pose(ctx, b.f, b.p, b.cam, b.cam_off, b.cam_rot, 2,
+                              SOSVO_FLAG_CAM_ROT_IDENTITY | (cfg->ransac_flags & SOSVO_FLAG_GP3P), b.cn, B, Cc,
+                              cfg->ransac_threshold, cfg->ransac_max_iter, cfg->ransac_adaptive, seed, b.T_ransac,
+                              b.mask, b.idx, b.n_inl, b.info, nullptr));
+  SOSVO_HIP(ctx, hipMemcpyAsync(b.T, b.T_ransac, sizeof(double) * 12 * B, hipMemcpyDeviceToDevice, ctx->stream));
+  STAGE(sosvo_refine_abs_pose(ctx, b.f, b.p, b.cam, b.cam_off, b.cam_rot, 2, b.cn, B, Cc, b.idx, b.n_inl, cfg->lm_max_iter,
+                              b.T, b.lm_cost, b.lm_iters));
+  SOSVO_LAUNCH(ctx, batch_results_kernel, dim3(cdiv(B, 256)), dim3(256), 0, ctx->stream, B, b.T, b.n_inl, b.cn, b.info,
+               results);
+  SOSVO_LAUNCH_CHECK(ctx);
+  return SOSVO_OK;
+}
+
 // (median_wait / median_done: the token that serialises the VALU-bound median launches of the parts of a multi-stream
 // batch, see sosvo_frame_pair_batch_streams; nullptr for a plain call)
 static int32_t run_frame_pairs(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo_batch_cfg* cfg, const uint8_t* omni,
@@ -190,15 +392,8 @@ static int32_t run_frame_pairs(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo
   SOSVO_REQUIRE(ctx, ((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
   const Buffers b = carve(*cfg, workspace);
   SOSVO_REQUIRE(ctx, workspace_bytes >= b.bytes, "workspace too small (see sosvo_frame_pair_batch_workspace)");
-  const int B = cfg->n_pairs, F = 2 * B, NI = 2 * F, NM = cfg->nmask, cap = cfg->kp_cap, Fc = cfg->frame_cap, Cc = 2 * Fc;
-  const int h = F * NM;  // problems of one view: (frame, mask); the top view's come first (view-major images)
+  const int B = cfg->n_pairs, F = 2 * B;
   int32_t rc;
-#define STAGE(call)              \
-  do {                           \
-    rc = (call);                 \
-    if (rc != SOSVO_OK) return rc; \
-  } while (0)
-
   Foci foci;
   for (int k = 0; k < 3; ++k) {
     foci.top[k] = rig->F_top[k];
@@ -207,53 +402,12 @@ static int32_t run_frame_pairs(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo
   SOSVO_LAUNCH(ctx, batch_setup_kernel, dim3(cdiv(B > 18 ? B : 18, 256)), dim3(256), 0, ctx->stream, B, foci, b.ref_frame,
                b.cur_frame, b.cam_off, b.cam_rot);
   SOSVO_LAUNCH_CHECK(ctx);
-  // image front end: K1, K2 + K3, K4, K6 over all 2 * F panoramas
-  if (median_wait) SOSVO_HIP(ctx, hipStreamWaitEvent(ctx->stream, median_wait, 0));
-  const bool rows_known = cfg->median_ksize == 3 || cfg->median_ksize == 5 || cfg->median_ksize == 11;
-  if (rows_known) {
-    // rows beyond the reach of GFT on the masks and of ORB.compute on its keypoints are not computed (the range is a
-    // model constant; a 2-workgroup kernel per call keeps this entry point free of caller-side state)
-    STAGE(sosvo_gray_rows_needed(ctx, mask_bits, 2, cfg->rows, cfg->cols, NM, cfg->edge, pattern, cfg->cos_a, cfg->sin_a,
-                                 b.gray_rows));
-    STAGE(sosvo_unwrap_median_gray_rows(ctx, omni, unwrap_table, F, cfg->H, cfg->W, cfg->rows, cfg->cols, cfg->median_ksize,
-                                        b.gray_rows, b.gray));
-  } else {
-    STAGE(sosvo_unwrap_table(ctx, omni, unwrap_table, F, cfg->H, cfg->W, cfg->rows, cfg->cols, b.pano));
-    STAGE(sosvo_median_gray(ctx, b.pano, NI, cfg->rows, cfg->cols, cfg->median_ksize, b.gray));
-  }
-  if (median_done) SOSVO_HIP(ctx, hipEventRecord(median_done, ctx->stream));
-  STAGE(sosvo_detect_gft(ctx, b.gray, mask_bits, NI, F, cfg->rows, cfg->cols, NM, cfg->quality, cfg->min_distance,
-                         cfg->max_corners, cap, b.kp, b.n, b.status));
-  STAGE(sosvo_describe_orb_rows(ctx, b.gray, NI, cfg->rows, cfg->cols, NM, cap, b.kp, b.n, cfg->cos_a, cfg->sin_a, pattern,
-                                cfg->edge, rows_known ? b.gray_rows : nullptr, b.desc));
-  // static stereo per frame: query = bottom view, train = top view, bucket by bucket
-  const float *kp_top = b.kp, *kp_bot = b.kp + (size_t)h * cap * 2;
-  const uint8_t *desc_top = b.desc, *desc_bot = b.desc + (size_t)h * cap * 32;
-  const int32_t *n_top = b.n, *n_bot = b.n + h;
-  STAGE(sosvo_match_hamming(ctx, desc_bot, desc_top, n_bot, n_top, nullptr, nullptr, h, cap, cap, 1, b.s_keys));
-  STAGE(sosvo_sort_matches(ctx, b.s_keys, n_bot, nullptr, h, cap, b.s_order));
-  STAGE(sosvo_stereo_assemble(ctx, rig, kp_top, kp_bot, desc_top, desc_bot, n_top, n_bot, b.s_keys, b.s_order, F, NM, cap,
-                              Fc, b.m_top, b.m_bot, b.d_top, b.d_bot, b.X, b.b_top, b.b_bot, b.M, b.n_cand));
-  // frame-to-frame per pair and view: query = current frame, train = reference frame
-  STAGE(sosvo_match_hamming(ctx, b.d_top, b.d_top, b.M, b.M, b.cur_frame, b.ref_frame, B, Fc, Fc, 1, b.k_top));
-  STAGE(sosvo_sort_matches(ctx, b.k_top, b.M, b.cur_frame, B, Fc, b.o_top));
-  STAGE(sosvo_match_hamming(ctx, b.d_bot, b.d_bot, b.M, b.M, b.cur_frame, b.ref_frame, B, Fc, Fc, 1, b.k_bot));
-  STAGE(sosvo_sort_matches(ctx, b.k_bot, b.M, b.cur_frame, B, Fc, b.o_bot));
-  STAGE(sosvo_f2f_assemble(ctx, rig, b.m_top, b.m_bot, b.X, b.b_top, b.b_bot, b.M, Fc, b.ref_frame, b.cur_frame, b.k_top,
-                           b.o_top, b.k_bot, b.o_bot, B, Cc, b.f, b.p, b.cam, b.cq, b.ct, b.cn, b.cn_top));
-  // 3D-2D absolute pose: RANSAC, then LM on the inliers
-  STAGE(sosvo_ransac_abs_pose(ctx, b.f, b.p, b.cam, b.cam_off, b.cam_rot, 2,
-                              SOSVO_FLAG_CAM_ROT_IDENTITY | (cfg->ransac_flags & SOSVO_FLAG_GP3P), b.cn, B, Cc,
-                              cfg->ransac_threshold, cfg->ransac_max_iter, cfg->ransac_adaptive, cfg->seed, b.T_ransac,
-                              b.mask, b.idx, b.n_inl, b.info, nullptr));
-  SOSVO_HIP(ctx, hipMemcpyAsync(b.T, b.T_ransac, sizeof(double) * 12 * B, hipMemcpyDeviceToDevice, ctx->stream));
-  STAGE(sosvo_refine_abs_pose(ctx, b.f, b.p, b.cam, b.cam_off, b.cam_rot, 2, b.cn, B, Cc, b.idx, b.n_inl, cfg->lm_max_iter,
-                              b.T, b.lm_cost, b.lm_iters));
-  SOSVO_LAUNCH(ctx, batch_results_kernel, dim3(cdiv(B, 256)), dim3(256), 0, ctx->stream, B, b.T, b.n_inl, b.cn, b.info,
-               results);
-  SOSVO_LAUNCH_CHECK(ctx);
-#undef STAGE
-  return SOSVO_OK;
+  const FrontEndTmp fe{b.pano, b.gray, b.desc, b.kp, b.n, b.status, b.s_order, b.n_cand, b.gray_rows, b.s_keys};
+  const FrameStore store{b.m_top, b.m_bot, b.d_top, b.d_bot, b.X, b.b_top, b.b_bot, b.M};
+  STAGE(run_front_end(ctx, rig, cfg, F, omni, unwrap_table, mask_bits, pattern, fe, store, median_wait, median_done));
+  const TrackTmp tt{b.ref_frame, b.cur_frame, b.o_top, b.o_bot, b.cam, b.cq, b.ct, b.cn, b.cn_top, b.idx, b.n_inl, b.info,
+                    b.lm_iters, b.k_top, b.k_bot, b.mask, b.f, b.p, b.T_ransac, b.T, b.cam_off, b.cam_rot, b.lm_cost};
+  return run_tracking(ctx, rig, cfg, B, cfg->seed, store, tt, results);
 }
 
 int32_t sosvo_frame_pair_batch(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo_batch_cfg* cfg, const uint8_t* omni,
@@ -343,6 +497,103 @@ int32_t sosvo_frame_pair_batch_streams(sosvo_ctx* ctx, const sosvo_rig* rig, con
   return SOSVO_OK;
 }
 
+// ---- sequence mode ---------------------------------------------------------------------------------------
+static bool seq_shape_ok(const sosvo_batch_cfg* cfg, int32_t window, int32_t slots) {
+  return cfg && cfg->n_pairs > 0 && cfg->n_pairs <= 8192 && cfg->rows > 0 && cfg->cols > 0 && cfg->nmask >= 1 && cfg->nmask <= 32 &&
+         cfg->kp_cap > 0 && cfg->kp_cap <= 4096 && cfg->frame_cap > 0 && cfg->frame_cap <= 16384 && window >= 1 && window <= 16384 &&
+         slots >= window && slots <= 65535;
+}
+
+size_t sosvo_sequence_workspace(const sosvo_batch_cfg* cfg, int32_t window, int32_t slots) {
+  if (!seq_shape_ok(cfg, window, slots)) return 0;
+  return carve_seq(*cfg, window, slots, nullptr).bytes;
+}
+
+int32_t sosvo_sequence_front_end(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo_batch_cfg* cfg, int32_t window, int32_t slots,
+                                 const uint8_t* omni, int32_t n_frames, int32_t first_slot, const uint32_t* unwrap_table,
+                                 const uint32_t* mask_bits, const int8_t* pattern, void* workspace, size_t workspace_bytes) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, rig && cfg && omni && unwrap_table && mask_bits && pattern && workspace, "null pointer");
+  SOSVO_REQUIRE(ctx, seq_shape_ok(cfg, window, slots), "bad sequence configuration (window, slots, capacities)");
+  SOSVO_REQUIRE(ctx, n_frames >= 0 && n_frames <= window && first_slot >= 0 && first_slot + n_frames <= slots,
+                "frames do not fit the window / the store");
+  SOSVO_REQUIRE(ctx, ((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
+  const SeqBuffers b = carve_seq(*cfg, window, slots, workspace);
+  SOSVO_REQUIRE(ctx, workspace_bytes >= b.bytes, "workspace too small (see sosvo_sequence_workspace)");
+  if (n_frames == 0) return SOSVO_OK;
+  const size_t Fc = cfg->frame_cap, o = (size_t)first_slot * Fc;
+  const FrontEndTmp fe{b.pano, b.gray, b.desc, b.kp, b.n, b.status, b.s_order, b.n_cand, b.gray_rows, b.s_keys};
+  const FrameStore out{b.m_top + 2 * o, b.m_bot + 2 * o, b.d_top + 32 * o, b.d_bot + 32 * o,
+                       b.X + 3 * o, b.b_top + 3 * o, b.b_bot + 3 * o, b.M + first_slot};
+  return run_front_end(ctx, rig, cfg, n_frames, omni, unwrap_table, mask_bits, pattern, fe, out, nullptr, nullptr);
+}
+
+int32_t sosvo_sequence_track(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo_batch_cfg* cfg, int32_t window, int32_t slots,
+                             const int32_t* ref_slot, const int32_t* cur_slot, int32_t n_pairs, uint64_t seed, void* workspace,
+                             size_t workspace_bytes, double* results) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, rig && cfg && ref_slot && cur_slot && workspace && results, "null pointer");
+  SOSVO_REQUIRE(ctx, seq_shape_ok(cfg, window, slots), "bad sequence configuration (window, slots, capacities)");
+  SOSVO_REQUIRE(ctx, n_pairs >= 0 && n_pairs <= cfg->n_pairs, "more slot pairs than cfg->n_pairs");
+  SOSVO_REQUIRE(ctx, ((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
+  const SeqBuffers b = carve_seq(*cfg, window, slots, workspace);
+  SOSVO_REQUIRE(ctx, workspace_bytes >= b.bytes, "workspace too small (see sosvo_sequence_workspace)");
+  if (n_pairs == 0) return SOSVO_OK;
+  for (int i = 0; i < n_pairs; ++i)   // host arrays: a bad slot would index outside the store on the device
+    SOSVO_REQUIRE(ctx, ref_slot[i] >= 0 && ref_slot[i] < slots && cur_slot[i] >= 0 && cur_slot[i] < slots, "slot out of range");
+  Foci foci;
+  for (int k = 0; k < 3; ++k) {
+    foci.top[k] = rig->F_top[k];
+    foci.bot[k] = rig->F_bot[k];
+  }
+  SlotPairs sp;
+  for (int i = 0; i < kSeqArgPairs; ++i) {
+    sp.ref[i] = i < n_pairs ? ref_slot[i] : 0;
+    sp.cur[i] = i < n_pairs ? cur_slot[i] : 0;
+  }
+  if (n_pairs > kSeqArgPairs) {  // larger batches: the slot lists are copied (pageable host memory: the copy returns when staged)
+    SOSVO_HIP(ctx, hipMemcpyAsync(b.ref_frame, ref_slot, sizeof(int32_t) * n_pairs, hipMemcpyHostToDevice, ctx->stream));
+    SOSVO_HIP(ctx, hipMemcpyAsync(b.cur_frame, cur_slot, sizeof(int32_t) * n_pairs, hipMemcpyHostToDevice, ctx->stream));
+  }
+  SOSVO_LAUNCH(ctx, seq_setup_kernel, dim3(1), dim3(64), 0, ctx->stream, n_pairs > kSeqArgPairs ? 0 : n_pairs, sp, foci, b.ref_frame,
+               b.cur_frame, b.cam_off, b.cam_rot);
+  SOSVO_LAUNCH_CHECK(ctx);
+  const FrameStore store{b.m_top, b.m_bot, b.d_top, b.d_bot, b.X, b.b_top, b.b_bot, b.M};
+  const TrackTmp tt{b.ref_frame, b.cur_frame, b.o_top, b.o_bot, b.cam, b.cq, b.ct, b.cn, b.cn_top, b.idx, b.n_inl, b.info,
+                    b.lm_iters, b.k_top, b.k_bot, b.mask, b.f, b.p, b.T_ransac, b.T, b.cam_off, b.cam_rot, b.lm_cost};
+  return run_tracking(ctx, rig, cfg, n_pairs, seed, store, tt, results);
+}
+
+int32_t sosvo_sequence_copy_slot(sosvo_ctx* ctx, const sosvo_batch_cfg* cfg, int32_t window, int32_t slots, int32_t src_slot,
+                                 int32_t dst_slot, void* workspace, size_t workspace_bytes) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, cfg && workspace, "null pointer");
+  SOSVO_REQUIRE(ctx, seq_shape_ok(cfg, window, slots), "bad sequence configuration (window, slots, capacities)");
+  SOSVO_REQUIRE(ctx, src_slot >= 0 && src_slot < slots && dst_slot >= 0 && dst_slot < slots, "slot out of range");
+  SOSVO_REQUIRE(ctx, ((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
+  const SeqBuffers b = carve_seq(*cfg, window, slots, workspace);
+  SOSVO_REQUIRE(ctx, workspace_bytes >= b.bytes, "workspace too small (see sosvo_sequence_workspace)");
+  if (src_slot == dst_slot) return SOSVO_OK;
+  SOSVO_LAUNCH(ctx, seq_copy_slot_kernel, dim3(1), dim3(1024), 0, ctx->stream, src_slot, dst_slot, cfg->frame_cap, b.m_top,
+               b.m_bot, reinterpret_cast<uint4*>(b.d_top), reinterpret_cast<uint4*>(b.d_bot), b.X, b.b_top, b.b_bot, b.M);
+  SOSVO_LAUNCH_CHECK(ctx);
+  return SOSVO_OK;
+}
+
+int32_t sosvo_sequence_frame_counts(sosvo_ctx* ctx, const sosvo_batch_cfg* cfg, int32_t window, int32_t slots, int32_t first_slot,
+                                    int32_t n, void* workspace, size_t workspace_bytes, int32_t* counts_host) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, cfg && workspace && counts_host, "null pointer");
+  SOSVO_REQUIRE(ctx, seq_shape_ok(cfg, window, slots), "bad sequence configuration (window, slots, capacities)");
+  SOSVO_REQUIRE(ctx, first_slot >= 0 && n >= 0 && first_slot + n <= slots, "slots out of range");
+  const SeqBuffers b = carve_seq(*cfg, window, slots, workspace);
+  SOSVO_REQUIRE(ctx, workspace_bytes >= b.bytes, "workspace too small (see sosvo_sequence_workspace)");
+  if (n == 0) return SOSVO_OK;
+  SOSVO_HIP(ctx, hipMemcpyAsync(counts_host, b.M + first_slot, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
+  SOSVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SOSVO_OK;
+}
+
 size_t sosvo_rgbd_pair_batch_workspace(const sosvo_rgbd_batch_cfg* cfg) {
   if (!cfg || cfg->n_pairs <= 0 || cfg->rows <= 0 || cfg->cols <= 0 || cfg->kp_cap <= 0 || cfg->frame_cap <= 0) return 0;
   return carve_rgbd(*cfg, nullptr).bytes;
@@ -361,11 +612,6 @@ int32_t sosvo_rgbd_pair_batch(sosvo_ctx* ctx, const sosvo_rgbd_cam* cam, const s
   SOSVO_REQUIRE(ctx, workspace_bytes >= b.bytes, "workspace too small (see sosvo_rgbd_pair_batch_workspace)");
   const int B = cfg->n_pairs, F = 2 * B, cap = cfg->kp_cap, Fc = cfg->frame_cap;
   int32_t rc;
-#define STAGE(call)              \
-  do {                           \
-    rc = (call);                 \
-    if (rc != SOSVO_OK) return rc; \
-  } while (0)
   SOSVO_LAUNCH(ctx, pair_index_kernel, dim3(cdiv(B, 256)), dim3(256), 0, ctx->stream, B, b.ref_frame, b.cur_frame);
   SOSVO_LAUNCH_CHECK(ctx);
   // RGBDFrame.establish_keypoints for all 2 B frames: [median,] gray, whole-image GFT (one mask), ORB descriptors,

@@ -708,6 +708,49 @@ class Context(object):
                    _ptr(workspace), int(workspace.numel()), _ptr(results))
         return results
 
+    # ---- sequence mode (include/sosvo.h "Sequence mode") -----------------------------------------
+    def sequence_workspace(self, cfg, window, slots):
+        return int(self._lib.sosvo_sequence_workspace(ctypes.cast(ctypes.pointer(cfg), c_p), int(window), int(slots)))
+
+    def sequence_front_end(self, rig, cfg, window, slots, omni, first_slot, unwrap_table, mask_bits, pattern, workspace):
+        """omni [n,H,W,3] u8 (n <= window) -> store slots first_slot .. first_slot + n - 1 (asynchronous)."""
+        _check(omni, torch.uint8, "omni", (None, cfg.H, cfg.W, 3))
+        _check(unwrap_table, torch.uint32, "unwrap_table", (2, cfg.rows, cfg.cols, 2))
+        _check(mask_bits, torch.uint32, "mask_bits", (2, cfg.rows, cfg.cols))
+        _check(pattern, torch.int8, "pattern", (512, 2))
+        _check(workspace, torch.uint8, "workspace", ndim=1)
+        self._call(self._lib.sosvo_sequence_front_end, ctypes.cast(ctypes.pointer(rig), c_p), ctypes.cast(ctypes.pointer(cfg), c_p),
+                   int(window), int(slots), _ptr(omni), int(omni.shape[0]), int(first_slot), _ptr(unwrap_table), _ptr(mask_bits),
+                   _ptr(pattern), _ptr(workspace), int(workspace.numel()))
+
+    def sequence_track(self, rig, cfg, window, slots, ref_slots, cur_slots, seed, workspace, results):
+        """ref_slots / cur_slots: host int sequences of equal length n <= cfg.n_pairs -> results[:n] [n,16] f64 (device,
+        asynchronous); pair i samples with seed + i."""
+        n = len(ref_slots)
+        if len(cur_slots) != n:
+            raise SosvoError("ref_slots and cur_slots must have the same length")
+        _check(workspace, torch.uint8, "workspace", ndim=1)
+        _check(results, torch.float64, "results", (None, 16))
+        if results.shape[0] < n:
+            raise SosvoError("results holds fewer rows than slot pairs")
+        ref = (ctypes.c_int32 * max(n, 1))(*[int(x) for x in ref_slots])
+        cur = (ctypes.c_int32 * max(n, 1))(*[int(x) for x in cur_slots])
+        self._call(self._lib.sosvo_sequence_track, ctypes.cast(ctypes.pointer(rig), c_p), ctypes.cast(ctypes.pointer(cfg), c_p),
+                   int(window), int(slots), ctypes.cast(ref, c_p), ctypes.cast(cur, c_p), n, int(seed), _ptr(workspace),
+                   int(workspace.numel()), _ptr(results))
+        return results
+
+    def sequence_copy_slot(self, cfg, window, slots, src, dst, workspace):
+        self._call(self._lib.sosvo_sequence_copy_slot, ctypes.cast(ctypes.pointer(cfg), c_p), int(window), int(slots), int(src),
+                   int(dst), _ptr(workspace), int(workspace.numel()))
+
+    def sequence_frame_counts(self, cfg, window, slots, first_slot, n, workspace):
+        """-> list of n ints (StereoPanoramicFrame.num_valid_keypoints of the slots); synchronises the stream."""
+        out = (ctypes.c_int32 * max(int(n), 1))()
+        self._call(self._lib.sosvo_sequence_frame_counts, ctypes.cast(ctypes.pointer(cfg), c_p), int(window), int(slots),
+                   int(first_slot), int(n), _ptr(workspace), int(workspace.numel()), ctypes.cast(out, c_p))
+        return [int(out[i]) for i in range(int(n))]
+
     def rgbd_pair_batch_workspace(self, cfg):
         return int(self._lib.sosvo_rgbd_pair_batch_workspace(ctypes.cast(ctypes.pointer(cfg), c_p)))
 

@@ -298,6 +298,8 @@ class TrackerStereoSE3(TrackerSE3):
         self.T_C_curr_frame_wrt_S_est."""
         self.num_tracked_correspondences = 0
         self.inlier_tracked_correspondences_ratio = 0.
+        if isinstance(current_frame, DeviceStereoFrame):
+            return self._track_device_frame(reference_frame, current_frame)
         ref, cur = reference_frame.pano_correspondences, current_frame.pano_correspondences
         (t_top, _, _), (q_top, _, _), _ = match_features_frame_to_frame(
             cam_model=self.omnistereo_model, train_kpts=ref.kpts_top, train_desc=ref.desc_top, query_kpts=cur.kpts_top,
@@ -340,12 +342,92 @@ class TrackerStereoSE3(TrackerSE3):
         return True, "tracking used %d inlier point correspondences" % (self.num_tracked_correspondences)
 
 
+    def _track_device_frame(self, reference_frame, current_frame):
+        """track_frame on frames of a SequenceEngine's store: the [16] record (refined pose, inliers, correspondences,
+        status) of the pair -- the speculative one when the reference is the frame's predecessor, one serial tracking
+        call against the keyframe slot otherwise -- put through the same bookkeeping as above."""
+        eng = current_frame.engine
+        if current_frame.spec_record is not None and getattr(reference_frame, "seq_index", None) == current_frame.seq_index - 1:
+            rec = current_frame.spec_record
+        else:
+            rec = eng.track(eng.key_slot, current_frame.slot, current_frame.seed)
+        num_initial_matches = int(rec[13])
+        if num_initial_matches < 2 * self.n_points_for_RANSAC_model * (0.33 * self.number_of_cams):
+            return False, "Cannot track on only %d point correspondences" % (num_initial_matches)
+        self.indices_inliers_combined = None    # (the inlier list stays on the device)
+        self.num_tracked_correspondences = int(rec[12])
+        self.inlier_tracked_correspondences_ratio = float(self.num_tracked_correspondences) / float(num_initial_matches)
+        T_homo = np.identity(4)
+        T_homo[:3] = rec[:12].reshape(3, 4)
+        T_homo[:3, 3] = T_homo[:3, 3] * current_frame.conversion_factor_length_to_m
+        current_frame.T_frame_wrt_tracking_ref_frame = T_homo
+        T_key = self.T_Ckey_wrt_S_est_list[-1] if self.T_Ckey_wrt_S_est_list else np.identity(4)
+        self.T_C_curr_frame_wrt_S_est = T_key.dot(T_homo)
+        return True, "tracking used %d inlier point correspondences" % (self.num_tracked_correspondences)
+
+
 class StereoPanoramicKeyFrame(StereoPanoramicFrame):
     """pose_est_tools.py:625-632: a frame promoted to keyframe (a blind copy of its attributes)."""
 
     def __init__(self, frame, **kwargs):
         copy_only_attributes(objfrom=frame, objto=self)
         self.children_ids = []
+
+
+class DeviceStereoFrame(StereoPanoramicFrame):
+    """A StereoPanoramicFrame whose correspondences live in the frame store of a pipeline.SequenceEngine (HBM) instead
+    of host arrays: run_VO's sequence mode builds these, `window` frames per batched front-end pass.  Same attributes as
+    the host frame except pano_correspondences / the bearing arrays, which stay on the device (slot `slot` of the
+    store while the frame's window is current; the keyframe slot once promoted)."""
+
+    def __init__(self, engine, info, stereo_camera_model, frame_id, seq_index, **kwargs):
+        self.frame_id = frame_id
+        self.parent_id = kwargs.get("parent_id", -1)
+        self.T_frame_wrt_tracking_ref_frame = np.identity(4)
+        self.panoramic_image_top = self.panoramic_image_bottom = None
+        self.use_midpoint_triangulation, self.use_opengv_triangulation = True, False
+        self.conversion_factor_length_to_m = get_length_units_conversion_factor(stereo_camera_model.units, "m")
+        self.first_row_to_crop_bottom = 0
+        self.total_time = 0.
+        self.median_win_size = engine.cfg.median_ksize
+        self.min_disp, self.max_u_dist = engine.rig_cfg.stereo_min_disp, engine.rig_cfg.stereo_max_hdiff
+        self.min_range, self.max_range = engine.rig_cfg.min_range, engine.rig_cfg.max_range
+        self.pano_correspondences = None
+        self.engine, self.slot, self.seq_index = engine, int(info["slot"]), int(seq_index)
+        self.seed, self.spec_record = int(info["seed"]), info["spec"]
+        self.num_valid_keypoints = int(info["count"])
+
+    def promote(self):
+        self.engine.promote(self.slot)
+
+
+def sequence_engine_for(tracker, camera_model, first_image, window):
+    """The pipeline.SequenceEngine that computes what `tracker` (a TrackerStereoSE3 with the reference's settings) and
+    StereoPanoramicFrame compute, or None when the configuration has no batched counterpart (then run_VO keeps the
+    per-frame mirror path)."""
+    from ..pipeline import RigConfig, SequenceEngine
+    om = camera_model
+    if (tracker.detection_method != "GFT" or tracker.matching_type != "BF" or tracker.k_best_matches != 1
+            or tracker.use_descriptor_radius_match_for_motion):
+        return None
+    top, bot = om.top_model, om.bot_model
+    if not (np.array_equal(tracker.cam_rotations[0], np.identity(3)) and np.array_equal(tracker.cam_rotations[1], np.identity(3))
+            and np.array_equal(tracker.cam_offsets[0], top.F[:3, 0]) and np.array_equal(tracker.cam_offsets[1], bot.F[:3, 0])):
+        return None
+    if om.current_omni_img is None:
+        om.current_omni_img = first_image
+    model = om._device_model()
+    from_m = get_length_units_conversion_factor("m", om.units)
+    geo = [(m.panorama.cols, m.panorama.rows, m.panorama.pixel_size, m.panorama.cyl_height_max) for m in (top, bot)]
+    rig = RigConfig(pano_top=geo[0], pano_bot=geo[1], F_top=top.F[:3, 0], F_bot=bot.F[:3, 0], min_range=0.5 * from_m,
+                    max_range=7.0 * from_m, stereo_min_disp=1.0, stereo_max_hdiff=2.5,
+                    f2f_max_hdiff=tracker.max_horizontal_diff_f2f_matches, pct_good_matches=tracker.percentage_good_matches)
+    nfeat = tracker.num_features_detection_for_static_stereo
+    cap = int(min(4096, max(64, -(-int(nfeat) // 64) * 64)))      # as GUMStereo._front_end (the mirror path's capacity)
+    return SequenceEngine(om._context(), model, rig, window=window, num_of_features=nfeat, kp_cap=cap, frame_cap=4096,
+                          median_win_size=11, thr=tracker.backprojection_score_threshold_3D_to_2D,
+                          max_iter=tracker.max_ransac_iterations_3D_to_2D, adaptive=True, lm_iter=pyopengv.LM_MAX_ITERATIONS,
+                          ransac_solver="GP3P")
 
 
 class RGBDFrame(object):
@@ -480,13 +562,20 @@ def _is_rgbd_model(camera_model):
 
 def run_VO(visualizer_3D_VO, camera_model, gt_poses_filename=None, est_poses_filename="estimated_frame_poses_TUM.txt",
            img_filename_template=None, depth_filename_template=None, img_indices=(), results_path="~/temp", thread_name="",
-           _live_frames=None, _keyframe_thresholds=None):
+           _live_frames=None, _keyframe_thresholds=None, frame_window=None):
     """pose_est_tools.py:1264-1678 without the 3-D visualisation (visualizer_3D_VO must be None): the frame loop,
     the keyframe policy (translation 0.01-0.20 m or rotation 1-10 degrees wrt the keyframe, enough tracked
     correspondences and keypoints), pose chaining through the keyframes, and the result files
         estimated_frame_poses_TUM.txt, gt_associated_frame_poses_TUM.txt  "idx tx ty tz qx qy qz qw" [m]
         keyframe_ids.txt, printed_messages.log
-    -> dict(poses=[(idx, T 4x4)], keyframe_ids=[...], tracked=number of tracked frames, message=summary)."""
+    -> dict(poses=[(idx, T 4x4)], keyframe_ids=[...], tracked=number of tracked frames, message=summary).
+
+    frame_window: SEQUENCE MODE of the omnistereo path (pipeline.SequenceEngine): the front ends of `frame_window` frames
+    run as ONE batch on the GPU and the frames are tracked from the device-resident frame store (speculatively against
+    their predecessors, serially against the keyframe where that guess fails).  None = 32 for an image sequence, 1 for a
+    live source; 0 = the per-frame mirror path (StereoPanoramicFrame on host arrays, one set of C-ABI calls per stage).
+    The pose file does not depend on the window size (byte-identical for 1, 2, 32, ...); the mirror path agrees with
+    it to rounding (its bearings go through numpy's trigonometry, the store's through the library's)."""
     from .common_cv import get_depthmap_float32_from_png, get_images, imread
     from .common_tools import get_poses_from_file
     if visualizer_3D_VO is not None:
@@ -535,6 +624,38 @@ def run_VO(visualizer_3D_VO, camera_model, gt_poses_filename=None, est_poses_fil
         img_indices = [0]
         frames = _live_frames
     tracker = trackerClass(camera_model=camera_model, show_3D_points=False, results_path=results_path)
+    if frame_window is None:
+        frame_window = 32 if _live_frames is None else 1
+    engine_state = dict(engine=None, tried=False, window_s=0.0, windows=0)
+    if not rgbd and int(frame_window) > 0:
+        source = frames
+
+        def frames():   # the same frames, `frame_window` at a time through the batched front end
+            it = iter(source())
+            seq_index = 0
+            while True:
+                chunk = []
+                for item in it:
+                    chunk.append(item)
+                    if len(chunk) >= int(frame_window):
+                        break
+                if not chunk:
+                    return
+                if not engine_state["tried"]:
+                    engine_state["tried"] = True
+                    engine_state["engine"] = sequence_engine_for(tracker, camera_model, chunk[0][1], int(frame_window))
+                eng = engine_state["engine"]
+                if eng is None:          # no batched counterpart of this configuration: the per-frame path
+                    for item in chunk:
+                        yield item
+                    continue
+                t0 = time.process_time()
+                infos = eng.push_window([item[1] for item in chunk])
+                engine_state["window_s"] += time.process_time() - t0
+                engine_state["windows"] += 1
+                for item, info in zip(chunk, infos):
+                    yield item[0], item[1], None, info, seq_index
+                    seq_index += 1
     if gt_poses_filename is None or not os.path.exists(gt_poses_filename):
         n_gt = max(len(img_indices), img_indices[-1] + 1)
         gt_list = n_gt * [np.identity(4)]   # (a live run has no ground truth: identity for every frame, as :1012)
@@ -572,14 +693,19 @@ def run_VO(visualizer_3D_VO, camera_model, gt_poses_filename=None, est_poses_fil
         t_frame = time.process_time()
         t0 = time.process_time()
         try:
-            idx, img, depth_map = next(frame_iter)
+            item = next(frame_iter)
         except StopIteration:
             break
+        idx, img, depth_map = item[:3]
+        dev_info = item[3] if len(item) > 3 else None
         img_index_number += 1
         if img_index_number > 0:
             acc["read"] += time.process_time() - t0
         t0 = time.process_time()
-        if rgbd:
+        if dev_info is not None:
+            current_frame = DeviceStereoFrame(engine_state["engine"], dev_info, camera_model, frame_id=idx, seq_index=item[4],
+                                              parent_id=current_keyframe_id)
+        elif rgbd:
             current_frame = RGBDFrame(rgbd_camera_model=camera_model, frame_id=idx, rgb_img=img, depth_map=depth_map,
                                       parent_id=current_keyframe_id)
         else:
@@ -633,6 +759,8 @@ def run_VO(visualizer_3D_VO, camera_model, gt_poses_filename=None, est_poses_fil
             tracked_wrt_keyframe = 0
             tracked_prev_avg = 0.
             reference_frame = KeyFrameClass(frame=current_frame)
+            if dev_info is not None:
+                current_frame.promote()   # the frame's record moves to the store's keyframe slot
             current_keyframe_id = reference_frame.frame_id
             print(current_keyframe_id, file=kf_file)
             keyframe_ids.append(current_keyframe_id)
@@ -673,11 +801,16 @@ def run_VO(visualizer_3D_VO, camera_model, gt_poses_filename=None, est_poses_fil
     say(summary)
     for f in (est_file, gt_file, kf_file, log):
         f.close()
-    return dict(poses=poses_out, keyframe_ids=keyframe_ids, tracked=n_done, message=summary)
+    out = dict(poses=poses_out, keyframe_ids=keyframe_ids, tracked=n_done, message=summary)
+    if engine_state["engine"] is not None:
+        eng = engine_state["engine"]
+        out["sequence_mode"] = dict(frame_window=eng.W, windows=engine_state["windows"], serial_tracking_calls=eng.serial_calls,
+                                    front_end_and_speculation_s=engine_state["window_s"])
+    return out
 
 
 def run_VO_live(visualizer_3D_VO, camera_model, cam_working_thread, est_poses_filename="estimated_frame_poses_TUM.txt",
-                results_path="~/temp", thread_name=""):
+                results_path="~/temp", thread_name="", frame_window=None):
     """pose_est_tools.py:960-1262: the VO loop on the frames of a running camera thread.  `cam_working_thread` is the
     reference's CamAsWorkingThread contract (webcam_live.py:256-291; `omnistereo.webcam_live.FrameSourceThread` here):
     `.current_frame` = the most recent omni image (None when the source ends), `.quit_flag`.  Each pass of the loop
@@ -697,11 +830,11 @@ def run_VO_live(visualizer_3D_VO, camera_model, cam_working_thread, est_poses_fi
             idx += 1
     return run_VO(visualizer_3D_VO, camera_model, gt_poses_filename=None, est_poses_filename=est_poses_filename,
                   results_path=results_path, thread_name=thread_name, _live_frames=frames,
-                  _keyframe_thresholds=(0.05, 0.50, np.deg2rad(5.0), np.deg2rad(60.0)))
+                  _keyframe_thresholds=(0.05, 0.50, np.deg2rad(5.0), np.deg2rad(60.0)), frame_window=frame_window)
 
 
 def driver_VO_live(camera_model, scene_path_vo_results, cam_working_thread, visualize_VO=False, use_multithreads_for_VO=True,
-                   thread_name="LIVE"):
+                   thread_name="LIVE", frame_window=None):
     """pose_est_tools.py:1743-1797: start the camera thread, run run_VO_live (on a worker thread or inline), then stop
     and join the camera thread."""
     if visualize_VO:
@@ -718,7 +851,8 @@ def driver_VO_live(camera_model, scene_path_vo_results, cam_working_thread, visu
         while cam_working_thread.current_frame is None and cam_working_thread.is_alive() and not cam_working_thread.quit_flag:
             time.sleep(0.001)   # (the reference starts tracking at once and stops if no frame has arrived yet)
     kwargs = dict(visualizer_3D_VO=None, camera_model=camera_model, cam_working_thread=cam_working_thread,
-                  est_poses_filename=est_poses_filename, results_path=scene_path_vo_results, thread_name=thread_name)
+                  est_poses_filename=est_poses_filename, results_path=scene_path_vo_results, thread_name=thread_name,
+                  frame_window=frame_window)
     result, failure = {}, []
     try:
         if use_multithreads_for_VO:
@@ -743,7 +877,7 @@ def driver_VO_live(camera_model, scene_path_vo_results, cam_working_thread, visu
 
 def driver_VO(camera_model, scene_path, scene_path_vo_results, scene_img_filename_template, depth_filename_template,
               num_scene_images, visualize_VO=False, use_multithreads_for_VO=True, step_for_scene_images=1, first_image_index=0,
-              last_image_index=-1, thread_name=""):
+              last_image_index=-1, thread_name="", frame_window=None):
     """pose_est_tools.py:1680-1741: frame index list, ground truth file discovery (gt_TUM.txt unless the scene is a
     static one), run_VO on a worker thread (as the reference does next to its GUI loop) or inline."""
     if visualize_VO:
@@ -766,7 +900,7 @@ def driver_VO(camera_model, scene_path, scene_path_vo_results, scene_img_filenam
     kwargs = dict(visualizer_3D_VO=None, camera_model=camera_model, gt_poses_filename=gt_poses_filename,
                   est_poses_filename=est_poses_filename, img_filename_template=scene_img_filename_template,
                   depth_filename_template=depth_filename_template, img_indices=vo_frame_indices,
-                  results_path=scene_path_vo_results, thread_name=thread_name)
+                  results_path=scene_path_vo_results, thread_name=thread_name, frame_window=frame_window)
     result = {}
     if use_multithreads_for_VO:
         # one libsosvo context per host thread: the worker creates its own

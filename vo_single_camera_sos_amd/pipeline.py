@@ -355,6 +355,111 @@ class FramePairBatch(object):
         return self.out
 
 
+class SequenceEngine(object):
+    """Sequence mode of the SOS hot path (include/sosvo.h "Sequence mode"; the reference's VO loop, run_VO,
+    pose_est_tools.py:1416-1628): the front end of every frame is computed ONCE, `window` frames per batch, into a
+    frame store in HBM, and frames are tracked against keyframes by slot number.
+
+    The keyframe chain is serial (the policy at :1509-1565 needs each tracked pose), but a tracking record is a pure
+    function of (reference frame, current frame, seed): push_window() therefore also tracks every frame of the window
+    against its PREDECESSOR in one batched call (on these sequences nearly every frame is promoted to keyframe, so the
+    predecessor usually IS the reference); resolve() hands that record out when the guess was right and runs one serial
+    tracking call when it was not.  Either way the records are those of the serial loop, whatever the window size.
+
+    Store layout: two window halves [0, W) and [W, 2W) used alternately (the last frame of the previous window stays
+    readable) and slot 2W for the current keyframe."""
+
+    def __init__(self, ctx, model, rig, window=32, num_of_features=1000, kp_cap=None, frame_cap=2048, median_win_size=11,
+                 quality=0.01, min_distance=5.0, edge=31, thr=None, max_iter=210, adaptive=True, lm_iter=30,
+                 ransac_solver="GP3P"):
+        """Defaults: the trackers' settings (pose_est_tools.py:672-707: 5-degree threshold, the iteration budget of
+        compute_num_of_iterations_RANSAC = 210 with the adaptive stop, generalised P3P; LM 30 iterations)."""
+        from . import _lib, orb_pattern
+        assert isinstance(ctx, Context)
+        self.ctx, self.model, self.rig_cfg, self.rig = ctx, model, rig, rig.as_struct()
+        self.W = max(1, int(window))
+        self.slots, self.key_slot = 2 * self.W + 1, 2 * self.W
+        if kp_cap is None:
+            kp_cap = int(min(1024, max(64, -(-int(num_of_features) // 64) * 64)))
+        cos_a, sin_a = orb_pattern.angle_cos_sin(orb_pattern.GFT_KEYPOINT_ANGLE)
+        c = _lib.BatchCfg()
+        c.n_pairs, c.H, c.W, c.rows, c.cols, c.nmask = self.W, model.H, model.W, model.rows, model.cols, model.nmask
+        c.kp_cap, c.frame_cap, c.median_ksize, c.max_corners, c.edge = int(kp_cap), int(frame_cap), int(median_win_size), \
+            int(num_of_features), int(edge)
+        c.ransac_max_iter, c.ransac_adaptive, c.lm_max_iter = int(max_iter), 1 if adaptive else 0, int(lm_iter)
+        c.quality, c.min_distance = float(quality), float(min_distance)
+        c.ransac_threshold = float(1.0 - np.cos(np.deg2rad(5.0))) if thr is None else float(thr)
+        c.seed, c.cos_a, c.sin_a = 0, float(cos_a), float(sin_a)
+        if str(ransac_solver).upper() not in ("P3P", "GP3P"):
+            raise ValueError("ransac_solver: P3P or GP3P")
+        c.ransac_flags, c.reserved = (_lib.FLAG_GP3P if str(ransac_solver).upper() == "GP3P" else 0), 0
+        self.cfg = c
+        if getattr(model, "unwrap_table", None) is None:  # once per model
+            model.unwrap_table = ctx.unwrap_prepare(model.omni_masks, model.map_x, model.map_y, (model.H, model.W))
+        nbytes = ctx.sequence_workspace(c, self.W, self.slots)
+        if nbytes <= 0:
+            raise ValueError("bad sequence configuration")
+        dev = ctx.device
+        self.workspace = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        self.omni = torch.zeros((self.W, model.H, model.W, 3), dtype=torch.uint8, device=dev)
+        self._host = torch.zeros((self.W, model.H, model.W, 3), dtype=torch.uint8).pin_memory()
+        self.spec = torch.zeros((self.W, 16), dtype=torch.float64, device=dev)
+        self.one = torch.zeros((1, 16), dtype=torch.float64, device=dev)
+        self.half = 1            # the half the NEXT window goes to is 1 - half
+        self.last_slot = None    # slot of the newest frame of the sequence
+        self.frames_seen = 0     # frames pushed so far (frame t of the sequence is tracked with seed t - 1)
+        self.serial_calls = 0    # tracking calls the speculation did not cover
+
+    def push_window(self, images):
+        """images: list / array of n <= window omni frames [H,W,3] u8 (BGR) that continue the sequence.
+        -> list of n dicts(slot, count = StereoPanoramicFrame.num_valid_keypoints, seed, spec_ref = slot the speculative
+        record was tracked against or None, spec = that [16] record (numpy) or None).  One host synchronisation."""
+        n = len(images)
+        if n == 0:
+            return []
+        if n > self.W:
+            raise ValueError("more frames than the window holds")
+        c, m = self.ctx, self.model
+        for i in range(n):
+            self._host[i].copy_(torch.from_numpy(np.ascontiguousarray(images[i])))
+        self.omni[:n].copy_(self._host[:n], non_blocking=True)
+        self.half = 1 - self.half
+        first = self.half * self.W
+        c.sequence_front_end(self.rig, self.cfg, self.W, self.slots, self.omni[:n], first, m.unwrap_table, m.mask_bits,
+                             m.pattern, self.workspace)
+        # speculative tracking: frame i of the window against its predecessor (the first one against the previous
+        # window's last frame; the very first frame of the sequence has nothing to track against)
+        slots = [first + i for i in range(n)]
+        prev = ([self.last_slot] if self.last_slot is not None else []) + slots[:-1]
+        cur = slots if self.last_slot is not None else slots[1:]
+        seed0 = self.frames_seen - 1 if self.last_slot is not None else 0   # frame t tracks with seed t - 1
+        if cur:
+            c.sequence_track(self.rig, self.cfg, self.W, self.slots, prev, cur, seed0, self.workspace, self.spec)
+        counts = c.sequence_frame_counts(self.cfg, self.W, self.slots, first, n, self.workspace)   # synchronises
+        spec = self.spec[:len(cur)].cpu().numpy() if cur else np.zeros((0, 16))
+        out = []
+        for i in range(n):
+            t = self.frames_seen + i            # index of the frame in the sequence
+            j = i if self.last_slot is not None else i - 1
+            has = j >= 0 and len(cur) > 0
+            out.append(dict(slot=slots[i], count=counts[i], seed=max(t - 1, 0), spec_ref=prev[j] if has else None,
+                            spec=spec[j].copy() if has else None))
+        self.frames_seen += n
+        self.last_slot = slots[-1]
+        return out
+
+    def track(self, ref_slot, cur_slot, seed):
+        """One serial tracking call (reference slot, current slot, seed) -> [16] record (numpy); synchronises."""
+        self.serial_calls += 1
+        self.ctx.sequence_track(self.rig, self.cfg, self.W, self.slots, [int(ref_slot)], [int(cur_slot)], int(seed),
+                                self.workspace, self.one)
+        return self.one.cpu().numpy()[0]
+
+    def promote(self, slot):
+        """The frame in `slot` becomes the keyframe: its record is copied to the keyframe slot (asynchronous)."""
+        self.ctx.sequence_copy_slot(self.cfg, self.W, self.slots, int(slot), self.key_slot, self.workspace)
+
+
 def rgbd_solver_flags(pose_est_algorithm):
     """TrackerSE3.pose_est_algorithm (pose_est_tools.py:697; the names pyopengv.absolute_pose_ransac accepts, :89-107)
     -> the SOSVO_FLAG_* bits of the central RANSAC.  Unknown names raise, so that a batched engine can never silently run
