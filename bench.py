@@ -106,6 +106,74 @@ def other_configs_subrecords(timeout_s=420):
     return out
 
 
+def sequence_subrecord(seq_omni, seq_poses, pano_width, mirror_frames=32):
+    """SEQUENCE MODE (SURVEY 8(e) caveat; the reference's VO loop, pose_est_tools.py:1416-1628): run_VO on ONE synthetic
+    sequence held in host memory -- every frame's front end computed once, `frame_window` frames per batched pass, tracking
+    against keyframes from the device-resident frame store -- timed end to end by the host clock (engine set-up, host-to-
+    device copies of the frames and the keyframe policy on the host included), beside the same loop at frame_window 1 and the
+    per-frame mirror path (StereoPanoramicFrame on host arrays, one set of stage calls per frame: what the reference's loop
+    does call by call).  The reference-style per-phase averages are the ones run_VO itself logs (process time)."""
+    import contextlib
+    import io
+    import re
+    import tempfile
+    from vo_single_camera_sos_amd.omnistereo import transformations as tr
+    from vo_single_camera_sos_amd.omnistereo.gum import synthetic_gums
+    from vo_single_camera_sos_amd.omnistereo.panorama import Panorama
+    from vo_single_camera_sos_amd.omnistereo.pose_est_tools import run_VO
+    N = seq_omni.shape[0]
+    out = {"frames": N, "panorama_width": pano_width, "data": "synthetic (one room, random-walk trajectory, steps <= 40 mm / 2 deg)",
+           "tracker": "reference settings: GFT 1000 per mask, GP3P RANSAC <= 210 iterations (adaptive), 5 deg threshold, LM"}
+    texts = {}
+    for label, window, n in (("frame_window_32", 32, N), ("frame_window_1", 1, N), ("mirror_per_frame", 0, min(N, mirror_frames))):
+        gs = synthetic_gums()
+        for m in (gs.top_model, gs.bot_model):
+            m.panorama = Panorama(m, width=pano_width)
+        gs.make_annulus_masks(seq_omni.shape[1:3])
+
+        def frames(n=n):
+            for k in range(n):
+                yield k, seq_omni[k], None
+        with tempfile.TemporaryDirectory() as d, contextlib.redirect_stdout(io.StringIO()):
+            if label == "frame_window_32":   # library scratch, unwrap table, first-use costs: outside the clock
+                run_VO(None, gs, results_path=d, _live_frames=lambda: frames(4), frame_window=4)
+                torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = run_VO(None, gs, results_path=d, _live_frames=frames, frame_window=window)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            texts[label] = open(os.path.join(d, "estimated_frame_poses_TUM.txt")).read()
+        rec = {"frames": n, "frames_per_s": n / dt, "ms_per_frame": 1e3 * dt / n, "tracked": r["tracked"],
+               "keyframes": len(r["keyframe_ids"])}
+        for key, pat in (("image_read_avg_s", "Image Read Avg Time"), ("frame_setup_avg_s", "Frame Setup Avg Time"),
+                         ("frame_tracking_avg_s", "Frame Tracking Avg Time"), ("overall_frame_vo_avg_s", "Overall Frame VO Avg Time")):
+            mt = re.search(pat + r": ([0-9.eE+-]+) seconds", r["message"])
+            rec[key] = float(mt.group(1)) if mt else None
+        if "sequence_mode" in r:
+            rec.update(serial_tracking_calls=r["sequence_mode"]["serial_tracking_calls"], windows=r["sequence_mode"]["windows"],
+                       host_wall_s=dict(r["sequence_mode"]["stage_s"], total=dt))
+        # per-hop accuracy against the planted trajectory (relative pose of consecutive frames)
+        rot, tra = [], []
+        P = r["poses"]
+        for k in range(1, len(P)):
+            Tg = [np.identity(4), np.identity(4)]
+            for j, q in enumerate((k - 1, k)):
+                Tg[j][:3, :3], Tg[j][:3, 3] = seq_poses[q][0], seq_poses[q][1] * 1e-3
+            E = tr.rpe(tr.concatenate_matrices(tr.inverse_matrix(Tg[0]), Tg[1]),
+                       tr.concatenate_matrices(tr.inverse_matrix(P[k - 1][1]), P[k][1]))
+            rot.append(np.degrees(tr.rpe_rotation_metric(E)))
+            tra.append(1e3 * tr.rpe_translation_metric(E))
+        rec.update(per_hop_rotation_error_deg_median=float(np.median(rot)), per_hop_translation_error_mm_median=float(np.median(tra)))
+        out[label] = rec
+    out["pose_file_identical_window_32_vs_1"] = texts["frame_window_32"] == texts["frame_window_1"]
+    n_m = out["mirror_per_frame"]["frames"]
+    a = np.loadtxt(io.StringIO(texts["frame_window_32"]))[:n_m]
+    b = np.loadtxt(io.StringIO(texts["mirror_per_frame"]))
+    out["mirror_max_abs_pose_difference"] = float(np.abs(a - b).max())
+    out["value"], out["unit"] = out["frame_window_32"]["frames_per_s"], "frames/s"
+    return out
+
+
 def opencv_opengv_baseline(omni, model, rig_kw, args, n_pairs):
     """if cv2 / pyopengv happen to be importable on this box, time the reference's own third-party calls
     (written against their public API; no reference file is shipped) on a bounded sample and report that as the primary
@@ -280,6 +348,8 @@ def parse():
     ap.add_argument("--no-sub", action="store_true",
                     help="skip the sub-records (ORB-detector path, GP3P hypotheses, BASELINE configs 3 and 5)")
     ap.add_argument("--sub-steps", type=int, default=5, help="timed steps of each in-process sub-record")
+    ap.add_argument("--sequence-frames", type=int, default=256,
+                    help="frames of the synthetic sequence of the `sequence` sub-record (run_VO in sequence mode); 0 = skip")
     ap.add_argument("--dump-records", default=None,
                     help="rank 0 writes the last step's gathered [N*B,16] records (global pair order) to this .npy file")
     return ap.parse_args()
@@ -365,6 +435,9 @@ def main():
     # rank r owns the global pairs [r*B, (r+1)*B) of ONE job of world*B pairs: pair g is rendered from seed + g and
     # its RANSAC samples from seed + g, so the gathered records equal those of a single process over the same pairs
     omni, poses = synthetic.make_frame_pairs(gs, B, seed=args.seed, workers=workers, first=rank * B)
+    seq_omni = None
+    if world == 1 and not args.no_sub and args.sequence_frames > 0:   # (rendered here: forked workers, before any GPU call)
+        seq_omni, seq_poses = synthetic.make_sequence(gs, args.sequence_frames, seed=args.seed + 7, workers=workers)
     dist = None
     # (SOSVO_BENCH_FORCE_DIST=1: a launcher-started single rank also goes through init_process_group + the RCCL
     # gather -- tests/test_gpu_bench_rccl.py rehearses the N > 1 code path on the one-GPU box that way)
@@ -609,6 +682,11 @@ def main():
         dist.destroy_process_group()
     eng.close()
     if rank == 0:
+        if sub_other and seq_omni is not None:
+            try:
+                out["sequence"] = sequence_subrecord(seq_omni, seq_poses, args.pano_width)
+            except Exception as e:  # the headline number does not depend on it
+                out["sequence"] = {"error": repr(e)}
         if sub_other:
             torch.cuda.synchronize()
             out.update(other_configs_subrecords())

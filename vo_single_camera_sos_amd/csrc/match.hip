@@ -3,20 +3,19 @@
 // Reference call sites: cv2.BFMatcher(NORM_HAMMING).match / knnMatch at
 // omnistereo/camera_models.py:442 / :420 and sorted(matches, key=distance) at :444.
 //
-// Mapping to CDNA4: one query descriptor lives in 8 VGPRs of one lane (QPT queries per
-// lane to reuse every LDS read), the train set streams through an 8 KB LDS tile and is
-// read back as wave-wide broadcasts (all lanes read the same 32 bytes), distance is
-// 8 x (v_xor_b32 + accumulating v_bcnt_u32_b32).  The result is carried as the packed key
-// (distance << 20 | train index): an unsigned min over keys is exactly "smallest
+// Mapping to CDNA4: the 1-NN / 2-NN search is an exact integer contraction on the MATRIX cores
+// (hamming = |q| + |t| - 2 q.t on descriptors unpacked to one byte per bit, v_mfma_i32_32x32x32_i8; see
+// match_hamming_mfma_kernel) -- the step around it is VALU-issue bound, the matrix pipe was idle.  The result is
+// carried as the packed key (distance << 20 | train index): an unsigned min over keys is exactly "smallest
 // distance, first train index wins", so partial results of train-range splits merge with
-// one atomicMin and stay bit-identical to a sequential scan.  No MFMA: there is no
-// contraction here, only popcounts.
+// one atomicMin and stay bit-identical to a sequential scan.  Round 1-2 ran this stage on the VALU (one query per
+// lane in 8 VGPRs, train tile in LDS read as broadcasts, 8 x (v_xor + v_bcnt) per pair: 18 VALU wave-instructions per
+// 64 pairs against ~2.5 now); the radius search (not on the VO path) still does.
 #include "common.h"
 
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kTrainTile = 256;  // descriptors per LDS tile (8 KB)
 
 __device__ __forceinline__ uint32_t hamming256(const uint4& a0, const uint4& a1, const uint4& b0,
                                                const uint4& b1) {
@@ -31,81 +30,159 @@ __device__ __forceinline__ uint32_t hamming256(const uint4& a0, const uint4& a1,
   return d;
 }
 
-template <int QPT, int K>
-__global__ __launch_bounds__(kThreads) void match_hamming_kernel(
+// ---- K7 on the matrix pipe ------------------------------------------------------------------------------
+// hamming(q, t) = |q| + |t| - 2 q.t on 0/1 vectors: the pair distances of a (32 trains x 32 queries) tile are ONE exact
+// integer contraction over K = 256, i.e. eight v_mfma_i32_32x32x32_i8 on descriptors unpacked to one byte per bit.  The
+// step around this kernel is VALU-issue bound and MFMA issues beside VALU, so the 8 x (xor + popcount) per pair of the
+// kernel above (18 VALU wave-instructions per 64 pairs) become 2 per 64 pairs (key formation + running minimum) plus the
+// unpacking, and the contraction itself runs on the otherwise idle matrix cores.
+//   unpacking: any permutation of the 256 bit positions applied to both sides keeps q.t, so the cheapest one is used:
+//     dword w of a descriptor -> K-block w; lane half h (= lane / 32) takes the bits {s + 4 h + 8 b}: operand dword s =
+//     (x >> (s + 4 h)) & 0x01010101, byte b.  A operands (trains): unpacked once per workgroup into an LDS tile (row pitch
+//     272 B: conflict-free ds_read_b128 across the 16-lane groups); B operands (queries): 32 VGPRs per 32-query tile, resident.
+//   epilogue: accumulator r of lane l is (train row 8 (r / 4) + 4 (l / 32) + r % 4, query column l % 32).  With
+//     base[row] = |t| << 20 | train index (LDS), the signed partial key base - (q.t << 21) = ((|t| - 2 q.t) << 20) + index
+//     orders exactly like the packed key of the VALU kernel (|q| is constant per lane and added at the end), so the same
+//     signed min / first-index tie rule holds; rows past the train count carry base = 2^30 and never win.
+constexpr int kMmaTrainTile = 128;                  // trains per LDS tile
+constexpr int kMmaRowPitch = 272;                   // bytes per unpacked train row (256 + 16)
+constexpr int32_t kMmaInvalid = 1 << 30;
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+typedef int v16i32 __attribute__((ext_vector_type(16)));
+
+template <int QT, int K>
+__global__ __launch_bounds__(kThreads) void match_hamming_mfma_kernel(
     const uint4* __restrict__ q_desc, const uint4* __restrict__ t_desc, const int32_t* __restrict__ nq,
     const int32_t* __restrict__ nt, const int32_t* __restrict__ q_slot, const int32_t* __restrict__ t_slot,
     int q_stride, int t_stride, int nsplit, uint32_t* __restrict__ keys) {
   SOSVO_LATENCY_BOUND_PRIO();
-  __shared__ uint4 tile[kTrainTile * 2];
-  const int tid = threadIdx.x;
-  // XCD-aware grid: workgroups go round-robin over the 8 XCDs by linear id, so the problem index (all
-  // workgroups busy) is the fastest dimension and the query tile (early exit beyond nq) the second.
+  __shared__ __attribute__((aligned(16))) uint8_t tile[kMmaTrainTile * kMmaRowPitch];
+  __shared__ __attribute__((aligned(16))) int32_t base[kMmaTrainTile];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 31, half = lane >> 5;
   const int p = blockIdx.x;
-  const int qs = q_slot ? q_slot[p] : p;  // which block of query rows / counts this problem uses
-  const int ts = t_slot ? t_slot[p] : p;
-  const int nqp = min(nq[qs], q_stride);
-  const int ntp = min(nt[ts], t_stride);
-  const int q0 = blockIdx.y * (kThreads * QPT);
+  const int qs = q_slot ? q_slot[p] : p, ts = t_slot ? t_slot[p] : p;
+  const int nqp = min(nq[qs], q_stride), ntp = min(nt[ts], t_stride);
+  constexpr int kQPerWg = (kThreads / 64) * 32 * QT;
+  const int q0 = blockIdx.y * kQPerWg;
   if (q0 >= nqp) return;  // uniform over the workgroup
-
-  // train range of this split, whole tiles
-  const int tiles = (ntp + kTrainTile - 1) / kTrainTile;
+  const int tiles = (ntp + kMmaTrainTile - 1) / kMmaTrainTile;
   const int tiles_per = (tiles + nsplit - 1) / nsplit;
-  const int tb = blockIdx.z * tiles_per * kTrainTile;
-  const int te = min(ntp, tb + tiles_per * kTrainTile);
+  const int tb = blockIdx.z * tiles_per * kMmaTrainTile;
+  const int te = min(ntp, tb + tiles_per * kMmaTrainTile);
   if (nsplit > 1 && tb >= te) return;  // keys were pre-set to NONE
 
-  uint4 qa[QPT], qb[QPT];
-  uint32_t best[QPT], second[QPT];
-  // One query per lane (the small per-bucket problems): a wave whose 64 rows all lie beyond nq sits out the distance
-  // loop (wave-uniform, scalar test per train tile); it still loads its share of the tile.  With 4 queries per lane the
-  // same test inside the unrolled loop costs more than the ragged tail it saves (measured), so it is not applied there.
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  bool live[QPT];
+  // ---- this wave's queries: unpacked B operands, resident
+  v4i32 bq[QT][8];
+  int32_t pq[QT];
+  int32_t best[QT], second[QT];
+  // (a wave whose first tile lies beyond the query count sits out the contraction; a dead SECOND tile is computed on a
+  // repeated row and never stored: no branch inside the MFMA sequence)
+  const bool wave_live = q0 + wave * QT * 32 < nqp;  // wave-uniform
 #pragma unroll
-  for (int r = 0; r < QPT; ++r) {
-    live[r] = q0 + r * kThreads + wave * 64 < nqp;
-    const int qi = q0 + r * kThreads + tid;
-    const bool valid = qi < nqp;
-    const size_t row = (size_t)qs * q_stride + (valid ? qi : q0);
-    qa[r] = q_desc[row * 2 + 0];
-    qb[r] = q_desc[row * 2 + 1];
-    best[r] = SOSVO_KEY_NONE;
-    second[r] = SOSVO_KEY_NONE;
+  for (int t = 0; t < QT; ++t) {
+    const int qbase = q0 + (wave * QT + t) * 32;
+    const int qi = qbase + col;
+    const size_t row = (size_t)qs * q_stride + (qi < nqp ? qi : q0);
+    const uint4 a = q_desc[row * 2 + 0], b = q_desc[row * 2 + 1];
+    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    int32_t pc = 0;
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+      pc += __popc(w[kb]);
+      const uint32_t x = w[kb] >> (4 * half);
+      bq[t][kb] = v4i32{(int)(x & 0x01010101u), (int)((x >> 1) & 0x01010101u), (int)((x >> 2) & 0x01010101u),
+                        (int)((x >> 3) & 0x01010101u)};
+    }
+    pq[t] = pc;
+    best[t] = kMmaInvalid;
+    second[t] = kMmaInvalid;
   }
 
   const uint4* tsrc = t_desc + (size_t)ts * t_stride * 2;
-  for (int t0 = tb; t0 < te; t0 += kTrainTile) {
-    const int lim = min(kTrainTile, te - t0);
+  for (int t0 = tb; t0 < te; t0 += kMmaTrainTile) {
+    const int lim = min(kMmaTrainTile, te - t0);
+    const int nrb = (lim + 31) >> 5;  // 32-row blocks that hold a train
     __syncthreads();
-    for (int i = tid; i < lim * 2; i += kThreads) tile[i] = tsrc[(size_t)t0 * 2 + i];
+    // unpack the train tile: item = (train j, dword kb) -> 32 bytes (both halves)
+    for (int it = tid; it < nrb * 32 * 8; it += kThreads) {
+      const int j = it >> 3, kb = it & 7;
+      const uint32_t x = j < lim ? reinterpret_cast<const uint32_t*>(tsrc + (size_t)(t0 + j) * 2)[kb] : 0u;
+      uint4 lo, hi;
+      lo.x = x & 0x01010101u;
+      lo.y = (x >> 1) & 0x01010101u;
+      lo.z = (x >> 2) & 0x01010101u;
+      lo.w = (x >> 3) & 0x01010101u;
+      hi.x = (x >> 4) & 0x01010101u;
+      hi.y = (x >> 5) & 0x01010101u;
+      hi.z = (x >> 6) & 0x01010101u;
+      hi.w = (x >> 7) & 0x01010101u;
+      uint4* dst = reinterpret_cast<uint4*>(tile + j * kMmaRowPitch + kb * 32);
+      dst[0] = lo;
+      dst[1] = hi;
+    }
+    for (int j = tid; j < nrb * 32; j += kThreads) {
+      int32_t v = kMmaInvalid;
+      if (j < lim) {
+        const uint4 a = tsrc[(size_t)(t0 + j) * 2 + 0], b = tsrc[(size_t)(t0 + j) * 2 + 1];
+        const int32_t pc = __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w) + __popc(b.x) + __popc(b.y) + __popc(b.z) +
+                           __popc(b.w);
+        v = (pc << SOSVO_KEY_SHIFT) + (t0 + j);
+      }
+      base[j] = v;
+    }
     __syncthreads();
-    if (QPT == 1 && !live[0]) continue;
-#pragma unroll 4
-    for (int j = 0; j < lim; ++j) {
-      const uint4 ta = tile[2 * j + 0];
-      const uint4 tb4 = tile[2 * j + 1];
-      const uint32_t tj = (uint32_t)(t0 + j);
+    if (!wave_live) continue;  // (uniform per wave; the barriers above are reached by every wave)
+    for (int rb = 0; rb < nrb; ++rb) {
+      v16i32 acc[QT];
 #pragma unroll
-      for (int r = 0; r < QPT; ++r) {
-        const uint32_t key = (hamming256(qa[r], qb[r], ta, tb4) << SOSVO_KEY_SHIFT) | tj;
-        if (K == 2) second[r] = min(second[r], max(best[r], key));
-        best[r] = min(best[r], key);
+      for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0;
+      const uint8_t* arow = tile + (rb * 32 + col) * kMmaRowPitch + half * 16;
+#pragma unroll
+      for (int kb = 0; kb < 8; ++kb) {
+        const v4i32 a = *reinterpret_cast<const v4i32*>(arow + kb * 32);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[t][kb], acc[t], 0, 0, 0);
+      }
+      int32_t bs[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const v4i32 b4 = *reinterpret_cast<const v4i32*>(base + rb * 32 + 8 * g + 4 * half);
+        bs[4 * g + 0] = b4.x;
+        bs[4 * g + 1] = b4.y;
+        bs[4 * g + 2] = b4.z;
+        bs[4 * g + 3] = b4.w;
+      }
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int32_t key = bs[r] - (acc[t][r] << (SOSVO_KEY_SHIFT + 1));
+          if (K == 2) second[t] = min(second[t], max(best[t], key));
+          best[t] = min(best[t], key);
+        }
       }
     }
   }
 
+  // ---- the two lane halves of a column hold the same query: merge, add |q|, store
 #pragma unroll
-  for (int r = 0; r < QPT; ++r) {
-    const int qi = q0 + r * kThreads + tid;
-    if (qi < nqp) {
+  for (int t = 0; t < QT; ++t) {
+    const int32_t ob = __shfl_xor(best[t], 32), os = __shfl_xor(second[t], 32);
+    const int32_t mb = min(best[t], ob);
+    const int32_t ms = min(min(second[t], os), max(best[t], ob));
+    const int qi = q0 + (wave * QT + t) * 32 + col;
+    if (half == 0 && qi < nqp) {
       uint32_t* out = keys + ((size_t)p * q_stride + qi) * K;
+      const uint32_t add = (uint32_t)pq[t] << SOSVO_KEY_SHIFT;
+      const uint32_t kb1 = mb >= kMmaInvalid ? SOSVO_KEY_NONE : (uint32_t)mb + add;
       if (K == 1 && nsplit > 1) {
-        atomicMin(out, best[r]);
+        atomicMin(out, kb1);
       } else {
-        out[0] = best[r];
-        if (K == 2) out[1] = second[r];
+        out[0] = kb1;
+        if (K == 2) out[1] = ms >= kMmaInvalid ? SOSVO_KEY_NONE : (uint32_t)ms + add;
       }
     }
   }
@@ -314,14 +391,15 @@ int32_t sosvo_match_hamming(sosvo_ctx* ctx, const uint8_t* q_desc, const uint8_t
   const uint4* q4 = reinterpret_cast<const uint4*>(q_desc);
   const uint4* t4 = reinterpret_cast<const uint4*>(t_desc);
 
-  // Queries per lane: 4 when there is enough work to still fill the chip, else 1.
-  const int qpt = (q_stride >= 1024) ? 4 : 1;
-  const int gx = cdiv(q_stride, kThreads * qpt);
+  // Matrix-pipe kernel (see match_hamming_mfma_kernel): 4 waves x QT tiles of 32 queries per workgroup.
+  const int qt = (q_stride >= 1024) ? 2 : 1;
+  const int q_per_wg = (kThreads / 64) * 32 * qt;
+  const int gx = cdiv(q_stride, q_per_wg);
   // Split the train range over grid.z until ~2k workgroups exist (1-NN only: the split
   // results merge with atomicMin on the packed key).
   int nsplit = 1;
   if (k == 1) {
-    const int tiles = cdiv(t_stride, kTrainTile);
+    const int tiles = cdiv(t_stride, kMmaTrainTile);
     nsplit = cdiv(2048, gx * nprob);
     if (nsplit > tiles) nsplit = tiles;
     if (nsplit < 1) nsplit = 1;
@@ -331,19 +409,19 @@ int32_t sosvo_match_hamming(sosvo_ctx* ctx, const uint8_t* q_desc, const uint8_t
     SOSVO_HIP(ctx, hipMemsetAsync(keys, 0xFF, (size_t)nprob * q_stride * sizeof(uint32_t), ctx->stream));
   dim3 grid(nprob, gx, nsplit), block(kThreads);
   if (k == 1) {
-    if (qpt == 4)
-      SOSVO_LAUNCH(ctx,(match_hamming_kernel<4, 1>), grid, block, 0, ctx->stream, q4, t4, nq, nt,
-                         q_slot, t_slot, q_stride, t_stride, nsplit, keys);
+    if (qt == 2)
+      SOSVO_LAUNCH(ctx, (match_hamming_mfma_kernel<2, 1>), grid, block, 0, ctx->stream, q4, t4, nq, nt, q_slot, t_slot, q_stride,
+                   t_stride, nsplit, keys);
     else
-      SOSVO_LAUNCH(ctx,(match_hamming_kernel<1, 1>), grid, block, 0, ctx->stream, q4, t4, nq, nt,
-                         q_slot, t_slot, q_stride, t_stride, nsplit, keys);
+      SOSVO_LAUNCH(ctx, (match_hamming_mfma_kernel<1, 1>), grid, block, 0, ctx->stream, q4, t4, nq, nt, q_slot, t_slot, q_stride,
+                   t_stride, nsplit, keys);
   } else {
-    if (qpt == 4)
-      SOSVO_LAUNCH(ctx,(match_hamming_kernel<4, 2>), grid, block, 0, ctx->stream, q4, t4, nq, nt,
-                         q_slot, t_slot, q_stride, t_stride, nsplit, keys);
+    if (qt == 2)
+      SOSVO_LAUNCH(ctx, (match_hamming_mfma_kernel<2, 2>), grid, block, 0, ctx->stream, q4, t4, nq, nt, q_slot, t_slot, q_stride,
+                   t_stride, nsplit, keys);
     else
-      SOSVO_LAUNCH(ctx,(match_hamming_kernel<1, 2>), grid, block, 0, ctx->stream, q4, t4, nq, nt,
-                         q_slot, t_slot, q_stride, t_stride, nsplit, keys);
+      SOSVO_LAUNCH(ctx, (match_hamming_mfma_kernel<1, 2>), grid, block, 0, ctx->stream, q4, t4, nq, nt, q_slot, t_slot, q_stride,
+                   t_stride, nsplit, keys);
   }
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;

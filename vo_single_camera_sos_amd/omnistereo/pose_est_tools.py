@@ -649,9 +649,9 @@ def run_VO(visualizer_3D_VO, camera_model, gt_poses_filename=None, est_poses_fil
                     for item in chunk:
                         yield item
                     continue
-                t0 = time.process_time()
+                t0 = time.perf_counter()
                 infos = eng.push_window([item[1] for item in chunk])
-                engine_state["window_s"] += time.process_time() - t0
+                engine_state["window_s"] += time.perf_counter() - t0
                 engine_state["windows"] += 1
                 for item, info in zip(chunk, infos):
                     yield item[0], item[1], None, info, seq_index
@@ -805,7 +805,7 @@ def run_VO(visualizer_3D_VO, camera_model, gt_poses_filename=None, est_poses_fil
     if engine_state["engine"] is not None:
         eng = engine_state["engine"]
         out["sequence_mode"] = dict(frame_window=eng.W, windows=engine_state["windows"], serial_tracking_calls=eng.serial_calls,
-                                    front_end_and_speculation_s=engine_state["window_s"])
+                                    front_end_and_speculation_s=engine_state["window_s"], stage_s=dict(eng.stage_s))
     return out
 
 

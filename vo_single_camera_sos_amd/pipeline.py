@@ -409,6 +409,8 @@ class SequenceEngine(object):
         self.last_slot = None    # slot of the newest frame of the sequence
         self.frames_seen = 0     # frames pushed so far (frame t of the sequence is tracked with seed t - 1)
         self.serial_calls = 0    # tracking calls the speculation did not cover
+        self._host_np = self._host.numpy()
+        self.stage_s = dict(stage_to_pinned=0.0, enqueue=0.0, wait_and_readback=0.0, serial_track=0.0)   # host wall clock
 
     def push_window(self, images):
         """images: list / array of n <= window omni frames [H,W,3] u8 (BGR) that continue the sequence.
@@ -419,9 +421,12 @@ class SequenceEngine(object):
             return []
         if n > self.W:
             raise ValueError("more frames than the window holds")
+        import time
         c, m = self.ctx, self.model
+        t0 = time.perf_counter()
         for i in range(n):
-            self._host[i].copy_(torch.from_numpy(np.ascontiguousarray(images[i])))
+            np.copyto(self._host_np[i], images[i])
+        t1 = time.perf_counter()
         self.omni[:n].copy_(self._host[:n], non_blocking=True)
         self.half = 1 - self.half
         first = self.half * self.W
@@ -435,8 +440,13 @@ class SequenceEngine(object):
         seed0 = self.frames_seen - 1 if self.last_slot is not None else 0   # frame t tracks with seed t - 1
         if cur:
             c.sequence_track(self.rig, self.cfg, self.W, self.slots, prev, cur, seed0, self.workspace, self.spec)
+        t2 = time.perf_counter()
         counts = c.sequence_frame_counts(self.cfg, self.W, self.slots, first, n, self.workspace)   # synchronises
         spec = self.spec[:len(cur)].cpu().numpy() if cur else np.zeros((0, 16))
+        t3 = time.perf_counter()
+        self.stage_s["stage_to_pinned"] += t1 - t0
+        self.stage_s["enqueue"] += t2 - t1
+        self.stage_s["wait_and_readback"] += t3 - t2
         out = []
         for i in range(n):
             t = self.frames_seen + i            # index of the frame in the sequence
@@ -450,10 +460,14 @@ class SequenceEngine(object):
 
     def track(self, ref_slot, cur_slot, seed):
         """One serial tracking call (reference slot, current slot, seed) -> [16] record (numpy); synchronises."""
+        import time
+        t0 = time.perf_counter()
         self.serial_calls += 1
         self.ctx.sequence_track(self.rig, self.cfg, self.W, self.slots, [int(ref_slot)], [int(cur_slot)], int(seed),
                                 self.workspace, self.one)
-        return self.one.cpu().numpy()[0]
+        rec = self.one.cpu().numpy()[0]
+        self.stage_s["serial_track"] += time.perf_counter() - t0
+        return rec
 
     def promote(self, slot):
         """The frame in `slot` becomes the keyframe: its record is copied to the keyframe slot (asynchronous)."""

@@ -177,6 +177,36 @@ def trajectory(n_frames, seed=0, max_t=40.0, max_deg=2.0):
     return poses
 
 
+def _render_seq_frame(args):
+    gums, seed, R, t, k = args
+    return render_omni(gums, Room(seed=seed), R, t, 2.0, np.random.default_rng(seed + 1 + k))
+
+
+def _render_seq_frame_pooled(args):
+    return _render_seq_frame((_POOL_GUMS,) + args)
+
+
+def make_sequence(gums, n_frames, seed=0, max_t=40.0, max_deg=2.0, workers=1):
+    """-> (omni [n_frames, H, W, 3] u8, poses list of (R, t [mm])): ONE room seen along a random-walk trajectory (frame k
+    from pose k; pixel noise seeded per frame, so the frames do not depend on the number of workers).  workers > 1 renders
+    in forked processes: call it BEFORE the process touches the GPU."""
+    global _POOL_GUMS
+    W, H = gums.top_model.image_size
+    if gums.top_model.mask is None:
+        gums.make_annulus_masks((H, W))
+    poses = trajectory(n_frames, seed, max_t, max_deg)
+    jobs = [(seed, R, t, k) for k, (R, t) in enumerate(poses)]
+    if workers > 1 and n_frames > 1:
+        import multiprocessing
+        _POOL_GUMS = gums
+        with multiprocessing.get_context("fork").Pool(min(int(workers), n_frames)) as pool:
+            frames = pool.map(_render_seq_frame_pooled, jobs, chunksize=max(1, n_frames // (4 * int(workers))))
+        _POOL_GUMS = None
+    else:
+        frames = [_render_seq_frame((gums,) + j) for j in jobs]
+    return np.stack(frames), poses
+
+
 def _write_gt_tum(filename, poses):
     from .omnistereo.transformations import quaternion_from_matrix
     with open(filename, "w") as f:
