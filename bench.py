@@ -34,6 +34,22 @@ def b_alg_c2(H, W, kpts):
     return 2 * H * W * 3 + 4 * kpts * 12 + 2 * kpts + 96
 
 
+def profile_meta(csv_path, run_cfg):
+    """The <tag>_meta.json written beside a profile summary by scripts/profile_bench.sh (commit, detector, solver, panorama
+    width, pairs per launch, streams) compared with THIS run: -> dict(profile_commit, stale (bool or "unknown"), differs)."""
+    tag = os.path.basename(csv_path).split("_")[0]
+    meta_path = os.path.join(os.path.dirname(csv_path), tag + "_meta.json")
+    if not os.path.exists(meta_path):
+        return {"profile_commit": None, "stale": "unknown (no metadata beside the summary)"}
+    meta = json.load(open(meta_path))
+    differs = sorted(k for k, v in run_cfg.items() if k in meta and meta[k] != v)
+    import subprocess
+    head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    if head and meta.get("commit") and head != meta["commit"]:
+        differs.append("commit")
+    return {"profile_commit": meta.get("commit"), "stale": bool(differs), "differs": differs}
+
+
 def pmc_traffic(kernel, pairs_per_launch, pmc_csv=None):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 --pmc summary of this same command
     (profiles/*/*_pmc_hbm_per_kernel.csv, written by scripts/summarize_pmc.py from separate FETCH_SIZE and
@@ -240,70 +256,114 @@ def host_cores():
         return max(1, os.cpu_count() or 1)
 
 
+MIX_KEYS = {"unwrap_median_gray_kernel": ["median_gray_kernel<11, 1>"], "median_gray_kernel": ["median_gray_kernel<11, 0>"],
+            "ransac_score_kernel": ["ransac_score_kernel<1, 4>"], "ransac_select_kernel": ["ransac_select_kernel<1>"],
+            "gft_select_kernel": ["gft_select_kernel<2048, 256>", "gft_select_kernel<4096, 256>"],
+            "match_hamming_mfma_kernel": ["match_hamming_mfma_kernel<2, 1>", "match_hamming_mfma_kernel<1, 1>"]}
+SIMD_GINST_NS = 1024 / 2.4   # issue cycles (normalised to 2.4 GHz, as scripts/isa_mix.py prices them) -> 1 / (ginst/s) helper
+
+
+def newest_isa_mix():
+    """(kernels dict, relative path, commit) of the newest committed profiles/*/*isa_mix.json."""
+    import glob
+    for path in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*isa_mix.json")))):
+        doc = json.load(open(path))
+        return doc["kernels"], os.path.relpath(path, ROOT), doc.get("commit")
+    return {}, None, None
+
+
+def mix_cycles(label, mix, default=4.4):
+    """Issue cycles (at 2.4 GHz) per VALU wave-instruction of the kernel a profile label names, from its OWN static mix."""
+    keys = MIX_KEYS.get(label, [label])
+    vals = [mix[k]["issue_cycles_per_valu_inst"] for k in keys if k in mix]
+    if not vals:
+        vals = [v["issue_cycles_per_valu_inst"] for k, v in mix.items() if k.split("<")[0] == label]
+    return (sum(vals) / len(vals), True) if vals else (default, False)
+
+
 def valu_issue(kernel, pairs_per_launch, avg_launch_s):
     """VALU instruction issue rate of `kernel` against the SIMDs' issue limit: the figure that actually bounds the
     dominant kernel.  Instruction count per launch from the newest committed SQ-counter summary
     (profiles/*/*_sq_per_kernel.csv: rocprofv3 --pmc SQ_INSTS_VALU ... of this command at B = 64, one stream); issue
-    cost per instruction from the kernel's static instruction mix (profiles/*/*_isa_mix.json, scripts/isa_mix.py:
-    2.8 SIMD-cycles for a plain VOP2 encoding, 4.4 for VOP3 / SDWA / DPP / 64-bit ops, both measured on the MI355X by
-    scripts/valu_rate.hip).  None without the summaries."""
+    cost per instruction from the kernel's static instruction mix (profiles/*/*isa_mix.json, scripts/isa_mix.py) priced
+    with the per-opcode rates MEASURED on the MI355X (scripts/valu_clock.hip, profiles/round3/valu_clock.txt: 2.50 real
+    shader cycles per wave-instruction per SIMD for the fast class at 2.2-2.35 GHz, 4.2-4.3 for the slow class at
+    2.37-2.39 GHz; quoted here normalised to 2.4 GHz: 2.7 / 4.4).  None without the summaries."""
     import csv
     import glob
     label = kernel.strip("()").split("<")[0]
-    cyc, mix_src = 4.4, None
-    for path in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*isa_mix.json")))):
-        mix = json.load(open(path))["kernels"]
-        key = {"unwrap_median_gray_kernel": "median_gray_kernel<11, 1>", "median_gray_kernel": "median_gray_kernel<11, 0>"}.get(label, label)
-        if key in mix:
-            cyc, mix_src = mix[key]["issue_cycles_per_valu_inst"], os.path.relpath(path, ROOT)
-            break
+    mix, mix_src, mix_commit = newest_isa_mix()
+    cyc, _ = mix_cycles(label, mix)
     for path in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*sq_per_kernel.csv")))):
         with open(path) as fh:
             for row in csv.DictReader(fh):
                 if row.get("label") == label:
                     insts = float(row["valu_insts"]) * pairs_per_launch / 64.0  # the SQ pass ran 64 pairs per launch
-                    limit = 1024 * 2.4e9 / cyc  # wave-instructions/s of 1024 SIMDs at 2.4 GHz
+                    limit = 1024 * 2.4e9 / cyc  # wave-instructions/s of 1024 SIMDs
                     guide = 1024 * 2.4e9 / 2.0  # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles
                     return {"kernel": kernel, "valu_wave_insts_per_launch": insts, "achieved_ginst_s": insts / avg_launch_s / 1e9,
                             "issue_cycles_per_inst": cyc, "issue_limit_ginst_s": limit / 1e9,
                             "frac": insts / avg_launch_s / limit,
                             "frac_vs_guide_2cyc": insts / avg_launch_s / guide,
                             "guide_limit_ginst_s": guide / 1e9,
-                            "source": os.path.relpath(path, ROOT), "mix_source": mix_src,
+                            "measured_real_cycles": {"fast_class": 2.50, "slow_class": 4.27, "fast_class_8_waves_per_simd": 2.25,
+                                                     "shader_clock_GHz_under_load": [2.2, 2.4],
+                                                     "source": "profiles/round3/valu_clock.txt"},
+                            "source": os.path.relpath(path, ROOT), "mix_source": mix_src, "mix_commit": mix_commit,
                             "note": "instruction count from the SQ pass; duration of isolated launches of the kernel "
                                     "(roofline.isolated_launch_ms): in the timed region the launches share the SIMDs with "
                                     "the other streams' kernels -- the whole step is accounted in valu_issue_step.  frac: "
-                                    "against the ceiling of the kernel's own instruction mix (per-opcode issue rates measured "
-                                    "by scripts/valu_rate.hip: ~2.7 cycles for the fast class, ~4.4 for the slow one); "
-                                    "frac_vs_guide_2cyc: against one wave64 VALU instruction per 2 SIMD-cycles, the guide's "
-                                    "figure, which no opcode reached in that micro-benchmark"}
+                                    "against the ceiling of the kernel's own instruction mix at the MEASURED per-class issue "
+                                    "costs (2.50 / 4.27 real shader cycles, s_memtime, at the 4 waves per SIMD this kernel "
+                                    "runs at); frac_vs_guide_2cyc: against one wave64 VALU instruction per 2 SIMD-cycles at "
+                                    "2.4 GHz, the guide's figure -- the SIMD approaches it only with 8 resident waves (2.25) "
+                                    "and the clock drops to 2.2-2.3 GHz under fast-class load"}
     return None
 
 
-def valu_issue_step(pairs_per_step, ms_per_step, dominant_cycles):
+def valu_issue_step(pairs_per_step, ms_per_step):
     """The whole step against the SIMDs' VALU issue rate: VALU wave-instructions of ALL kernels of a step (newest SQ
-    summary, scaled from its 64 pairs per launch) x issue cycles per instruction (the dominant kernel's measured mix,
-    4.4 for the others: a lower bound for the FP64-heavy ones) over 1024 SIMDs at 2.4 GHz = the time the step would
-    take if every issue slot were used.  frac = that bound / the measured time per step."""
+    summary, scaled from its 64 pairs per launch), each kernel priced by ITS OWN static instruction mix (newest
+    profiles/*/*isa_mix.json; 4.4 for a kernel the mix file does not know), over 1024 SIMDs = the time the step would
+    take if every issue slot were used.  frac = that bound / the measured time per step; frac_vs_guide_2cyc prices every
+    instruction at the guide's 2 cycles instead."""
     import csv
     import glob
+    mix, mix_src, mix_commit = newest_isa_mix()
     for path in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*sq_per_kernel.csv")))):
-        cyc, total, dom = 0.0, 0.0, 0.0
+        cyc, total, dom, per_kernel, unknown = 0.0, 0.0, 0.0, {}, []
+        steps_profiled = None
         with open(path) as fh:
-            for row in csv.DictReader(fh):
-                if not row["label"].endswith("_kernel"):
-                    continue  # (torch's own fill / copy kernels of the set-up)
-                per_step = float(row["valu_insts"]) * float(row["dispatches"]) / 5.0  # the SQ pass timed 5 steps (2 warm-up + 3)
-                is_dom = row["label"] in ("unwrap_median_gray_kernel", "median_gray_kernel")
-                cyc += per_step * (dominant_cycles if is_dom else 4.4)
-                total += per_step
-                dom += per_step if is_dom else 0.0
+            rows = list(csv.DictReader(fh))
+        for row in rows:
+            if row["label"] in ("unwrap_median_gray_kernel", "median_gray_kernel"):
+                steps_profiled = float(row["dispatches"])   # one launch of the dominant kernel per step in the one-stream SQ pass
+        if not steps_profiled:
+            continue
+        for row in rows:
+            if not row["label"].endswith("_kernel"):
+                continue  # (torch's own fill / copy kernels of the set-up)
+            per_step = float(row["valu_insts"]) * float(row["dispatches"]) / steps_profiled
+            c, known = mix_cycles(row["label"], mix)
+            if not known:
+                unknown.append(row["label"])
+            is_dom = row["label"] in ("unwrap_median_gray_kernel", "median_gray_kernel")
+            cyc += per_step * c
+            total += per_step
+            dom += per_step if is_dom else 0.0
+            per_kernel[row["label"]] = {"share_of_valu_insts": per_step, "issue_cycles_per_inst": c}
         if total > 0:
             scale = pairs_per_step / 64.0
             bound_ms = cyc * scale / (1024 * 2.4e9) * 1e3
+            guide_ms = total * 2.0 * scale / (1024 * 2.4e9) * 1e3
+            for v in per_kernel.values():
+                v["share_of_valu_insts"] /= total
+            top = dict(sorted(per_kernel.items(), key=lambda kv: -kv[1]["share_of_valu_insts"])[:8])
             return {"valu_wave_insts_per_step": total * scale, "dominant_kernel_share": dom / total,
                     "issue_bound_ms_per_step": bound_ms, "measured_ms_per_step": ms_per_step, "frac": bound_ms / ms_per_step,
-                    "source": os.path.relpath(path, ROOT)}
+                    "guide_2cyc_bound_ms_per_step": guide_ms, "frac_vs_guide_2cyc": guide_ms / ms_per_step,
+                    "per_kernel": top, "kernels_without_mix": unknown,
+                    "source": os.path.relpath(path, ROOT), "mix_source": mix_src, "mix_commit": mix_commit}
     return None
 
 
@@ -348,6 +408,8 @@ def parse():
     ap.add_argument("--no-sub", action="store_true",
                     help="skip the sub-records (ORB-detector path, GP3P hypotheses, BASELINE configs 3 and 5)")
     ap.add_argument("--sub-steps", type=int, default=5, help="timed steps of each in-process sub-record")
+    ap.add_argument("--orb-features-per-mask", type=int, default=230,
+                    help="ORB_create(nfeatures) per azimuthal mask of the orb_detector sub-record (12 masks x 230: ~2000 per view)")
     ap.add_argument("--sequence-frames", type=int, default=256,
                     help="frames of the synthetic sequence of the `sequence` sub-record (run_VO in sequence mode); 0 = skip")
     ap.add_argument("--dump-records", default=None,
@@ -623,14 +685,24 @@ def main():
                                                                % (na, cores, dta)}
                 except Exception as e:  # the one-core figure above stays the reported baseline
                     out["cpu_baseline_all_cores"] = {"error": repr(e)}
+        run_cfg = {"detector": args.detector, "ransac_solver": args.ransac_solver, "pano_width": args.pano_width,
+                   "pairs_per_launch": int(dom_pairs), "streams": eng.S}
         if out["valu_issue"]:
-            out["valu_issue_step"] = valu_issue_step(B, out["ms_per_step"], out["valu_issue"]["issue_cycles_per_inst"])
+            out["valu_issue_step"] = valu_issue_step(B, out["ms_per_step"])
+            for rec_ in (out["valu_issue"], out["valu_issue_step"]):
+                if rec_:   # (the SQ pass always runs one stream of 64 pairs per launch: compare the rest)
+                    rec_.update(profile_meta(os.path.join(ROOT, rec_["source"]),
+                                             {k: v for k, v in run_cfg.items() if k not in ("pairs_per_launch", "streams")}))
         out["traffic_step"] = traffic_step(B, eng.S, b_alg, args.pmc_csv)
+        if out["traffic_step"]:
+            out["traffic_step"].update(profile_meta(os.path.join(ROOT, out["traffic_step"]["source"]), run_cfg))
+        if traffic_src:
+            out["roofline"].update({"traffic_" + k: v for k, v in profile_meta(os.path.join(ROOT, traffic_src), run_cfg).items()})
         if n_gpus == 1 and not args.no_sub:
             # ---- sub-records of the same line (driver-timed): other detector / solver on the SAME frames, in this process
-            def sub_engine(gs_=None, rig_kw_=None, **kw):
+            def sub_engine(gs_=None, rig_kw_=None, num_of_features=None, **kw):
                 e2 = OverlappedFramePairs(local_rank, gs_ or gs, (H, W), RigConfig(**(rig_kw_ or rig_kw)), B, n_streams=args.streams,
-                                          num_of_features=args.features_per_mask, kp_cap=512, frame_cap=2048,
+                                          num_of_features=num_of_features or args.features_per_mask, kp_cap=512, frame_cap=2048,
                                           max_iter=args.iters, adaptive=False, seed=args.seed, **kw)
                 e2.load_frames(omni)
                 for _ in range(2):
@@ -654,7 +726,13 @@ def main():
                 return rec2
             try:
                 if args.detector != "ORB":
-                    out["orb_detector"] = sub_engine(detection_method="ORB", ransac_solver=args.ransac_solver)
+                    # the ORB detector AT THE METRIC'S LOAD (~2000 keypoints per view): without the median blur (the RGB-D
+                    # frames' setting, pose_est_tools.py:427) and with the per-mask quota that yields that count; on the
+                    # 11x11-median-blurred panoramas (the SOS frames' setting) FAST finds ~150 corners per view
+                    out["orb_detector"] = sub_engine(detection_method="ORB", ransac_solver=args.ransac_solver, median_win_size=0,
+                                                     num_of_features=args.orb_features_per_mask)
+                    out["orb_detector"]["setting"] = "ORB_create(%d).detect per mask + compute, median_win_size 0" % args.orb_features_per_mask
+                    out["orb_detector_median11"] = sub_engine(detection_method="ORB", ransac_solver=args.ransac_solver)
                 if args.ransac_solver != "GP3P":
                     out["gp3p"] = sub_engine(detection_method=args.detector, ransac_solver="GP3P")
                 if args.pano_width != 1200:

@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--pano-width", type=int, default=1440)
     ap.add_argument("--detector", default="GFT", choices=["GFT", "ORB", "FAST", "AGAST"])
     ap.add_argument("--kp-cap", type=int, default=512, help="keypoint capacity per (frame, mirror, mask)")
+    ap.add_argument("--median", type=int, default=11, help="median window (11 = the SOS frames' setting; 0 = none)")
+    ap.add_argument("--features", type=int, default=1000, help="detector budget per azimuthal mask")
     ap.add_argument("--solver", default="P3P", choices=["P3P", "GP3P"],
                     help="hypothesis generator of the non-central RANSAC: one-mirror P3P (bench default) or the generalised P3P")
     ap.add_argument("--rgbd", choices=["EPNP", "KNEIP"], default=None,
@@ -51,9 +53,9 @@ def main():
     omni, _ = synthetic.make_frame_pairs(gs, B, seed=args.seed, workers=args.workers)  # before the GPU is touched (fork)
     import torch
     from vo_single_camera_sos_amd.pipeline import OverlappedFramePairs, RigConfig
-    eng = OverlappedFramePairs(0, gs, (480, 640), RigConfig(**rig_kw), B, n_streams=2, num_of_features=1000, kp_cap=args.kp_cap,
+    eng = OverlappedFramePairs(0, gs, (480, 640), RigConfig(**rig_kw), B, n_streams=2, num_of_features=args.features, kp_cap=args.kp_cap,
                                frame_cap=2048, max_iter=args.iters, adaptive=False, seed=args.seed, detection_method=args.detector,
-                               ransac_solver=args.solver)
+                               ransac_solver=args.solver, median_win_size=args.median)
     assert not any(int(p.fe.status.max().item()) for p in eng.parts) or args.detector != "GFT"
     eng.load_frames(omni)
     eng.step()
@@ -62,8 +64,8 @@ def main():
     model = eng.model
     ca, sa = orb_pattern.angle_cos_sin(-1.0)
     im_kw = dict(map_x=model.map_x.cpu().numpy(), map_y=model.map_y.cpu().numpy(), omni_masks=model.omni_masks.cpu().numpy(),
-                 mask_bits=model.mask_bits_host, nmask=model.nmask, max_corners=1000, pattern=model.pattern_host, cos_a=ca,
-                 sin_a=sa, kp_cap=args.kp_cap, method=args.detector)
+                 mask_bits=model.mask_bits_host, nmask=model.nmask, max_corners=args.features, pattern=model.pattern_host, cos_a=ca,
+                 sin_a=sa, kp_cap=args.kp_cap, method=args.detector, median_ksize=args.median)
     per = -(-B // args.workers)
     jobs = [(rig_kw, im_kw, omni[2 * lo: 2 * min(B, lo + per)], eng.thr, args.iters, args.seed + lo, args.solver == "GP3P")
             for lo in range(0, B, per)]
@@ -80,7 +82,9 @@ def main():
         if not (exact and close):
             bad += 1
             print("pair %d differs: gpu %s\n               cpu %s" % (i, rec[i], want[i]))
-    print("detector %s, solver %s:" % (args.detector, args.solver), end=" ")
+    n_kp = np.concatenate([p.fe.n.cpu().numpy().reshape(2, -1, model.nmask).sum(-1) for p in eng.parts], axis=1)
+    print("detector %s (median %d, %d per mask: %.0f keypoints per view), solver %s:"
+          % (args.detector, args.median, args.features, n_kp.mean(), args.solver), end=" ")
     print("soak: %d / %d pairs identical (counts, status, winning iteration exact; pose rel-tol 1e-6); %d / %d refined poses "
           "bit-identical; inliers %.0f mean" % (B - bad, B, exact_pose, B, rec[:, 12].mean()))
     eng.close()

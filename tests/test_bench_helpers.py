@@ -22,7 +22,10 @@ def test_profile_summaries_feed_the_roofline_fields():
     assert b.pmc_traffic("no_such_kernel", 256) == (None, None)
     vi = b.valu_issue("unwrap_median_gray_kernel", 256, 2.42e-3)       # round-2 launch time
     assert vi["mix_source"] and 3.0 < vi["issue_cycles_per_inst"] < 4.4 and 0.8 < vi["frac"] < 1.05
-    step = b.valu_issue_step(768, 14.1, vi["issue_cycles_per_inst"])
+    step = b.valu_issue_step(768, 14.1)
     assert 0.55 < step["dominant_kernel_share"] < 0.75 and 0.7 < step["frac"] < 1.05
+    assert 0.4 < step["frac_vs_guide_2cyc"] < step["frac"] and step["per_kernel"] and step["mix_source"]   # priced per kernel
+    meta = b.profile_meta(os.path.join(ROOT, step["source"]), {"detector": "GFT"})
+    assert "stale" in meta
     assert b.b_alg_c2(480, 640, 2000) == 1943296                                   # algorithmic bytes per pair
     assert b.host_cores() >= 1

@@ -157,7 +157,9 @@ class OverlappedFramePairs(object):
 
     def __init__(self, device, gums, omni_shape, rig, n_pairs, n_streams=2, num_of_features=1000, kp_cap=512,
                  frame_cap=2048, max_iter=2000, adaptive=False, seed=0, detection_method="GFT", lm_iter=30, thr=None,
-                 serialize_medians=True, ransac_solver="P3P"):
+                 serialize_medians=True, ransac_solver="P3P", median_win_size=11):
+        """median_win_size: StereoPanoramicFrame.median_win_size (11, pose_est_tools.py:296); 0 = no median blur (the
+        RGB-D frames' setting, :427) -- then the colour panoramas are materialised and only converted to gray."""
         from .frontend import DeviceImageModel, ImageFrontEnd
         from .parallel import shard_range
         self.main = Context(device)                       # model constants + result collection: torch's current stream
@@ -177,7 +179,8 @@ class OverlappedFramePairs(object):
             with torch.cuda.stream(p.stream):
                 p.ctx = Context(self.device.index, p.stream)
                 p.fe = ImageFrontEnd(p.ctx, m, 2 * (hi - lo), detection_method=detection_method,
-                                     num_of_features=num_of_features, kp_cap=kp_cap, keep_panoramas=False)
+                                     num_of_features=num_of_features, kp_cap=kp_cap, keep_panoramas=False,
+                                     median_win_size=median_win_size)
                 p.pipe = FramePairPipeline(p.ctx, rig, hi - lo, frame_cap=frame_cap, max_iter=max_iter, adaptive=adaptive,
                                            seed=seed + lo, front_end=p.fe, lm_iter=lm_iter, thr=thr,
                                            ransac_solver=ransac_solver)
