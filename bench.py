@@ -380,6 +380,8 @@ def parse():
                          "ORB: FAST/Harris pyramid detector (finds few corners on an 11x11-median-blurred panorama)")
     ap.add_argument("--features-per-mask", type=int, default=1000,
                     help="detector budget per azimuthal mask (reference default 1000, pose_est_tools.py:862)")
+    ap.add_argument("--median-win-size", type=int, default=11,
+                    help="StereoPanoramicFrame.median_win_size (11); 0 = no median blur (the ORB detector then finds its quota)")
     ap.add_argument("--pano-width", type=int, default=1440,
                     help="panorama columns.  The reference default (camera_models.py:3107) is 1200 -> 1200 x 122, where "
                          "GFT's minDistance 5 and ORB.compute's 31-px border cap the count at ~1250 keypoints per view; "
@@ -518,7 +520,7 @@ def main():
     eng = OverlappedFramePairs(local_rank, gs, (H, W), RigConfig(**rig_kw), B, n_streams=args.streams,
                                num_of_features=args.features_per_mask, kp_cap=512, frame_cap=2048, max_iter=args.iters,
                                adaptive=False, seed=args.seed + rank * B, detection_method=args.detector,
-                               ransac_solver=args.ransac_solver)
+                               ransac_solver=args.ransac_solver, median_win_size=args.median_win_size)
     model, dev = eng.model, eng.device
     eng.load_frames(omni)
     gathered = torch.empty((n_gpus * B, 16), dtype=torch.float64, device=dev) if dist else None
@@ -629,11 +631,12 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/f32/f64",  # images + Hamming in u8 / bits, corner response in f32, geometry + RANSAC + LM in f64
             "data": "synthetic",
-            "config": {"workload": "C2: 640x480 BGR omni frame pair -> 2 x %dx%d panoramas per frame, 11x11 median, "
+            "config": {"workload": "C2: 640x480 BGR omni frame pair -> 2 x %dx%d panoramas per frame, %s, "
                                    "%s detector (budget %d per azimuthal mask x %d masks) + ORB descriptors, "
                                    "%d bucket + 2 frame-to-frame BF Hamming matchings, midpoint triangulation, "
                                    "non-central %s RANSAC %d iterations fixed, LM"
-                                   % (pano.cols, pano.rows, args.detector, args.features_per_mask, model.nmask,
+                                   % (pano.cols, pano.rows, "11x11 median" if args.median_win_size == 11 else
+                                      "median window %d" % args.median_win_size, args.detector, args.features_per_mask, model.nmask,
                                       2 * model.nmask, "P3P (one-mirror samples)" if args.ransac_solver == "P3P" else
                                       "GP3P (samples across both mirrors)", args.iters),
                        "keypoint_capacity_hit": bool(cap_hit),
@@ -724,6 +727,41 @@ def main():
                         "tracked_ok": int((r2[:, 14] == 0).sum()), "inliers_per_pair_mean": float(r2[:, 12].mean())}
                 e2.close()
                 return rec2
+            def c_abi_streams():
+                """The SAME step through the C ABI's one-call entry (what a non-Python host binds): B pairs per call over the
+                library's internal HIP streams, calls enqueued back to back (sosvo_frame_pair_batch_streams_enqueue, two
+                alternating record buffers, one join at the end) and, beside it, with the join after every call."""
+                from vo_single_camera_sos_amd.device import Context
+                from vo_single_camera_sos_amd.pipeline import FramePairBatch
+                c2 = Context(local_rank)
+                fb = FramePairBatch(c2, model, RigConfig(**rig_kw), B, num_of_features=args.features_per_mask, kp_cap=512,
+                                    frame_cap=2048, max_iter=args.iters, seed=args.seed + rank * B, n_streams=args.streams,
+                                    ransac_solver=args.ransac_solver)
+                fb.load_frames(omni)
+                bufs = [fb.out, torch.zeros_like(fb.out)]
+                res = {}
+                for label, joined in (("enqueue_back_to_back", False), ("join_every_call", True)):
+                    for k in range(2):
+                        fb.step() if joined else fb.enqueue(bufs[k & 1])
+                    fb.join()
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for k in range(args.steps):
+                        fb.step() if joined else fb.enqueue(bufs[k & 1])
+                    fb.join()
+                    torch.cuda.synchronize()
+                    dt2 = time.perf_counter() - t1
+                    last = fb.out if joined else bufs[(args.steps - 1) & 1]
+                    res[label] = {"value": B * args.steps / dt2, "unit": "frame-pairs/s", "ms_per_step": 1e3 * dt2 / args.steps,
+                                  "same_records_as_engine": bool(np.array_equal(last.cpu().numpy(), rec))}
+                res["value"], res["unit"], res["steps"], res["streams"] = res["enqueue_back_to_back"]["value"], "frame-pairs/s", args.steps, args.streams
+                res["ratio_to_engine"] = res["value"] / out["value"]
+                c2.close()
+                return res
+            try:
+                out["c_abi_streams"] = c_abi_streams()
+            except Exception as e:
+                out["c_abi_streams"] = {"error": repr(e)}
             try:
                 if args.detector != "ORB":
                     # the ORB detector AT THE METRIC'S LOAD (~2000 keypoints per view): without the median blur (the RGB-D

@@ -542,6 +542,20 @@ int32_t sosvo_frame_pair_batch_streams(sosvo_ctx* ctx, const sosvo_rig* rig_host
                                        const uint32_t* mask_bits, const int8_t* pattern, void* workspace,
                                        size_t workspace_bytes, double* results);
 
+/* Back-to-back batches without the join: ..._enqueue does everything sosvo_frame_pair_batch_streams does EXCEPT making the
+ * context's stream wait for the parts, so the parts of the next call start while this call's later stages still run (part s
+ * of call k + 1 follows part s of call k on the same internal stream; the medians' turn-taking goes on across calls) -- the
+ * overlap the Python engine (pipeline.OverlappedFramePairs) has, for a host that calls the C ABI.  The caller then
+ *   - hands every call inputs that are ready on the context's stream at the time of the call (as before),
+ *   - alternates (at least) two `results` buffers if something still reads the previous call's records, and
+ *   - calls ..._join(ctx) before reading records on the context's stream: it makes that stream wait for every part of
+ *     the LATEST call (hence, in stream order, of all earlier ones).  The workspace may be the same for every call. */
+int32_t sosvo_frame_pair_batch_streams_enqueue(sosvo_ctx* ctx, const sosvo_rig* rig_host, const sosvo_batch_cfg* cfg_host,
+                                               int32_t n_streams, const uint8_t* omni, const uint32_t* unwrap_table,
+                                               const uint32_t* mask_bits, const int8_t* pattern, void* workspace,
+                                               size_t workspace_bytes, double* results);
+int32_t sosvo_frame_pair_batch_streams_join(sosvo_ctx* ctx);
+
 /* ---- Sequence mode: every frame's front end ONCE, tracking against keyframes -----------------------------
  * The reference's VO loop (run_VO, omnistereo/pose_est_tools.py:1416-1628) builds ONE StereoPanoramicFrame per image
  * (:1447-1463: unwrap, median, detection, static stereo, triangulation) and tracks it against the current KEYFRAME

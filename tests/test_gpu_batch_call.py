@@ -85,6 +85,30 @@ def test_streams_variant_repeats_itself_over_many_overlapped_steps(ctx):
     assert not bad, bad
 
 
+def test_enqueue_without_join_overlaps_calls_and_keeps_the_records(ctx):
+    """sosvo_frame_pair_batch_streams_enqueue x 8 (two alternating record buffers, ONE join at the end) == the joined
+    call; the join alone makes the context's stream wait (nothing is read before it)."""
+    B, nfeat, cap = 4, 300, 320
+    model, rig, omni = _setup(ctx, B)
+    one = FramePairBatch(ctx, model, rig, B, num_of_features=nfeat, kp_cap=cap, frame_cap=1024, max_iter=300, seed=11)
+    one.load_frames(omni)
+    want = one.step().clone()
+    ctx.synchronize()
+    multi = FramePairBatch(ctx, model, rig, B, num_of_features=nfeat, kp_cap=cap, frame_cap=1024, max_iter=300, seed=11, n_streams=3)
+    multi.load_frames(omni)
+    bufs = [torch.zeros_like(multi.out), torch.zeros_like(multi.out)]
+    for k in range(8):
+        multi.enqueue(bufs[k & 1])
+    multi.join()
+    ctx.synchronize()
+    assert torch.equal(bufs[0], want) and torch.equal(bufs[1], want)
+    bufs[0].zero_()
+    multi.enqueue(bufs[0])
+    got = multi.step()          # a joined call right behind an un-joined one: same stream order, both complete after it
+    ctx.synchronize()
+    assert torch.equal(got, want) and torch.equal(bufs[0], want)
+
+
 def test_argument_errors(ctx):
     model, rig, omni = _setup(ctx, 1)
     batch = FramePairBatch(ctx, model, rig, 1, num_of_features=100, frame_cap=512, max_iter=50)

@@ -92,6 +92,8 @@ SIGNATURES = {
     "sosvo_frame_pair_batch": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
     "sosvo_frame_pair_batch_streams_workspace": (ctypes.c_size_t, [c_p, c_i32]),
     "sosvo_frame_pair_batch_streams": (c_i32, [c_p, c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
+    "sosvo_frame_pair_batch_streams_enqueue": (c_i32, [c_p, c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
+    "sosvo_frame_pair_batch_streams_join": (c_i32, [c_p]),
     "sosvo_sequence_workspace": (ctypes.c_size_t, [c_p, c_i32, c_i32]),
     "sosvo_sequence_front_end": (c_i32, [c_p, c_p, c_p, c_i32, c_i32, c_p, c_i32, c_i32, c_p, c_p, c_p, c_p, ctypes.c_size_t]),
     "sosvo_sequence_track": (c_i32, [c_p, c_p, c_p, c_i32, c_i32, c_p, c_p, c_i32, c_u64, c_p, ctypes.c_size_t, c_p]),

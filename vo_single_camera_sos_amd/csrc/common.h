@@ -33,6 +33,7 @@ struct sosvo_ctx {
   sosvo_ctx* sub[kSosvoMaxSubStreams];
   hipEvent_t sub_done[kSosvoMaxSubStreams], sub_median[kSosvoMaxSubStreams], sub_begin;
   int32_t n_sub;
+  int32_t sub_last;  // parts of the most recent sosvo_frame_pair_batch_streams[_enqueue] call (their medians' token chain goes on)
 };
 
 // Brackets the kernel launches of the enclosing scope with a HIP event pair when profiling is on.

@@ -441,9 +441,9 @@ size_t sosvo_frame_pair_batch_streams_workspace(const sosvo_batch_cfg* cfg, int3
   return total;
 }
 
-int32_t sosvo_frame_pair_batch_streams(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo_batch_cfg* cfg, int32_t n_streams,
-                                       const uint8_t* omni, const uint32_t* unwrap_table, const uint32_t* mask_bits,
-                                       const int8_t* pattern, void* workspace, size_t workspace_bytes, double* results) {
+static int32_t batch_streams(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo_batch_cfg* cfg, int32_t n_streams,
+                             const uint8_t* omni, const uint32_t* unwrap_table, const uint32_t* mask_bits,
+                             const int8_t* pattern, void* workspace, size_t workspace_bytes, double* results, bool join) {
   SOSVO_ENTER(ctx);
   SOSVO_REQUIRE(ctx, rig && cfg && omni && unwrap_table && mask_bits && pattern && workspace && results, "null pointer");
   SOSVO_REQUIRE(ctx, n_streams >= 1 && n_streams <= kSosvoMaxSubStreams, "n_streams out of range (1..4)");
@@ -469,7 +469,9 @@ int32_t sosvo_frame_pair_batch_streams(sosvo_ctx* ctx, const sosvo_rig* rig, con
   // every part starts after the work already queued on the caller's stream ...
   SOSVO_HIP(ctx, hipEventRecord(ctx->sub_begin, ctx->stream));
   char* ws = reinterpret_cast<char*>(workspace);
-  hipEvent_t token = nullptr;  // ... and the medians take turns: part s waits for the median of part s - 1
+  // ... and the medians take turns: part s waits for the median of part s - 1, the first part for the LAST part of the
+  // previous call (its parts may still be running when calls are enqueued back to back, see ..._enqueue)
+  hipEvent_t token = ctx->sub_last > 0 ? ctx->sub_median[ctx->sub_last - 1] : nullptr;
   for (int s = 0; s < n_streams; ++s) {
     int lo, hi;
     part_range(cfg->n_pairs, s, n_streams, &lo, &hi);
@@ -492,8 +494,29 @@ int32_t sosvo_frame_pair_batch_streams(sosvo_ctx* ctx, const sosvo_rig* rig, con
     SOSVO_HIP(ctx, hipEventRecord(ctx->sub_done[s], sc->stream));
     ws += bytes;
   }
+  ctx->sub_last = n_streams;
   // ... and the caller's stream continues after all of them
-  for (int s = 0; s < n_streams; ++s) SOSVO_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->sub_done[s], 0));
+  if (join)
+    for (int s = 0; s < n_streams; ++s) SOSVO_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->sub_done[s], 0));
+  return SOSVO_OK;
+}
+
+int32_t sosvo_frame_pair_batch_streams(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo_batch_cfg* cfg, int32_t n_streams,
+                                       const uint8_t* omni, const uint32_t* unwrap_table, const uint32_t* mask_bits,
+                                       const int8_t* pattern, void* workspace, size_t workspace_bytes, double* results) {
+  return batch_streams(ctx, rig, cfg, n_streams, omni, unwrap_table, mask_bits, pattern, workspace, workspace_bytes, results, true);
+}
+
+int32_t sosvo_frame_pair_batch_streams_enqueue(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo_batch_cfg* cfg,
+                                               int32_t n_streams, const uint8_t* omni, const uint32_t* unwrap_table,
+                                               const uint32_t* mask_bits, const int8_t* pattern, void* workspace,
+                                               size_t workspace_bytes, double* results) {
+  return batch_streams(ctx, rig, cfg, n_streams, omni, unwrap_table, mask_bits, pattern, workspace, workspace_bytes, results, false);
+}
+
+int32_t sosvo_frame_pair_batch_streams_join(sosvo_ctx* ctx) {
+  SOSVO_ENTER(ctx);
+  for (int s = 0; s < ctx->sub_last; ++s) SOSVO_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->sub_done[s], 0));
   return SOSVO_OK;
 }
 

@@ -686,9 +686,16 @@ class Context(object):
     def frame_pair_batch_streams_workspace(self, cfg, n_streams):
         return int(self._lib.sosvo_frame_pair_batch_streams_workspace(ctypes.cast(ctypes.pointer(cfg), c_p), int(n_streams)))
 
-    def frame_pair_batch(self, rig, cfg, omni, unwrap_table, mask_bits, pattern, workspace, results=None, n_streams=1):
+    def frame_pair_batch_join(self):
+        """sosvo_frame_pair_batch_streams_join: the context's stream waits for every part of the latest enqueue."""
+        self._call(self._lib.sosvo_frame_pair_batch_streams_join)
+
+    def frame_pair_batch(self, rig, cfg, omni, unwrap_table, mask_bits, pattern, workspace, results=None, n_streams=1,
+                         join=True):
         """omni [2B,H,W,3] u8, unwrap_table [2,rows,cols,2] u32, mask_bits [2,rows,cols] u32, pattern [512,2] i8,
-        workspace u8 [>= frame_pair_batch_workspace(cfg)] -> results [B,16] f64 (see include/sosvo.h)."""
+        workspace u8 [>= frame_pair_batch_workspace(cfg)] -> results [B,16] f64 (see include/sosvo.h).
+        join=False (n_streams > 1 only): sosvo_frame_pair_batch_streams_enqueue -- call frame_pair_batch_join() before
+        reading the records on this context's stream."""
         B = int(cfg.n_pairs)
         _check(omni, torch.uint8, "omni", (2 * B, cfg.H, cfg.W, 3))
         _check(unwrap_table, torch.uint32, "unwrap_table", (2, cfg.rows, cfg.cols, 2))
@@ -699,7 +706,8 @@ class Context(object):
             results = torch.empty((B, 16), dtype=torch.float64, device=omni.device)
         _check(results, torch.float64, "results", (B, 16))
         if int(n_streams) > 1:   # the batch split over internal HIP streams of the library
-            self._call(self._lib.sosvo_frame_pair_batch_streams, ctypes.cast(ctypes.pointer(rig), c_p),
+            fn = self._lib.sosvo_frame_pair_batch_streams if join else self._lib.sosvo_frame_pair_batch_streams_enqueue
+            self._call(fn, ctypes.cast(ctypes.pointer(rig), c_p),
                        ctypes.cast(ctypes.pointer(cfg), c_p), int(n_streams), _ptr(omni), _ptr(unwrap_table), _ptr(mask_bits),
                        _ptr(pattern), _ptr(workspace), int(workspace.numel()), _ptr(results))
             return results

@@ -354,6 +354,19 @@ class FramePairBatch(object):
         return self.ctx.frame_pair_batch(self.rig, self.cfg, self.omni, m.unwrap_table, m.mask_bits, m.pattern, self.workspace,
                                          results=self.out, n_streams=self.n_streams)
 
+    def enqueue(self, results=None):
+        """A step WITHOUT the join (sosvo_frame_pair_batch_streams_enqueue, n_streams > 1): consecutive calls overlap on
+        the library's internal streams.  Pass alternating `results` buffers while something still reads the previous
+        step's records; call join() before reading records on the context's stream."""
+        m = self.model
+        return self.ctx.frame_pair_batch(self.rig, self.cfg, self.omni, m.unwrap_table, m.mask_bits, m.pattern, self.workspace,
+                                         results=self.out if results is None else results, n_streams=self.n_streams,
+                                         join=self.n_streams <= 1)
+
+    def join(self):
+        if self.n_streams > 1:
+            self.ctx.frame_pair_batch_join()
+
     def results(self):
         return self.out
 
