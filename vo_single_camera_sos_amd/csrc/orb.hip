@@ -537,19 +537,29 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   return a;
 }
 
-// Harris response of the 7x7 block around (cx, cy), k = 0.04, by ONE WAVE: lane (dy + 3) * 7 + (dx + 3) < 49 evaluates the
-// 3x3 Sobel pair at its pixel (reflect-101 at the level border), the three sums of products are integer wave reductions
-// (exact, order-free), the float expression keeps the oracle's operation order.  Every lane returns the response.
-__device__ __forceinline__ float harris_response_wave(const uint8_t* __restrict__ im, int h, int w, int cx, int cy, int lane) {
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+
+// Harris response of the 7x7 block around (cx, cy), k = 0.04, by ONE WAVE.  The block's 3x3 Sobel pairs read the 9 x 9
+// pixels around the candidate; they arrive as 27 unaligned dwords (harris_fetch: lane t < 27 -> patch row t / 3, dword
+// t % 3; issued one candidate AHEAD of their use), go through a 108-byte LDS patch of the wave, and lane
+// (dy + 3) * 7 + (dx + 3) < 49 evaluates its pair from eight LDS bytes -- 27 global loads per candidate instead of 392 byte
+// loads.  (Candidates lie >= 31 px inside the level, so no tap leaves the image.)  The three sums of products are integer
+// wave reductions (exact, order-free), the float expression keeps the oracle's operation order.
+__device__ __forceinline__ uint32_t harris_fetch(const uint8_t* __restrict__ im, int w, int cx, int cy, int lane) {
+  const int t = lane < 27 ? lane : 0, r = t / 3, k = t - 3 * r;
+  return *reinterpret_cast<const u32_unaligned*>(im + (size_t)(cy - 4 + r) * w + (cx - 4) + 4 * k);
+}
+__device__ __forceinline__ float harris_response_wave(uint32_t fetched, volatile uint32_t* patch, int lane) {
+  __builtin_amdgcn_wave_barrier();  // (the previous candidate's reads of the patch are done: one wave, LDS in order)
+  if (lane < 27) patch[lane] = fetched;
+  __builtin_amdgcn_wave_barrier();
   int a = 0, b = 0, c = 0;
   if (lane < 49) {
-    const int dy = lane / 7 - 3, dx = lane - (lane / 7) * 7 - 3;
-    const int y = cy + dy, x = cx + dx;
-    const int ym = refl101(y - 1, h) * w, y0 = refl101(y, h) * w, yp = refl101(y + 1, h) * w;
-    const int xm = refl101(x - 1, w), x0 = refl101(x, w), xp = refl101(x + 1, w);
-    const int p00 = im[ym + xm], p01 = im[ym + x0], p02 = im[ym + xp];
-    const int p10 = im[y0 + xm], p12 = im[y0 + xp];
-    const int p20 = im[yp + xm], p21 = im[yp + x0], p22 = im[yp + xp];
+    const int dy = lane / 7, dx = lane - dy * 7;  // pixel (dy + 1, dx + 1) of the 9 x 9 patch (12-byte rows)
+    const volatile uint8_t* q = reinterpret_cast<const volatile uint8_t*>(patch) + dy * 12 + dx;
+    const int p00 = q[0], p01 = q[1], p02 = q[2];
+    const int p10 = q[12], p12 = q[14];
+    const int p20 = q[24], p21 = q[25], p22 = q[26];
     const int Ix = (p12 - p10) * 2 + (p02 - p00) + (p22 - p20);
     const int Iy = (p21 - p01) * 2 + (p20 - p00) + (p22 - p02);
     a = Ix * Ix;
@@ -566,6 +576,46 @@ __device__ __forceinline__ float harris_response_wave(const uint8_t* __restrict_
   const float s4 = (scale * scale) * (scale * scale);
   const float fa = (float)a, fb = (float)b, fc = (float)c;
   return (((fa * fb) - (fc * fc)) - ((0.04f * (fa + fb)) * (fa + fb))) * s4;
+}
+
+// Intensity-centroid moments of the radius-15 disc around (cx, cy) by ONE WAVE: the 31 patch rows are 31 x 8 unaligned
+// dwords (columns cx - 15 .. cx + 16), four per lane; every lane adds its four pixels' u * I and (through its row's v) v * I
+// where |u| <= umax(|v|) (OpenCV's disc: 15 15 15 15 14 14 14 13 13 12 11 10 9 8 6 3, here as nibbles of one literal), and
+// two integer wave reductions finish m10 and m01 -- 4 dword loads per lane instead of 31 byte loads.
+__device__ __forceinline__ void ic_moments_wave(const uint8_t* __restrict__ im, int w, int cx, int cy, int lane, int& m10_out,
+                                                int& m01_out) {
+  constexpr unsigned long long kUmax = 0x3689ABCDDEEEFFFFULL;  // nibble |v| = umax(|v|)
+  int m10 = 0, m01 = 0;
+  uint32_t x[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = min(q * 64 + lane, 247), r = idx >> 3, k = idx & 7;
+    x[q] = *reinterpret_cast<const u32_unaligned*>(im + (size_t)(cy - kHalfPatch + r) * w + (cx - kHalfPatch) + 4 * k);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = q * 64 + lane, r = idx >> 3, k = idx & 7, v = r - kHalfPatch;
+    if (idx < 248) {
+      const int d = (int)((kUmax >> (4 * (v < 0 ? -v : v))) & 15ULL);
+      int rs = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int u = 4 * k + b - kHalfPatch, val = (int)((x[q] >> (8 * b)) & 255u);
+        if ((u < 0 ? -u : u) <= d) {
+          m10 += u * val;
+          rs += val;
+        }
+      }
+      m01 += v * rs;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    m10 += __shfl_xor(m10, o);
+    m01 += __shfl_xor(m01, o);
+  }
+  m10_out = m10;
+  m01_out = m01;
 }
 
 // Bounding box of every mask on every pyramid level of every mask set (depends on the masks only; cheap enough to
@@ -625,10 +675,10 @@ __global__ __launch_bounds__(kThreads) void orb_select_kernel(LevelSrc S, const 
   __shared__ unsigned long long ckey[kCandMax];  // ordered(harris) << 32 | (0xFFFFFFFF - linear index)
   __shared__ uint32_t kept[kCandMax];            // candidates that pass the FAST-score threshold (compacted)
   __shared__ int hist[256];
+  __shared__ uint32_t hpatch[kThreads / 64][28];  // the 9 x 12-byte Harris patch of each wave
   __shared__ int s_nc, s_thr, s_keep, s_nout, s_nk;
   const int tid = threadIdx.x, p = blockIdx.x, lane = tid & 63, wid = tid >> 6;
   const int img = p / nmask, m = p - img * nmask;
-  const int kumax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
   if (tid == 0) s_nout = 0;
   __syncthreads();
   for (int l = 0; l < P.ndet; ++l) {
@@ -708,9 +758,15 @@ __global__ __launch_bounds__(kThreads) void orb_select_kernel(LevelSrc S, const 
     __syncthreads();
     const int nc = s_nk;
     // 3. Harris response of the survivors -> sort keys
+    uint32_t xy_next = wid < nc ? kept[wid] : 0u, fetched = 0u;
+    if (wid < nc) fetched = harris_fetch(im, w, (int)(xy_next & 0xFFFFu), (int)(xy_next >> 16), lane);
     for (int j = wid; j < nc; j += kThreads / 64) {
-      const uint32_t xy = kept[j];
-      const float r = harris_response_wave(im, h, w, (int)(xy & 0xFFFFu), (int)(xy >> 16), lane);
+      const uint32_t xy = xy_next, cur = fetched;
+      if (j + kThreads / 64 < nc) {  // the next candidate's 27 dwords fly while this one is reduced
+        xy_next = kept[j + kThreads / 64];
+        fetched = harris_fetch(im, w, (int)(xy_next & 0xFFFFu), (int)(xy_next >> 16), lane);
+      }
+      const float r = harris_response_wave(cur, hpatch[wid], lane);
       if (lane == 0) {
         const uint32_t lin = (xy >> 16) * (uint32_t)w + (xy & 0xFFFFu);
         ckey[j] = ((unsigned long long)sosvo_float_ordered(r) << 32) | (0xFFFFFFFFu - lin);
@@ -771,22 +827,8 @@ __global__ __launch_bounds__(kThreads) void orb_select_kernel(LevelSrc S, const 
       const unsigned long long key = ckey[j];
       const uint32_t lin = 0xFFFFFFFFu - (uint32_t)key;
       const int cy = (int)(lin / (uint32_t)w), cx = (int)(lin - (uint32_t)cy * (uint32_t)w);
-      int m10 = 0, m01 = 0;
-      if (lane < 2 * kHalfPatch + 1) {
-        const int v = lane - kHalfPatch, d = kumax[v < 0 ? -v : v];
-        const uint8_t* row = im + (size_t)refl101(cy + v, h) * w;
-        int rs = 0;
-        for (int u = -d; u <= d; ++u) {
-          const int val = row[refl101(cx + u, w)];
-          m10 += u * val;
-          rs += val;
-        }
-        m01 = v * rs;
-      }
-      for (int o = 32; o > 0; o >>= 1) {
-        m10 += __shfl_down(m10, o);
-        m01 += __shfl_down(m01, o);
-      }
+      int m10, m01;
+      ic_moments_wave(im, w, cx, cy, lane, m10, m01);
       if (lane == 0) {
         const size_t o = (size_t)p * cap + base_out + j;
         kp4[4 * o + 0] = (float)cx * P.scale[l];
