@@ -441,11 +441,9 @@ size_t sosvo_frame_pair_batch_streams_workspace(const sosvo_batch_cfg* cfg, int3
   return total;
 }
 
-static int32_t batch_streams(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo_batch_cfg* cfg, int32_t n_streams,
+static int32_t sosvo_frame_pair_batch_streams_impl(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo_batch_cfg* cfg, int32_t n_streams,
                              const uint8_t* omni, const uint32_t* unwrap_table, const uint32_t* mask_bits,
                              const int8_t* pattern, void* workspace, size_t workspace_bytes, double* results, bool join) {
-  SOSVO_ENTER(ctx);
-  SOSVO_REQUIRE(ctx, rig && cfg && omni && unwrap_table && mask_bits && pattern && workspace && results, "null pointer");
   SOSVO_REQUIRE(ctx, n_streams >= 1 && n_streams <= kSosvoMaxSubStreams, "n_streams out of range (1..4)");
   SOSVO_REQUIRE(ctx, cfg->n_pairs >= n_streams && cfg->n_pairs <= 8192, "n_pairs out of range (n_streams..8192)");
   SOSVO_REQUIRE(ctx, ((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
@@ -504,14 +502,18 @@ static int32_t batch_streams(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo_b
 int32_t sosvo_frame_pair_batch_streams(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo_batch_cfg* cfg, int32_t n_streams,
                                        const uint8_t* omni, const uint32_t* unwrap_table, const uint32_t* mask_bits,
                                        const int8_t* pattern, void* workspace, size_t workspace_bytes, double* results) {
-  return batch_streams(ctx, rig, cfg, n_streams, omni, unwrap_table, mask_bits, pattern, workspace, workspace_bytes, results, true);
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, rig && cfg && omni && unwrap_table && mask_bits && pattern && workspace && results, "null pointer");
+  return sosvo_frame_pair_batch_streams_impl(ctx, rig, cfg, n_streams, omni, unwrap_table, mask_bits, pattern, workspace, workspace_bytes, results, true);
 }
 
 int32_t sosvo_frame_pair_batch_streams_enqueue(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo_batch_cfg* cfg,
                                                int32_t n_streams, const uint8_t* omni, const uint32_t* unwrap_table,
                                                const uint32_t* mask_bits, const int8_t* pattern, void* workspace,
                                                size_t workspace_bytes, double* results) {
-  return batch_streams(ctx, rig, cfg, n_streams, omni, unwrap_table, mask_bits, pattern, workspace, workspace_bytes, results, false);
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, rig && cfg && omni && unwrap_table && mask_bits && pattern && workspace && results, "null pointer");
+  return sosvo_frame_pair_batch_streams_impl(ctx, rig, cfg, n_streams, omni, unwrap_table, mask_bits, pattern, workspace, workspace_bytes, results, false);
 }
 
 int32_t sosvo_frame_pair_batch_streams_join(sosvo_ctx* ctx) {
