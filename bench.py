@@ -34,20 +34,31 @@ def b_alg_c2(H, W, kpts):
     return 2 * H * W * 3 + 4 * kpts * 12 + 2 * kpts + 96
 
 
+def csrc_hash():
+    """Short content hash of the library's device sources (csrc/*.hip, *.h): what a profile summary is tied to."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "vo_single_camera_sos_amd", "csrc", "*.hip")) +
+                       glob.glob(os.path.join(ROOT, "vo_single_camera_sos_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def profile_meta(csv_path, run_cfg):
-    """The <tag>_meta.json written beside a profile summary by scripts/profile_bench.sh (commit, detector, solver, panorama
-    width, pairs per launch, streams) compared with THIS run: -> dict(profile_commit, stale (bool or "unknown"), differs)."""
+    """The <tag>_meta.json written beside a profile summary by scripts/profile_bench.sh (hash of the device sources,
+    detector, solver, panorama width, pairs per launch, streams) compared with THIS run: -> dict(profile_commit,
+    profile_csrc_hash, stale (bool or "unknown"), differs)."""
     tag = os.path.basename(csv_path).split("_")[0]
     meta_path = os.path.join(os.path.dirname(csv_path), tag + "_meta.json")
     if not os.path.exists(meta_path):
         return {"profile_commit": None, "stale": "unknown (no metadata beside the summary)"}
     meta = json.load(open(meta_path))
     differs = sorted(k for k, v in run_cfg.items() if k in meta and meta[k] != v)
-    import subprocess
-    head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-    if head and meta.get("commit") and head != meta["commit"]:
-        differs.append("commit")
-    return {"profile_commit": meta.get("commit"), "stale": bool(differs), "differs": differs}
+    if meta.get("csrc_hash") and meta["csrc_hash"] != csrc_hash():
+        differs.append("device sources (csrc_hash)")
+    return {"profile_commit": meta.get("commit"), "profile_csrc_hash": meta.get("csrc_hash"), "stale": bool(differs), "differs": differs}
 
 
 def pmc_traffic(kernel, pairs_per_launch, pmc_csv=None):
@@ -404,6 +415,9 @@ def parse():
                          "per-kernel averages then cover the timed region only)")
     ap.add_argument("--pmc-csv", default=None, help="per-kernel PMC summary for roofline.traffic (default: newest in profiles/)")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--frames-cache", default=None,
+                    help=".npz the rendered frame pairs are kept in / taken from (one rank only; the rocprofv3 passes of "
+                         "scripts/profile_bench.sh render once, outside the profiler)")
     ap.add_argument("--ransac-solver", default="P3P", choices=["P3P", "GP3P"],
                     help="P3P: the three solve points of a sample from one mirror (BASELINE config 2's \"P3P RANSAC\"); GP3P: "
                          "generalised P3P on samples across both mirrors (what the reference's non-central RANSAC uses)")
@@ -498,7 +512,17 @@ def main():
     workers = args.render_workers if args.render_workers > 0 else max(1, min(16, host_cores() // max(1, world)))
     # rank r owns the global pairs [r*B, (r+1)*B) of ONE job of world*B pairs: pair g is rendered from seed + g and
     # its RANSAC samples from seed + g, so the gathered records equal those of a single process over the same pairs
-    omni, poses = synthetic.make_frame_pairs(gs, B, seed=args.seed, workers=workers, first=rank * B)
+    cache = args.frames_cache if (args.frames_cache and world == 1) else None
+    if cache and os.path.exists(cache):   # (the profile passes render once: scripts/profile_bench.sh)
+        z = np.load(cache)
+        assert z["omni"].shape[0] >= 2 * B and int(z["seed"]) == args.seed and int(z["pano_width"]) == args.pano_width, "stale frames cache"
+        omni = np.ascontiguousarray(z["omni"][:2 * B])
+        poses = [(z["R"][i], z["t"][i]) for i in range(B)]
+    else:
+        omni, poses = synthetic.make_frame_pairs(gs, B, seed=args.seed, workers=workers, first=rank * B)
+        if cache:
+            np.savez(cache, omni=omni, R=np.stack([p_[0] for p_ in poses]), t=np.stack([p_[1] for p_ in poses]), seed=args.seed,
+                     pano_width=args.pano_width)
     seq_omni = None
     if world == 1 and not args.no_sub and args.sequence_frames > 0:   # (rendered here: forked workers, before any GPU call)
         seq_omni, seq_poses = synthetic.make_sequence(gs, args.sequence_frames, seed=args.seed + 7, workers=workers)

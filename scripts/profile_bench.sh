@@ -9,9 +9,13 @@ set -e -o pipefail
 TAG=${1:-run}
 PAIRS_PER_LAUNCH=${2:-256}   # pairs one kernel launch covers = pairs-per-gpu / streams (bench defaults: 768 / 3)
 EXTRA_ARGS=${EXTRA_ARGS:-}   # e.g. EXTRA_ARGS="--ransac-solver GP3P" or "--detector ORB" for the other configurations
-ARGS="--steps 10 --warmup 2 --no-cpu --no-h2d --no-isolated --no-sub --render-workers 1 $EXTRA_ARGS"
+CACHE=gpurun_out/${TAG}_frames.npz
+ARGS="--steps 10 --warmup 2 --no-cpu --no-h2d --no-isolated --no-sub --render-workers 1 --frames-cache $CACHE $EXTRA_ARGS"
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
+# render the frames ONCE, outside the profiler (forked workers), into the cache every pass below reads
+python3 bench.py --steps 1 --warmup 0 --no-cpu --no-h2d --no-isolated --no-sub --frames-cache $CACHE $EXTRA_ARGS > gpurun_out/${TAG}_plain.log 2>&1
+echo "frames rendered"
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$TAG --output-format csv -- python3 bench.py $ARGS > gpurun_out/prof_${TAG}_bench.log 2>&1
 echo "stats pass done"
 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_${TAG}_fetch --output-format csv -- python3 bench.py $ARGS > gpurun_out/pmc_${TAG}_fetch.log 2>&1
@@ -20,7 +24,7 @@ rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_${TAG}_write --output-format csv --
 echo "write pass done"
 if [ "${SQ_PASS:-1}" = "1" ]; then
   # 4. instruction counters (their own pass; one stream, 64 pairs per launch -- bench.py's valu_issue scales from that)
-  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES -d gpurun_out/pmc_${TAG}_sq --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu --no-h2d --no-isolated --no-sub --render-workers 1 --streams 1 --pairs-per-gpu 64 $EXTRA_ARGS > gpurun_out/pmc_${TAG}_sq.log 2>&1
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES -d gpurun_out/pmc_${TAG}_sq --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu --no-h2d --no-isolated --no-sub --render-workers 1 --frames-cache $CACHE --streams 1 --pairs-per-gpu 64 $EXTRA_ARGS > gpurun_out/pmc_${TAG}_sq.log 2>&1
   echo "sq pass done"
   python3 scripts/summarize_sq.py gpurun_out/pmc_${TAG}_sq > gpurun_out/${TAG}_sq_per_kernel.csv
 fi
@@ -31,10 +35,13 @@ grep -h '^{"metric"' gpurun_out/prof_${TAG}_bench.log > gpurun_out/${TAG}_bench_
 # GPU box (no .git there) -- the caller passes it as COMMIT=...
 python3 - "$TAG" "$PAIRS_PER_LAUNCH" "$EXTRA_ARGS" <<'PY'
 import json, os, sys
+sys.path.insert(0, os.getcwd())
+import bench
 tag, ppl, extra = sys.argv[1], int(sys.argv[2]), sys.argv[3].split()
 def opt(name, default):
     return extra[extra.index(name) + 1] if name in extra else default
-meta = {"commit": os.environ.get("COMMIT") or None, "detector": opt("--detector", "GFT"), "ransac_solver": opt("--ransac-solver", "P3P"),
+meta = {"commit": os.environ.get("COMMIT") or None, "csrc_hash": bench.csrc_hash(), "detector": opt("--detector", "GFT"), "ransac_solver": opt("--ransac-solver", "P3P"),
         "pano_width": int(opt("--pano-width", 1440)), "pairs_per_launch": ppl, "streams": int(opt("--streams", 3)), "extra_args": extra}
 json.dump(meta, open("gpurun_out/%s_meta.json" % tag, "w"))
 PY
+rm -f $CACHE
