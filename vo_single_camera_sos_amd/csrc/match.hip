@@ -34,21 +34,35 @@ __device__ __forceinline__ uint32_t hamming256(const uint4& a0, const uint4& a1,
 // hamming(q, t) = |q| + |t| - 2 q.t on 0/1 vectors: the pair distances of a (32 trains x 32 queries) tile are ONE exact
 // integer contraction over K = 256, i.e. eight v_mfma_i32_32x32x32_i8 on descriptors unpacked to one byte per bit.  The
 // step around this kernel is VALU-issue bound and MFMA issues beside VALU, so the 8 x (xor + popcount) per pair of the
-// kernel above (18 VALU wave-instructions per 64 pairs) become 2 per 64 pairs (key formation + running minimum) plus the
-// unpacking, and the contraction itself runs on the otherwise idle matrix cores.
+// round-2 kernel (18 VALU wave-instructions per 64 pairs) shrink to HALF an instruction per pair-element, and the
+// contraction itself runs on the otherwise idle matrix cores:
+//   operand values: a train bit is the byte 16, a query bit the byte -16, so the contraction yields -256 q.t = (-2 q.t) << 7;
+//     the accumulator is not cleared but STARTS at base7[row] = |t| << 7 | row-in-tile (the 16 accumulator registers of a
+//     lane are 4 x ds_read_b128 of that LDS table), so after the eight MFMAs every accumulator register already IS the
+//     tile-local partial key ((|t| - 2 q.t) << 7) + row -- ordered like the packed key (|q| is constant per lane): the
+//     epilogue is one v_min3_i32 per TWO pair-elements.  Once per 128-train tile the winner is widened to
+//     ((|t| - 2 q.t) << 20) + train index; |q| << 20 is added at the very end.  Rows past the train count start at 2^24.
 //   unpacking: any permutation of the 256 bit positions applied to both sides keeps q.t, so the cheapest one is used:
 //     dword w of a descriptor -> K-block w; lane half h (= lane / 32) takes the bits {s + 4 h + 8 b}: operand dword s =
-//     (x >> (s + 4 h)) & 0x01010101, byte b.  A operands (trains): unpacked once per workgroup into an LDS tile (row pitch
-//     272 B: conflict-free ds_read_b128 across the 16-lane groups); B operands (queries): 32 VGPRs per 32-query tile, resident.
-//   epilogue: accumulator r of lane l is (train row 8 (r / 4) + 4 (l / 32) + r % 4, query column l % 32).  With
-//     base[row] = |t| << 20 | train index (LDS), the signed partial key base - (q.t << 21) = ((|t| - 2 q.t) << 20) + index
-//     orders exactly like the packed key of the VALU kernel (|q| is constant per lane and added at the end), so the same
-//     signed min / first-index tie rule holds; rows past the train count carry base = 2^30 and never win.
+//     ((h ? x : x << 4) >> s) & 0x10101010, byte b.  A operands (trains): unpacked once per workgroup into an LDS tile (row
+//     pitch 272 B: conflict-free ds_read_b128 across the 16-lane groups); B operands (queries): 32 VGPRs per 32-query tile.
+//   accumulator r of lane l is (train row 8 (r / 4) + 4 (l / 32) + r % 4, query column l % 32).
+// Built with -mllvm -amdgpu-mfma-vgpr-form (csrc/Makefile): the accumulators live in VGPRs, no v_accvgpr_read per element.
+// Keep the MFMA sequence branch-free: a first version with a wave-uniform `if` around every MFMA made the compiler
+// shuttle the accumulators between register files around each instruction, and under load (another stream's kernels on
+// the same CUs) ~8 % of the launches returned a wrong key (tests/test_gpu_batch_call.py holds the regression).
 constexpr int kMmaTrainTile = 128;                  // trains per LDS tile
 constexpr int kMmaRowPitch = 272;                   // bytes per unpacked train row (256 + 16)
-constexpr int32_t kMmaInvalid = 1 << 30;
+constexpr int32_t kMmaInvalid7 = 1 << 24;           // base7 of a row without a train
+constexpr int32_t kMmaInvalid = 1 << 30;            // "no train seen yet" in the wide partial key
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 typedef int v16i32 __attribute__((ext_vector_type(16)));
+
+// the two smallest of {b, s, k} given b <= s
+__device__ __forceinline__ void two_smallest(int32_t& b, int32_t& s, int32_t k) {
+  s = max(min(b, s), min(max(b, s), k));  // median of three (v_med3_i32)
+  b = min(b, k);
+}
 
 template <int QT, int K>
 __global__ __launch_bounds__(kThreads) void match_hamming_mfma_kernel(
@@ -57,7 +71,7 @@ __global__ __launch_bounds__(kThreads) void match_hamming_mfma_kernel(
     int q_stride, int t_stride, int nsplit, uint32_t* __restrict__ keys) {
   SOSVO_LATENCY_BOUND_PRIO();
   __shared__ __attribute__((aligned(16))) uint8_t tile[kMmaTrainTile * kMmaRowPitch];
-  __shared__ __attribute__((aligned(16))) int32_t base[kMmaTrainTile];
+  __shared__ __attribute__((aligned(16))) int32_t base7[kMmaTrainTile];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 31, half = lane >> 5;
   const int p = blockIdx.x;
@@ -72,7 +86,7 @@ __global__ __launch_bounds__(kThreads) void match_hamming_mfma_kernel(
   const int te = min(ntp, tb + tiles_per * kMmaTrainTile);
   if (nsplit > 1 && tb >= te) return;  // keys were pre-set to NONE
 
-  // ---- this wave's queries: unpacked B operands, resident
+  // ---- this wave's queries: unpacked B operands (-16 per set bit), resident
   v4i32 bq[QT][8];
   int32_t pq[QT];
   int32_t best[QT], second[QT];
@@ -81,8 +95,7 @@ __global__ __launch_bounds__(kThreads) void match_hamming_mfma_kernel(
   const bool wave_live = q0 + wave * QT * 32 < nqp;  // wave-uniform
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
-    const int qbase = q0 + (wave * QT + t) * 32;
-    const int qi = qbase + col;
+    const int qi = q0 + (wave * QT + t) * 32 + col;
     const size_t row = (size_t)qs * q_stride + (qi < nqp ? qi : q0);
     const uint4 a = q_desc[row * 2 + 0], b = q_desc[row * 2 + 1];
     const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -90,9 +103,14 @@ __global__ __launch_bounds__(kThreads) void match_hamming_mfma_kernel(
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
       pc += __popc(w[kb]);
-      const uint32_t x = w[kb] >> (4 * half);
-      bq[t][kb] = v4i32{(int)(x & 0x01010101u), (int)((x >> 1) & 0x01010101u), (int)((x >> 2) & 0x01010101u),
-                        (int)((x >> 3) & 0x01010101u)};
+      const uint32_t y = half ? w[kb] : w[kb] << 4;
+      uint32_t n[4];
+#pragma unroll
+      for (int sft = 0; sft < 4; ++sft) {
+        const uint32_t m = (y >> sft) & 0x10101010u;
+        n[sft] = (m << 4) - m;  // 0x10 -> 0xF0 = -16 per byte (no carry between bytes)
+      }
+      bq[t][kb] = v4i32{(int)n[0], (int)n[1], (int)n[2], (int)n[3]};
     }
     pq[t] = pc;
     best[t] = kMmaInvalid;
@@ -104,41 +122,51 @@ __global__ __launch_bounds__(kThreads) void match_hamming_mfma_kernel(
     const int lim = min(kMmaTrainTile, te - t0);
     const int nrb = (lim + 31) >> 5;  // 32-row blocks that hold a train
     __syncthreads();
-    // unpack the train tile: item = (train j, dword kb) -> 32 bytes (both halves)
+    // unpack the train tile (16 per set bit): item = (train j, dword kb) -> 32 bytes (both lane halves)
     for (int it = tid; it < nrb * 32 * 8; it += kThreads) {
       const int j = it >> 3, kb = it & 7;
       const uint32_t x = j < lim ? reinterpret_cast<const uint32_t*>(tsrc + (size_t)(t0 + j) * 2)[kb] : 0u;
       uint4 lo, hi;
-      lo.x = x & 0x01010101u;
-      lo.y = (x >> 1) & 0x01010101u;
-      lo.z = (x >> 2) & 0x01010101u;
-      lo.w = (x >> 3) & 0x01010101u;
-      hi.x = (x >> 4) & 0x01010101u;
-      hi.y = (x >> 5) & 0x01010101u;
-      hi.z = (x >> 6) & 0x01010101u;
-      hi.w = (x >> 7) & 0x01010101u;
+      lo.x = (x << 4) & 0x10101010u;
+      lo.y = (x << 3) & 0x10101010u;
+      lo.z = (x << 2) & 0x10101010u;
+      lo.w = (x << 1) & 0x10101010u;
+      hi.x = x & 0x10101010u;
+      hi.y = (x >> 1) & 0x10101010u;
+      hi.z = (x >> 2) & 0x10101010u;
+      hi.w = (x >> 3) & 0x10101010u;
       uint4* dst = reinterpret_cast<uint4*>(tile + j * kMmaRowPitch + kb * 32);
       dst[0] = lo;
       dst[1] = hi;
     }
     for (int j = tid; j < nrb * 32; j += kThreads) {
-      int32_t v = kMmaInvalid;
+      int32_t v = kMmaInvalid7;
       if (j < lim) {
         const uint4 a = tsrc[(size_t)(t0 + j) * 2 + 0], b = tsrc[(size_t)(t0 + j) * 2 + 1];
         const int32_t pc = __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w) + __popc(b.x) + __popc(b.y) + __popc(b.z) +
                            __popc(b.w);
-        v = (pc << SOSVO_KEY_SHIFT) + (t0 + j);
+        v = (pc << 7) + j;
       }
-      base[j] = v;
+      base7[j] = v;
     }
     __syncthreads();
     if (!wave_live) continue;  // (uniform per wave; the barriers above are reached by every wave)
+    int32_t b7[QT], s7[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) b7[t] = s7[t] = kMmaInvalid;
     for (int rb = 0; rb < nrb; ++rb) {
       v16i32 acc[QT];
 #pragma unroll
-      for (int t = 0; t < QT; ++t)
+      for (int g = 0; g < 4; ++g) {
+        const v4i32 b4 = *reinterpret_cast<const v4i32*>(base7 + rb * 32 + 8 * g + 4 * half);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0;
+        for (int t = 0; t < QT; ++t) {
+          acc[t][4 * g + 0] = b4.x;
+          acc[t][4 * g + 1] = b4.y;
+          acc[t][4 * g + 2] = b4.z;
+          acc[t][4 * g + 3] = b4.w;
+        }
+      }
       const uint8_t* arow = tile + (rb * 32 + col) * kMmaRowPitch + half * 16;
 #pragma unroll
       for (int kb = 0; kb < 8; ++kb) {
@@ -146,24 +174,28 @@ __global__ __launch_bounds__(kThreads) void match_hamming_mfma_kernel(
 #pragma unroll
         for (int t = 0; t < QT; ++t) acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[t][kb], acc[t], 0, 0, 0);
       }
-      int32_t bs[16];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const v4i32 b4 = *reinterpret_cast<const v4i32*>(base + rb * 32 + 8 * g + 4 * half);
-        bs[4 * g + 0] = b4.x;
-        bs[4 * g + 1] = b4.y;
-        bs[4 * g + 2] = b4.z;
-        bs[4 * g + 3] = b4.w;
-      }
 #pragma unroll
       for (int t = 0; t < QT; ++t) {
+        if (K == 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int32_t key = bs[r] - (acc[t][r] << (SOSVO_KEY_SHIFT + 1));
-          if (K == 2) second[t] = min(second[t], max(best[t], key));
-          best[t] = min(best[t], key);
+          // a CHAIN min(min(best, a), b) per pair of elements: one v_min3_i32 each (no inline asm here: the compiler's
+          // hazard recogniser has to see the reads of the MFMA results to place the wait states)
+          for (int r = 0; r < 16; r += 2) b7[t] = min(min(b7[t], acc[t][r]), acc[t][r + 1]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) two_smallest(b7[t], s7[t], acc[t][r]);
         }
       }
+    }
+    // widen the tile's winner(s): ((|t| - 2 q.t) << 7) + row  ->  ((|t| - 2 q.t) << 20) + train index
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      const int32_t kb1 = b7[t] < (1 << 23) ? ((b7[t] >> 7) << SOSVO_KEY_SHIFT) + (t0 + (b7[t] & 127)) : kMmaInvalid;
+      if (K == 2) {
+        const int32_t ks1 = s7[t] < (1 << 23) ? ((s7[t] >> 7) << SOSVO_KEY_SHIFT) + (t0 + (s7[t] & 127)) : kMmaInvalid;
+        second[t] = min(max(best[t], kb1), min(second[t], ks1));
+      }
+      best[t] = min(best[t], kb1);
     }
   }
 
