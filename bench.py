@@ -739,7 +739,7 @@ def main():
             out["roofline"].update({"traffic_" + k: v for k, v in profile_meta(os.path.join(ROOT, traffic_src), run_cfg).items()})
         if n_gpus == 1 and not args.no_sub:
             # ---- sub-records of the same line (driver-timed): other detector / solver on the SAME frames, in this process
-            def sub_engine(gs_=None, rig_kw_=None, num_of_features=None, **kw):
+            def sub_engine(gs_=None, rig_kw_=None, num_of_features=None, pmc_tag=None, **kw):
                 e2 = OverlappedFramePairs(local_rank, gs_ or gs, (H, W), RigConfig(**(rig_kw_ or rig_kw)), B, n_streams=args.streams,
                                           num_of_features=num_of_features or args.features_per_mask, kp_cap=512, frame_cap=2048,
                                           max_iter=args.iters, adaptive=False, seed=args.seed, **kw)
@@ -749,6 +749,7 @@ def main():
                     e2.results()
                     e2.consumed()
                 torch.cuda.synchronize()
+                e2.profile_enable(True)
                 t1 = time.perf_counter()
                 for _ in range(args.sub_steps):
                     e2.step()
@@ -756,11 +757,36 @@ def main():
                     e2.consumed()
                 torch.cuda.synchronize()
                 dt2 = time.perf_counter() - t1
+                prof2 = e2.profile_read()
+                e2.profile_enable(False)
                 r2 = r2.cpu().numpy()
                 nk = np.concatenate([p.fe.n.cpu().numpy().reshape(2, -1, model.nmask).sum(-1) for p in e2.parts], axis=1)
                 rec2 = {"value": B * args.sub_steps / dt2, "unit": "frame-pairs/s", "ms_per_step": 1e3 * dt2 / args.sub_steps,
                         "steps": args.sub_steps, "pairs_per_step": B, "keypoints_per_view_mean": float(nk.mean()),
                         "tracked_ok": int((r2[:, 14] == 0).sum()), "inliers_per_pair_mean": float(r2[:, 12].mean())}
+                # roofline of this configuration: its dominant kernel by the library's own HIP-event profile
+                pk = {}
+                for name, ms in prof2:
+                    e_ = pk.setdefault(name, [0, 0.0, float("inf")])
+                    e_[0] += 1
+                    e_[1] += ms
+                    e_[2] = min(e_[2], ms)
+                if pk:
+                    d2 = max(pk.items(), key=lambda kv: kv[1][1])
+                    avg2 = d2[1][1] / d2[1][0] / 1e3
+                    ppl2 = B / float(e2.S)
+                    ba2 = b_alg_c2(H, W, int(round(float(nk.mean()))))
+                    import glob as _glob
+                    tr2, src2 = (None, None)
+                    if pmc_tag:
+                        cands = sorted(_glob.glob(os.path.join(ROOT, "profiles", "*", "*" + pmc_tag + "*_pmc_hbm_per_kernel.csv")))
+                        if cands:
+                            tr2, src2 = pmc_traffic(d2[0], ppl2, cands[-1])
+                    rec2["roofline"] = {"bound": "hbm", "kernel": d2[0], "achieved": ba2 * ppl2 / avg2 / 1e9, "peak": HBM_PEAK_GBS,
+                                        "unit": "GB/s", "frac": ba2 * ppl2 / avg2 / 1e9 / HBM_PEAK_GBS, "traffic": tr2,
+                                        "traffic_source": src2, "avg_launch_ms": avg2 * 1e3, "min_launch_ms": d2[1][2],
+                                        "algorithmic_bytes_per_pair": ba2, "pairs_per_launch": ppl2}
+                    rec2["kernels_ms_per_step"] = {k: v[1] / args.sub_steps for k, v in sorted(pk.items(), key=lambda kv: -kv[1][1])[:8]}
                 e2.close()
                 return rec2
             def c_abi_streams():
@@ -821,11 +847,11 @@ def main():
                     # frames' setting, pose_est_tools.py:427) and with the per-mask quota that yields that count; on the
                     # 11x11-median-blurred panoramas (the SOS frames' setting) FAST finds ~150 corners per view
                     out["orb_detector"] = sub_engine(detection_method="ORB", ransac_solver=args.ransac_solver, median_win_size=0,
-                                                     num_of_features=args.orb_features_per_mask)
+                                                     num_of_features=args.orb_features_per_mask, pmc_tag="orb")
                     out["orb_detector"]["setting"] = "ORB_create(%d).detect per mask + compute, median_win_size 0" % args.orb_features_per_mask
                     out["orb_detector_median11"] = sub_engine(detection_method="ORB", ransac_solver=args.ransac_solver)
                 if args.ransac_solver != "GP3P":
-                    out["gp3p"] = sub_engine(detection_method=args.detector, ransac_solver="GP3P")
+                    out["gp3p"] = sub_engine(detection_method=args.detector, ransac_solver="GP3P", pmc_tag="gp3p")
                 if args.pano_width != 1200:
                     # the reference's default panorama width (demo_vo_sos.py: 1200 columns -> 1200 x 122 panoramas, fewer
                     # keypoints per view than the 2000 BASELINE's metric names) on the same omni frames
