@@ -61,6 +61,26 @@ def profile_meta(csv_path, run_cfg):
     return {"profile_commit": meta.get("commit"), "profile_csrc_hash": meta.get("csrc_hash"), "stale": bool(differs), "differs": differs}
 
 
+RUN_CFG = {"detector": "GFT", "ransac_solver": "P3P", "pano_width": 1440}   # main() overwrites it with the run's own
+
+
+def profile_summaries(suffix):
+    """Committed profile summaries profiles/*/*<suffix>, best match for THIS run first: those whose <tag>_meta.json names the
+    run's detector / solver / panorama width, then (by name, newest round last) the ones without metadata; summaries of
+    another configuration (meta present and different) come last."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*" + suffix)))
+    def rank(path):
+        tag = os.path.basename(path).split("_")[0]
+        meta_path = os.path.join(os.path.dirname(path), tag + "_meta.json")
+        if not os.path.exists(meta_path):
+            return 1
+        meta = json.load(open(meta_path))
+        same = all(meta.get(k) == v for k, v in RUN_CFG.items())
+        return 2 if same else 0
+    return sorted(paths, key=lambda q: (rank(q), q))   # callers walk it in reverse: best match first
+
+
 def pmc_traffic(kernel, pairs_per_launch, pmc_csv=None):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 --pmc summary of this same command
     (profiles/*/*_pmc_hbm_per_kernel.csv, written by scripts/summarize_pmc.py from separate FETCH_SIZE and
@@ -69,7 +89,7 @@ def pmc_traffic(kernel, pairs_per_launch, pmc_csv=None):
     import csv
     import glob
     label = kernel.strip("()").split("<")[0]
-    paths = [pmc_csv] if pmc_csv else sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*pmc_hbm_per_kernel.csv")))
+    paths = [pmc_csv] if pmc_csv else profile_summaries("pmc_hbm_per_kernel.csv")
     for path in reversed(paths):
         if not os.path.exists(path):
             continue
@@ -87,7 +107,7 @@ def traffic_step(pairs_per_step, streams, b_alg_pair, pmc_csv=None):
     its ratio to the algorithmic bytes.  None without a summary."""
     import csv
     import glob
-    paths = [pmc_csv] if pmc_csv else sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*pmc_hbm_per_kernel.csv")))
+    paths = [pmc_csv] if pmc_csv else profile_summaries("pmc_hbm_per_kernel.csv")
     for path in reversed(paths):
         if not os.path.exists(path):
             continue
@@ -305,7 +325,7 @@ def valu_issue(kernel, pairs_per_launch, avg_launch_s):
     label = kernel.strip("()").split("<")[0]
     mix, mix_src, mix_commit = newest_isa_mix()
     cyc, _ = mix_cycles(label, mix)
-    for path in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*sq_per_kernel.csv")))):
+    for path in reversed(profile_summaries("sq_per_kernel.csv")):
         with open(path) as fh:
             for row in csv.DictReader(fh):
                 if row.get("label") == label:
@@ -341,7 +361,7 @@ def valu_issue_step(pairs_per_step, ms_per_step):
     import csv
     import glob
     mix, mix_src, mix_commit = newest_isa_mix()
-    for path in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*sq_per_kernel.csv")))):
+    for path in reversed(profile_summaries("sq_per_kernel.csv")):
         cyc, total, dom, per_kernel, unknown = 0.0, 0.0, 0.0, {}, []
         steps_profiled = None
         with open(path) as fh:
@@ -499,6 +519,7 @@ def main():
 
     B = args.pairs_per_gpu
     H, W = 480, 640
+    RUN_CFG.update(detector=args.detector, ransac_solver=args.ransac_solver, pano_width=args.pano_width)
     gs = synthetic_gums()
     for m in (gs.top_model, gs.bot_model):
         m.panorama = Panorama(m, width=args.pano_width)
