@@ -60,3 +60,10 @@ def test_plain_c_program_matches_ctypes_path(ctx, tmp_path):
     r2 = subprocess.run([exe, inp, outp, "2"], capture_output=True, text=True, timeout=120)
     assert r2.returncode == 0, r2.stderr
     assert np.array_equal(np.fromfile(outp, dtype=np.float64).reshape(B, 16).view(np.uint64), want.view(np.uint64))
+    # back-to-back enqueue + one join, and the same frames through the SEQUENCE entry points (front ends in windows of three
+    # frames into a frame store, then the slot pairs): the pair batch's records, bit for bit
+    for mode, text in (("enqueue", "the two record buffers agree"), ("sequence", "sequence: 4 frames")):
+        r4 = subprocess.run([exe, inp, outp, mode], capture_output=True, text=True, timeout=120)
+        assert r4.returncode == 0, r4.stdout[-500:] + r4.stderr[-500:]
+        assert text in r4.stdout, r4.stdout
+        assert np.array_equal(np.fromfile(outp, dtype=np.float64).reshape(B, 16).view(np.uint64), want.view(np.uint64)), mode
