@@ -246,7 +246,7 @@ def main():
                           "algorithm": algo, "value": S5 * B / dt, "ms_per_step": 1e3 * dt, "pairs_per_step": S5 * B, "streams": S5,
                           "tracked_ok": int((rec[:, 14] == 0).sum()), "inliers_mean": float(rec[:, 12].mean()),
                           "correspondences_mean": float(rec[:, 13].mean()),
-                          "roofline": roofline(per, dom, b_alg, B, "c5_" + algo.lower()),
+                          "roofline": roofline(per, dom, b_alg, B, "c5" + algo.lower()),
                           "kernels_ms_per_step": {k: v[1] / nsteps for k, v in sorted(per.items(), key=lambda kv: -kv[1][1])},
                           "data": "synthetic (%d distinct pairs)" % (S5 * B)}))
         for _, c, _ in insts:
