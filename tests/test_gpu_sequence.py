@@ -134,3 +134,26 @@ def test_run_vo_pose_file_does_not_depend_on_the_frame_window(ctx, tmp_path):
     T_gt[:3, :3], T_gt[:3, 3] = poses[n - 1][0], poses[n - 1][1] * 1e-3
     E = tr.rpe(T_gt, outs[32]["poses"][n - 1][1])
     assert tr.rpe_rotation_metric(E) < np.deg2rad(25.0) and tr.rpe_translation_metric(E) < 2.0, E
+
+
+def test_run_vo_stops_at_an_untrackable_frame_like_the_mirror_path(ctx, tmp_path):
+    """A black frame in the middle of a sequence has no correspondences: the reference's loop warns and stops
+    (pose_est_tools.py:1490-1494).  Sequence mode (any window) and the per-frame mirror path stop at the same frame with the
+    same poses before it."""
+    import demo_vo_sos
+    from vo_single_camera_sos_amd.omnistereo.common_cv import imwrite
+    gs, _ = _rig()
+    n = 9
+    seq = str(tmp_path / "seq_black")
+    synthetic.write_sos_sequence(seq, gs, n_frames=n, seed=5, max_t=40.0, max_deg=2.0)
+    imwrite(os.path.join(seq, "omni", "image-0005.png"), np.zeros((480, 640, 3), np.uint8))
+    gums = os.path.join(seq, "gums-calibrated.json")
+    outs = {}
+    for w in (4, 1, 0):
+        with pytest.warns(UserWarning):
+            outs[w] = demo_vo_sos.main_sos_vo([seq, "--calibrated_gums_file", gums, "--frame_window", str(w),
+                                               "--use_multithreads_for_VO", "false"])
+    for w in (4, 1, 0):
+        assert [p[0] for p in outs[w]["poses"]] == [0, 1, 2, 3, 4], (w, [p[0] for p in outs[w]["poses"]])
+    for (i, Ta), (_, Tb), (_, Tc) in zip(outs[4]["poses"], outs[1]["poses"], outs[0]["poses"]):
+        assert np.array_equal(Ta, Tb) and np.allclose(Ta, Tc, rtol=1e-6, atol=1e-9), i
