@@ -119,14 +119,15 @@ int32_t sosvo_median_gray(sosvo_ctx* ctx, const uint8_t* img, int32_t nimg, int3
  * sosvo_median_gray on its output): every lane unwraps its source pixel from the table on the fly, so the
  * colour panoramas (camera_models.py:2991-2996 -> :1711 -> :1714) are never written to HBM.
  *   omni [nframes, H, W, 3] u8, table from sosvo_unwrap_prepare -> gray [2 * nframes, rows, cols] u8
- *   (view-major).  ksize in {3, 5, 11}.                                                            */
+ *   (view-major).  ksize in {3, 5, 11}; 0 / 1 = no median: the pixel is unwrapped and converted to gray at once.   */
 int32_t sosvo_unwrap_median_gray(sosvo_ctx* ctx, const uint8_t* omni, const uint32_t* table, int32_t nframes,
                                  int32_t H, int32_t W, int32_t rows, int32_t cols, int32_t ksize, uint8_t* gray);
 
 /* The same with the output restricted to the rows a consumer can reach: row_range = int32 [2][2] in DEVICE memory
  * (view-major: first row, last row + 1 of the top and of the bottom panoramas), written by sosvo_gray_rows_needed;
  * NULL = all rows (sosvo_unwrap_median_gray).  Rows outside a view's range are neither computed nor written (the
- * caller's buffer keeps what it held); inside, the result is sosvo_unwrap_median_gray's bit for bit. */
+ * caller's buffer keeps what it held); inside, the result is sosvo_unwrap_median_gray's bit for bit.  (ksize 0 / 1 writes
+ * every row and does not read row_range.) */
 int32_t sosvo_unwrap_median_gray_rows(sosvo_ctx* ctx, const uint8_t* omni, const uint32_t* table, int32_t nframes,
                                       int32_t H, int32_t W, int32_t rows, int32_t cols, int32_t ksize,
                                       const int32_t* row_range, uint8_t* gray);

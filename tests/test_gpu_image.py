@@ -132,7 +132,7 @@ def test_get_panoramic_image_mirror_method(ctx, rig):
     assert np.array_equal(pn.panoramic_img, out)
 
 
-@pytest.mark.parametrize("pshape,k", [((40, 72), 11), ((41, 71), 5), ((13, 130), 3), ((1, 5), 11)])
+@pytest.mark.parametrize("pshape,k", [((40, 72), 11), ((41, 71), 5), ((13, 130), 3), ((1, 5), 11), ((40, 72), 0), ((17, 301), 1)])
 def test_fused_unwrap_median_gray_equals_oracle_chain(ctx, pshape, k):
     """sosvo_unwrap_median_gray (K1 inside the median kernel, no colour panorama in HBM) against
     oracle.unwrap -> oracle.median_gray; taps on the first/last bytes of a frame included."""

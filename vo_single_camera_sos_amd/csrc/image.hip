@@ -220,6 +220,27 @@ __global__ __launch_bounds__(kThreads) void gray_kernel(const uint8_t* __restric
   gray[i] = bgr2gray(img[3 * i], img[3 * i + 1], img[3 * i + 2]);
 }
 
+// K1 + K3 without a median (median_win_size 0 / 1: the RGB-D frames' setting, and the setting under which the ORB detector
+// finds its quota on panoramas): every lane unwraps its pixel from the table and converts it to gray at once -- the colour
+// panoramas (2.5 MB per frame pair) are neither written nor read.  Same arithmetic as unwrap_lut_kernel + gray_kernel.
+__global__ __launch_bounds__(kThreads) void unwrap_gray_kernel(const uint8_t* __restrict__ omni, const uint2* __restrict__ table,
+                                                               int nframes, int H, int W, int npix, uint8_t* __restrict__ gray) {
+  const int gx = (npix + kThreads - 1) / kThreads;   // XCD-aware 1-D grid as in unwrap_lut_kernel: one image on one XCD
+  const int q = blockIdx.x >> 3;
+  const int grp = q / gx, blk = q - grp * gx;
+  const int img = grp * 8 + (blockIdx.x & 7);
+  if (img >= 2 * nframes) return;  // uniform
+  const int pix = blk * kThreads + threadIdx.x;
+  if (pix >= npix) return;
+  const int view = img / nframes, frame = img - view * nframes;
+  const uint8_t* src = omni + (size_t)frame * H * W * 3;
+  const uint2 e = table[(size_t)view * npix + pix];
+  unsigned long long v[2];
+  unwrap_gather(src, H * W * 3, W, e, v);
+  const uint32_t bgr = unwrap_blend(H * W * 3, W, e, v);
+  gray[(size_t)img * npix + pix] = bgr2gray((int)(bgr & 255u), (int)((bgr >> 8) & 255u), (int)((bgr >> 16) & 255u));
+}
+
 // 64-bit wave ballot of "byte `byte` of x has its top bit set", as ONE SDWA compare (all lanes must be active).
 __device__ __forceinline__ unsigned long long ballot_byte_sign(uint32_t x, int byte, uint32_t vzero) {
   unsigned long long bal;
@@ -588,8 +609,15 @@ int32_t sosvo_unwrap_median_gray_rows(sosvo_ctx* ctx, const uint8_t* omni, const
   SOSVO_REQUIRE(ctx, H > 0 && W > 0 && H <= 16384 && W <= 16384 && rows > 0 && cols > 0 && rows * (int64_t)cols < (1 << 28),
                 "image sizes out of range");
   SOSVO_REQUIRE(ctx, ((uintptr_t)table & 7) == 0, "table must be 8-byte aligned");
-  SOSVO_REQUIRE(ctx, ksize == 3 || ksize == 5 || ksize == 11, "ksize must be 3, 5 or 11");
+  SOSVO_REQUIRE(ctx, ksize == 0 || ksize == 1 || ksize == 3 || ksize == 5 || ksize == 11, "ksize must be 0/1 (no median), 3, 5 or 11");
   if (nframes == 0) return SOSVO_OK;
+  if (ksize <= 1) {  // no median: unwrap straight to gray (every row: nothing is skipped, row_range is not consulted)
+    const int npix = rows * cols;
+    SOSVO_LAUNCH(ctx, unwrap_gray_kernel, dim3((unsigned)(cdiv(npix, kThreads) * 8 * cdiv(2 * nframes, 8))), dim3(kThreads), 0,
+                 ctx->stream, omni, reinterpret_cast<const uint2*>(table), nframes, H, W, npix, gray);
+    SOSVO_LAUNCH_CHECK(ctx);
+    return SOSVO_OK;
+  }
   return launch_median<true>(ctx, omni, reinterpret_cast<const uint2*>(table), nframes, H, W, 2 * nframes, rows, cols, ksize,
                              row_range, gray);
 }

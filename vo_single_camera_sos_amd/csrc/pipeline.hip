@@ -34,7 +34,7 @@ Buffers carve(const sosvo_batch_cfg& c, void* ws) {
   Buffers b;
   const size_t B = c.n_pairs, F = 2 * B, NI = 2 * F, P = NI * c.nmask, cap = c.kp_cap, Fc = c.frame_cap, Cc = 2 * Fc;
   const size_t npx = (size_t)c.rows * c.cols;
-  const bool fused = c.median_ksize == 3 || c.median_ksize == 5 || c.median_ksize == 11;  // K1 inside the median kernel
+  const bool fused = c.median_ksize <= 1 || c.median_ksize == 3 || c.median_ksize == 5 || c.median_ksize == 11;  // K1 inside the median / gray kernel
   b.pano = fused ? nullptr : cv.take<uint8_t>(NI * npx * 3);
   b.gray = cv.take<uint8_t>(NI * npx);
   b.kp = cv.take<float>(P * cap * 2);
@@ -137,7 +137,7 @@ SeqBuffers carve_seq(const sosvo_batch_cfg& c, int window, int slots, void* ws) 
   SeqBuffers b;
   const size_t B = c.n_pairs, F = window, NI = 2 * F, P = NI * c.nmask, cap = c.kp_cap, Fc = c.frame_cap, Cc = 2 * Fc, S = slots;
   const size_t npx = (size_t)c.rows * c.cols;
-  const bool fused = c.median_ksize == 3 || c.median_ksize == 5 || c.median_ksize == 11;
+  const bool fused = c.median_ksize <= 1 || c.median_ksize == 3 || c.median_ksize == 5 || c.median_ksize == 11;
   b.pano = fused ? nullptr : cv.take<uint8_t>(NI * npx * 3);
   b.gray = cv.take<uint8_t>(NI * npx);
   b.kp = cv.take<float>(P * cap * 2);
@@ -325,6 +325,9 @@ static int32_t run_front_end(sosvo_ctx* ctx, const sosvo_rig* rig, const sosvo_b
                                  t.gray_rows));
     STAGE(sosvo_unwrap_median_gray_rows(ctx, omni, unwrap_table, F, cfg->H, cfg->W, cfg->rows, cfg->cols, cfg->median_ksize,
                                         t.gray_rows, t.gray));
+  } else if (cfg->median_ksize <= 1) {  // no median: unwrap straight to gray, every row
+    STAGE(sosvo_unwrap_median_gray_rows(ctx, omni, unwrap_table, F, cfg->H, cfg->W, cfg->rows, cfg->cols, cfg->median_ksize,
+                                        nullptr, t.gray));
   } else {
     STAGE(sosvo_unwrap_table(ctx, omni, unwrap_table, F, cfg->H, cfg->W, cfg->rows, cfg->cols, t.pano));
     STAGE(sosvo_median_gray(ctx, t.pano, NI, cfg->rows, cfg->cols, cfg->median_ksize, t.gray));

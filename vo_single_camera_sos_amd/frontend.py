@@ -74,7 +74,7 @@ class ImageFrontEnd(object):
         dev, m = ctx.device, model
         NI, P = 2 * self.F, 2 * self.F * m.nmask
         self.omni = torch.zeros((self.F, m.H, m.W, 3), dtype=torch.uint8, device=dev)
-        self.keep_panoramas = bool(keep_panoramas) or self.median_win_size not in (3, 5, 11)
+        self.keep_panoramas = bool(keep_panoramas) or self.median_win_size not in (0, 1, 3, 5, 11)
         self.pano = torch.zeros((2, self.F, m.rows, m.cols, 3), dtype=torch.uint8, device=dev) if self.keep_panoramas else None
         self.gray = torch.zeros((NI, m.rows, m.cols), dtype=torch.uint8, device=dev)
         self.kp = torch.zeros((P, self.kp_cap, 2), dtype=torch.float32, device=dev)
