@@ -180,3 +180,38 @@ def test_feature_matcher_mirror_on_float_descriptors_and_flann(ctx):
     ml = FeatureMatcher("ORB", "FLANN", 1, context=ctx).match(rng.integers(0, 256, (30, 32), dtype=np.uint8),
                                                                rng.integers(0, 256, (40, 32), dtype=np.uint8))
     assert len(ml) == 30
+
+
+def test_matrix_pipe_tile_boundaries_and_extreme_descriptors(ctx):
+    """The MFMA matcher's tiling (32-query tiles, 32-row blocks, 128-train LDS tiles, train-range splits merged by atomicMin,
+    two query tiles per wave from a stride of 1024 on) at every boundary, 1-NN and 2-NN; and the arithmetic's extremes: all-zero
+    and all-one descriptors (|q| + |t| - 2 q.t = 0 and 256, partial keys of both signs), identical rows (ties -> first
+    train index)."""
+    sizes = [0, 1, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 383, 385]
+    rng = np.random.default_rng(77)
+    for stride in (400, 1100):
+        P = len(sizes)
+        nq = np.array(sizes, dtype=np.int32)
+        nt = np.array(sizes[::-1], dtype=np.int32)
+        if stride > 1024:
+            nq[-1], nt[0], nq[3], nt[5] = 1100, 1100, 1025, 1024
+        for k in (1, 2):
+            _check(ctx, P, stride, stride, nq, nt, k, seed=int(stride + k))
+    # extremes
+    q = rng.integers(0, 256, (2, 96, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (2, 160, 32), dtype=np.uint8)
+    q[0, 0] = 0
+    q[0, 1] = 255
+    t[0, 5] = 255
+    t[0, 9] = 0
+    t[0, 130] = 255          # a second all-ones row in the next LDS tile: the first one (index 5) must win for q[0, 1]
+    t[1, :] = t[1, 0]        # every train row identical: index 0 wins everywhere, the second neighbour is index 1
+    nq, nt = np.array([96, 96], np.int32), np.array([160, 160], np.int32)
+    for k in (1, 2):
+        got = _run(ctx, q, t, nq, nt, k)
+        for p in range(2):
+            assert np.array_equal(got[p], oracle.match_hamming(q[p], t[p], k=k)), (k, p)
+    got = _run(ctx, q, t, nq, nt, 2)
+    assert got[0, 0, 0] == (0 << 20 | 9) and got[0, 1, 0] == (0 << 20 | 5) and got[0, 1, 1] == (0 << 20 | 130)
+    assert (got[1, :, 0] & 0xFFFFF == 0).all() and (got[1, :, 1] & 0xFFFFF == 1).all()
+    assert int(np.unpackbits(q[0, 0] ^ t[0, 5]).sum()) == 256   # (the table holds the largest distance, too)
