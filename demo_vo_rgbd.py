@@ -32,6 +32,9 @@ def main_rgbd_vo(argv=None):
     parser.add_argument("--last_image_index", default=-1, type=int)
     parser.add_argument("--step", default=1, type=int)
     parser.add_argument("--use_multithreads_for_VO", default=True, type="bool")
+    parser.add_argument("--frame_window", default=-1, type=int,
+                        help="sequence mode: frames per batched front-end pass on the GPU (-1 = default 32; 0 = the per-frame "
+                             "mirror path).  The pose file does not depend on the window size.")
     args = parser.parse_args(argv)
 
     from vo_single_camera_sos_amd.omnistereo.camera_models import RGBDCamModel
@@ -65,7 +68,8 @@ def main_rgbd_vo(argv=None):
                     num_scene_images=num_scene_images, visualize_VO=args.visualize_VO,
                     use_multithreads_for_VO=args.use_multithreads_for_VO, step_for_scene_images=args.step,
                     first_image_index=args.first_image_index, last_image_index=args.last_image_index,
-                    thread_name="%s-%s" % (scene_name, "RGB-D"))
+                    thread_name="%s-%s" % (scene_name, "RGB-D"),
+                    frame_window=None if args.frame_window < 0 else args.frame_window)
     print("GOODBYE!")
     return out
 

@@ -627,6 +627,26 @@ int32_t sosvo_rgbd_pair_batch(sosvo_ctx* ctx, const sosvo_rgbd_cam* cam_host, co
                               const uint8_t* bgr, const float* depth, const uint32_t* mask_bits, const int8_t* pattern,
                               void* workspace, size_t workspace_bytes, double* results);
 
+/* ---- RGB-D sequence mode (the same split for the perspective path: demo_vo_rgbd.py's loop) ------------------
+ * run_VO builds ONE RGBDFrame per image (pose_est_tools.py:1440-1446, :600-623) and tracks it against the current keyframe
+ * (TrackerRGBDSE3.track_frame, :896-954).  Frame store, window, slots, seeds and the speculation argument exactly as in the
+ * omnistereo sequence mode above; cfg: sosvo_rgbd_batch_cfg as for sosvo_rgbd_pair_batch (n_pairs = slot pairs one
+ * ..._track call may hold).
+ *   bgr [n_frames, rows, cols, 3] u8, depth [n_frames, rows, cols] f32 (device)                                      */
+size_t sosvo_rgbd_sequence_workspace(const sosvo_rgbd_batch_cfg* cfg, int32_t window, int32_t slots);
+int32_t sosvo_rgbd_sequence_front_end(sosvo_ctx* ctx, const sosvo_rgbd_cam* cam_host, const sosvo_rgbd_batch_cfg* cfg_host,
+                                      int32_t window, int32_t slots, const uint8_t* bgr, const float* depth, int32_t n_frames,
+                                      int32_t first_slot, const uint32_t* mask_bits, const int8_t* pattern, void* workspace,
+                                      size_t workspace_bytes);
+int32_t sosvo_rgbd_sequence_track(sosvo_ctx* ctx, const sosvo_rgbd_batch_cfg* cfg_host, int32_t window, int32_t slots,
+                                  const int32_t* ref_slot_host, const int32_t* cur_slot_host, int32_t n_pairs, uint64_t seed,
+                                  void* workspace, size_t workspace_bytes, double* results);
+int32_t sosvo_rgbd_sequence_copy_slot(sosvo_ctx* ctx, const sosvo_rgbd_batch_cfg* cfg_host, int32_t window, int32_t slots,
+                                      int32_t src_slot, int32_t dst_slot, void* workspace, size_t workspace_bytes);
+int32_t sosvo_rgbd_sequence_frame_counts(sosvo_ctx* ctx, const sosvo_rgbd_batch_cfg* cfg_host, int32_t window, int32_t slots,
+                                         int32_t first_slot, int32_t n, void* workspace, size_t workspace_bytes,
+                                         int32_t* counts_host);
+
 #ifdef __cplusplus
 }
 #endif

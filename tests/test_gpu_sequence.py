@@ -157,3 +157,45 @@ def test_run_vo_stops_at_an_untrackable_frame_like_the_mirror_path(ctx, tmp_path
         assert [p[0] for p in outs[w]["poses"]] == [0, 1, 2, 3, 4], (w, [p[0] for p in outs[w]["poses"]])
     for (i, Ta), (_, Tb), (_, Tc) in zip(outs[4]["poses"], outs[1]["poses"], outs[0]["poses"]):
         assert np.array_equal(Ta, Tb) and np.allclose(Ta, Tc, rtol=1e-6, atol=1e-9), i
+
+
+def test_rgbd_sequence_engine_and_demo(ctx, tmp_path):
+    """RGB-D sequence mode: (i) RGBDSequenceEngine's records equal sosvo_rgbd_pair_batch on (frame t - 1, frame t) with the
+    sequence's seed, for several windows, bit for bit; (ii) demo_vo_rgbd.main_rgbd_vo writes the byte-identical pose file for
+    frame windows 8 and 1, and the per-frame mirror path (frame_window 0) gives the same poses (its frames are computed by the
+    same kernels, one frame per call)."""
+    import demo_vo_rgbd
+    from vo_single_camera_sos_amd.pipeline import RGBDCamConfig, RGBDPairBatch, RGBDSequenceEngine
+    n = 12
+    seq = str(tmp_path / "seq_rgbd")
+    synthetic.write_rgbd_sequence(seq, n_frames=n, seed=41, max_t=40.0, max_deg=2.0, depth_is_Z=False)
+    from vo_single_camera_sos_amd.omnistereo.common_cv import get_depthmap_float32_from_png, get_images, imread
+    names = get_images(os.path.join(seq, "rgbd", "rgb", "*.png"), indices_list=None, return_names_only=True)
+    dnames = get_images(os.path.join(seq, "rgbd", "depth", "*.png"), indices_list=None, return_names_only=True)
+    bgr = np.stack([np.ascontiguousarray(imread(f)[..., ::-1]) for f in names])       # as run_VO hands them over (:1430)
+    depth = np.stack([get_depthmap_float32_from_png(f, 1.0 / 1000.0) for f in dnames])
+    cam = RGBDCamConfig(fx=554.256258, fy=554.256258, center_x=319.5, center_y=239.5, depth_is_Z=False, min_range=0.8, max_range=7.0)
+    kw = dict(num_of_features=1000, max_iter=210, adaptive=True, pose_est_algorithm="EPNP")
+    want = []
+    for t in range(1, 6):
+        pb = RGBDPairBatch(ctx, cam, 1, seed=t - 1, **kw)
+        pb.load_frames(bgr[t - 1:t + 1], depth[t - 1:t + 1])
+        want.append(pb.step().cpu().numpy()[0].copy())
+    want = np.stack(want)
+    assert (want[:, 14] == 0).all() and (want[:, 12] > 100).all(), want[:, 12:16]
+    for window in (1, 4, 6):
+        eng = RGBDSequenceEngine(ctx, cam, window=window, **kw)
+        got = []
+        for w0 in range(0, 6, window):
+            for info in eng.push_window([(bgr[i], depth[i]) for i in range(w0, min(6, w0 + window))]):
+                if info["spec"] is not None:
+                    got.append(info["spec"])
+        assert np.array_equal(np.stack(got), want), window
+    outs, texts = {}, {}
+    for w in (8, 1, 0):
+        outs[w] = demo_vo_rgbd.main_rgbd_vo([seq, "--is_synthetic", "true", "--frame_window", str(w)])
+        assert outs[w]["tracked"] == n - 1, (w, outs[w]["tracked"])
+        texts[w] = open(os.path.join(seq, "results-rgbd", "estimated_frame_poses_TUM.txt")).read()
+    assert texts[8] == texts[1] and "sequence_mode" in outs[8] and "sequence_mode" not in outs[0]
+    for (i, Ta), (_, Tb) in zip(outs[8]["poses"], outs[0]["poses"]):
+        assert np.allclose(Ta, Tb, rtol=1e-9, atol=1e-12), (i, np.abs(Ta - Tb).max())

@@ -99,6 +99,11 @@ SIGNATURES = {
     "sosvo_sequence_track": (c_i32, [c_p, c_p, c_p, c_i32, c_i32, c_p, c_p, c_i32, c_u64, c_p, ctypes.c_size_t, c_p]),
     "sosvo_sequence_copy_slot": (c_i32, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p, ctypes.c_size_t]),
     "sosvo_sequence_frame_counts": (c_i32, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p, ctypes.c_size_t, c_p]),
+    "sosvo_rgbd_sequence_workspace": (ctypes.c_size_t, [c_p, c_i32, c_i32]),
+    "sosvo_rgbd_sequence_front_end": (c_i32, [c_p, c_p, c_p, c_i32, c_i32, c_p, c_p, c_i32, c_i32, c_p, c_p, c_p, ctypes.c_size_t]),
+    "sosvo_rgbd_sequence_track": (c_i32, [c_p, c_p, c_i32, c_i32, c_p, c_p, c_i32, c_u64, c_p, ctypes.c_size_t, c_p]),
+    "sosvo_rgbd_sequence_copy_slot": (c_i32, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p, ctypes.c_size_t]),
+    "sosvo_rgbd_sequence_frame_counts": (c_i32, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p, ctypes.c_size_t, c_p]),
     "sosvo_rgbd_pair_batch_workspace": (ctypes.c_size_t, [c_p]),
     "sosvo_rgbd_pair_batch": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
 }

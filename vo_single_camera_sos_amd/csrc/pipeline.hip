@@ -270,6 +270,82 @@ RgbdBuffers carve_rgbd(const sosvo_rgbd_batch_cfg& c, void* ws) {
   return b;
 }
 
+// RGB-D sequence mode: a store of `slots` RGBDFrame records (keypoints with valid depth, descriptors, points, bearings)
+struct RgbdSeqBuffers {
+  uint8_t *gray, *desc;                        // front-end temporaries of one window
+  float* kp;
+  int32_t *n, *status;
+  uint8_t* d;                                  // the frame store (slot-major)
+  float* m;
+  double *X, *b;
+  int32_t* M;
+  uint8_t* mask;                               // tracking of up to cfg.n_pairs slot pairs per call
+  int32_t *ref_frame, *cur_frame, *order, *cq, *ct, *cn, *idx, *n_inl, *info, *lm_iters;
+  uint32_t* keys;
+  double *f, *p, *T_ransac, *T, *lm_cost;
+  size_t bytes;
+};
+
+RgbdSeqBuffers carve_rgbd_seq(const sosvo_rgbd_batch_cfg& c, int window, int slots, void* ws) {
+  Carver cv{reinterpret_cast<char*>(ws)};
+  RgbdSeqBuffers b;
+  const size_t B = c.n_pairs, F = window, S = slots, cap = c.kp_cap, Fc = c.frame_cap, npx = (size_t)c.rows * c.cols;
+  b.gray = cv.take<uint8_t>(F * npx);
+  b.kp = cv.take<float>(F * cap * 2);
+  b.n = cv.take<int32_t>(F);
+  b.status = cv.take<int32_t>(F);
+  b.desc = cv.take<uint8_t>(F * cap * 32);
+  b.m = cv.take<float>(S * Fc * 2);
+  b.d = cv.take<uint8_t>(S * Fc * 32);
+  b.X = cv.take<double>(S * Fc * 3);
+  b.b = cv.take<double>(S * Fc * 3);
+  b.M = cv.take<int32_t>(S);
+  b.ref_frame = cv.take<int32_t>(B);
+  b.cur_frame = cv.take<int32_t>(B);
+  b.keys = cv.take<uint32_t>(B * Fc);
+  b.order = cv.take<int32_t>(B * Fc);
+  b.f = cv.take<double>(B * Fc * 3);
+  b.p = cv.take<double>(B * Fc * 3);
+  b.cq = cv.take<int32_t>(B * Fc);
+  b.ct = cv.take<int32_t>(B * Fc);
+  b.cn = cv.take<int32_t>(B);
+  b.T_ransac = cv.take<double>(B * 12);
+  b.mask = cv.take<uint8_t>(B * Fc);
+  b.idx = cv.take<int32_t>(B * Fc);
+  b.n_inl = cv.take<int32_t>(B);
+  b.info = cv.take<int32_t>(B * 4);
+  b.T = cv.take<double>(B * 12);
+  b.lm_cost = cv.take<double>(B);
+  b.lm_iters = cv.take<int32_t>(B);
+  b.bytes = cv.off;
+  return b;
+}
+
+__global__ void rgbd_seq_setup_kernel(int npairs, SlotPairs sp, int32_t* __restrict__ ref_frame, int32_t* __restrict__ cur_frame) {
+  const int i = threadIdx.x;
+  if (i < npairs && i < kSeqArgPairs) {
+    ref_frame[i] = sp.ref[i];
+    cur_frame[i] = sp.cur[i];
+  }
+}
+
+__global__ void rgbd_seq_copy_slot_kernel(int src, int dst, int Fc, float* m, uint4* d, double* X, double* b, int32_t* M) {
+  const int n = M[src];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const size_t s = (size_t)src * Fc + i, t = (size_t)dst * Fc + i;
+    m[2 * t] = m[2 * s];
+    m[2 * t + 1] = m[2 * s + 1];
+    d[2 * t] = d[2 * s];
+    d[2 * t + 1] = d[2 * s + 1];
+    for (int k = 0; k < 3; ++k) {
+      X[3 * t + k] = X[3 * s + k];
+      b[3 * t + k] = b[3 * s + k];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) M[dst] = n;
+}
+
 __global__ void pair_index_kernel(int npairs, int32_t* __restrict__ ref_frame, int32_t* __restrict__ cur_frame) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < npairs) {
@@ -627,6 +703,62 @@ size_t sosvo_rgbd_pair_batch_workspace(const sosvo_rgbd_batch_cfg* cfg) {
   return carve_rgbd(*cfg, nullptr).bytes;
 }
 
+// RGBDFrame.establish_keypoints for F frames (pose_est_tools.py:600-623): [median,] gray, whole-image GFT (one mask), ORB
+// descriptors, depth back-projection + range filter + bearings -> F frame records at the store pointers.
+struct RgbdFrontTmp {
+  uint8_t *gray, *desc;
+  float* kp;
+  int32_t *n, *status;
+};
+struct RgbdStore {
+  float* m;
+  uint8_t* d;
+  double *X, *b;
+  int32_t* M;
+};
+static int32_t run_rgbd_front_end(sosvo_ctx* ctx, const sosvo_rgbd_cam* cam, const sosvo_rgbd_batch_cfg* cfg, int F,
+                                  const uint8_t* bgr, const float* depth, const uint32_t* mask_bits, const int8_t* pattern,
+                                  const RgbdFrontTmp& t, const RgbdStore& o) {
+  const int cap = cfg->kp_cap, Fc = cfg->frame_cap;
+  int32_t rc;
+  STAGE(sosvo_median_gray(ctx, bgr, F, cfg->rows, cfg->cols, cfg->median_ksize, t.gray));
+  STAGE(sosvo_detect_gft(ctx, t.gray, mask_bits, F, F, cfg->rows, cfg->cols, 1, cfg->quality, cfg->min_distance,
+                         cfg->max_corners, cap, t.kp, t.n, t.status));
+  STAGE(sosvo_describe_orb(ctx, t.gray, F, cfg->rows, cfg->cols, 1, cap, t.kp, t.n, cfg->cos_a, cfg->sin_a, pattern, cfg->edge,
+                           t.desc));
+  STAGE(sosvo_rgbd_assemble(ctx, cam, t.kp, t.desc, t.n, depth, F, cfg->rows, cfg->cols, cap, Fc, o.m, o.d, o.X, o.b, o.M));
+  return SOSVO_OK;
+}
+
+// TrackerRGBDSE3.track_frame (pose_est_tools.py:896-954) for B (reference slot, current slot) pairs of a frame store:
+// query = current frame, train = reference frame; central RANSAC (problem i samples with seed + i) + LM.
+struct RgbdTrackTmp {
+  int32_t *ref_frame, *cur_frame, *order, *cq, *ct, *cn, *idx, *n_inl, *info, *lm_iters;
+  uint32_t* keys;
+  uint8_t* mask;
+  double *f, *p, *T_ransac, *T, *lm_cost;
+};
+static int32_t run_rgbd_tracking(sosvo_ctx* ctx, const sosvo_rgbd_batch_cfg* cfg, int B, uint64_t seed, const RgbdStore& s,
+                                 const RgbdTrackTmp& b, double* results) {
+  const int Fc = cfg->frame_cap;
+  int32_t rc;
+  STAGE(sosvo_match_hamming(ctx, s.d, s.d, s.M, s.M, b.cur_frame, b.ref_frame, B, Fc, Fc, 1, b.keys));
+  STAGE(sosvo_sort_matches(ctx, b.keys, s.M, b.cur_frame, B, Fc, b.order));
+  STAGE(sosvo_f2f_assemble_central(ctx, cfg->pct_good_matches, cfg->f2f_max_hdiff, s.m, s.X, s.b, s.M, Fc, b.ref_frame,
+                                   b.cur_frame, b.keys, b.order, B, Fc, b.f, b.p, b.cq, b.ct, b.cn));
+  STAGE(sosvo_ransac_abs_pose(ctx, b.f, b.p, nullptr, nullptr, nullptr, 1,
+                              cfg->flags & (SOSVO_FLAG_EPNP | SOSVO_FLAG_GP3P | SOSVO_FLAG_TWOPT), b.cn, B, Fc,
+                              cfg->ransac_threshold, cfg->ransac_max_iter, cfg->ransac_adaptive, seed, b.T_ransac, b.mask, b.idx,
+                              b.n_inl, b.info, nullptr));
+  SOSVO_HIP(ctx, hipMemcpyAsync(b.T, b.T_ransac, sizeof(double) * 12 * B, hipMemcpyDeviceToDevice, ctx->stream));
+  STAGE(sosvo_refine_abs_pose(ctx, b.f, b.p, nullptr, nullptr, nullptr, 1, b.cn, B, Fc, b.idx, b.n_inl, cfg->lm_max_iter, b.T,
+                              b.lm_cost, b.lm_iters));
+  SOSVO_LAUNCH(ctx, batch_results_kernel, dim3(cdiv(B, 256)), dim3(256), 0, ctx->stream, B, b.T, b.n_inl, b.cn, b.info,
+               results);
+  SOSVO_LAUNCH_CHECK(ctx);
+  return SOSVO_OK;
+}
+
 int32_t sosvo_rgbd_pair_batch(sosvo_ctx* ctx, const sosvo_rgbd_cam* cam, const sosvo_rgbd_batch_cfg* cfg,
                               const uint8_t* bgr, const float* depth, const uint32_t* mask_bits, const int8_t* pattern,
                               void* workspace, size_t workspace_bytes, double* results) {
@@ -638,33 +770,106 @@ int32_t sosvo_rgbd_pair_batch(sosvo_ctx* ctx, const sosvo_rgbd_cam* cam, const s
   SOSVO_REQUIRE(ctx, ((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
   const RgbdBuffers b = carve_rgbd(*cfg, workspace);
   SOSVO_REQUIRE(ctx, workspace_bytes >= b.bytes, "workspace too small (see sosvo_rgbd_pair_batch_workspace)");
-  const int B = cfg->n_pairs, F = 2 * B, cap = cfg->kp_cap, Fc = cfg->frame_cap;
+  const int B = cfg->n_pairs, F = 2 * B;
   int32_t rc;
   SOSVO_LAUNCH(ctx, pair_index_kernel, dim3(cdiv(B, 256)), dim3(256), 0, ctx->stream, B, b.ref_frame, b.cur_frame);
   SOSVO_LAUNCH_CHECK(ctx);
-  // RGBDFrame.establish_keypoints for all 2 B frames: [median,] gray, whole-image GFT (one mask), ORB descriptors,
-  // depth back-projection + range filter + bearings
-  STAGE(sosvo_median_gray(ctx, bgr, F, cfg->rows, cfg->cols, cfg->median_ksize, b.gray));
-  STAGE(sosvo_detect_gft(ctx, b.gray, mask_bits, F, F, cfg->rows, cfg->cols, 1, cfg->quality, cfg->min_distance,
-                         cfg->max_corners, cap, b.kp, b.n, b.status));
-  STAGE(sosvo_describe_orb(ctx, b.gray, F, cfg->rows, cfg->cols, 1, cap, b.kp, b.n, cfg->cos_a, cfg->sin_a, pattern, cfg->edge,
-                           b.desc));
-  STAGE(sosvo_rgbd_assemble(ctx, cam, b.kp, b.desc, b.n, depth, F, cfg->rows, cfg->cols, cap, Fc, b.m, b.d, b.X, b.b, b.M));
-  // TrackerRGBDSE3.track_frame per pair: query = current frame, train = reference frame
-  STAGE(sosvo_match_hamming(ctx, b.d, b.d, b.M, b.M, b.cur_frame, b.ref_frame, B, Fc, Fc, 1, b.keys));
-  STAGE(sosvo_sort_matches(ctx, b.keys, b.M, b.cur_frame, B, Fc, b.order));
-  STAGE(sosvo_f2f_assemble_central(ctx, cfg->pct_good_matches, cfg->f2f_max_hdiff, b.m, b.X, b.b, b.M, Fc, b.ref_frame,
-                                   b.cur_frame, b.keys, b.order, B, Fc, b.f, b.p, b.cq, b.ct, b.cn));
-  STAGE(sosvo_ransac_abs_pose(ctx, b.f, b.p, nullptr, nullptr, nullptr, 1, cfg->flags & (SOSVO_FLAG_EPNP | SOSVO_FLAG_GP3P | SOSVO_FLAG_TWOPT), b.cn, B, Fc,
-                              cfg->ransac_threshold, cfg->ransac_max_iter, cfg->ransac_adaptive, cfg->seed, b.T_ransac,
-                              b.mask, b.idx, b.n_inl, b.info, nullptr));
-  SOSVO_HIP(ctx, hipMemcpyAsync(b.T, b.T_ransac, sizeof(double) * 12 * B, hipMemcpyDeviceToDevice, ctx->stream));
-  STAGE(sosvo_refine_abs_pose(ctx, b.f, b.p, nullptr, nullptr, nullptr, 1, b.cn, B, Fc, b.idx, b.n_inl, cfg->lm_max_iter, b.T,
-                              b.lm_cost, b.lm_iters));
-  SOSVO_LAUNCH(ctx, batch_results_kernel, dim3(cdiv(B, 256)), dim3(256), 0, ctx->stream, B, b.T, b.n_inl, b.cn, b.info,
-               results);
+  const RgbdFrontTmp fe{b.gray, b.desc, b.kp, b.n, b.status};
+  const RgbdStore store{b.m, b.d, b.X, b.b, b.M};
+  STAGE(run_rgbd_front_end(ctx, cam, cfg, F, bgr, depth, mask_bits, pattern, fe, store));
+  const RgbdTrackTmp tt{b.ref_frame, b.cur_frame, b.order, b.cq, b.ct, b.cn, b.idx, b.n_inl, b.info, b.lm_iters, b.keys, b.mask,
+                        b.f, b.p, b.T_ransac, b.T, b.lm_cost};
+  return run_rgbd_tracking(ctx, cfg, B, cfg->seed, store, tt, results);
+}
+
+// ---- RGB-D sequence mode -------------------------------------------------------------------------------------
+static bool rgbd_seq_shape_ok(const sosvo_rgbd_batch_cfg* cfg, int32_t window, int32_t slots) {
+  return cfg && cfg->n_pairs > 0 && cfg->n_pairs <= 8192 && cfg->rows > 0 && cfg->cols > 0 && cfg->kp_cap > 0 && cfg->kp_cap <= 4096 &&
+         cfg->frame_cap > 0 && cfg->frame_cap <= 16384 && window >= 1 && window <= 16384 && slots >= window && slots <= 65535;
+}
+
+size_t sosvo_rgbd_sequence_workspace(const sosvo_rgbd_batch_cfg* cfg, int32_t window, int32_t slots) {
+  if (!rgbd_seq_shape_ok(cfg, window, slots)) return 0;
+  return carve_rgbd_seq(*cfg, window, slots, nullptr).bytes;
+}
+
+int32_t sosvo_rgbd_sequence_front_end(sosvo_ctx* ctx, const sosvo_rgbd_cam* cam, const sosvo_rgbd_batch_cfg* cfg, int32_t window,
+                                      int32_t slots, const uint8_t* bgr, const float* depth, int32_t n_frames, int32_t first_slot,
+                                      const uint32_t* mask_bits, const int8_t* pattern, void* workspace, size_t workspace_bytes) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, cam && cfg && bgr && depth && mask_bits && pattern && workspace, "null pointer");
+  SOSVO_REQUIRE(ctx, rgbd_seq_shape_ok(cfg, window, slots), "bad sequence configuration (window, slots, capacities)");
+  SOSVO_REQUIRE(ctx, n_frames >= 0 && n_frames <= window && first_slot >= 0 && first_slot + n_frames <= slots,
+                "frames do not fit the window / the store");
+  SOSVO_REQUIRE(ctx, ((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
+  const RgbdSeqBuffers b = carve_rgbd_seq(*cfg, window, slots, workspace);
+  SOSVO_REQUIRE(ctx, workspace_bytes >= b.bytes, "workspace too small (see sosvo_rgbd_sequence_workspace)");
+  if (n_frames == 0) return SOSVO_OK;
+  const size_t Fc = cfg->frame_cap, o = (size_t)first_slot * Fc;
+  const RgbdFrontTmp fe{b.gray, b.desc, b.kp, b.n, b.status};
+  const RgbdStore out{b.m + 2 * o, b.d + 32 * o, b.X + 3 * o, b.b + 3 * o, b.M + first_slot};
+  return run_rgbd_front_end(ctx, cam, cfg, n_frames, bgr, depth, mask_bits, pattern, fe, out);
+}
+
+int32_t sosvo_rgbd_sequence_track(sosvo_ctx* ctx, const sosvo_rgbd_batch_cfg* cfg, int32_t window, int32_t slots,
+                                  const int32_t* ref_slot, const int32_t* cur_slot, int32_t n_pairs, uint64_t seed, void* workspace,
+                                  size_t workspace_bytes, double* results) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, cfg && ref_slot && cur_slot && workspace && results, "null pointer");
+  SOSVO_REQUIRE(ctx, rgbd_seq_shape_ok(cfg, window, slots), "bad sequence configuration (window, slots, capacities)");
+  SOSVO_REQUIRE(ctx, n_pairs >= 0 && n_pairs <= cfg->n_pairs, "more slot pairs than cfg->n_pairs");
+  SOSVO_REQUIRE(ctx, ((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
+  const RgbdSeqBuffers b = carve_rgbd_seq(*cfg, window, slots, workspace);
+  SOSVO_REQUIRE(ctx, workspace_bytes >= b.bytes, "workspace too small (see sosvo_rgbd_sequence_workspace)");
+  if (n_pairs == 0) return SOSVO_OK;
+  for (int i = 0; i < n_pairs; ++i)
+    SOSVO_REQUIRE(ctx, ref_slot[i] >= 0 && ref_slot[i] < slots && cur_slot[i] >= 0 && cur_slot[i] < slots, "slot out of range");
+  SlotPairs sp;
+  for (int i = 0; i < kSeqArgPairs; ++i) {
+    sp.ref[i] = i < n_pairs ? ref_slot[i] : 0;
+    sp.cur[i] = i < n_pairs ? cur_slot[i] : 0;
+  }
+  if (n_pairs > kSeqArgPairs) {
+    SOSVO_HIP(ctx, hipMemcpyAsync(b.ref_frame, ref_slot, sizeof(int32_t) * n_pairs, hipMemcpyHostToDevice, ctx->stream));
+    SOSVO_HIP(ctx, hipMemcpyAsync(b.cur_frame, cur_slot, sizeof(int32_t) * n_pairs, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    SOSVO_LAUNCH(ctx, rgbd_seq_setup_kernel, dim3(1), dim3(64), 0, ctx->stream, n_pairs, sp, b.ref_frame, b.cur_frame);
+    SOSVO_LAUNCH_CHECK(ctx);
+  }
+  const RgbdStore store{b.m, b.d, b.X, b.b, b.M};
+  const RgbdTrackTmp tt{b.ref_frame, b.cur_frame, b.order, b.cq, b.ct, b.cn, b.idx, b.n_inl, b.info, b.lm_iters, b.keys, b.mask,
+                        b.f, b.p, b.T_ransac, b.T, b.lm_cost};
+  return run_rgbd_tracking(ctx, cfg, n_pairs, seed, store, tt, results);
+}
+
+int32_t sosvo_rgbd_sequence_copy_slot(sosvo_ctx* ctx, const sosvo_rgbd_batch_cfg* cfg, int32_t window, int32_t slots,
+                                      int32_t src_slot, int32_t dst_slot, void* workspace, size_t workspace_bytes) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, cfg && workspace, "null pointer");
+  SOSVO_REQUIRE(ctx, rgbd_seq_shape_ok(cfg, window, slots), "bad sequence configuration (window, slots, capacities)");
+  SOSVO_REQUIRE(ctx, src_slot >= 0 && src_slot < slots && dst_slot >= 0 && dst_slot < slots, "slot out of range");
+  SOSVO_REQUIRE(ctx, ((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
+  const RgbdSeqBuffers b = carve_rgbd_seq(*cfg, window, slots, workspace);
+  SOSVO_REQUIRE(ctx, workspace_bytes >= b.bytes, "workspace too small (see sosvo_rgbd_sequence_workspace)");
+  if (src_slot == dst_slot) return SOSVO_OK;
+  SOSVO_LAUNCH(ctx, rgbd_seq_copy_slot_kernel, dim3(1), dim3(1024), 0, ctx->stream, src_slot, dst_slot, cfg->frame_cap, b.m,
+               reinterpret_cast<uint4*>(b.d), b.X, b.b, b.M);
   SOSVO_LAUNCH_CHECK(ctx);
-#undef STAGE
+  return SOSVO_OK;
+}
+
+int32_t sosvo_rgbd_sequence_frame_counts(sosvo_ctx* ctx, const sosvo_rgbd_batch_cfg* cfg, int32_t window, int32_t slots,
+                                         int32_t first_slot, int32_t n, void* workspace, size_t workspace_bytes,
+                                         int32_t* counts_host) {
+  SOSVO_ENTER(ctx);
+  SOSVO_REQUIRE(ctx, cfg && workspace && counts_host, "null pointer");
+  SOSVO_REQUIRE(ctx, rgbd_seq_shape_ok(cfg, window, slots), "bad sequence configuration (window, slots, capacities)");
+  SOSVO_REQUIRE(ctx, first_slot >= 0 && n >= 0 && first_slot + n <= slots, "slots out of range");
+  const RgbdSeqBuffers b = carve_rgbd_seq(*cfg, window, slots, workspace);
+  SOSVO_REQUIRE(ctx, workspace_bytes >= b.bytes, "workspace too small (see sosvo_rgbd_sequence_workspace)");
+  if (n == 0) return SOSVO_OK;
+  SOSVO_HIP(ctx, hipMemcpyAsync(counts_host, b.M + first_slot, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
+  SOSVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SOSVO_OK;
 }
 

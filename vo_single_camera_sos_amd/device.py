@@ -759,6 +759,44 @@ class Context(object):
                    int(first_slot), int(n), _ptr(workspace), int(workspace.numel()), ctypes.cast(out, c_p))
         return [int(out[i]) for i in range(int(n))]
 
+    # ---- RGB-D sequence mode ------------------------------------------------------------------------
+    def rgbd_sequence_workspace(self, cfg, window, slots):
+        return int(self._lib.sosvo_rgbd_sequence_workspace(ctypes.cast(ctypes.pointer(cfg), c_p), int(window), int(slots)))
+
+    def rgbd_sequence_front_end(self, cam, cfg, window, slots, bgr, depth, first_slot, mask_bits, pattern, workspace):
+        _check(bgr, torch.uint8, "bgr", (None, cfg.rows, cfg.cols, 3))
+        _check(depth, torch.float32, "depth", (bgr.shape[0], cfg.rows, cfg.cols))
+        _check(mask_bits, torch.uint32, "mask_bits", (1, cfg.rows, cfg.cols))
+        _check(pattern, torch.int8, "pattern", (512, 2))
+        _check(workspace, torch.uint8, "workspace", ndim=1)
+        self._call(self._lib.sosvo_rgbd_sequence_front_end, ctypes.cast(ctypes.pointer(cam), c_p), ctypes.cast(ctypes.pointer(cfg), c_p),
+                   int(window), int(slots), _ptr(bgr), _ptr(depth), int(bgr.shape[0]), int(first_slot), _ptr(mask_bits),
+                   _ptr(pattern), _ptr(workspace), int(workspace.numel()))
+
+    def rgbd_sequence_track(self, cfg, window, slots, ref_slots, cur_slots, seed, workspace, results):
+        n = len(ref_slots)
+        if len(cur_slots) != n:
+            raise SosvoError("ref_slots and cur_slots must have the same length")
+        _check(workspace, torch.uint8, "workspace", ndim=1)
+        _check(results, torch.float64, "results", (None, 16))
+        if results.shape[0] < n:
+            raise SosvoError("results holds fewer rows than slot pairs")
+        ref = (ctypes.c_int32 * max(n, 1))(*[int(x) for x in ref_slots])
+        cur = (ctypes.c_int32 * max(n, 1))(*[int(x) for x in cur_slots])
+        self._call(self._lib.sosvo_rgbd_sequence_track, ctypes.cast(ctypes.pointer(cfg), c_p), int(window), int(slots),
+                   ctypes.cast(ref, c_p), ctypes.cast(cur, c_p), n, int(seed), _ptr(workspace), int(workspace.numel()), _ptr(results))
+        return results
+
+    def rgbd_sequence_copy_slot(self, cfg, window, slots, src, dst, workspace):
+        self._call(self._lib.sosvo_rgbd_sequence_copy_slot, ctypes.cast(ctypes.pointer(cfg), c_p), int(window), int(slots), int(src),
+                   int(dst), _ptr(workspace), int(workspace.numel()))
+
+    def rgbd_sequence_frame_counts(self, cfg, window, slots, first_slot, n, workspace):
+        out = (ctypes.c_int32 * max(int(n), 1))()
+        self._call(self._lib.sosvo_rgbd_sequence_frame_counts, ctypes.cast(ctypes.pointer(cfg), c_p), int(window), int(slots),
+                   int(first_slot), int(n), _ptr(workspace), int(workspace.numel()), ctypes.cast(out, c_p))
+        return [int(out[i]) for i in range(int(n))]
+
     def rgbd_pair_batch_workspace(self, cfg):
         return int(self._lib.sosvo_rgbd_pair_batch_workspace(ctypes.cast(ctypes.pointer(cfg), c_p)))
 

@@ -499,6 +499,46 @@ class RGBDKeyFrame(RGBDFrame):
         self.children_ids = []
 
 
+class DeviceRGBDFrame(RGBDFrame):
+    """An RGBDFrame whose keypoints, descriptors, points and bearings live in the frame store of a
+    pipeline.RGBDSequenceEngine (HBM): run_VO's sequence mode builds these, `window` frames per batched front-end pass."""
+
+    def __init__(self, engine, info, rgbd_camera_model, frame_id, seq_index, **kwargs):
+        self.rgbd_camera_model = rgbd_camera_model
+        self.frame_id = frame_id
+        self.parent_id = kwargs.get("parent_id", -1)
+        self.T_frame_wrt_tracking_ref_frame = np.identity(4)
+        self.conversion_factor_length_to_m = get_length_units_conversion_factor(rgbd_camera_model.units, "m")
+        self.total_time = 0.
+        self.median_win_size = engine.cfg.median_ksize
+        self.min_range, self.max_range = engine.cam_cfg.min_range, engine.cam_cfg.max_range
+        self.mask = None
+        self.rgb_img = self.depth_map = self.current_depth = None
+        self.keypoints_and_descriptors = self.bearing_vectors = self.keypoints_3D_points = None
+        self.engine, self.slot, self.seq_index = engine, int(info["slot"]), int(seq_index)
+        self.seed, self.spec_record = int(info["seed"]), info["spec"]
+        self.num_valid_keypoints = int(info["count"])
+
+    def promote(self):
+        self.engine.promote(self.slot)
+
+
+def rgbd_sequence_engine_for(tracker, camera_model, first_rgb, window):
+    """The pipeline.RGBDSequenceEngine that computes what `tracker` (a TrackerRGBDSE3) and RGBDFrame compute, or None when
+    the configuration has no batched counterpart (then run_VO keeps the per-frame mirror path)."""
+    from ..pipeline import RGBDCamConfig, RGBDSequenceEngine
+    if (tracker.detection_method != "GFT" or tracker.matching_type != "BF" or tracker.k_best_matches != 1
+            or tracker.use_descriptor_radius_match_for_motion):
+        return None
+    cm = camera_model
+    cam = RGBDCamConfig(cm.fx, cm.fy, cm.center_x, cm.center_y, cm.focal_length_m, cm.depth_is_Z, 0.8, 7.0,
+                        f2f_max_hdiff=tracker.max_horizontal_diff_f2f_matches, pct_good_matches=tracker.percentage_good_matches)
+    return RGBDSequenceEngine(cm._context(), cam, window=window, image_shape=np.asarray(first_rgb).shape[:2],
+                              num_of_features=tracker.num_features_detection_for_motion, median_win_size=0,
+                              thr=tracker.backprojection_score_threshold_3D_to_2D, max_iter=tracker.max_ransac_iterations_3D_to_2D,
+                              adaptive=True, lm_iter=pyopengv.LM_MAX_ITERATIONS, pose_est_algorithm=tracker.pose_est_algorithm)
+
+
 class TrackerRGBDSE3(TrackerSE3):
     """pose_est_tools.py:880-958: central 3D-2D tracking of RGB-D frames."""
 
@@ -521,6 +561,8 @@ class TrackerRGBDSE3(TrackerSE3):
         """pose_est_tools.py:896-954 -> (ok, message)."""
         self.num_tracked_correspondences = 0
         self.inlier_tracked_correspondences_ratio = 0.
+        if isinstance(current_frame, DeviceRGBDFrame):
+            return self._track_device_frame(reference_frame, current_frame)
         ref, cur = reference_frame.keypoints_and_descriptors, current_frame.keypoints_and_descriptors
         (t_idx, _, _), (q_idx, _, _), _ = match_features_frame_to_frame(
             cam_model=self.camera_model, train_kpts=ref.keypoints, train_desc=ref.descriptors, query_kpts=cur.keypoints,
@@ -555,6 +597,34 @@ class TrackerRGBDSE3(TrackerSE3):
         return True, "tracking used %d inlier point correspondences" % (self.num_tracked_correspondences)
 
 
+def _rgbd_track_device_frame(self, reference_frame, current_frame):
+    """TrackerRGBDSE3.track_frame on frames of an RGBDSequenceEngine's store: the [16] record of the pair (the speculative
+    one when the reference is the frame's predecessor, one serial call against the keyframe slot otherwise) put through the
+    bookkeeping of track_frame above."""
+    eng = current_frame.engine
+    if current_frame.spec_record is not None and getattr(reference_frame, "seq_index", None) == current_frame.seq_index - 1:
+        rec = current_frame.spec_record
+    else:
+        rec = eng.track(eng.key_slot, current_frame.slot, current_frame.seed)
+    num_initial_matches = int(rec[13])
+    if num_initial_matches < 2 * self.n_points_for_RANSAC_model * self.number_of_cams:
+        return False, "Cannot track on only %d point correspondences" % (num_initial_matches)
+    self.num_tracked_correspondences = int(rec[12])
+    self.inlier_tracked_correspondences_ratio = float(self.num_tracked_correspondences) / float(num_initial_matches)
+    if self.num_tracked_correspondences < self.n_points_for_RANSAC_model:
+        return False, "RANSAC (%s) found no model among %d correspondences" % (self.pose_est_algorithm, num_initial_matches)
+    T_homo = np.identity(4)
+    T_homo[:3] = rec[:12].reshape(3, 4)
+    T_homo[:3, 3] = T_homo[:3, 3] * current_frame.conversion_factor_length_to_m
+    current_frame.T_frame_wrt_tracking_ref_frame = T_homo
+    T_key = self.T_Ckey_wrt_S_est_list[-1] if self.T_Ckey_wrt_S_est_list else np.identity(4)
+    self.T_C_curr_frame_wrt_S_est = tr.concatenate_matrices(T_key, T_homo)
+    return True, "tracking used %d inlier point correspondences" % (self.num_tracked_correspondences)
+
+
+TrackerRGBDSE3._track_device_frame = _rgbd_track_device_frame
+
+
 def _is_rgbd_model(camera_model):
     from .camera_models import RGBDCamModel
     return isinstance(camera_model, RGBDCamModel)
@@ -570,7 +640,7 @@ def run_VO(visualizer_3D_VO, camera_model, gt_poses_filename=None, est_poses_fil
         keyframe_ids.txt, printed_messages.log
     -> dict(poses=[(idx, T 4x4)], keyframe_ids=[...], tracked=number of tracked frames, message=summary).
 
-    frame_window: SEQUENCE MODE of the omnistereo path (pipeline.SequenceEngine): the front ends of `frame_window` frames
+    frame_window: SEQUENCE MODE (pipeline.SequenceEngine / RGBDSequenceEngine): the front ends of `frame_window` frames
     run as ONE batch on the GPU and the frames are tracked from the device-resident frame store (speculatively against
     their predecessors, serially against the keyframe where that guess fails).  None = 32 for an image sequence, 1 for a
     live source; 0 = the per-frame mirror path (StereoPanoramicFrame on host arrays, one set of C-ABI calls per stage).
@@ -627,7 +697,7 @@ def run_VO(visualizer_3D_VO, camera_model, gt_poses_filename=None, est_poses_fil
     if frame_window is None:
         frame_window = 32 if _live_frames is None else 1
     engine_state = dict(engine=None, tried=False, window_s=0.0, windows=0)
-    if not rgbd and int(frame_window) > 0:
+    if int(frame_window) > 0:
         source = frames
 
         def frames():   # the same frames, `frame_window` at a time through the batched front end
@@ -643,14 +713,15 @@ def run_VO(visualizer_3D_VO, camera_model, gt_poses_filename=None, est_poses_fil
                     return
                 if not engine_state["tried"]:
                     engine_state["tried"] = True
-                    engine_state["engine"] = sequence_engine_for(tracker, camera_model, chunk[0][1], int(frame_window))
+                    engine_state["engine"] = (rgbd_sequence_engine_for if rgbd else sequence_engine_for)(
+                        tracker, camera_model, chunk[0][1], int(frame_window))
                 eng = engine_state["engine"]
                 if eng is None:          # no batched counterpart of this configuration: the per-frame path
                     for item in chunk:
                         yield item
                     continue
                 t0 = time.perf_counter()
-                infos = eng.push_window([item[1] for item in chunk])
+                infos = eng.push_window([(item[1], item[2]) if rgbd else item[1] for item in chunk])
                 engine_state["window_s"] += time.perf_counter() - t0
                 engine_state["windows"] += 1
                 for item, info in zip(chunk, infos):
@@ -703,8 +774,8 @@ def run_VO(visualizer_3D_VO, camera_model, gt_poses_filename=None, est_poses_fil
             acc["read"] += time.process_time() - t0
         t0 = time.process_time()
         if dev_info is not None:
-            current_frame = DeviceStereoFrame(engine_state["engine"], dev_info, camera_model, frame_id=idx, seq_index=item[4],
-                                              parent_id=current_keyframe_id)
+            current_frame = (DeviceRGBDFrame if rgbd else DeviceStereoFrame)(
+                engine_state["engine"], dev_info, camera_model, frame_id=idx, seq_index=item[4], parent_id=current_keyframe_id)
         elif rgbd:
             current_frame = RGBDFrame(rgbd_camera_model=camera_model, frame_id=idx, rgb_img=img, depth_map=depth_map,
                                       parent_id=current_keyframe_id)

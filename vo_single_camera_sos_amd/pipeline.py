@@ -371,19 +371,84 @@ class FramePairBatch(object):
         return self.out
 
 
-class SequenceEngine(object):
-    """Sequence mode of the SOS hot path (include/sosvo.h "Sequence mode"; the reference's VO loop, run_VO,
-    pose_est_tools.py:1416-1628): the front end of every frame is computed ONCE, `window` frames per batch, into a
-    frame store in HBM, and frames are tracked against keyframes by slot number.
+class _SequenceBase(object):
+    """Window / slot bookkeeping shared by the sequence engines (include/sosvo.h "Sequence mode"): two window halves
+    [0, W) and [W, 2W) used alternately (the last frame of the previous window stays readable) and slot 2W for the current
+    keyframe.  A tracking record is a pure function of (reference frame, current frame, seed): push_window() tracks every
+    frame of the window against its PREDECESSOR in one batched call; the VO loop takes that record where the predecessor
+    was the reference and asks for one serial track() call where it was not.  Either way the records are those of the
+    serial loop, whatever the window size.  Subclasses provide _stage / _front_end / _track / _counts / _copy."""
 
-    The keyframe chain is serial (the policy at :1509-1565 needs each tracked pose), but a tracking record is a pure
-    function of (reference frame, current frame, seed): push_window() therefore also tracks every frame of the window
-    against its PREDECESSOR in one batched call (on these sequences nearly every frame is promoted to keyframe, so the
-    predecessor usually IS the reference); resolve() hands that record out when the guess was right and runs one serial
-    tracking call when it was not.  Either way the records are those of the serial loop, whatever the window size.
+    def _init_windows(self, window):
+        self.W = max(1, int(window))
+        self.slots, self.key_slot = 2 * self.W + 1, 2 * self.W
+        self.half = 1            # the half the NEXT window goes to is 1 - half
+        self.last_slot = None    # slot of the newest frame of the sequence
+        self.frames_seen = 0     # frames pushed so far (frame t of the sequence is tracked with seed t - 1)
+        self.serial_calls = 0    # tracking calls the speculation did not cover
+        self.stage_s = dict(stage_to_pinned=0.0, enqueue=0.0, wait_and_readback=0.0, serial_track=0.0)   # host wall clock
 
-    Store layout: two window halves [0, W) and [W, 2W) used alternately (the last frame of the previous window stays
-    readable) and slot 2W for the current keyframe."""
+    def push_window(self, images):
+        """images: list of n <= window frames that continue the sequence (omnistereo: omni images [H,W,3] u8; RGB-D:
+        (bgr, depth) tuples).  -> list of n dicts(slot, count = num_valid_keypoints, seed, spec_ref = slot the speculative
+        record was tracked against or None, spec = that [16] record (numpy) or None).  One host synchronisation."""
+        import time
+        n = len(images)
+        if n == 0:
+            return []
+        if n > self.W:
+            raise ValueError("more frames than the window holds")
+        t0 = time.perf_counter()
+        self._stage(images)
+        t1 = time.perf_counter()
+        self.half = 1 - self.half
+        first = self.half * self.W
+        self._front_end(n, first)
+        # speculative tracking: frame i of the window against its predecessor (the first one against the previous
+        # window's last frame; the very first frame of the sequence has nothing to track against)
+        slots = [first + i for i in range(n)]
+        prev = ([self.last_slot] if self.last_slot is not None else []) + slots[:-1]
+        cur = slots if self.last_slot is not None else slots[1:]
+        seed0 = self.frames_seen - 1 if self.last_slot is not None else 0   # frame t tracks with seed t - 1
+        if cur:
+            self._track(prev, cur, seed0, self.spec)
+        t2 = time.perf_counter()
+        counts = self._counts(first, n)   # synchronises
+        spec = self.spec[:len(cur)].cpu().numpy() if cur else np.zeros((0, 16))
+        t3 = time.perf_counter()
+        self.stage_s["stage_to_pinned"] += t1 - t0
+        self.stage_s["enqueue"] += t2 - t1
+        self.stage_s["wait_and_readback"] += t3 - t2
+        out = []
+        for i in range(n):
+            t = self.frames_seen + i            # index of the frame in the sequence
+            j = i if self.last_slot is not None else i - 1
+            has = j >= 0 and len(cur) > 0
+            out.append(dict(slot=slots[i], count=counts[i], seed=max(t - 1, 0), spec_ref=prev[j] if has else None,
+                            spec=spec[j].copy() if has else None))
+        self.frames_seen += n
+        self.last_slot = slots[-1]
+        return out
+
+    def track(self, ref_slot, cur_slot, seed):
+        """One serial tracking call (reference slot, current slot, seed) -> [16] record (numpy); synchronises."""
+        import time
+        t0 = time.perf_counter()
+        self.serial_calls += 1
+        self._track([int(ref_slot)], [int(cur_slot)], int(seed), self.one)
+        rec = self.one.cpu().numpy()[0]
+        self.stage_s["serial_track"] += time.perf_counter() - t0
+        return rec
+
+    def promote(self, slot):
+        """The frame in `slot` becomes the keyframe: its record is copied to the keyframe slot (asynchronous)."""
+        self._copy(int(slot), self.key_slot)
+
+
+class SequenceEngine(_SequenceBase):
+    """Sequence mode of the SOS hot path (the reference's VO loop, run_VO, pose_est_tools.py:1416-1628): the front end of
+    every frame is computed ONCE, `window` frames per batch, into a frame store in HBM, and frames are tracked against
+    keyframes by slot number (see _SequenceBase)."""
 
     def __init__(self, ctx, model, rig, window=32, num_of_features=1000, kp_cap=None, frame_cap=2048, median_win_size=11,
                  quality=0.01, min_distance=5.0, edge=31, thr=None, max_iter=210, adaptive=True, lm_iter=30,
@@ -393,8 +458,7 @@ class SequenceEngine(object):
         from . import _lib, orb_pattern
         assert isinstance(ctx, Context)
         self.ctx, self.model, self.rig_cfg, self.rig = ctx, model, rig, rig.as_struct()
-        self.W = max(1, int(window))
-        self.slots, self.key_slot = 2 * self.W + 1, 2 * self.W
+        self._init_windows(window)
         if kp_cap is None:
             kp_cap = int(min(1024, max(64, -(-int(num_of_features) // 64) * 64)))
         cos_a, sin_a = orb_pattern.angle_cos_sin(orb_pattern.GFT_KEYPOINT_ANGLE)
@@ -419,75 +483,30 @@ class SequenceEngine(object):
         self.workspace = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
         self.omni = torch.zeros((self.W, model.H, model.W, 3), dtype=torch.uint8, device=dev)
         self._host = torch.zeros((self.W, model.H, model.W, 3), dtype=torch.uint8).pin_memory()
+        self._host_np = self._host.numpy()
         self.spec = torch.zeros((self.W, 16), dtype=torch.float64, device=dev)
         self.one = torch.zeros((1, 16), dtype=torch.float64, device=dev)
-        self.half = 1            # the half the NEXT window goes to is 1 - half
-        self.last_slot = None    # slot of the newest frame of the sequence
-        self.frames_seen = 0     # frames pushed so far (frame t of the sequence is tracked with seed t - 1)
-        self.serial_calls = 0    # tracking calls the speculation did not cover
-        self._host_np = self._host.numpy()
-        self.stage_s = dict(stage_to_pinned=0.0, enqueue=0.0, wait_and_readback=0.0, serial_track=0.0)   # host wall clock
 
-    def push_window(self, images):
-        """images: list / array of n <= window omni frames [H,W,3] u8 (BGR) that continue the sequence.
-        -> list of n dicts(slot, count = StereoPanoramicFrame.num_valid_keypoints, seed, spec_ref = slot the speculative
-        record was tracked against or None, spec = that [16] record (numpy) or None).  One host synchronisation."""
+    def _stage(self, images):
         n = len(images)
-        if n == 0:
-            return []
-        if n > self.W:
-            raise ValueError("more frames than the window holds")
-        import time
-        c, m = self.ctx, self.model
-        t0 = time.perf_counter()
         for i in range(n):
             np.copyto(self._host_np[i], images[i])
-        t1 = time.perf_counter()
         self.omni[:n].copy_(self._host[:n], non_blocking=True)
-        self.half = 1 - self.half
-        first = self.half * self.W
-        c.sequence_front_end(self.rig, self.cfg, self.W, self.slots, self.omni[:n], first, m.unwrap_table, m.mask_bits,
-                             m.pattern, self.workspace)
-        # speculative tracking: frame i of the window against its predecessor (the first one against the previous
-        # window's last frame; the very first frame of the sequence has nothing to track against)
-        slots = [first + i for i in range(n)]
-        prev = ([self.last_slot] if self.last_slot is not None else []) + slots[:-1]
-        cur = slots if self.last_slot is not None else slots[1:]
-        seed0 = self.frames_seen - 1 if self.last_slot is not None else 0   # frame t tracks with seed t - 1
-        if cur:
-            c.sequence_track(self.rig, self.cfg, self.W, self.slots, prev, cur, seed0, self.workspace, self.spec)
-        t2 = time.perf_counter()
-        counts = c.sequence_frame_counts(self.cfg, self.W, self.slots, first, n, self.workspace)   # synchronises
-        spec = self.spec[:len(cur)].cpu().numpy() if cur else np.zeros((0, 16))
-        t3 = time.perf_counter()
-        self.stage_s["stage_to_pinned"] += t1 - t0
-        self.stage_s["enqueue"] += t2 - t1
-        self.stage_s["wait_and_readback"] += t3 - t2
-        out = []
-        for i in range(n):
-            t = self.frames_seen + i            # index of the frame in the sequence
-            j = i if self.last_slot is not None else i - 1
-            has = j >= 0 and len(cur) > 0
-            out.append(dict(slot=slots[i], count=counts[i], seed=max(t - 1, 0), spec_ref=prev[j] if has else None,
-                            spec=spec[j].copy() if has else None))
-        self.frames_seen += n
-        self.last_slot = slots[-1]
-        return out
+        self._n = n
 
-    def track(self, ref_slot, cur_slot, seed):
-        """One serial tracking call (reference slot, current slot, seed) -> [16] record (numpy); synchronises."""
-        import time
-        t0 = time.perf_counter()
-        self.serial_calls += 1
-        self.ctx.sequence_track(self.rig, self.cfg, self.W, self.slots, [int(ref_slot)], [int(cur_slot)], int(seed),
-                                self.workspace, self.one)
-        rec = self.one.cpu().numpy()[0]
-        self.stage_s["serial_track"] += time.perf_counter() - t0
-        return rec
+    def _front_end(self, n, first):
+        m = self.model
+        self.ctx.sequence_front_end(self.rig, self.cfg, self.W, self.slots, self.omni[:n], first, m.unwrap_table, m.mask_bits,
+                                    m.pattern, self.workspace)
 
-    def promote(self, slot):
-        """The frame in `slot` becomes the keyframe: its record is copied to the keyframe slot (asynchronous)."""
-        self.ctx.sequence_copy_slot(self.cfg, self.W, self.slots, int(slot), self.key_slot, self.workspace)
+    def _track(self, ref_slots, cur_slots, seed, out):
+        self.ctx.sequence_track(self.rig, self.cfg, self.W, self.slots, ref_slots, cur_slots, seed, self.workspace, out)
+
+    def _counts(self, first, n):
+        return self.ctx.sequence_frame_counts(self.cfg, self.W, self.slots, first, n, self.workspace)
+
+    def _copy(self, src, dst):
+        self.ctx.sequence_copy_slot(self.cfg, self.W, self.slots, src, dst, self.workspace)
 
 
 def rgbd_solver_flags(pose_est_algorithm):
@@ -695,3 +714,66 @@ class RGBDPairBatch(object):
 
     def results(self):
         return self.out
+
+
+class RGBDSequenceEngine(_SequenceBase):
+    """Sequence mode of the RGB-D path (demo_vo_rgbd.py's loop: one RGBDFrame per image, pose_est_tools.py:1440-1446, tracked
+    against the current keyframe, :896-954) on the sosvo_rgbd_sequence_* entry points; push_window() takes (bgr, depth)
+    tuples.  Same store layout, seeds and speculation as SequenceEngine."""
+
+    def __init__(self, ctx, cam, window=32, image_shape=(480, 640), num_of_features=1000, kp_cap=None, frame_cap=None,
+                 median_win_size=0, quality=0.01, min_distance=5.0, edge=31, thr=None, max_iter=210, adaptive=True, lm_iter=30,
+                 mask=None, pose_est_algorithm="EPNP"):
+        from . import _lib, orb_pattern
+        assert isinstance(ctx, Context)
+        self.ctx, self.cam_cfg, self.cam = ctx, cam, cam.as_struct()
+        self._init_windows(window)
+        rows, cols = int(image_shape[0]), int(image_shape[1])
+        kp_cap = int(kp_cap) if kp_cap else int(min(4096, max(1088, -(-int(num_of_features) // 64) * 64)))
+        cos_a, sin_a = orb_pattern.angle_cos_sin(orb_pattern.GFT_KEYPOINT_ANGLE)
+        c = _lib.RgbdBatchCfg()
+        c.n_pairs, c.rows, c.cols, c.kp_cap, c.frame_cap = self.W, rows, cols, kp_cap, int(frame_cap) if frame_cap else kp_cap
+        c.median_ksize, c.max_corners, c.edge = int(median_win_size), int(num_of_features), int(edge)
+        c.ransac_max_iter, c.ransac_adaptive, c.lm_max_iter = int(max_iter), 1 if adaptive else 0, int(lm_iter)
+        c.flags = rgbd_solver_flags(pose_est_algorithm)
+        c.quality, c.min_distance = float(quality), float(min_distance)
+        c.ransac_threshold = float(1.0 - np.cos(np.deg2rad(5.0))) if thr is None else float(thr)
+        c.pct_good_matches, c.f2f_max_hdiff = float(cam.pct_good_matches), float(cam.f2f_max_hdiff)
+        c.seed, c.cos_a, c.sin_a = 0, float(cos_a), float(sin_a)
+        self.cfg = c
+        dev = ctx.device
+        mb = np.ones((1, rows, cols), np.uint32) if mask is None else (np.asarray(mask) != 0).astype(np.uint32).reshape(1, rows, cols)
+        self.mask_bits = torch.from_numpy(mb).to(dev)
+        self.pattern = torch.from_numpy(orb_pattern.orb_pattern()).to(dev)
+        nbytes = ctx.rgbd_sequence_workspace(c, self.W, self.slots)
+        if nbytes <= 0:
+            raise ValueError("bad sequence configuration")
+        self.workspace = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        self.bgr = torch.zeros((self.W, rows, cols, 3), dtype=torch.uint8, device=dev)
+        self.depth = torch.zeros((self.W, rows, cols), dtype=torch.float32, device=dev)
+        self._host_bgr = torch.zeros((self.W, rows, cols, 3), dtype=torch.uint8).pin_memory()
+        self._host_depth = torch.zeros((self.W, rows, cols), dtype=torch.float32).pin_memory()
+        self._np_bgr, self._np_depth = self._host_bgr.numpy(), self._host_depth.numpy()
+        self.spec = torch.zeros((self.W, 16), dtype=torch.float64, device=dev)
+        self.one = torch.zeros((1, 16), dtype=torch.float64, device=dev)
+
+    def _stage(self, images):
+        n = len(images)
+        for i, (bgr, depth) in enumerate(images):
+            np.copyto(self._np_bgr[i], bgr)
+            np.copyto(self._np_depth[i], np.asarray(depth, dtype=np.float32))
+        self.bgr[:n].copy_(self._host_bgr[:n], non_blocking=True)
+        self.depth[:n].copy_(self._host_depth[:n], non_blocking=True)
+
+    def _front_end(self, n, first):
+        self.ctx.rgbd_sequence_front_end(self.cam, self.cfg, self.W, self.slots, self.bgr[:n], self.depth[:n], first,
+                                         self.mask_bits, self.pattern, self.workspace)
+
+    def _track(self, ref_slots, cur_slots, seed, out):
+        self.ctx.rgbd_sequence_track(self.cfg, self.W, self.slots, ref_slots, cur_slots, seed, self.workspace, out)
+
+    def _counts(self, first, n):
+        return self.ctx.rgbd_sequence_frame_counts(self.cfg, self.W, self.slots, first, n, self.workspace)
+
+    def _copy(self, src, dst):
+        self.ctx.rgbd_sequence_copy_slot(self.cfg, self.W, self.slots, src, dst, self.workspace)
