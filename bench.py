@@ -153,6 +153,46 @@ def other_configs_subrecords(timeout_s=420):
     return out
 
 
+def sequence_rgbd_subrecord(bgr, depth, mirror_frames=32):
+    """The RGB-D counterpart of `sequence`: run_VO on an in-memory RGB-D sequence (640x480, radial depth) in sequence mode
+    (frame_window 32) and through the per-frame mirror classes, host clock around run_VO."""
+    import contextlib
+    import io
+    import tempfile
+    from vo_single_camera_sos_amd.omnistereo.camera_models import RGBDCamModel
+    from vo_single_camera_sos_amd.omnistereo.pose_est_tools import run_VO
+    N = bgr.shape[0]
+    out = {"frames": N, "data": "synthetic (one room, random-walk trajectory)",
+           "tracker": "reference settings: GFT 1000, EPnP RANSAC <= 210 iterations (adaptive), 5 deg threshold, LM"}
+    texts = {}
+    for label, window, n in (("frame_window_32", 32, N), ("mirror_per_frame", 0, min(N, mirror_frames))):
+        cam = RGBDCamModel(fx=554.256258, fy=554.256258, center_x=319.5, center_y=239.5, scaling_factor=1. / 1000.0,
+                           do_undistortion=False, depth_is_Z=False, focal_length_m=1. / 1000.0)
+
+        def frames(n=n):
+            for k in range(n):
+                yield k, bgr[k], depth[k]
+        with tempfile.TemporaryDirectory() as d, contextlib.redirect_stdout(io.StringIO()):
+            if label == "frame_window_32":
+                run_VO(None, cam, results_path=d, _live_frames=lambda: frames(4), frame_window=4)
+                torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = run_VO(None, cam, results_path=d, _live_frames=frames, frame_window=window)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            texts[label] = open(os.path.join(d, "estimated_frame_poses_TUM.txt")).read()
+        out[label] = {"frames": n, "frames_per_s": n / dt, "ms_per_frame": 1e3 * dt / n, "tracked": r["tracked"],
+                      "keyframes": len(r["keyframe_ids"])}
+        if "sequence_mode" in r:
+            out[label]["serial_tracking_calls"] = r["sequence_mode"]["serial_tracking_calls"]
+    n_m = out["mirror_per_frame"]["frames"]
+    a = np.loadtxt(io.StringIO(texts["frame_window_32"]))[:n_m]
+    b = np.loadtxt(io.StringIO(texts["mirror_per_frame"]))
+    out["mirror_max_abs_pose_difference"] = float(np.abs(a - b).max())
+    out["value"], out["unit"] = out["frame_window_32"]["frames_per_s"], "frames/s"
+    return out
+
+
 def sequence_subrecord(seq_omni, seq_poses, pano_width, mirror_frames=32):
     """SEQUENCE MODE (SURVEY 8(e) caveat; the reference's VO loop, pose_est_tools.py:1416-1628): run_VO on ONE synthetic
     sequence held in host memory -- every frame's front end computed once, `frame_window` frames per batched pass, tracking
@@ -547,6 +587,7 @@ def main():
     seq_omni = None
     if world == 1 and not args.no_sub and args.sequence_frames > 0:   # (rendered here: forked workers, before any GPU call)
         seq_omni, seq_poses = synthetic.make_sequence(gs, args.sequence_frames, seed=args.seed + 7, workers=workers)
+        seq_bgr, seq_depth, _ = synthetic.make_rgbd_sequence(min(128, args.sequence_frames), seed=args.seed + 9, workers=workers)
     dist = None
     # (SOSVO_BENCH_FORCE_DIST=1: a launcher-started single rank also goes through init_process_group + the RCCL
     # gather -- tests/test_gpu_bench_rccl.py rehearses the N > 1 code path on the one-GPU box that way)
@@ -903,6 +944,10 @@ def main():
                 out["sequence"] = sequence_subrecord(seq_omni, seq_poses, args.pano_width)
             except Exception as e:  # the headline number does not depend on it
                 out["sequence"] = {"error": repr(e)}
+            try:
+                out["sequence_rgbd"] = sequence_rgbd_subrecord(seq_bgr, seq_depth)
+            except Exception as e:
+                out["sequence_rgbd"] = {"error": repr(e)}
         if sub_other:
             torch.cuda.synchronize()
             out.update(other_configs_subrecords())

@@ -207,6 +207,26 @@ def make_sequence(gums, n_frames, seed=0, max_t=40.0, max_deg=2.0, workers=1):
     return np.stack(frames), poses
 
 
+def _render_rgbd_seq_frame(args):
+    seed, R, t, k, depth_is_Z, yaw_deg = args
+    room = Room(seed=seed, half_x=(1800.0, 2600.0), half_y=(2500.0, 3500.0), cells=(150.0, 40.0), yaw_deg=yaw_deg)
+    return render_rgbd(room, R, t, np.random.default_rng(seed + 1 + k), depth_is_Z=depth_is_Z)
+
+
+def make_rgbd_sequence(n_frames, seed=0, max_t=40.0, max_deg=2.0, depth_is_Z=False, yaw_deg=40.0, workers=1):
+    """-> (bgr [n, 480, 640, 3] u8, depth [n, 480, 640] f32 metres, poses): one room along a random-walk trajectory, as
+    write_rgbd_sequence renders it (frames do not depend on the number of workers; fork before the GPU is touched)."""
+    poses = trajectory(n_frames, seed, max_t, max_deg)
+    jobs = [(seed, R, t, k, depth_is_Z, yaw_deg) for k, (R, t) in enumerate(poses)]
+    if workers > 1 and n_frames > 1:
+        import multiprocessing
+        with multiprocessing.get_context("fork").Pool(min(int(workers), n_frames)) as pool:
+            frames = pool.map(_render_rgbd_seq_frame, jobs, chunksize=max(1, n_frames // (4 * int(workers))))
+    else:
+        frames = [_render_rgbd_seq_frame(j) for j in jobs]
+    return np.stack([f[0] for f in frames]), np.stack([f[1] for f in frames]), poses
+
+
 def _write_gt_tum(filename, poses):
     from .omnistereo.transformations import quaternion_from_matrix
     with open(filename, "w") as f:
