@@ -16,7 +16,7 @@ NOT_COMPUTE = {"sosvo_abi_version", "sosvo_create", "sosvo_destroy", "sosvo_set_
                "sosvo_last_error", "sosvo_timer_start", "sosvo_timer_stop", "sosvo_timer_elapsed_ms", "sosvo_profile_enable",
                "sosvo_profile_count", "sosvo_profile_get", "sosvo_orb_pyramid_pixels", "sosvo_frame_pair_batch_workspace",
                "sosvo_rgbd_pair_batch_workspace", "sosvo_frame_pair_batch_streams_workspace", "sosvo_debug_fill_scratch",
-               "sosvo_sequence_workspace", "sosvo_frame_pair_batch_streams_join"}
+               "sosvo_sequence_workspace", "sosvo_rgbd_sequence_workspace", "sosvo_frame_pair_batch_streams_join"}
 
 
 def _dummy_args(argtypes, ctx_value):
@@ -45,7 +45,8 @@ def test_null_arguments_are_refused_not_dereferenced(ctx):
         assert name in msg and len(msg) > len(name) + 2, (name, msg)
     # workspace queries of a bad configuration answer 0 bytes
     assert lib.sosvo_frame_pair_batch_workspace(None) == 0 and lib.sosvo_rgbd_pair_batch_workspace(None) == 0
-    assert lib.sosvo_frame_pair_batch_streams_workspace(None, 2) == 0 and lib.sosvo_sequence_workspace(None, 4, 9) == 0
+    assert lib.sosvo_frame_pair_batch_streams_workspace(None, 2) == 0 and lib.sosvo_sequence_workspace(None, 4, 9) == 0 \
+        and lib.sosvo_rgbd_sequence_workspace(None, 4, 9) == 0
     assert lib.sosvo_frame_pair_batch_streams_join(None) == -1 and lib.sosvo_frame_pair_batch_streams_join(ctx._h) == 0
     # the context is still good for real work
     q = torch.randint(0, 256, (1, 8, 32), dtype=torch.uint8, device=ctx.device)
