@@ -641,20 +641,31 @@ def main():
     # The dominant kernel on its own (nothing else on the chip): in the timed region its launches share the SIMDs with the
     # other streams' kernels, at the lowest wave priority, so their durations say how the step is scheduled, not how good
     # the kernel is.  A few isolated launches of one part's K1+K2+K3 give the kernel's own duration.
-    iso_ms, iso_pairs = None, None
+    # With SOSVO_HINT_SHARED_DEVICE (set on the parts of a multi-stream engine) the kernel keeps to three workgroups per CU;
+    # `isolated_launch_ms` is the kernel as it runs alone (hint off), `isolated_launch_ms_shared_hint` as the step launches it.
+    iso_ms, iso_pairs, iso_hint_ms = None, None, None
     if rank == 0 and not args.no_isolated:
         part = eng.parts[0]
-        torch.cuda.synchronize()
-        evs = []
-        with torch.cuda.stream(part.stream):
-            for _ in range(6):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(part.stream)
-                part.fe.run_images()
-                e1.record(part.stream)
-                evs.append((e0, e1))
-        torch.cuda.synchronize()
-        iso_ms = float(np.median([a.elapsed_time(b) for a, b in evs[1:]]))
+
+        def isolated():
+            torch.cuda.synchronize()
+            evs = []
+            with torch.cuda.stream(part.stream):
+                for _ in range(6):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(part.stream)
+                    part.fe.run_images()
+                    e1.record(part.stream)
+                    evs.append((e0, e1))
+            torch.cuda.synchronize()
+            return float(np.median([a.elapsed_time(b) for a, b in evs[1:]]))
+
+        if eng.S > 1:
+            iso_hint_ms = isolated()
+            part.ctx.set_hint_shared_device(False)
+        iso_ms = isolated()
+        if eng.S > 1:
+            part.ctx.set_hint_shared_device(True)
         iso_pairs = part.hi - part.lo
 
     # PCIe-inclusive rate (never `value`): the same K steps with the omni frames handed over in pinned HOST memory and
@@ -747,7 +758,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": dom_avg_s * 1e3, "launches": dom[1][0],
-                         "isolated_launch_ms": iso_ms,
+                         "isolated_launch_ms": iso_ms, "isolated_launch_ms_shared_hint": iso_hint_ms,
                          "achieved_isolated": b_alg * iso_pairs / (iso_ms * 1e-3) / 1e9 if iso_ms else None,
                          "frac_isolated": b_alg * iso_pairs / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if iso_ms else None,
                          "algorithmic_bytes_per_pair": b_alg, "algorithmic_bytes_per_launch": b_alg_launch,

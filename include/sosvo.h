@@ -58,6 +58,12 @@ int32_t sosvo_abi_version(void);
 int32_t sosvo_create(sosvo_ctx** out, int32_t device, void* stream);
 int32_t sosvo_destroy(sosvo_ctx* ctx);
 int32_t sosvo_set_stream(sosvo_ctx* ctx, void* stream);
+/* Hints that change scheduling, never results.  SOSVO_HINT_SHARED_DEVICE (value != 0): kernels of OTHER contexts / streams
+ * run on the device at the same time (a batch split over streams): the register-filling median kernel then keeps to three
+ * workgroups per CU so that the others find wave slots (+1.3 % on the three-stream step, -2.5 % for that kernel alone).
+ * sosvo_frame_pair_batch_streams sets it on its internal contexts itself. */
+#define SOSVO_HINT_SHARED_DEVICE 1
+int32_t sosvo_set_hint(sosvo_ctx* ctx, int32_t hint, int32_t value);
 int32_t sosvo_synchronize(sosvo_ctx* ctx);
 const char* sosvo_last_error(const sosvo_ctx* ctx);
 

@@ -12,7 +12,7 @@ from vo_single_camera_sos_amd import _lib
 
 pytestmark = pytest.mark.gpu
 
-NOT_COMPUTE = {"sosvo_abi_version", "sosvo_create", "sosvo_destroy", "sosvo_set_stream", "sosvo_synchronize",
+NOT_COMPUTE = {"sosvo_abi_version", "sosvo_create", "sosvo_destroy", "sosvo_set_stream", "sosvo_set_hint", "sosvo_synchronize",
                "sosvo_last_error", "sosvo_timer_start", "sosvo_timer_stop", "sosvo_timer_elapsed_ms", "sosvo_profile_enable",
                "sosvo_profile_count", "sosvo_profile_get", "sosvo_orb_pyramid_pixels", "sosvo_frame_pair_batch_workspace",
                "sosvo_rgbd_pair_batch_workspace", "sosvo_frame_pair_batch_streams_workspace", "sosvo_debug_fill_scratch",
@@ -47,6 +47,7 @@ def test_null_arguments_are_refused_not_dereferenced(ctx):
     assert lib.sosvo_frame_pair_batch_workspace(None) == 0 and lib.sosvo_rgbd_pair_batch_workspace(None) == 0
     assert lib.sosvo_frame_pair_batch_streams_workspace(None, 2) == 0 and lib.sosvo_sequence_workspace(None, 4, 9) == 0 \
         and lib.sosvo_rgbd_sequence_workspace(None, 4, 9) == 0
+    assert lib.sosvo_set_hint(None, 1, 1) == -1 and lib.sosvo_set_hint(ctx._h, 99, 1) == -1 and lib.sosvo_set_hint(ctx._h, 1, 0) == 0
     assert lib.sosvo_frame_pair_batch_streams_join(None) == -1 and lib.sosvo_frame_pair_batch_streams_join(ctx._h) == 0
     # the context is still good for real work
     q = torch.randint(0, 256, (1, 8, 32), dtype=torch.uint8, device=ctx.device)

@@ -37,6 +37,7 @@ SIGNATURES = {
     "sosvo_create": (c_i32, [ctypes.POINTER(c_p), c_i32, c_p]),
     "sosvo_destroy": (c_i32, [c_p]),
     "sosvo_set_stream": (c_i32, [c_p, c_p]),
+    "sosvo_set_hint": (c_i32, [c_p, c_i32, c_i32]),
     "sosvo_synchronize": (c_i32, [c_p]),
     "sosvo_last_error": (ctypes.c_char_p, [c_p]),
     "sosvo_timer_start": (c_i32, [c_p]),
@@ -108,6 +109,7 @@ SIGNATURES = {
     "sosvo_rgbd_pair_batch": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
 }
 
+HINT_SHARED_DEVICE = 1
 FLAG_CAM_ROT_IDENTITY = 1
 FLAG_EPNP = 2
 FLAG_GP3P = 4

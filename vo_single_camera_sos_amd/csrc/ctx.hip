@@ -31,6 +31,13 @@ int32_t sosvo_create(sosvo_ctx** out, int32_t device, void* stream) {
   return SOSVO_OK;
 }
 
+int32_t sosvo_set_hint(sosvo_ctx* ctx, int32_t hint, int32_t value) {
+  if (!ctx) return SOSVO_ERR_ARG;
+  if (hint != SOSVO_HINT_SHARED_DEVICE) return sosvo_fail(ctx, SOSVO_ERR_ARG, __func__, "unknown hint");
+  ctx->hint_shared_device = value != 0;
+  return SOSVO_OK;
+}
+
 int32_t sosvo_destroy(sosvo_ctx* ctx) {
   if (!ctx) return SOSVO_OK;
   (void)hipSetDevice(ctx->device);

@@ -459,7 +459,13 @@ int32_t launch_median(sosvo_ctx* ctx, const uint8_t* img, const uint2* table, in
   constexpr auto k5 = median_gray_kernel<5, FUSED>;
   constexpr auto k3 = median_gray_kernel<3, FUSED>;
   SosvoProfScope prof(ctx, FUSED ? "unwrap_median_gray_kernel" : "median_gray_kernel");
-  hipLaunchKernelGGL(ksize == 11 ? k11 : (ksize == 5 ? k5 : k3), grid, block, 0, ctx->stream, img, table, nframes, H, W, nimg,
+  // SOSVO_HINT_SHARED_DEVICE: the median's 127 VGPRs x 4 waves fill a SIMD's register file, so while it runs the other
+  // streams' kernels only get wave slots as its workgroups retire.  41 KB of (unused) dynamic LDS per workgroup caps it at
+  // THREE workgroups per CU: a quarter of every SIMD's registers stays free for them.  Alone the kernel loses 2.5 % (2.38 ->
+  // 2.44 ms per 256 pairs: three waves still saturate the SIMD's issue port), the three-stream step gains 1.3 % (measured:
+  // 12.57 -> 12.41 ms per 768 pairs; two workgroups per CU: 13.1 ms).
+  const size_t lds_pad = ctx->hint_shared_device && ksize == 11 ? 41000 : 0;
+  hipLaunchKernelGGL(ksize == 11 ? k11 : (ksize == 5 ? k5 : k3), grid, block, lds_pad, ctx->stream, img, table, nframes, H, W, nimg,
                      rows, cols, strips, row_range, gray);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;

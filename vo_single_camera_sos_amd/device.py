@@ -85,6 +85,10 @@ class Context(object):
                                                msg.decode() if msg else ""))
 
     # ---- plumbing ----------------------------------------------------------------------
+    def set_hint_shared_device(self, on=True):
+        """sosvo_set_hint(SOSVO_HINT_SHARED_DEVICE): other contexts' kernels run beside this one's (scheduling only)."""
+        self._call(self._lib.sosvo_set_hint, _lib.HINT_SHARED_DEVICE, 1 if on else 0)
+
     def set_stream(self, stream):
         """Enqueue on `stream` (a torch.cuda.Stream) from now on, e.g. the capture stream of a HIP graph."""
         self._call(self._lib.sosvo_set_stream, c_p(stream.cuda_stream))

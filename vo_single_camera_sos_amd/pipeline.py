@@ -178,6 +178,8 @@ class OverlappedFramePairs(object):
             p.stream = torch.cuda.Stream(self.device)
             with torch.cuda.stream(p.stream):
                 p.ctx = Context(self.device.index, p.stream)
+                if self.S > 1:
+                    p.ctx.set_hint_shared_device(True)   # the parts run side by side: leave wave slots for each other
                 p.fe = ImageFrontEnd(p.ctx, m, 2 * (hi - lo), detection_method=detection_method,
                                      num_of_features=num_of_features, kp_cap=kp_cap, keep_panoramas=False,
                                      median_win_size=median_win_size)
