@@ -283,16 +283,45 @@ __global__ __launch_bounds__(kThreads) void mask_bbox_kernel(const uint32_t* __r
   }
 }
 
-// One workgroup per problem (image, mask).  Phase 1 walks the candidate records of the waves of min_eigen_kernel whose
-// (strip, row chunk) meets the mask's bounding box, keeps those of this mask above the threshold and builds the sort
-// keys in LDS; phase 2 rank-sorts them (descending value, higher
-// address first) into global memory; phase 3 -- the keys are dead, the 32 KB of LDS become the cell grid --
-// is the greedy minimum-distance pass by the first wave, 64 candidates at a time: every lane tests its
-// candidate against the grid of already accepted points (9 cells x 2 slots) and against the earlier lanes
-// of its batch (64 shuffles -> a 64-bit conflict mask); a short scalar pass over the batch then replays the
-// sequential acceptance rule exactly (accept iff no conflict with anything accepted before).
-// (NT threads per workgroup: 256, or 1024 for the whole-image variant whose 128 KB of LDS allow one workgroup per CU anyway --
-// sixteen waves share the sort passes instead of four)
+// LOGR consecutive steps of a bitonic merge (strides jtop, jtop / 2, ...) on 2^LOGR keys per thread: the keys
+// i + m * jl (jl = the lowest stride) form a closed set under those steps, and they share the merge direction (bit k of i).
+template <int LOGR, int NT>
+__device__ __forceinline__ void bitonic_pass(unsigned long long* keys, int N, int k, int jtop, int tid) {
+  constexpr int R = 1 << LOGR;
+  const int jl = jtop >> (LOGR - 1);
+  for (int t = tid; t < (N >> LOGR); t += NT) {
+    const int i = ((t & ~(jl - 1)) << LOGR) | (t & (jl - 1));
+    const bool desc = (i & k) == 0;
+    unsigned long long v[R];
+#pragma unroll
+    for (int m = 0; m < R; ++m) v[m] = keys[i + m * jl];
+#pragma unroll
+    for (int sb = LOGR - 1; sb >= 0; --sb) {
+#pragma unroll
+      for (int m = 0; m < R; ++m) {
+        if (m & (1 << sb)) continue;
+        const unsigned long long a = v[m], b = v[m | (1 << sb)];
+        const bool sw = (a < b) == desc;
+        v[m] = sw ? b : a;
+        v[m | (1 << sb)] = sw ? a : b;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < R; ++m) keys[i + m * jl] = v[m];
+  }
+}
+
+// One workgroup per problem (image, mask).  Phase 1 gathers the candidate records of the waves of min_eigen_kernel whose
+// (strip, row chunk) meets the mask's bounding box (region counts fetched NT at a time, the waves share the regions, one
+// LDS atomic per wave and 64 records), keeps those of this mask above the threshold and builds the sort keys in LDS; phase 2
+// sorts them (bitonic, descending value, higher address first; three steps per pass over the keys); phase 3 -- the keys are
+// dead, their LDS becomes the cell grid -- is the greedy minimum-distance pass, 64 candidates per round: the candidates are
+// tested against the grid of already accepted points (9 cells x 2 slots) and against each other (a 64 x 64 conflict matrix),
+// both spread over the workgroup's waves, and the first wave then replays the sequential acceptance rule exactly (accept iff
+// no conflict with anything accepted before) -- in parallel for the candidates nothing earlier in the round can touch, on
+// the scalar unit for the few others.  Round 3: 566 -> ~190 us per whole-image problem of 8 k candidates / 2000 corners
+// (region walk 223 -> 25, sort 104 -> 84, greedy 234 -> 70).
+// (NT threads per workgroup: 256, or 1024 for the whole-image variant whose 128 KB of LDS allow one workgroup per CU anyway)
 template <int CAND, int NT>
 __global__ __launch_bounds__(NT) void gft_select_kernel(const uint2* __restrict__ cand,
                                                               const uint32_t* __restrict__ wcnt, int strips, int nchunks,
@@ -314,6 +343,9 @@ __global__ __launch_bounds__(NT) void gft_select_kernel(const uint2* __restrict_
   if (redo && redo_pass == 1 && redo[p] == 0) return;  // uniform
   __shared__ unsigned long long lds_u64[CAND];
   __shared__ int s_count, s_accepted, s_overflow;
+  __shared__ int s_region[NT];  // phase 1: record counts of the regions in flight
+  __shared__ unsigned long long s_conf[64];  // phase 3: conflict rows of the round
+  __shared__ unsigned long long s_prior;     // phase 3: candidates of the round that conflict with an earlier round's points
   unsigned long long* keys = lds_u64;
   uint32_t* grid = reinterpret_cast<uint32_t*>(lds_u64);  // phase 3: 2 slots per cell, pixel index + 1 (0 = empty)
   uint32_t* acc_list = grid + 2 * kSelGridCells;          // phase 3 fallback: accepted pixel indices (<= 1024)
@@ -326,6 +358,7 @@ __global__ __launch_bounds__(NT) void gft_select_kernel(const uint2* __restrict_
     s_count = 0;
     s_accepted = 0;
     s_overflow = 0;
+    s_prior = 0ULL;
   }
   __syncthreads();
   // ---- phase 1: candidates ------------------------------------------------------------------------------
@@ -338,27 +371,52 @@ __global__ __launch_bounds__(NT) void gft_select_kernel(const uint2* __restrict_
     const uint32_t* mb = mask_bits + (size_t)(img / images_per_maskset) * rows * cols;
     const int s0 = bx0 / kEigStripW, s1 = bx1 / kEigStripW;
     const int c0 = by0 / chunk_rows, c1 = by1 / chunk_rows;
-    for (int c = c0; c <= c1; ++c)
-      for (int sidx = s0; sidx <= s1; ++sidx) {
-        const int w = (img * nchunks + c) * strips + sidx;  // the wave numbering of min_eigen_kernel
-        const int have = (int)wcnt[w];
-        if (have > wcap && tid == 0) s_overflow = 1;
-        const uint2* region = cand + (size_t)w * wcap;
-        for (int i = tid; i < min(have, wcap); i += NT) {
-          const uint2 r = region[i];
-          const float v = __uint_as_float(r.x);
-          if (!(v > thr) || !((mb[r.y] >> m) & 1u)) continue;
-          const int slot = atomicAdd(&s_count, 1);
-          if (slot < CAND) keys[slot] = ((unsigned long long)sosvo_float_ordered(v) << 32) | r.y;
+    // The regions (strip, row chunk) that meet the bounding box, NT at a time: every thread fetches ONE region's count (the
+    // dependent global loads of a region-by-region walk were most of this phase), then the waves take the regions round-robin,
+    // 64 records per step, and claim their key slots with one LDS atomic per wave and step.
+    const int ns = s1 - s0 + 1, R = (c1 - c0 + 1) * ns;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    for (int rb = 0; rb < R; rb += NT) {
+      if (rb + tid < R) {
+        const int rg = rb + tid, c = c0 + rg / ns, sidx = s0 + rg % ns;
+        const int have = (int)wcnt[(img * nchunks + c) * strips + sidx];  // the wave numbering of min_eigen_kernel
+        if (have > wcap) s_overflow = 1;
+        s_region[tid] = min(have, wcap);
+      }
+      __syncthreads();
+      const int rend = min(NT, R - rb);
+      for (int rr = wave; rr < rend; rr += NT / 64) {
+        const int have = s_region[rr];
+        const int rg = rb + rr, c = c0 + rg / ns, sidx = s0 + rg % ns;
+        const uint2* region = cand + (size_t)((img * nchunks + c) * strips + sidx) * wcap;
+        for (int i0 = 0; i0 < have; i0 += 64) {
+          const int i = i0 + lane;
+          uint2 r = make_uint2(0u, 0u);
+          bool keep = false;
+          if (i < have) {
+            r = region[i];
+            keep = __uint_as_float(r.x) > thr && ((mb[r.y] >> m) & 1u);
+          }
+          const unsigned long long km = __ballot(keep);
+          if (km) {  // uniform
+            const int leader = __ffsll((long long)km) - 1;
+            int slot0 = 0;
+            if (lane == leader) slot0 = atomicAdd(&s_count, __popcll(km));
+            slot0 = __shfl(slot0, leader);
+            const int slot = slot0 + __popcll(km & ((1ULL << lane) - 1ULL));
+            if (keep && slot < CAND) keys[slot] = ((unsigned long long)sosvo_float_ordered(__uint_as_float(r.x)) << 32) | r.y;
+          }
         }
       }
+      __syncthreads();  // s_region is rewritten by the next tile
+    }
   }
   __syncthreads();
   const int total = s_count;
   if (redo && redo_pass == 0) {  // uniform decision of the whole workgroup
     const int cx0_ = bx0 / cell, cy0_ = by0 / cell;
     const int gw_ = bw > 0 ? bx1 / cell - cx0_ + 1 : 0, gh_ = bh > 0 ? by1 / cell - cy0_ + 1 : 0;
-    const bool fits = total <= CAND && gw_ * gh_ <= kSelGridCells;
+    const bool fits = total <= CAND && (gw_ + 2) * (gh_ + 2) <= kSelGridCells;  // (the bordered grid of phase 3)
     if (tid == 0) redo[p] = fits ? 0 : 1;
     if (!fits) return;
   }
@@ -368,17 +426,16 @@ __global__ __launch_bounds__(NT) void gft_select_kernel(const uint2* __restrict_
   while (N < n) N <<= 1;
   for (int i = n + tid; i < N; i += NT) keys[i] = 0ULL;  // padding sorts last
   __syncthreads();
-  for (int k = 2; k <= N; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < N / 2; t += NT) {
-        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), ixj = i | j;
-        const unsigned long long a = keys[i], b = keys[ixj];
-        const bool desc = (i & k) == 0;
-        if ((a < b) == desc) {
-          keys[i] = b;
-          keys[ixj] = a;
-        }
-      }
+  for (int k = 2, lk = 1; k <= N; k <<= 1, ++lk) {
+    // the lk steps of this merge (strides k / 2 ... 1), up to three per pass over the keys (8 keys per thread in registers:
+    // a third of the LDS traffic and of the barriers of one step per pass -- the sort is LDS-bandwidth-bound)
+    for (int left = lk, j = k >> 1; left > 0;) {
+      const int take = left >= 3 ? 3 : left;
+      if (take == 3) bitonic_pass<3, NT>(keys, N, k, j, tid);
+      else if (take == 2) bitonic_pass<2, NT>(keys, N, k, j, tid);
+      else bitonic_pass<1, NT>(keys, N, k, j, tid);
+      j >>= take;
+      left -= take;
       __syncthreads();
     }
   }
@@ -393,29 +450,125 @@ __global__ __launch_bounds__(NT) void gft_select_kernel(const uint2* __restrict_
   const int gw = bw > 0 ? bx1 / cell - cx0 + 1 : 0, gh = bh > 0 ? by1 / cell - cy0 + 1 : 0;
   const bool use_grid = gw * gh <= kSelGridCells;
   const int limit_list = 1024;
+  const float md2 = min_distance * min_distance;
+  const bool spaced = min_distance >= 1.0f;
+  int limit = cap;
+  if (max_corners > 0 && max_corners < limit) limit = max_corners;
+  // The usual case runs on integers (squared distances below 2^31, thresholds below 2^24: the comparisons are the float
+  // ones exactly) with a one-cell border around the grid, and on ALL waves of the workgroup -- see below.
+  constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+  const int gwp = gw + 2;
+  const bool fast = spaced && n > 0 && cell <= 2048 && rows <= 32768 && cols <= 32768 && gwp * (gh + 2) <= kSelGridCells;  // uniform
   __syncthreads();  // keys are dead from here on; sorted[] is visible to the whole workgroup
-  for (int i = tid; i < (use_grid ? gw * gh * 2 : 0); i += NT) grid[i] = 0u;
+  if (fast) {
+    for (int i = tid; i < gwp * (gh + 2) * 2; i += NT) grid[i] = kEmpty;
+  } else {
+    for (int i = tid; i < (use_grid ? gw * gh * 2 : 0); i += NT) grid[i] = 0u;
+  }
   __syncthreads();
-  // ---- phase 3: greedy minimum-distance pass, first wave ----------------------------------------------------
-  // 64 candidates per round.  Every lane tests its candidate against the points accepted in earlier rounds
-  // (cell grid: 9 cells x 2 slots, packed coordinates + 1).  The survivors are then taken in order: the first
-  // one alive is accepted (wave-uniform), its coordinates are broadcast (v_readlane) and every later survivor
-  // closer than minDistance dies -- exactly the sequential rule, in as many steps as points get accepted.
-  if (tid < 64) {
-    const float md2 = min_distance * min_distance;
+  // ---- phase 3: greedy minimum-distance pass ----------------------------------------------------------------
+  // 64 candidates per round, in order (every wave holds the round's candidates, one per lane).  (i) Conflicts with points
+  // accepted in earlier rounds: cell grid with a border, 9 cells x 2 slots of packed coordinates, no bounds tests, empty
+  // slots masked; one cell per work item, the hits OR-ed into s_prior.  (ii) Conflicts INSIDE the round: a 64 x 64 bit
+  // matrix, row j = ballot(candidate closer than minDistance to candidate j), one row per work item, left in s_conf.
+  // (iii) After the barrier the first wave replays the sequential rule: a survivor of (i) with no EARLIER survivor in its
+  // row is accepted whatever happens to the others (decided by all lanes at once); the remaining ones are taken in order on
+  // the scalar unit (find-first-bit, two v_readlane, mask tests).  The one-wave form further down recomputes a row per
+  // accepted point: a dependent chain of ~10 instructions of a wave that runs alone, 90 ns per point.
+  if (fast) {
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const uint32_t thr_i = (uint32_t)ceilf(md2);  // integer d2 < md2  <=>  d2 < ceil(md2)
+    const uint32_t magic = cell > 1 ? 0xFFFFFFFFu / (uint32_t)cell + 1u : 0u;  // v / cell = mulhi(v, magic) for v < 2^16
+    int accepted = 0;                                 // uniform over the workgroup
+    uint32_t xy_next = lane < n ? sorted[lane] : 0u;  // one coalesced read per 64 candidates, requested a round ahead
+    for (int k0 = 0; k0 < n && accepted < limit; k0 += 64) {
+      const int kend = min(64, n - k0);
+      const bool active = lane < kend;
+      const uint32_t xy = xy_next;
+      xy_next = k0 + 64 + lane < n ? sorted[k0 + 64 + lane] : 0u;
+      const int y = (int)(xy >> 16), x = (int)(xy & 0xFFFFu);
+      // cell in the bordered grid (every candidate of this mask lies inside the mask's bounding box)
+      const int xc = active ? (int)(cell > 1 ? __umulhi((uint32_t)x, magic) : (uint32_t)x) - cx0 + 1 : 1;
+      const int yc = active ? (int)(cell > 1 ? __umulhi((uint32_t)y, magic) : (uint32_t)y) - cy0 + 1 : 1;
+      const int cidx = (yc * gwp + xc) * 2;
+      // (i) + (ii): 9 cell tests and kend matrix rows are 9 + kend work items dealt round-robin over the waves (a lone wave
+      // issues an instruction every 5+ cycles and waits for every dependent one: the round is latency, so it is spread)
+      constexpr int NWV = NT / 64;
+      for (int c9 = wave; c9 < 9; c9 += NWV) {  // uniform per wave
+        const uint2 q2 = *reinterpret_cast<const uint2*>(&grid[cidx + (c9 / 3 - 1) * gwp * 2 + (c9 % 3 - 1) * 2]);
+        const uint32_t hit = ((uint32_t)(q2.x != kEmpty) & (uint32_t)(dist2_packed(xy, q2.x) < thr_i)) |
+                             ((uint32_t)(q2.y != kEmpty) & (uint32_t)(dist2_packed(xy, q2.y) < thr_i));
+        const unsigned long long hb = __ballot(active && hit != 0u);  // conflict with a point accepted in an earlier round
+        if (hb && lane == 0) atomicOr(&s_prior, hb);
+      }
+      {
+        // rows first + t * NWV, four at a time (independent chains: the scheduler interleaves them); a wave's rows gather in
+        // its lanes and leave with one LDS store
+        const int first = (wave + NWV - 9 % NWV) % NWV;  // item 9 + j goes to wave (9 + j) % NWV
+        uint32_t glo = 0u, ghi = 0u;
+        int t = 0;
+        for (int jb = first; jb < kend; jb += 4 * NWV, t += 4) {  // uniform per wave
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int j = min(jb + u * NWV, 63);  // (rows beyond kend: computed, never stored)
+            const unsigned long long row = __ballot(active && dist2_packed(xy, (uint32_t)__builtin_amdgcn_readlane((int)xy, j)) < thr_i);
+            const bool here = lane == t + u;
+            glo = here ? (uint32_t)row : glo;
+            ghi = here ? (uint32_t)(row >> 32) : ghi;
+          }
+        }
+        const int jmine = first + lane * NWV;
+        if (jmine < kend) s_conf[jmine] = ((unsigned long long)ghi << 32) | glo;
+      }
+      __syncthreads();
+      if (wave == 0) {
+        // (iii) a survivor without an EARLIER survivor in its row is accepted whatever happens to the others; the rest are
+        // taken in order on the scalar unit: accepted iff no accepted earlier candidate is in their row
+        const unsigned long long alive0 = __ballot(active) & ~s_prior;
+        const unsigned long long mine = active ? s_conf[lane] : 0ULL;
+        const unsigned long long lt = (1ULL << lane) - 1ULL;
+        const bool surv = (alive0 >> lane) & 1ULL;
+        const unsigned long long fr = __ballot(surv && (mine & alive0 & lt) == 0ULL);
+        unsigned long long pending = alive0 & ~fr, acc = fr;
+        const int rlo = (int)(uint32_t)mine, rhi = (int)(uint32_t)(mine >> 32);
+        while (pending) {
+          const int j = __ffsll((long long)pending) - 1;
+          pending &= pending - 1ULL;
+          const unsigned long long row = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(rhi, j) << 32) |
+                                         (uint32_t)__builtin_amdgcn_readlane(rlo, j);
+          if ((row & acc & ((1ULL << j) - 1ULL)) == 0ULL) acc |= 1ULL << j;
+        }
+        // the sequential pass stops at `limit` points: the first `room` of the accepted ones, in order
+        const int room = limit - accepted;
+        acc = __ballot(((acc >> lane) & 1ULL) && __popcll(acc & lt) < room);
+        if ((acc >> lane) & 1ULL) {
+          const int pos = accepted + __popcll(acc & ((1ULL << lane) - 1ULL));
+          kp[((size_t)p * cap + pos) * 2] = (float)x;
+          kp[((size_t)p * cap + pos) * 2 + 1] = (float)y;
+          if (atomicCAS(&grid[cidx], kEmpty, xy) != kEmpty) grid[cidx + 1] = xy;
+        }
+        if (lane == 0) {
+          s_accepted = accepted + __popcll(acc);
+          s_prior = 0ULL;  // (read above by this wave only; the others add to it after the barrier)
+        }
+      }
+      __syncthreads();
+      accepted = s_accepted;
+    }
+  } else
+  if (tid < 64) {  // one-wave form (float distances; the accepted points in a list when the grid does not fit)
     const int lane = tid;
-    const bool spaced = min_distance >= 1.0f;
-    int limit = cap;
-    if (max_corners > 0 && max_corners < limit) limit = max_corners;
     if (!use_grid && limit_list < limit) {
       limit = limit_list;
       stt |= 2;
     }
     int accepted = 0;
+    uint32_t xy_next = lane < n ? sorted[lane] : 0u;  // one coalesced read per 64 candidates, requested a round ahead
     for (int k0 = 0; k0 < n && accepted < limit; k0 += 64) {
       const int kend = min(64, n - k0);
       const bool active = lane < kend;
-      const uint32_t xy = active ? sorted[k0 + lane] : 0u;  // one coalesced read per 64 candidates
+      const uint32_t xy = xy_next;
+      xy_next = k0 + 64 + lane < n ? sorted[k0 + 64 + lane] : 0u;
       const int y = (int)(xy >> 16), x = (int)(xy & 0xFFFFu);
       bool prior = false;  // conflict with a point accepted in an earlier round
       if (active && spaced) {
