@@ -322,6 +322,13 @@ __device__ __forceinline__ void bitonic_pass(unsigned long long* keys, int N, in
 // the scalar unit for the few others.  Round 3: 566 -> ~190 us per whole-image problem of 8 k candidates / 2000 corners
 // (region walk 223 -> 25, sort 104 -> 84, greedy 234 -> 70).
 // (NT threads per workgroup: 256, or 1024 for the whole-image variant whose 128 KB of LDS allow one workgroup per CU anyway)
+// Squared distance of two points packed as y << 16 | x (coordinates below 32768): v_pk_sub_i16 + v_dot2_i32_i16
+__device__ __forceinline__ uint32_t dist2_packed(uint32_t a, uint32_t b) {
+  typedef short short2v __attribute__((ext_vector_type(2)));
+  const short2v d = __builtin_bit_cast(short2v, a) - __builtin_bit_cast(short2v, b);
+  return (uint32_t)__builtin_amdgcn_sdot2(d, d, 0, false);
+}
+
 template <int CAND, int NT>
 __global__ __launch_bounds__(NT) void gft_select_kernel(const uint2* __restrict__ cand,
                                                               const uint32_t* __restrict__ wcnt, int strips, int nchunks,
