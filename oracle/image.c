@@ -225,8 +225,8 @@ int32_t orc_gft_select(const float* eig, const uint32_t* mask_bits, int32_t whic
     const int cell = (int)lrint(min_distance);
     const int gw = (cols + cell - 1) / cell, gh = (rows + cell - 1) / cell;
     /* up to 8 points per cell is ample for cell size == min distance */
-    int16_t* gx = (int16_t*)malloc(sizeof(int16_t) * (size_t)gw * gh * 8);
-    int16_t* gy = (int16_t*)malloc(sizeof(int16_t) * (size_t)gw * gh * 8);
+    int32_t* gx = (int32_t*)malloc(sizeof(int32_t) * (size_t)gw * gh * 8); /* (32-bit: images may be wider than 32767) */
+    int32_t* gy = (int32_t*)malloc(sizeof(int32_t) * (size_t)gw * gh * 8);
     uint8_t* gn = (uint8_t*)calloc((size_t)gw * gh, 1);
     const float md2 = (float)(min_distance * min_distance);
     for (int k = 0; k < nc; ++k) {
@@ -252,8 +252,8 @@ int32_t orc_gft_select(const float* eig, const uint32_t* mask_bits, int32_t whic
       if (good) {
         const int c = yc * gw + xc;
         if (gn[c] < 8) {
-          gx[c * 8 + gn[c]] = (int16_t)x;
-          gy[c * 8 + gn[c]] = (int16_t)y;
+          gx[c * 8 + gn[c]] = x;
+          gy[c * 8 + gn[c]] = y;
           gn[c]++;
         }
         kp_xy[2 * ncorners] = (float)x;

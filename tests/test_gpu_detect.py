@@ -58,6 +58,47 @@ def test_detect_gft_matches_oracle(ctx, shape, nmask, max_corners, cap):
     assert n[3 * nmask:].sum() == 0 and total > 20 * nmask
 
 
+@pytest.mark.parametrize("min_distance", [0.0, 0.5, 1.0, 1.4, 2.5, 7.5, 10.0, 33.3, 3000.0])
+@pytest.mark.parametrize("max_corners", [0, 37, 300])
+def test_detect_gft_minimum_distances_and_budgets(ctx, min_distance, max_corners):
+    """The greedy pass on its integer grid form (fractional distances: d2 < md^2 <=> d2 < ceil(md^2); cell size 1; cells of
+    several pixels), on its one-wave float form (cells beyond 2048 pixels), without a distance at all, with a budget that
+    ends the pass inside a round -- raw noise (thousands of candidates, many conflicts inside a round of 64), three masks
+    (256-thread workgroups) and a whole-image mask with capacity 2048 (the 1024-thread variant)."""
+    rng = np.random.default_rng(int(min_distance * 10) + max_corners)
+    for shape, nmask, cap in (((70, 180), 3, 512), ((96, 200), 1, 2048)):
+        imgs = rng.integers(0, 256, size=(2,) + shape, dtype=np.uint8)
+        imgs[1] = oracle.median_gray(_textured(rng, shape + (3,)), 0)
+        bits = _sector_masks(shape[0], shape[1], nmask, rng)[None]
+        t_img, t_bits = _to(ctx.device, imgs, bits)
+        kp, n, status = ctx.detect_gft(t_img, t_bits, 2, nmask, cap, quality=0.002, min_distance=min_distance, max_corners=max_corners)
+        ctx.synchronize()
+        kp, n, status = kp.cpu().numpy(), n.cpu().numpy(), status.cpu().numpy()
+        for i in range(2):
+            eig = oracle.min_eigen(imgs[i])
+            for m in range(nmask):
+                want, _ = oracle.gft_select(eig, bits[0], m, 0.002, min_distance, max_corners)
+                p = i * nmask + m
+                if len(want) > cap or status[p]:   # more candidates than the workgroup sorts / corners than the capacity: flagged
+                    assert status[p] != 0 or n[p] == cap, (shape, i, m, status[p])
+                    continue
+                assert n[p] == len(want), (shape, i, m, n[p], len(want))
+                assert np.array_equal(kp[p, : n[p]], want), (shape, i, m)
+
+
+def test_detect_gft_on_an_image_wider_than_the_integer_grid_form(ctx):
+    """cols > 32768: the packed 16-bit distances of the grid form do not apply, the float form runs."""
+    rng = np.random.default_rng(77)
+    img = rng.integers(0, 256, size=(1, 12, 40000), dtype=np.uint8)
+    bits = np.ones((1, 12, 40000), np.uint32)
+    t_img, t_bits = _to(ctx.device, img, bits)
+    kp, n, status = ctx.detect_gft(t_img, t_bits, 1, 1, 1024, quality=0.5, min_distance=9.0, max_corners=500)
+    ctx.synchronize()
+    want, _ = oracle.gft_select(oracle.min_eigen(img[0]), bits[0], 0, 0.5, 9.0, 500)
+    assert status.item() == 0 and n.item() == len(want) and len(want) > 100
+    assert np.array_equal(kp[0, : len(want)].cpu().numpy(), want)
+
+
 def test_min_distance_and_ties_on_synthetic_response(ctx):
     """Plateaus of equal gray values give exactly tied responses: the order must be 'higher address first'."""
     img = np.zeros((60, 90), np.uint8)

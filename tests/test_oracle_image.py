@@ -1,6 +1,7 @@
 """CPU: pin the image-stage oracle (OpenCV semantics restated; the reference holds no golden vectors for
 these stages) with hand-checkable known answers and independent numpy/scipy evaluations."""
 import numpy as np
+import pytest
 import scipy.ndimage as ndi
 
 import oracle
@@ -80,6 +81,26 @@ def test_gft_selection_rules():
     assert maxv3 == 0.5 and kp3.tolist() == [[31.0, 5.0], [20.0, 20.0]]
     kp4, _ = oracle.gft_select(eig, mask, 7)
     assert kp4.shape == (0, 2)
+
+
+@pytest.mark.parametrize("shape,md", [((12, 40000), 9.0), ((60, 90), 2.5), ((40, 300), 7.5)])
+def test_gft_minimum_distance_equals_the_all_pairs_rule(shape, md):
+    """The cell grid of the selection is an accelerator only: the corners are those of the plain rule 'accept a candidate
+    iff no accepted one is closer than the distance' over the sorted candidates -- also on an image wider than 32767
+    columns (the grid's coordinates were 16-bit until round 3) and with a fractional distance."""
+    rng = np.random.default_rng(shape[1])
+    img = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    bits = np.ones(shape, np.uint32)
+    eig = oracle.min_eigen(img)
+    want, _ = oracle.gft_select(eig, bits, 0, 0.5, md, 300)
+    cand, _ = oracle.gft_select(eig, bits, 0, 0.5, 0.0, 0)
+    acc = []
+    for x, y in cand:
+        if all(np.float32((x - ax) ** 2 + (y - ay) ** 2) >= np.float32(md * md) for ax, ay in acc):
+            acc.append((x, y))
+            if len(acc) == 300:
+                break
+    assert len(want) > 20 and np.array_equal(want, np.array(acc, np.float32))
 
 
 def test_gauss7_is_normalised_and_symmetric():
