@@ -962,13 +962,21 @@ int32_t sosvo_detect_gft(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* ma
                        strips, nchunks, chunk_rows, wcap, mask_bits, mstat, images_per_maskset, nmask, rows, cols, quality, (float)min_distance, cell,
                        max_corners, cap, sorted_g, sorted_stride, kp, n, status, nullptr, 0, nimg);
   } else {
+    // Few problems (a window of a sequence, a handful of large frames): eight waves per workgroup share the rounds of the
+    // greedy pass and the sort; many problems (the C2 batch: 4096 per launch): four, so that twice as many are resident.
     SOSVO_PROFILE(ctx, "gft_select_kernel");
-    hipLaunchKernelGGL((gft_select_kernel<kCandCapSmall, kThreads>), dim3(xcd_grid(nimg, nmask)), dim3(kThreads), 0, ctx->stream, cand, wcnt,
-                       strips, nchunks, chunk_rows, wcap, mask_bits, mstat, images_per_maskset, nmask, rows, cols, quality, (float)min_distance, cell,
-                       max_corners, cap, sorted_g, sorted_stride, kp, n, status, redo, 0, nimg);
-    hipLaunchKernelGGL((gft_select_kernel<kCandCap, kThreads>), dim3(xcd_grid(nimg, nmask)), dim3(kThreads), 0, ctx->stream, cand, wcnt,
-                       strips, nchunks, chunk_rows, wcap, mask_bits, mstat, images_per_maskset, nmask, rows, cols, quality, (float)min_distance, cell,
-                       max_corners, cap, sorted_g, sorted_stride, kp, n, status, redo, 1, nimg);
+    auto launch = [&](auto small, auto full, int nt) {
+      hipLaunchKernelGGL(small, dim3(xcd_grid(nimg, nmask)), dim3(nt), 0, ctx->stream, cand, wcnt, strips, nchunks, chunk_rows, wcap,
+                         mask_bits, mstat, images_per_maskset, nmask, rows, cols, quality, (float)min_distance, cell, max_corners, cap,
+                         sorted_g, sorted_stride, kp, n, status, redo, 0, nimg);
+      hipLaunchKernelGGL(full, dim3(xcd_grid(nimg, nmask)), dim3(nt), 0, ctx->stream, cand, wcnt, strips, nchunks, chunk_rows, wcap,
+                         mask_bits, mstat, images_per_maskset, nmask, rows, cols, quality, (float)min_distance, cell, max_corners, cap,
+                         sorted_g, sorted_stride, kp, n, status, redo, 1, nimg);
+    };
+    if (P <= 1024)
+      launch(gft_select_kernel<kCandCapSmall, 512>, gft_select_kernel<kCandCap, 512>, 512);
+    else
+      launch(gft_select_kernel<kCandCapSmall, kThreads>, gft_select_kernel<kCandCap, kThreads>, kThreads);
   }
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
