@@ -164,7 +164,8 @@ int32_t sosvo_gray_rows_needed(sosvo_ctx* ctx, const uint32_t* mask_bits, int32_
  *   status [nimg*nmask] i32 (optional): bit 0 = more candidates than the selection keeps (4096; 16384 when
  *   cap > 1024: the large-mask variant for whole-image detection, e.g. the RGB-D frames) -- the result then
  *   depends on which were kept; bit 1 = mask too large for the on-chip grid (3584 / 15872 cells of
- *   minDistance^2 pixels) and more than 1024 corners wanted. */
+ *   minDistance^2 pixels) and more than 1024 corners wanted, or more than 1024 corners were the THIRD of their grid
+ *   cell (possible from minDistance ~30 px on; up to 1024 of them are kept exactly in an overflow list). */
 int32_t sosvo_detect_gft(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* mask_bits, int32_t nimg,
                          int32_t images_per_maskset, int32_t rows, int32_t cols, int32_t nmask,
                          double quality, double min_distance, int32_t max_corners, int32_t cap,

@@ -171,6 +171,8 @@ def main():
             st = torch.cuda.Stream(ctx.device)
             with torch.cuda.stream(st):
                 c = Context(0, st)
+                if S > 1:
+                    c.set_hint_shared_device(True)   # the parts run side by side (sosvo_set_hint)
                 fe = ImageFrontEnd(c, model, n, num_of_features=1000, kp_cap=1024, keep_panoramas=False)
                 pipe = FramePairPipeline(c, rig, n // 2, frame_cap=8192, max_iter=10, seed=0, front_end=fe)
                 fe.load_frames(omni3[lo:lo + n])

@@ -353,6 +353,7 @@ __global__ __launch_bounds__(NT) void gft_select_kernel(const uint2* __restrict_
   __shared__ int s_region[NT];  // phase 1: record counts of the regions in flight
   __shared__ unsigned long long s_conf[64];  // phase 3: conflict rows of the round
   __shared__ unsigned long long s_prior;     // phase 3: candidates of the round that conflict with an earlier round's points
+  __shared__ int s_ovf;                      // phase 3: accepted points that found both slots of their grid cell taken
   unsigned long long* keys = lds_u64;
   uint32_t* grid = reinterpret_cast<uint32_t*>(lds_u64);  // phase 3: 2 slots per cell, pixel index + 1 (0 = empty)
   uint32_t* acc_list = grid + 2 * kSelGridCells;          // phase 3 fallback: accepted pixel indices (<= 1024)
@@ -366,6 +367,7 @@ __global__ __launch_bounds__(NT) void gft_select_kernel(const uint2* __restrict_
     s_accepted = 0;
     s_overflow = 0;
     s_prior = 0ULL;
+    s_ovf = 0;
   }
   __syncthreads();
   // ---- phase 1: candidates ------------------------------------------------------------------------------
@@ -508,6 +510,10 @@ __global__ __launch_bounds__(NT) void gft_select_kernel(const uint2* __restrict_
         const unsigned long long hb = __ballot(active && hit != 0u);  // conflict with a point accepted in an earlier round
         if (hb && lane == 0) atomicOr(&s_prior, hb);
       }
+      for (int a = wave, novf = min(s_ovf, limit_list); a < novf; a += NWV) {  // (normally empty) uniform per wave
+        const unsigned long long hb = __ballot(active && dist2_packed(xy, acc_list[a]) < thr_i);
+        if (hb && lane == 0) atomicOr(&s_prior, hb);
+      }
       {
         // rows first + t * NWV, four at a time (independent chains: the scheduler interleaves them); a wave's rows gather in
         // its lanes and leave with one LDS store
@@ -552,7 +558,12 @@ __global__ __launch_bounds__(NT) void gft_select_kernel(const uint2* __restrict_
           const int pos = accepted + __popcll(acc & ((1ULL << lane) - 1ULL));
           kp[((size_t)p * cap + pos) * 2] = (float)x;
           kp[((size_t)p * cap + pos) * 2 + 1] = (float)y;
-          if (atomicCAS(&grid[cidx], kEmpty, xy) != kEmpty) grid[cidx + 1] = xy;
+          // a cell of round(minDistance) pixels holds two points -- or, from a distance of ~30 pixels on, three in a
+          // triangle: the third goes to the overflow list every candidate is tested against
+          if (atomicCAS(&grid[cidx], kEmpty, xy) != kEmpty && atomicCAS(&grid[cidx + 1], kEmpty, xy) != kEmpty) {
+            const int o = atomicAdd(&s_ovf, 1);
+            if (o < limit_list) acc_list[o] = xy;
+          }
         }
         if (lane == 0) {
           s_accepted = accepted + __popcll(acc);
@@ -562,6 +573,7 @@ __global__ __launch_bounds__(NT) void gft_select_kernel(const uint2* __restrict_
       __syncthreads();
       accepted = s_accepted;
     }
+    if (s_ovf > limit_list) stt |= 2;
   } else
   if (tid < 64) {  // one-wave form (float distances; the accepted points in a list when the grid does not fit)
     const int lane = tid;
@@ -595,6 +607,11 @@ __global__ __launch_bounds__(NT) void gft_select_kernel(const uint2* __restrict_
               }
             }
           }
+          for (int a = 0, novf = min(s_ovf, limit_list); a < novf; ++a) {  // third points of their cells (normally none)
+            const uint32_t q = acc_list[a];
+            const float dx = (float)(x - (int)(q & 0xFFFFu)), dy = (float)(y - (int)(q >> 16));
+            prior = prior || (dx * dx + dy * dy < md2);
+          }
         } else {
           for (int a = 0; a < accepted; ++a) {
             const uint32_t q = acc_list[a];
@@ -624,7 +641,11 @@ __global__ __launch_bounds__(NT) void gft_select_kernel(const uint2* __restrict_
         if (spaced) {
           if (use_grid) {
             uint32_t* c = &grid[((y / cell - cy0) * gw + (x / cell - cx0)) * 2];
-            if (atomicCAS(&c[0], 0u, xy + 1u) != 0u) c[1] = xy + 1u;
+            if (atomicCAS(&c[0], 0u, xy + 1u) != 0u && atomicCAS(&c[1], 0u, xy + 1u) != 0u) {  // third point of a cell
+              const int o = atomicAdd(&s_ovf, 1);
+              if (o < limit_list) acc_list[o] = xy;
+              else stt |= 2;
+            }
           } else {
             acc_list[pos] = xy;
           }
