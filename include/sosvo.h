@@ -203,7 +203,9 @@ int32_t sosvo_describe_orb_rows(sosvo_ctx* ctx, const uint8_t* gray, int32_t nim
  *       every mask resized level by level (kept where > 254); call once per model
  *   sosvo_detect_orb: gray [nimg, rows, cols] u8 -> kp4 [nimg*nmask, cap, 4] f32 = (x, y in level-0
  *       coordinates, angle in degrees, level), resp [nimg*nmask, cap] f32 (Harris), n [nimg*nmask] i32;
- *       keypoints ordered by level, then response descending, then (y, x).
+ *       keypoints ordered by level, then response descending, then (y, x).  Per (problem, level) any number of FAST
+ *       maxima is handled; only a retainBest set (best 2 n_l by FAST score, ties kept) of more than 2048 keypoints --
+ *       thousands tied at the threshold score -- is cut to 2048 (which of the tied ones go on is then unspecified).
  * ---- K6': ORB descriptors for oriented multi-level keypoints
  * Replaces .compute(image, keypoints) on ORB's own keypoints (camera_models.py:1765): keypoints within
  * 31 px of the level-0 border are removed (kp4 / n compacted in place), each level is blurred 7x7 sigma 2,

@@ -159,3 +159,24 @@ def test_detect_describe_orb_equals_the_two_calls(ctx, shape, nmask, nfeatures, 
         assert k == len(kept) and np.array_equal(desc_f[p, :k].cpu().numpy(), want_d), p
     if shape[0] > 62:
         assert int(nn.sum()) > 5 * nmask
+
+
+def test_detect_orb_on_noise_with_more_local_maxima_than_the_candidate_list(ctx):
+    """A noise image has thousands of FAST local maxima per level (the on-chip candidate list holds 2048): the retainBest
+    threshold still comes from ALL of them and exactly the retained ones go on (found by scripts/fuzz_parity.py)."""
+    rng = np.random.default_rng(45)
+    imgs = rng.integers(0, 256, (2, 147, 360), dtype=np.uint8)
+    bits = np.ones((1, 147, 360), np.uint32)
+    bits[0, :, 200:] |= 2
+    t_img, t_bits = _to(ctx.device, imgs, bits)
+    pyr = ctx.orb_mask_pyramid(t_bits, 2)
+    kp4, resp, n = ctx.detect_orb(t_img, pyr, 2, 2, 230, 1024)
+    ctx.synchronize()
+    kp4, resp, n = kp4.cpu().numpy(), resp.cpu().numpy(), n.cpu().numpy()
+    for i in range(2):
+        want = oracle.orb_detect(imgs[i], bits[0], 2, 230, 1024)
+        for m in range(2):
+            wkp, wresp = want[m]
+            p = i * 2 + m
+            assert n[p] == len(wkp) and len(wkp) > 100
+            assert np.array_equal(kp4[p, :n[p]], wkp) and np.array_equal(resp[p, :n[p]], wresp), (i, m)

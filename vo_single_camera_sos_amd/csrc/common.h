@@ -129,8 +129,10 @@ __host__ __device__ static inline float sosvo_ordered_float(uint32_t u) {
 }
 
 #ifdef __HIPCC__
-// Stable position of a lane's element among the valid elements of a 256-thread workgroup round:
-// wave ballot prefix + running base (*s_running is advanced by the round's total).  wave_off: 5 ints of LDS.
+// Stable position of a lane's element among the valid elements of a workgroup round of NW waves (256 threads unless
+// said otherwise): wave ballot prefix + running base (*s_running is advanced by the round's total).  wave_off: NW + 1
+// ints of LDS.
+template <int NW = 4>
 __device__ __forceinline__ int sosvo_block_compact_pos(bool valid, int* wave_off, int* s_running, int tid) {
   const int lane = tid & 63, wid = tid >> 6;
   const unsigned long long bal = __ballot(valid);
@@ -139,8 +141,8 @@ __device__ __forceinline__ int sosvo_block_compact_pos(bool valid, int* wave_off
   __syncthreads();
   if (tid == 0) {
     wave_off[0] = *s_running;
-    for (int w = 0; w < 4; ++w) wave_off[w + 1] += wave_off[w];
-    *s_running = wave_off[4];
+    for (int w = 0; w < NW; ++w) wave_off[w + 1] += wave_off[w];
+    *s_running = wave_off[NW];
   }
   __syncthreads();
   return wave_off[wid] + __popcll(bal & ((1ULL << lane) - 1ULL));

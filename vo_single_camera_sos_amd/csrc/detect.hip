@@ -748,7 +748,10 @@ __global__ __launch_bounds__(kThreads) void gauss7_kernel(const uint8_t* __restr
 // ---- K6b: border rule + descriptors ---------------------------------------------------------------------
 constexpr int kPatchMaxR = 23, kPatchRows = 48, kPatchStride = 64;
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
-__global__ __launch_bounds__(kThreads) void orb_describe_kernel(const uint8_t* __restrict__ blurred, int rows, int cols,
+// (NT threads: a problem's keypoints are shared by NT / 64 waves, one keypoint per wave and step -- 256 for the C2 batch of
+// 4096 problems, 512 when a launch has few problems, 1024 for the whole-image problems of up to 4096 keypoints)
+template <int NT>
+__global__ __launch_bounds__(NT) void orb_describe_kernel(const uint8_t* __restrict__ blurred, int rows, int cols,
                                                                 int nmask, int cap, float* __restrict__ kp,
                                                                 int32_t* __restrict__ n_io, float cos_a, float sin_a,
                                                                 const int8_t* __restrict__ pattern, int edge,
@@ -758,8 +761,8 @@ __global__ __launch_bounds__(kThreads) void orb_describe_kernel(const uint8_t* _
   extern __shared__ float lds_kp[];  // [cap][2] compacted keypoints
   __shared__ int off[512];
   __shared__ uint16_t poff[512];
-  __shared__ uint32_t patch_lds[kThreads / 64][kPatchRows * kPatchStride / 4];
-  __shared__ int wave_off[5];
+  __shared__ uint32_t patch_lds[NT / 64][kPatchRows * kPatchStride / 4];
+  __shared__ int wave_off[NT / 64 + 1];
   __shared__ int s_running, s_R;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int p = xcd_problem(nimg_total, nmask);
@@ -771,7 +774,7 @@ __global__ __launch_bounds__(kThreads) void orb_describe_kernel(const uint8_t* _
     s_R = 0;
   }
   __syncthreads();
-  for (int i = tid; i < 512; i += kThreads) {
+  for (int i = tid; i < 512; i += NT) {
     const float px = (float)pattern[2 * i], py = (float)pattern[2 * i + 1];
     const float xr = (px * cos_a) - (py * sin_a), yr = (px * sin_a) + (py * cos_a);
     const int dx = __float2int_rn(xr), dy = __float2int_rn(yr);
@@ -800,12 +803,12 @@ __global__ __launch_bounds__(kThreads) void orb_describe_kernel(const uint8_t* _
   const int pdw = (PR + 3) >> 2;      // dwords per patch row
   const int pstride = pdw | 1;        // row pitch in dwords
   if (patch_ok)
-    for (int i = tid; i < 512; i += kThreads) {
+    for (int i = tid; i < 512; i += NT) {
       const int dy = (off[i] + R * cols + R) / cols - R;  // recover (dx, dy): |dx| <= R < cols
       const int dx = off[i] - dy * cols;
       poff[i] = (uint16_t)((dy + R) * (4 * pstride) + (dx + R));
     }
-  for (int i0 = 0; i0 < n; i0 += kThreads) {
+  for (int i0 = 0; i0 < n; i0 += NT) {
     const int i = i0 + tid;
     float x = 0.f, y = 0.f;
     bool keep = false;
@@ -816,7 +819,7 @@ __global__ __launch_bounds__(kThreads) void orb_describe_kernel(const uint8_t* _
       const int yi = __float2int_rn(y);
       keep = keep && yi >= y_first && yi <= y_last;
     }
-    const int pos = sosvo_block_compact_pos(keep, wave_off, &s_running, tid);
+    const int pos = sosvo_block_compact_pos<NT / 64>(keep, wave_off, &s_running, tid);
     if (keep) {
       lds_kp[2 * pos] = x;
       lds_kp[2 * pos + 1] = y;
@@ -824,7 +827,7 @@ __global__ __launch_bounds__(kThreads) void orb_describe_kernel(const uint8_t* _
   }
   __syncthreads();
   const int m = s_running;
-  for (int i = tid; i < 2 * m; i += kThreads) kp[(size_t)p * cap * 2 + i] = lds_kp[i];
+  for (int i = tid; i < 2 * m; i += NT) kp[(size_t)p * cap * 2 + i] = lds_kp[i];
   if (tid == 0) n_io[p] = m;
   const uint8_t* im = blurred + (size_t)img * rows * cols;
   if (patch_ok) {
@@ -860,11 +863,11 @@ __global__ __launch_bounds__(kThreads) void orb_describe_kernel(const uint8_t* _
     }
     int j = wid;
     if (j < m) issue(j);
-    for (; j < m; j += kThreads / 64) {
+    for (; j < m; j += NT / 64) {
 #pragma unroll
       for (int it = 0; it < kPatchRows / 4; ++it)
         if (it < nit) patch32[lidx[it]] = reg[it];
-      if (j + kThreads / 64 < m) issue(j + kThreads / 64);  // next keypoint's rows fly while this one is tested
+      if (j + NT / 64 < m) issue(j + NT / 64);  // next keypoint's rows fly while this one is tested
       unsigned long long* d = reinterpret_cast<unsigned long long*>(desc + ((size_t)p * cap + j) * 32);
       unsigned long long mine = 0ULL;
 #pragma unroll
@@ -876,7 +879,7 @@ __global__ __launch_bounds__(kThreads) void orb_describe_kernel(const uint8_t* _
     }
     return;
   }
-  for (int j = wid; j < m; j += kThreads / 64) {
+  for (int j = wid; j < m; j += NT / 64) {
     const uint8_t* c = im + (size_t)__float2int_rn(lds_kp[2 * j + 1]) * cols + __float2int_rn(lds_kp[2 * j]);
     unsigned long long* d = reinterpret_cast<unsigned long long*>(desc + ((size_t)p * cap + j) * 32);
 #pragma unroll
@@ -1028,9 +1031,19 @@ int32_t sosvo_describe_orb_rows(sosvo_ctx* ctx, const uint8_t* gray, int32_t nim
   rc = launch_gauss7_rows(ctx, gray, (long long)rows * cols, nimg, rows, cols, blurred, (long long)rows * cols, row_range,
                           nimg > 1 ? nimg / 2 : 1);
   if (rc != SOSVO_OK) return rc;
-  SOSVO_LAUNCH(ctx, orb_describe_kernel, dim3(xcd_grid(nimg, nmask)), dim3(kThreads), (size_t)cap * 2 * sizeof(float),
-               ctx->stream, blurred, rows, cols, nmask, cap, kp, n, cos_a, sin_a, pattern, edge, desc, nimg, row_range,
-               nimg > 1 ? nimg / 2 : 1);
+  const size_t lds_kp_bytes = (size_t)cap * 2 * sizeof(float);
+  const int irange = nimg > 1 ? nimg / 2 : 1;
+  SOSVO_PROFILE(ctx, "orb_describe_kernel");
+  auto launch = [&](auto kernel, int nt) {
+    hipLaunchKernelGGL(kernel, dim3(xcd_grid(nimg, nmask)), dim3(nt), lds_kp_bytes, ctx->stream, blurred, rows, cols, nmask, cap, kp,
+                       n, cos_a, sin_a, pattern, edge, desc, nimg, row_range, irange);
+  };
+  if (cap > 1024)
+    launch(orb_describe_kernel<1024>, 1024);
+  else if ((size_t)nimg * nmask <= 1024)
+    launch(orb_describe_kernel<512>, 512);
+  else
+    launch(orb_describe_kernel<kThreads>, kThreads);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
 }

@@ -701,7 +701,9 @@ __global__ __launch_bounds__(kThreads) void orb_select_kernel(LevelSrc S, const 
     const int bx0 = max(kEdge, (int)(0xFFFFFFFFu - bb[0])), by0 = max(kEdge, (int)(0xFFFFFFFFu - bb[1]));
     const int bx1 = min(w - kEdge, (int)bb[2]), by1 = min(h - kEdge, (int)bb[3]);  // exclusive
     const int rw = bb[2] ? max(0, bx1 - bx0) : 0, rh = bb[2] ? max(0, by1 - by0) : 0;
-    if (rw > 0 && rh > 0) {
+    // (the walk over the flag words; visit(x, y, FAST score) for every local maximum inside the mask)
+    auto walk = [&](auto visit) {
+      if (rw <= 0 || rh <= 0) return;
       const int st0 = bx0 / kFsStripW, ns = (bx1 - 1) / kFsStripW - st0 + 1;
       for (int i = tid; i < ns * rh; i += kThreads) {
         const int ry = i / ns, sidx = st0 + (i - ry * ns), y = by0 + ry;
@@ -715,23 +717,25 @@ __global__ __launch_bounds__(kThreads) void orb_select_kernel(LevelSrc S, const 
           const int x = xbase + __ffsll((long long)wd) - 1;
           wd &= wd - 1ULL;
           if (!((mk[(size_t)y * w + x] >> m) & 1u)) continue;
-          const int sv = sc[(size_t)y * w + x];
-          const int slot = atomicAdd(&s_nc, 1);
-          if (slot < kCandMax) {
-            cxy[slot] = ((uint32_t)y << 16) | (uint32_t)x;
-            cfast[slot] = (uint8_t)sv;
-            atomicAdd(&hist[sv], 1);
-          }
+          visit(x, y, (int)sc[(size_t)y * w + x]);
         }
       }
-    }
+    };
+    walk([&](int x, int y, int sv) {
+      atomicAdd(&hist[sv], 1);  // EVERY candidate counts for the threshold of step 2
+      const int slot = atomicAdd(&s_nc, 1);
+      if (slot < kCandMax) {
+        cxy[slot] = ((uint32_t)y << 16) | (uint32_t)x;
+        cfast[slot] = (uint8_t)sv;
+      }
+    });
     __syncthreads();
-    const int nc0 = min(s_nc, kCandMax);
-    if (nc0 == 0) continue;  // uniform: nothing on this level (s_nc is re-initialised behind the barrier of the next level's step 1)
+    const int nc_all = s_nc;
+    if (nc_all == 0) continue;  // uniform: nothing on this level (s_nc is re-initialised behind the barrier of the next level's step 1)
     // 2. retainBest(2 * quota) by FAST score, ties kept: the largest score t with #(score >= t) >= 2 quota
     if (wid == 0) {
       int thr = 0;
-      if (nc0 > 2 * quota) {  // uniform
+      if (nc_all > 2 * quota) {  // uniform
         const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
         int suf = h0 + h1 + h2 + h3;  // -> sum over the bins of lanes >= lane
 #pragma unroll
@@ -753,10 +757,22 @@ __global__ __launch_bounds__(kThreads) void orb_select_kernel(LevelSrc S, const 
     }
     __syncthreads();
     const int thr = s_thr;
-    for (int i = tid; i < nc0; i += kThreads)
-      if (cfast[i] >= thr) kept[atomicAdd(&s_nk, 1)] = cxy[i];  // order irrelevant: the sort keys are unique
+    if (nc_all <= kCandMax) {  // uniform
+      for (int i = tid; i < nc_all; i += kThreads)
+        if (cfast[i] >= thr) kept[atomicAdd(&s_nk, 1)] = cxy[i];  // order irrelevant: the sort keys are unique
+    } else {
+      // more local maxima than the LDS list holds (a noisy level-0 image: thousands): the threshold above is exact (the
+      // histogram saw them all), so a second walk keeps exactly the retained ones.  Only a retained set beyond kCandMax --
+      // thousands of candidates TIED at the threshold score -- is cut (an unspecified subset of it goes on).
+      walk([&](int x, int y, int sv) {
+        if (sv >= thr) {
+          const int slot = atomicAdd(&s_nk, 1);
+          if (slot < kCandMax) kept[slot] = ((uint32_t)y << 16) | (uint32_t)x;
+        }
+      });
+    }
     __syncthreads();
-    const int nc = s_nk;
+    const int nc = min(s_nk, kCandMax);
     // 3. Harris response of the survivors -> sort keys
     uint32_t xy_next = wid < nc ? kept[wid] : 0u, fetched = 0u;
     if (wid < nc) fetched = harris_fetch(im, w, (int)(xy_next & 0xFFFFu), (int)(xy_next >> 16), lane);
