@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Differential fuzzing of the stage entry points against the CPU oracle (test infrastructure: the oracle is the checker).
 
-    python scripts/fuzz_parity.py --minutes 10 --seed 1 [--stages median,gft,fast,agast,match,radius,orb,unwrap,ransac]
+    python scripts/fuzz_parity.py --minutes 10 --seed 1 [--stages median,gft,fast,agast,match,radius,orb,unwrap,ransac,describe]
 
 Every case draws its own sizes and parameters (image sizes around the strip / chunk / tile borders of the kernels, ragged
 problem counts, empty masks, fractional minimum distances, budgets that end a selection inside a round, duplicate
@@ -72,6 +72,8 @@ def _masks(rng, rows, cols, nmask):
 def fuzz_median(ctx, rng):
     k = int(rng.choice([3, 5, 11]))
     rows, cols, n = int(rng.integers(1, 90)), int(rng.integers(1, 260)), int(rng.integers(1, 4))
+    if rng.random() < 0.08:
+        rows, cols = int(rng.integers(90, 300)), int(rng.integers(260, 1500))
     img = rng.integers(0, 256, (n, rows, cols, 3), dtype=np.uint8)
     if rng.random() < 0.3:
         img[:, :, :, :] = (img >> int(rng.integers(4, 8))) << 4   # few distinct values: many ties inside a window
@@ -90,11 +92,17 @@ def fuzz_gft(ctx, rng):
     rows, cols = int(rng.integers(3, 140)), int(rng.integers(3, 420))
     nmask, ni = int(rng.integers(1, 7)), int(rng.integers(1, 4))
     cap = int(rng.choice([16, 64, 512, 1024, 2048]))
+    shape_mode = rng.random()
+    if shape_mode < 0.08:      # more than 1024 problems in one launch: the four-wave selection / descriptor workgroups
+        rows, cols, nmask, ni, cap = int(rng.integers(8, 36)), int(rng.integers(20, 90)), int(rng.integers(20, 33)), int(rng.integers(36, 60)), 64
+    elif shape_mode < 0.16:    # a large image: many strips and row chunks
+        rows, cols = int(rng.integers(140, 320)), int(rng.integers(420, 1500))
     q = float(10 ** rng.uniform(-3, -0.3))
     md = float(rng.choice([0.0, 0.7, 1.0, 1.5, 2.0, 3.0, 5.0, 7.5, 12.0, 25.0, 33.3, 40.0, 60.0]))
     mc = int(rng.choice([0, 1, 7, 50, 300, 1000]))
     params = dict(rows=rows, cols=cols, nmask=nmask, nimg=ni, cap=cap, quality=q, min_distance=md, max_corners=mc)
-    imgs = np.stack([_image(rng, rows, cols, int(rng.integers(0, 4))) for _ in range(ni)])
+    kinds = rng.integers(0, 4, ni)
+    imgs = np.stack([_image(rng, rows, cols, int(k)) for k in kinds])
     bits = _masks(rng, rows, cols, nmask)[None]
     t_img, t_bits = _dev(ctx, imgs, bits)
     kp, n, status = ctx.detect_gft(t_img, t_bits, ni, nmask, cap, quality=q, min_distance=md, max_corners=mc)
@@ -118,6 +126,8 @@ def fuzz_gft(ctx, rng):
 def _fast_like(ctx, rng, agast):
     import refflow
     rows, cols = int(rng.integers(8, 120)), int(rng.integers(8, 330))
+    if rng.random() < 0.08:
+        rows, cols = int(rng.integers(120, 400)), int(rng.integers(330, 1500))
     nmask, ni = int(rng.integers(1, 5)), int(rng.integers(1, 4))
     cap = int(rng.choice([8, 64, 1024, 4096]))
     thr = int(rng.choice([1, 5, 10, 20, 40, 80]))
@@ -215,6 +225,8 @@ def fuzz_radius(ctx, rng):
 
 def fuzz_orb(ctx, rng):
     rows, cols = int(rng.integers(70, 150)), int(rng.integers(70, 400))
+    if rng.random() < 0.08:
+        rows, cols = int(rng.integers(150, 300)), int(rng.integers(400, 1500))
     nmask, ni = int(rng.integers(1, 4)), int(rng.integers(1, 3))
     nfeat, cap = int(rng.choice([10, 60, 230, 500])), int(rng.choice([64, 512, 1024]))
     params = dict(rows=rows, cols=cols, nmask=nmask, nimg=ni, nfeatures=nfeat, cap=cap)
@@ -245,6 +257,40 @@ def fuzz_orb(ctx, rng):
             wd, kept = oracle.orb_describe_levels(imgs[i], wkp)
             if n2[p] != len(kept) or not np.array_equal(desc[p, :n2[p]], wd):
                 return params, "image %d mask %d: descriptors (%d, oracle %d)" % (i, m, n2[p], len(kept))
+    return params, None
+
+
+def fuzz_describe(ctx, rng):
+    rows, cols = int(rng.integers(64, 200)), int(rng.integers(64, 500))
+    nmask, ni = int(rng.integers(1, 5)), int(rng.integers(1, 4))
+    cap = int(rng.choice([8, 128, 1024, 2048]))
+    if rng.random() < 0.08:
+        rows, cols, nmask, ni, cap = 64, int(rng.integers(64, 90)), int(rng.integers(20, 33)), int(rng.integers(36, 56)), 16
+    angle = float(rng.choice([orb_pattern.GFT_KEYPOINT_ANGLE, 0.0, 37.5, 90.0, 180.0, 271.3]))
+    params = dict(rows=rows, cols=cols, nmask=nmask, nimg=ni, cap=cap, angle=angle)
+    imgs = np.stack([_image(rng, rows, cols, int(rng.integers(0, 3))) for _ in range(ni)])
+    P = ni * nmask
+    kp = np.zeros((P, cap, 2), np.float32)
+    n = rng.integers(0, cap + 1, P).astype(np.int32)
+    for p in range(P):
+        whole = rng.random() < 0.7
+        x, y = rng.uniform(0, cols, n[p]), rng.uniform(0, rows, n[p])
+        kp[p, :n[p], 0], kp[p, :n[p], 1] = (x.round(), y.round()) if whole else (x, y)
+        if n[p] >= 4:      # the border rule's edges
+            kp[p, :4] = [[31.0, 31.0], [30.99, 40.0], [cols - 31.0, 40.0], [cols - 31.01, rows - 31.01]]
+    pat = orb_pattern.orb_pattern()
+    ca, sa = orb_pattern.angle_cos_sin(angle)
+    t_img, t_kp, t_n, t_pat = _dev(ctx, imgs, kp, n, pat)
+    desc = ctx.describe_orb(t_img, t_kp, t_n, nmask, t_pat, ca, sa)
+    ctx.synchronize()
+    desc, kp_out, n_out = desc.cpu().numpy(), t_kp.cpu().numpy(), t_n.cpu().numpy()
+    blurred = [oracle.gauss7(im) for im in imgs]
+    for p in range(P):
+        wd, kept = oracle.orb_describe(blurred[p // nmask], kp[p, :n[p]], ca, sa, pat)
+        if n_out[p] != len(kept) or not np.array_equal(kp_out[p, :len(kept)], kp[p, kept]):
+            return params, "problem %d: border rule (%d kept, oracle %d)" % (p, n_out[p], len(kept))
+        if not np.array_equal(desc[p, :len(kept)], wd):
+            return params, "problem %d: descriptor bits" % p
     return params, None
 
 
@@ -350,7 +396,8 @@ def fuzz_ransac(ctx, rng):
 
 
 STAGES = {"median": fuzz_median, "gft": fuzz_gft, "fast": fuzz_fast, "agast": fuzz_agast, "match": fuzz_match,
-          "radius": fuzz_radius, "orb": fuzz_orb, "unwrap": fuzz_unwrap, "ransac": fuzz_ransac}
+          "radius": fuzz_radius, "orb": fuzz_orb, "unwrap": fuzz_unwrap, "ransac": fuzz_ransac,
+          "describe": fuzz_describe}
 
 
 def main():
