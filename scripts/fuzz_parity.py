@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Differential fuzzing of the stage entry points against the CPU oracle (test infrastructure: the oracle is the checker).
 
-    python scripts/fuzz_parity.py --minutes 10 --seed 1 [--stages median,gft,fast,agast,match,radius,orb,unwrap,ransac,describe]
+    python scripts/fuzz_parity.py --minutes 10 --seed 1 [--stages median,gft,fast,agast,match,radius,orb,unwrap,ransac,describe,relpose,l2sort]
 
 Every case draws its own sizes and parameters (image sizes around the strip / chunk / tile borders of the kernels, ragged
 problem counts, empty masks, fractional minimum distances, budgets that end a selection inside a round, duplicate
@@ -395,9 +395,69 @@ def fuzz_ransac(ctx, rng):
     return params, None
 
 
+def fuzz_relpose(ctx, rng):
+    from test_oracle_relpose import _two_views
+    P, S = int(rng.integers(1, 5)), int(rng.choice([16, 130, 600]))
+    algorithm = int(rng.choice([5, 7, 8]))
+    max_iter, adaptive, seed = int(rng.choice([1, 33, 200])), bool(rng.integers(0, 2)), int(rng.integers(0, 2 ** 31))
+    thr = float(rng.choice([2.0 * (1.0 - np.cos(np.deg2rad(1.0))), 2.0 * (1.0 - np.cos(np.deg2rad(0.1))), 1e-12]))
+    params = dict(P=P, S=S, algorithm=algorithm, max_iter=max_iter, adaptive=adaptive, seed=seed, thr=thr)
+    problems = []
+    for b in range(P):
+        n = int(rng.integers(0, S + 1))
+        a, c, _, _, _ = _two_views(rng, max(n, 1), noise_deg=float(rng.choice([0.0, 0.05, 0.5])), outlier_frac=float(rng.choice([0.0, 0.3, 0.9])))
+        problems.append((a[:n], c[:n]))
+    f1 = np.zeros((P, S, 3)); f2 = np.zeros((P, S, 3)); n_arr = np.zeros(P, np.int32)
+    for b, (a, c) in enumerate(problems):
+        n_arr[b] = a.shape[0]
+        f1[b, :n_arr[b]], f2[b, :n_arr[b]] = a, c
+    t1, t2, tn = _dev(ctx, f1, f2, n_arr)
+    out = ctx.ransac_rel_pose(t1, t2, tn, thr, max_iter, algorithm=algorithm, seed=seed, adaptive=adaptive, want_counts=True)
+    ctx.synchronize()
+    got = {k: v.cpu().numpy() for k, v in out.items()}
+    for b, (a, c) in enumerate(problems):
+        want = oracle.ransac_rel_pose(a, c, thr, max_iter, seed=seed + b, adaptive=adaptive, want_counts=True, algorithm=algorithm)
+        used = want["iters_used"]
+        if got["info"][b, 1] != used or got["info"][b, 0] != want["best_iter"] or got["info"][b, 2] != want["status"]:
+            return params, "problem %d: iterations / winner / status" % b
+        if not np.array_equal(got["counts"][b, :used], want["counts"][:used]):
+            return params, "problem %d: hypothesis counts" % b
+        if got["n_inliers"][b] != want["n_inliers"] or not np.array_equal(got["mask"][b, :n_arr[b]].astype(bool), want["mask"]):
+            return params, "problem %d: inlier mask" % b
+        if not np.array_equal(got["T"][b].view(np.uint64), want["T"].view(np.uint64)):
+            return params, "problem %d: pose bits" % b
+    return params, None
+
+
+def fuzz_l2sort(ctx, rng):
+    """float-descriptor matching (sosvo_match_l2) and the stable sort of match keys"""
+    P, Sq, St, k = int(rng.integers(1, 6)), int(rng.choice([1, 50, 257])), int(rng.choice([1, 64, 300])), int(rng.integers(1, 3))
+    D = int(rng.choice([32, 64, 128]))
+    params = dict(P=P, q_stride=Sq, t_stride=St, k=k, dim=D)
+    q = rng.integers(0, 8, (P, Sq, D)).astype(np.float32)   # small integers: exact sums, many ties
+    t = rng.integers(0, 8, (P, St, D)).astype(np.float32)
+    nq, nt = rng.integers(0, Sq + 1, P).astype(np.int32), rng.integers(0, St + 1, P).astype(np.int32)
+    tq, tt, tnq, tnt = _dev(ctx, q, t, nq, nt)
+    res = ctx.match_l2(tq, tt, tnq, tnt, k=k)
+    # Hamming keys for the sort: random keys with many equal distances
+    hk = (rng.integers(0, 6, (P, Sq, 1)).astype(np.uint32) << np.uint32(20)) | rng.integers(0, 1000, (P, Sq, 1)).astype(np.uint32)
+    (thk,) = _dev(ctx, hk)
+    order = ctx.sort_matches(thk, tnq)
+    ctx.synchronize()
+    res = res.cpu().numpy().view(np.uint64)
+    order = order.cpu().numpy()
+    for p in range(P):
+        if nq[p] and not np.array_equal(res[p, :nq[p]], oracle.match_l2(q[p, :nq[p]], t[p, :nt[p]].reshape(-1, D), k=k)):
+            return params, "problem %d: L2 matches" % p
+        wo = oracle.sort_matches(hk[p, :nq[p]])
+        if not np.array_equal(order[p, :nq[p]], wo):
+            return params, "problem %d: sort order" % p
+    return params, None
+
+
 STAGES = {"median": fuzz_median, "gft": fuzz_gft, "fast": fuzz_fast, "agast": fuzz_agast, "match": fuzz_match,
           "radius": fuzz_radius, "orb": fuzz_orb, "unwrap": fuzz_unwrap, "ransac": fuzz_ransac,
-          "describe": fuzz_describe}
+          "describe": fuzz_describe, "relpose": fuzz_relpose, "l2sort": fuzz_l2sort}
 
 
 def main():
