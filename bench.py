@@ -173,8 +173,8 @@ def sequence_rgbd_subrecord(bgr, depth, mirror_frames=32):
             for k in range(n):
                 yield k, bgr[k], depth[k]
         with tempfile.TemporaryDirectory() as d, contextlib.redirect_stdout(io.StringIO()):
-            if label == "frame_window_32":
-                run_VO(None, cam, results_path=d, _live_frames=lambda: frames(4), frame_window=4)
+            if label == "frame_window_32":   # first-use costs outside the clock (the same window: the allocator keeps its blocks)
+                run_VO(None, cam, results_path=d, _live_frames=lambda: frames(min(N, 34)), frame_window=32)
                 torch.cuda.synchronize()
             t0 = time.perf_counter()
             r = run_VO(None, cam, results_path=d, _live_frames=frames, frame_window=window)
@@ -185,6 +185,7 @@ def sequence_rgbd_subrecord(bgr, depth, mirror_frames=32):
                       "keyframes": len(r["keyframe_ids"])}
         if "sequence_mode" in r:
             out[label]["serial_tracking_calls"] = r["sequence_mode"]["serial_tracking_calls"]
+            out[label]["host_wall_s"] = dict(r["sequence_mode"]["stage_s"], total=dt)
     n_m = out["mirror_per_frame"]["frames"]
     a = np.loadtxt(io.StringIO(texts["frame_window_32"]))[:n_m]
     b = np.loadtxt(io.StringIO(texts["mirror_per_frame"]))
@@ -222,8 +223,8 @@ def sequence_subrecord(seq_omni, seq_poses, pano_width, mirror_frames=32):
             for k in range(n):
                 yield k, seq_omni[k], None
         with tempfile.TemporaryDirectory() as d, contextlib.redirect_stdout(io.StringIO()):
-            if label == "frame_window_32":   # library scratch, unwrap table, first-use costs: outside the clock
-                run_VO(None, gs, results_path=d, _live_frames=lambda: frames(4), frame_window=4)
+            if label == "frame_window_32":   # library scratch, unwrap table, first-use costs: outside the clock (same window size)
+                run_VO(None, gs, results_path=d, _live_frames=lambda: frames(min(N, 34)), frame_window=32)
                 torch.cuda.synchronize()
             t0 = time.perf_counter()
             r = run_VO(None, gs, results_path=d, _live_frames=frames, frame_window=window)
@@ -883,11 +884,13 @@ def main():
                     t1 = time.perf_counter()
                     for k in range(args.steps):
                         fb.step() if joined else fb.enqueue(bufs[k & 1])
+                    t_host = time.perf_counter() - t1     # the host's share: the calls return once everything is enqueued
                     fb.join()
                     torch.cuda.synchronize()
                     dt2 = time.perf_counter() - t1
                     last = fb.out if joined else bufs[(args.steps - 1) & 1]
                     res[label] = {"value": B * args.steps / dt2, "unit": "frame-pairs/s", "ms_per_step": 1e3 * dt2 / args.steps,
+                                  "host_ms_in_calls_per_step": 1e3 * t_host / args.steps,
                                   "same_records_as_engine": bool(np.array_equal(last.cpu().numpy(), rec))}
                 res["value"], res["unit"], res["steps"], res["streams"] = res["enqueue_back_to_back"]["value"], "frame-pairs/s", args.steps, args.streams
                 res["ratio_to_engine"] = res["value"] / out["value"]
