@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Differential fuzzing of the stage entry points against the CPU oracle (test infrastructure: the oracle is the checker).
 
-    python scripts/fuzz_parity.py --minutes 10 --seed 1 [--stages median,gft,fast,agast,match,radius,orb,unwrap,ransac,describe,relpose,l2sort]
+    python scripts/fuzz_parity.py --minutes 10 --seed 1 [--stages median,gft,fast,agast,match,radius,orb,unwrap,ransac,describe,relpose,l2sort,pipeline]
 
 Every case draws its own sizes and parameters (image sizes around the strip / chunk / tile borders of the kernels, ragged
 problem counts, empty masks, fractional minimum distances, budgets that end a selection inside a round, duplicate
@@ -455,9 +455,67 @@ def fuzz_l2sort(ctx, rng):
     return params, None
 
 
+def fuzz_pipeline(ctx, rng):
+    """Everything after detection (bucket matching, gates, triangulation, frame-to-frame matching, RANSAC, LM) on image-free
+    frames against the reference's control flow on the oracle (tests/refflow.py)."""
+    import refflow
+    import synth
+    from vo_single_camera_sos_amd.pipeline import FramePairPipeline, RigConfig
+    B, NM = int(rng.integers(1, 5)), int(rng.choice([1, 4, 12]))
+    cap = int(rng.choice([16, 64, 192]))
+    frame_cap = int(rng.choice([256, 2048]))
+    max_iter, adaptive = int(rng.choice([10, 100, 400])), bool(rng.integers(0, 2))
+    solver = str(rng.choice(["P3P", "GP3P"]))
+    rig_kw = dict(pano_top=synth.PANO_C2, pano_bot=synth.PANO_C2, F_top=synth.F_TOP, F_bot=synth.F_BOT,
+                  min_range=float(rng.choice([0.0, 500.0, 2000.0])), max_range=float(rng.choice([3000.0, 7000.0, 1e9])),
+                  stereo_min_disp=float(rng.choice([0.0, 1.0, 3.0])), stereo_max_hdiff=float(rng.choice([0.5, 2.5, 1e6])),
+                  f2f_max_hdiff=float(rng.choice([-1.0, 10.0, 75.0])), pct_good_matches=float(rng.choice([1.0, 0.8, 0.3])))
+    seed = int(rng.integers(0, 2 ** 31))
+    params = dict(B=B, nmask=NM, bucket_cap=cap, frame_cap=frame_cap, max_iter=max_iter, adaptive=adaptive, solver=solver, seed=seed,
+                  **{k: v for k, v in rig_kw.items() if isinstance(v, float)})
+    frames = []
+    for i in range(B):
+        P, desc = synth.make_scene(rng, int(rng.choice([0, 30, 400, 1500])))
+        R, t = synth.random_pose(rng)
+        kw = dict(nmask=NM, cap=cap, flip_prob=float(rng.choice([0.0, 0.04, 0.2])), distractors=float(rng.choice([0.0, 0.15, 1.0])))
+        frames.append(synth.observe_frame(rng, P, desc, np.eye(3), np.zeros(3), **kw))
+        frames.append(synth.observe_frame(rng, P, desc, R, t, **kw))
+    pipe = FramePairPipeline(ctx, RigConfig(**rig_kw), B, nmask=NM, bucket_cap=cap, frame_cap=frame_cap, max_iter=max_iter, adaptive=adaptive,
+                             seed=seed, ransac_solver=solver)
+    pipe.load_keypoints(synth.pack_buckets(frames, NM, cap))
+    pipe.step()
+    rec = pipe.results()
+    ctx.synchronize()
+    rec = rec.cpu().numpy()
+    mask = pipe.ransac["mask"].cpu().numpy()
+    M = pipe.frames["M"].cpu().numpy()
+    rp = refflow.RigParams(**rig_kw)
+    flagged = False
+    for i in range(B):
+        ref = refflow.stereo_frame(rp, *[frames[2 * i][k] for k in ("kp_top", "kp_bot", "desc_top", "desc_bot")])
+        cur = refflow.stereo_frame(rp, *[frames[2 * i + 1][k] for k in ("kp_top", "kp_bot", "desc_top", "desc_bot")])
+        if len(ref["X"]) > frame_cap or len(cur["X"]) > frame_cap:
+            flagged = True     # more stereo points than the frame store holds: documented truncation
+            continue
+        if M[2 * i] != len(ref["X"]) or M[2 * i + 1] != len(cur["X"]):
+            return params, "pair %d: stereo points (%d %d, oracle %d %d)" % (i, M[2 * i], M[2 * i + 1], len(ref["X"]), len(cur["X"]))
+        w = refflow.track_pair(rp, ref, cur, pipe.thr, max_iter, seed=seed + i, adaptive=adaptive, gp3p=solver == "GP3P")
+        n = len(w["corr"]["cam"])
+        if rec[i, 13] != n:
+            return params, "pair %d: correspondences (%d, oracle %d)" % (i, rec[i, 13], n)
+        if rec[i, 14] != w["ransac"]["status"] or rec[i, 15] != w["ransac"]["best_iter"] or rec[i, 12] != w["ransac"]["n_inliers"]:
+            return params, "pair %d: RANSAC status / winner / inliers" % i
+        if not np.array_equal(mask[i, :n].astype(bool), w["ransac"]["mask"]):
+            return params, "pair %d: inlier mask" % i
+        if not np.array_equal(rec[i, :12].reshape(3, 4), w["T"]):
+            return params, "pair %d: pose bits" % i
+    return params, ("flagged" if flagged else None)
+
+
 STAGES = {"median": fuzz_median, "gft": fuzz_gft, "fast": fuzz_fast, "agast": fuzz_agast, "match": fuzz_match,
           "radius": fuzz_radius, "orb": fuzz_orb, "unwrap": fuzz_unwrap, "ransac": fuzz_ransac,
-          "describe": fuzz_describe, "relpose": fuzz_relpose, "l2sort": fuzz_l2sort}
+          "describe": fuzz_describe, "relpose": fuzz_relpose, "l2sort": fuzz_l2sort,
+          "pipeline": fuzz_pipeline}
 
 
 def main():
