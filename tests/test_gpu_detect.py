@@ -99,12 +99,12 @@ def test_detect_gft_on_an_image_wider_than_the_integer_grid_form(ctx):
     assert np.array_equal(kp[0, : len(want)].cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("cols,x_off", [(1000, 0), (33600, 32600)])
-def test_detect_gft_three_corners_in_one_grid_cell(ctx, cols, x_off):
+@pytest.mark.parametrize("cols,x_off,nimg,nmask", [(1000, 0, 1, 1), (33600, 32600, 1, 1), (1000, 0, 33, 32)])
+def test_detect_gft_three_corners_in_one_grid_cell(ctx, cols, x_off, nimg, nmask):
     """From a minimum distance of ~30 pixels on, a cell of round(minDistance) pixels can hold THREE accepted corners (a
     triangle 40.3 / 40.3 / 41.0 pixels at distance 40): the third must still suppress its neighbours in LATER rounds of 64
     candidates (the on-chip grid has two slots per cell and an overflow list).  Both forms of the greedy pass: integer grid,
-    float one-wave (cols > 32768)."""
+    float one-wave (cols > 32768; or more than 1024 problems in the launch: four-wave workgroups)."""
     img = np.zeros((1, 330, cols), np.uint8)
 
     def blob(x, y, v):
@@ -115,16 +115,16 @@ def test_detect_gft_three_corners_in_one_grid_cell(ctx, cols, x_off):
         blob(ox + 100, oy + 45, 120 - k)                             # 21.6 px from the triangle's second corner only
     for i in range(90):                                              # > 64 candidates in between: the fourth blobs come in round 2+
         blob(420 + 12 * (i % 45), 100 + 100 * (i // 45), 200)
-    bits = np.ones(img.shape, np.uint32)
+    bits = np.full(img.shape, (1 << nmask) - 1, np.uint32)      # every mask = the whole image
     want, _ = oracle.gft_select(oracle.min_eigen(img[0]), bits[0], 0, 0.01, 40.0, 0)
     got_tri = {(int(x) - x_off, int(y)) for x, y in want}
     assert {(40, 40), (79, 50), (50, 79), (160, 200), (199, 210), (170, 239)} <= got_tri and (100, 45) not in got_tri
-    t_img, t_bits = _to(ctx.device, img, bits)
+    t_img, t_bits = _to(ctx.device, np.repeat(img, nimg, axis=0), bits)
     cap = 256 if cols < 32768 else 2048     # (the wide image's cell grid only fits the whole-image variant's LDS)
-    kp, n, status = ctx.detect_gft(t_img, t_bits, 1, 1, cap, min_distance=40.0, max_corners=0)
+    kp, n, status = ctx.detect_gft(t_img, t_bits, nimg, nmask, cap, min_distance=40.0, max_corners=0)
     ctx.synchronize()
-    assert status.item() == 0 and n.item() == len(want)
-    assert np.array_equal(kp[0, :len(want)].cpu().numpy(), want)
+    assert not status.any().item() and (n == len(want)).all().item()
+    assert (kp[:, :len(want)].cpu().numpy() == want[None]).all()
 
 
 def test_min_distance_and_ties_on_synthetic_response(ctx):

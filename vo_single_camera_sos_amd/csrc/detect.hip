@@ -467,7 +467,9 @@ __global__ __launch_bounds__(NT) void gft_select_kernel(const uint2* __restrict_
   // ones exactly) with a one-cell border around the grid, and on ALL waves of the workgroup -- see below.
   constexpr uint32_t kEmpty = 0xFFFFFFFFu;
   const int gwp = gw + 2;
-  const bool fast = spaced && n > 0 && cell <= 2048 && rows <= 32768 && cols <= 32768 && gwp * (gh + 2) <= kSelGridCells;  // uniform
+  // (workgroups of eight waves and more -- launches of few problems, where the pass is latency: the C2 batch of 4096 problems
+  // keeps the one-wave form, which issues fewer instructions in total: + 0.35 % on the issue-bound step, measured)
+  const bool fast = NT > 256 && spaced && n > 0 && cell <= 2048 && rows <= 32768 && cols <= 32768 && gwp * (gh + 2) <= kSelGridCells;  // uniform
   __syncthreads();  // keys are dead from here on; sorted[] is visible to the whole workgroup
   if (fast) {
     for (int i = tid; i < gwp * (gh + 2) * 2; i += NT) grid[i] = kEmpty;
