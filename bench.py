@@ -745,6 +745,7 @@ def main():
                        "keypoint_capacity_hit": bool(cap_hit),
                        "pairs_per_gpu": B, "global_pairs_per_step": n_gpus * B,
                        "parallelism": "pairs sharded over ranks, dp%d; %d HIP streams per GPU" % (n_gpus, eng.S),
+                       "hip_hardware_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default"),   # (the package asks for 16)
                        "keypoints_per_view_mean": float(n_kp.mean()), "stereo_points_per_frame_mean": float(M.mean()),
                        "correspondences_per_pair_mean": float(rec[:, 13].mean()),
                        "inliers_per_pair_mean": float(rec[:, 12].mean()), "tracked_ok": int(ok.sum()),
