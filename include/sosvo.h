@@ -436,7 +436,8 @@ typedef struct sosvo_rig {
  * m_top/m_bot [nframes,out_cap,2] f32, d_top/d_bot [nframes,out_cap,32] u8, X (frame [C]),
  * b_top/b_bot [nframes,out_cap,3] f64, M [nframes] i32 (count), n_cand [nframes] (optional:
  * candidates before the gates).  This is the PanoramicCorrespondences contract
- * (camera_models.py:291-362) in structure-of-arrays form.                                        */
+ * (camera_models.py:291-362) in structure-of-arrays form.  A frame with more survivors than out_cap keeps the first
+ * out_cap in that order (M = out_cap): what the reference's arrays hold, cut after out_cap rows.  */
 int32_t sosvo_stereo_assemble(sosvo_ctx* ctx, const sosvo_rig* rig_host, const float* kp_top,
                               const float* kp_bot, const uint8_t* desc_top, const uint8_t* desc_bot,
                               const int32_t* n_top, const int32_t* n_bot, const uint32_t* keys,

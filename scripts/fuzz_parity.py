@@ -495,8 +495,8 @@ def fuzz_pipeline(ctx, rng):
         ref = refflow.stereo_frame(rp, *[frames[2 * i][k] for k in ("kp_top", "kp_bot", "desc_top", "desc_bot")])
         cur = refflow.stereo_frame(rp, *[frames[2 * i + 1][k] for k in ("kp_top", "kp_bot", "desc_top", "desc_bot")])
         if len(ref["X"]) > frame_cap or len(cur["X"]) > frame_cap:
-            flagged = True     # more stereo points than the frame store holds: documented truncation
-            continue
+            flagged = True     # more stereo points than the frame store holds: the first frame_cap in order are kept (sosvo.h)
+            ref, cur = [{k: (v[:frame_cap] if k != "n_cand" else v) for k, v in fr.items()} for fr in (ref, cur)]
         if M[2 * i] != len(ref["X"]) or M[2 * i + 1] != len(cur["X"]):
             return params, "pair %d: stereo points (%d %d, oracle %d %d)" % (i, M[2 * i], M[2 * i + 1], len(ref["X"]), len(cur["X"]))
         w = refflow.track_pair(rp, ref, cur, pipe.thr, max_iter, seed=seed + i, adaptive=adaptive, gp3p=solver == "GP3P")
