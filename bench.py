@@ -484,7 +484,7 @@ def parse():
                          "generalised P3P on samples across both mirrors (what the reference's non-central RANSAC uses)")
     ap.add_argument("--no-sub", action="store_true",
                     help="skip the sub-records (ORB-detector path, GP3P hypotheses, BASELINE configs 3 and 5)")
-    ap.add_argument("--sub-steps", type=int, default=5, help="timed steps of each in-process sub-record")
+    ap.add_argument("--sub-steps", type=int, default=12, help="timed steps of each in-process sub-record")
     ap.add_argument("--orb-features-per-mask", type=int, default=230,
                     help="ORB_create(nfeatures) per azimuthal mask of the orb_detector sub-record (12 masks x 230: ~2000 per view)")
     ap.add_argument("--sequence-frames", type=int, default=256,
@@ -745,7 +745,7 @@ def main():
                        "keypoint_capacity_hit": bool(cap_hit),
                        "pairs_per_gpu": B, "global_pairs_per_step": n_gpus * B,
                        "parallelism": "pairs sharded over ranks, dp%d; %d HIP streams per GPU" % (n_gpus, eng.S),
-                       "hip_hardware_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default"),   # (the package asks for 16)
+                       "hip_hardware_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default"),   # (the package asks for 32)
                        "keypoints_per_view_mean": float(n_kp.mean()), "stereo_points_per_frame_mean": float(M.mean()),
                        "correspondences_per_pair_mean": float(rec[:, 13].mean()),
                        "inliers_per_pair_mean": float(rec[:, 12].mean()), "tracked_ok": int(ok.sum()),

@@ -57,7 +57,7 @@ static void* upload(FILE* f, size_t bytes) {
 int main(int argc, char** argv) {
   /* the library's internal streams + this program's own: more hardware queues than the runtime's default, so that streams
      do not share (and serialise on) one -- must happen before the first HIP call */
-  setenv("GPU_MAX_HW_QUEUES", "16", 0);
+  setenv("GPU_MAX_HW_QUEUES", "32", 0);
   if (argc != 3 && argc != 4) {
     fprintf(stderr, "usage: %s input.bin output.bin [internal streams 1..4 | graph | enqueue | sequence]\n", argv[0]);
     return 1;

@@ -13,7 +13,7 @@ CACHE=gpurun_out/${TAG}_frames.npz
 ARGS="--steps 10 --warmup 2 --no-cpu --no-h2d --no-isolated --no-sub --render-workers 1 --frames-cache $CACHE $EXTRA_ARGS"
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-export GPU_MAX_HW_QUEUES=16   # what the package asks for on import: under the profiler HIP is initialised before Python starts
+export GPU_MAX_HW_QUEUES=32   # what the package asks for on import: under the profiler HIP is initialised before Python starts
 # render the frames ONCE, outside the profiler (forked workers), into the cache every pass below reads
 python3 bench.py --steps 1 --warmup 0 --no-cpu --no-h2d --no-isolated --no-sub --frames-cache $CACHE $EXTRA_ARGS > gpurun_out/${TAG}_plain.log 2>&1
 echo "frames rendered"

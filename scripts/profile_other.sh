@@ -11,7 +11,7 @@ CFG=${2:-C3}
 ALGO=${3:-EPNP}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-export GPU_MAX_HW_QUEUES=16   # what the package asks for on import: under the profiler HIP is initialised before Python starts
+export GPU_MAX_HW_QUEUES=32   # what the package asks for on import: under the profiler HIP is initialised before Python starts
 if [ "$CFG" = "C3" ]; then
   FRAMES=${FRAMES:-48}
   ARGS="--only C3 --frames $FRAMES --render-workers 1 --steps 4 --cache gpurun_out/${TAG}_inputs.npz"

@@ -10,9 +10,10 @@ import os as _os
 # streams behind the one-call entry).  The ROCm runtime multiplexes a process's streams over GPU_MAX_HW_QUEUES hardware
 # queues, and streams that share one are serialised: with the runtime's default the host-fed step reaches 26 k pairs/s and
 # the one-call C entry falls to its join-every-call rate whenever other streams of the process are alive; with 12 or more
-# queues they reach 30 k and 99 % of the engine (measured, bench.py).  Read by the HIP runtime when it initialises, i.e. at the
+# queues they reach 30 k and 99 % of the engine (measured, bench.py); a long-lived process that has created several engines
+# (torch hands out its 32 pooled streams in turn) still loses ~10 % on a later engine at 16 and nothing at 32.  Read by the HIP runtime when it initialises, i.e. at the
 # first GPU call after this import; an explicit setting of the variable wins.  A C host sets it the same way before its
 # first HIP call.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 __all__ = ["_lib", "device"]
