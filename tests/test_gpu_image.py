@@ -149,8 +149,11 @@ def test_fused_unwrap_median_gray_equals_oracle_chain(ctx, pshape, k):
         table = ctx.unwrap_prepare(tm, t_mx, t_my, (37, 53))
         gray = ctx.unwrap_median_gray(t_omni, table, k)
         chain = ctx.median_gray(ctx.unwrap_table(t_omni, table), k)
+        ctx.set_hint_shared_device(True)     # sosvo_set_hint: a scheduling hint (three median workgroups per CU), never a result
+        hinted = ctx.unwrap_median_gray(t_omni, table, k)
+        ctx.set_hint_shared_device(False)
         ctx.synchronize()
-        assert torch.equal(gray.view_as(chain), chain)
+        assert torch.equal(gray.view_as(chain), chain) and torch.equal(hinted, gray)
         gray = gray.cpu().numpy().reshape(2, 3, *pshape)
         for v in range(2):
             for f in range(3):
