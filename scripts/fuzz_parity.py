@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Differential fuzzing of the stage entry points against the CPU oracle (test infrastructure: the oracle is the checker).
 
-    python scripts/fuzz_parity.py --minutes 10 --seed 1 [--stages median,gft,fast,agast,match,radius,orb,unwrap,ransac,describe,relpose,l2sort,pipeline]
+    python scripts/fuzz_parity.py --minutes 10 --seed 1 [--stages median,gft,fast,agast,match,radius,orb,unwrap,ransac,describe,relpose,l2sort,pipeline,rgbd]
 
 Every case draws its own sizes and parameters (image sizes around the strip / chunk / tile borders of the kernels, ragged
 problem counts, empty masks, fractional minimum distances, budgets that end a selection inside a round, duplicate
@@ -512,10 +512,65 @@ def fuzz_pipeline(ctx, rng):
     return params, ("flagged" if flagged else None)
 
 
+def fuzz_rgbd(ctx, rng):
+    """The RGB-D (perspective) path behind ONE C-ABI call (sosvo_rgbd_pair_batch) on small random frames -- textures shifted
+    between the frames of a pair, depth maps with holes / NaN / out-of-range values, both depth conventions, all solvers,
+    an optional median window -- against the reference's control flow on the oracle (tests/refflow.py)."""
+    import refflow
+    from vo_single_camera_sos_amd.pipeline import RGBDCamConfig, RGBDPairBatch
+    B = int(rng.integers(1, 4))
+    rows, cols = int(rng.integers(80, 200)), int(rng.integers(100, 320))
+    nfeat = int(rng.choice([50, 400, 2000]))
+    algo = str(rng.choice(["EPNP", "KNEIP", "GP3P", "TWOPT"]))
+    depth_is_Z = bool(rng.integers(0, 2))
+    ksize = int(rng.choice([0, 0, 3, 5]))
+    max_iter, adaptive, seed = int(rng.choice([20, 200])), bool(rng.integers(0, 2)), int(rng.integers(0, 2 ** 31))
+    thr = float(rng.choice([1.0 - np.cos(np.deg2rad(5.0)), 1.0 - np.cos(np.deg2rad(0.5))]))
+    fx, fy, cx, cy = 0.8 * cols, 0.8 * cols, 0.5 * cols - 0.5, 0.5 * rows - 0.5
+    params = dict(B=B, rows=rows, cols=cols, nfeat=nfeat, algo=algo, depth_is_Z=depth_is_Z, ksize=ksize, max_iter=max_iter,
+                  adaptive=adaptive, seed=seed, thr=thr)
+    bgr, depth = [], []
+    for i in range(B):
+        base = np.stack([_image(rng, rows + 8, cols + 8, int(rng.integers(0, 2))) for _ in range(3)], axis=-1)
+        dz = rng.uniform(0.5, 9.0, (rows + 8, cols + 8)).astype(np.float32)     # metres * 1000 below; some beyond the range gates
+        dz = np.kron(dz[::8, ::8], np.ones((8, 8), np.float32))[:rows + 8, :cols + 8]
+        sx, sy = int(rng.integers(0, 8)), int(rng.integers(0, 8))
+        for (ox, oy) in ((0, 0), (sx, sy)):
+            im = np.ascontiguousarray(base[oy:oy + rows, ox:ox + cols])
+            d = (1000.0 * dz[oy:oy + rows, ox:ox + cols]).astype(np.float32)
+            hole = rng.random((rows, cols)) < float(rng.choice([0.0, 0.1, 0.9]))
+            d[hole] = float(rng.choice([0.0, np.nan]))
+            bgr.append(im)
+            depth.append(d)
+    bgr, depth = np.stack(bgr), np.stack(depth)
+    cam = RGBDCamConfig(fx=fx, fy=fy, center_x=cx, center_y=cy, depth_is_Z=depth_is_Z, min_range=0.8, max_range=7.0)
+    one = RGBDPairBatch(ctx, cam, B, image_shape=(rows, cols), num_of_features=nfeat, max_iter=max_iter, adaptive=adaptive, seed=seed,
+                        thr=thr, pose_est_algorithm=algo, median_win_size=ksize)
+    one.load_frames(bgr, depth)
+    rec = one.step()
+    ctx.synchronize()
+    rec = rec.cpu().numpy()
+    ca, sa = orb_pattern.angle_cos_sin(orb_pattern.GFT_KEYPOINT_ANGLE)
+    rc = refflow.RGBDParams(fx, fy, cx, cy, cam.focal_length_m, depth_is_Z, 0.8, 7.0, cam.f2f_max_hdiff, 1.0)
+    frames = [refflow.rgbd_frame(rc, bgr[f], depth[f], nfeat, orb_pattern.orb_pattern(), ca, sa, median_ksize=ksize) for f in range(2 * B)]
+    for i in range(B):
+        w = refflow.track_pair_rgbd(rc, frames[2 * i], frames[2 * i + 1], thr, max_iter, seed=seed + i, adaptive=adaptive,
+                                    epnp=(algo == "EPNP"), gp3p=(algo == "GP3P"), twopt=(algo == "TWOPT"))
+        n = len(w["corr"]["q"])
+        if rec[i, 13] != n:
+            return params, "pair %d: correspondences (%d, oracle %d)" % (i, rec[i, 13], n)
+        if rec[i, 14] != w["ransac"]["status"] or rec[i, 15] != w["ransac"]["best_iter"] or rec[i, 12] != w["ransac"]["n_inliers"]:
+            return params, "pair %d: RANSAC status / winner / inliers (%s, oracle %d %d %d)" % (
+                i, rec[i, 12:16].tolist(), w["ransac"]["n_inliers"], w["ransac"]["status"], w["ransac"]["best_iter"])
+        if not np.array_equal(rec[i, :12].reshape(3, 4), w["T"]):
+            return params, "pair %d: pose bits" % i
+    return params, None
+
+
 STAGES = {"median": fuzz_median, "gft": fuzz_gft, "fast": fuzz_fast, "agast": fuzz_agast, "match": fuzz_match,
           "radius": fuzz_radius, "orb": fuzz_orb, "unwrap": fuzz_unwrap, "ransac": fuzz_ransac,
           "describe": fuzz_describe, "relpose": fuzz_relpose, "l2sort": fuzz_l2sort,
-          "pipeline": fuzz_pipeline}
+          "pipeline": fuzz_pipeline, "rgbd": fuzz_rgbd}
 
 
 def main():

@@ -18,7 +18,7 @@ def _harness():
 def test_generators_cover_the_promised_input_kinds():
     fp = _harness()
     assert set(fp.STAGES) >= {"median", "gft", "fast", "agast", "match", "radius", "orb", "unwrap", "ransac", "describe", "relpose",
-                              "l2sort", "pipeline"}
+                              "l2sort", "pipeline", "rgbd"}
     rng = np.random.default_rng(1)
     kinds = [fp._image(rng, 20, 30, k) for k in range(4)]
     assert all(im.shape == (20, 30) and im.dtype == np.uint8 for im in kinds)
