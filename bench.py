@@ -143,7 +143,7 @@ def other_configs_subrecords(timeout_s=420):
             if not line.startswith("{"):
                 continue
             d = json.loads(line)
-            key = "c3" if d["config"] == "C3" else "c5_" + d.get("algorithm", "").lower()
+            key = d["config"].lower() if d["config"].startswith("C3") else "c5_" + d.get("algorithm", "").lower()
             d.pop("config", None)
             out[key] = d
         if r.returncode != 0 and not out:
@@ -445,6 +445,123 @@ def valu_issue_step(pairs_per_step, ms_per_step):
     return None
 
 
+LINE_BUDGET = 4000   # bytes: the driver keeps an 8 KB tail of stdout and parses the LAST line (20.7 KB did not parse)
+
+
+def _sig(x, digits=5):
+    """Floats to `digits` significant digits (bytes of the line, not precision of the measurement: the detail file keeps all)."""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (digits, x))
+    return x
+
+
+def _pick(d, keys):
+    return {k: _sig(d[k]) for k in keys if isinstance(d, dict) and k in d}
+
+
+def _clip(s, n):
+    s = str(s)
+    return s if len(s) <= n else s[: n - 3] + "..."
+
+
+def compose_headline(out, detail_path=None):
+    """The ONE line the driver parses, from the full record `out` (which goes to `detail_path` on disk): the contract's
+    keys, `roofline`, `cpu_baseline`, and one number per sub-record.  Never more than LINE_BUDGET bytes: if a field should
+    ever push it over, the optional groups are dropped in a fixed order (tests/test_bench_line.py builds a worst case)."""
+    cfg = out.get("config", {})
+    line = {k: _sig(out.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                          "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["metric"] = _clip(line["metric"], 120)
+    line["config"] = dict(_pick(cfg, ("pairs_per_gpu", "global_pairs_per_step", "keypoints_per_view_mean",
+                                      "stereo_points_per_frame_mean", "correspondences_per_pair_mean", "inliers_per_pair_mean",
+                                      "tracked_ok", "rotation_error_deg_median", "translation_error_mm_median",
+                                      "keypoint_capacity_hit")),
+                          workload=_clip(cfg.get("workload", ""), 420), parallelism=_clip(cfg.get("parallelism", ""), 80))
+    rf = out.get("roofline") or {}
+    line["roofline"] = _pick(rf, ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_basis", "traffic", "traffic_source",
+                                  "traffic_stale", "avg_launch_ms", "min_launch_ms", "launches", "pairs_per_launch",
+                                  "isolated_launch_ms", "achieved_isolated", "frac_isolated", "algorithmic_bytes_per_pair",
+                                  "algorithmic_bytes_per_launch", "profile_events_in_timed_region"))
+    if "kernel" in line["roofline"]:
+        line["roofline"]["kernel"] = _clip(line["roofline"]["kernel"], 60)
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = dict(_pick(cb, ("value", "unit", "cores", "kind")), sample=_clip(cb.get("sample", ""), 160))
+    ca = out.get("cpu_baseline_all_cores")
+    if ca and "value" in ca:
+        line["cpu_baseline_all_cores"] = _pick(ca, ("value", "cores", "kind"))
+    extra = {}
+    if out.get("valu_issue"):
+        extra["valu_issue_frac"] = _sig(out["valu_issue"].get("frac"))
+    if out.get("valu_issue_step"):
+        extra["valu_issue_step_frac"] = _sig(out["valu_issue_step"].get("frac"))
+    if out.get("traffic_step"):
+        extra["traffic_step_bytes_per_pair"] = _sig(out["traffic_step"].get("bytes_per_pair"))
+        extra["traffic_step_stale"] = out["traffic_step"].get("stale")
+    line["bounds"] = extra
+    # one number (and its unit's worth of context) per sub-record; errors as short strings
+    sub = {}
+    for key in ("pcie_inclusive", "c_abi_streams", "orb_detector", "orb_detector_median11", "gp3p", "pano_1200", "c3", "c3_2880",
+                "c5_epnp", "c5_kneip", "sequence", "sequence_rgbd"):
+        d = out.get(key)
+        if not isinstance(d, dict):
+            continue
+        if "error" in d and "value" not in d:
+            sub[key] = {"error": _clip(d["error"], 80)}
+            continue
+        e = {"value": _sig(d.get("value"))}
+        if d.get("unit") and d["unit"] != "frame-pairs/s":
+            e["unit"] = d["unit"]
+        r2 = d.get("roofline")
+        if isinstance(r2, dict):
+            e["frac"] = _sig(r2.get("frac"), 3)
+            e["kernel"] = _clip(str(r2.get("kernel", "")).strip("()").split("<")[0], 32)
+        for k in ("keypoints_per_view_mean", "keypoints_per_view", "ratio_to_engine", "h2d_GBps", "same_results", "gpu_ms_per_frame"):
+            if k in d:
+                e[k] = _sig(d[k], 4)
+        sub[key] = e
+    for key in ("sub_error", "error"):
+        if key in out:
+            sub[key] = _clip(out[key], 120)
+    line["sub"] = sub
+    if out.get("accuracy_threshold_0p5deg") and "rotation_error_deg_median" in out["accuracy_threshold_0p5deg"]:
+        line["accuracy_0p5deg"] = _pick(out["accuracy_threshold_0p5deg"], ("rotation_error_deg_median", "translation_error_mm_median"))
+    if out.get("reference_libraries"):
+        line["reference_libraries"] = _pick(out["reference_libraries"], ("cv2", "pyopengv", "value"))
+    line["parity"] = "K1-K10 (OpenCV/OpenGV arithmetic) parity unpinned; geometry pinned by reference-generated fixtures"
+    line["detail"] = detail_path
+    for drop in (None, "reference_libraries", "accuracy_0p5deg", "bounds", "cpu_baseline_all_cores", "sub", "parity"):
+        if drop:
+            line.pop(drop, None)
+        text = json.dumps(line, separators=(",", ":"))
+        if len(text) <= LINE_BUDGET:
+            return text
+    line["config"].pop("workload", None)
+    return json.dumps(line, separators=(",", ":"))[:LINE_BUDGET * 2]
+
+
+def emit(out, detail_out):
+    """Write the full record to `detail_out` (and a copy under gpurun_out/ when that directory exists: it is what gpurun
+    brings back), then print the compact line as the LAST line of stdout."""
+    paths = [detail_out] if detail_out else []
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")) and detail_out:
+        paths.append(os.path.join(ROOT, "gpurun_out", os.path.basename(detail_out)))
+    written = None
+    for path in paths:
+        try:
+            with open(path, "w") as fh:
+                json.dump(out, fh, indent=1)
+            written = written or os.path.relpath(path, ROOT)
+        except OSError:
+            pass
+    sys.stdout.flush()
+    print(compose_headline(out, written), flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -495,6 +612,8 @@ def parse():
                     help="ORB_create(nfeatures) per azimuthal mask of the orb_detector sub-record (12 masks x 230: ~2000 per view)")
     ap.add_argument("--sequence-frames", type=int, default=256,
                     help="frames of the synthetic sequence of the `sequence` sub-record (run_VO in sequence mode); 0 = skip")
+    ap.add_argument("--detail-out", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="file the FULL record goes to (per-kernel tables, notes, sub-records); stdout carries the compact line")
     ap.add_argument("--dump-records", default=None,
                     help="rank 0 writes the last step's gathered [N*B,16] records (global pair order) to this .npy file")
     return ap.parse_args()
@@ -765,7 +884,13 @@ def main():
                                         "solver and range bin -- the error does not depend on the points' range)"},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "avg_launch_ms": dom_avg_s * 1e3, "launches": dom[1][0],
+                         "frac_basis": "avg_launch_ms: HIP events around every launch inside the timed region (the contract's "
+                                       "figure; launches share the chip with the other streams' kernels); frac_isolated: the "
+                                       "kernel alone, measured right after the timed region",
+                         "avg_launch_ms": dom_avg_s * 1e3, "min_launch_ms": dom[1][2], "launches": dom[1][0],
+                         "pairs_per_launch": dom_pairs,
+                         "profile_events_in_timed_region": "on (two HIP events per launch; the un-profiled C entry runs at "
+                                                           "c_abi_streams.ratio_to_engine of this rate)",
                          "isolated_launch_ms": iso_ms, "isolated_launch_ms_shared_hint": iso_hint_ms,
                          "achieved_isolated": b_alg * iso_pairs / (iso_ms * 1e-3) / 1e9 if iso_ms else None,
                          "frac_isolated": b_alg * iso_pairs / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if iso_ms else None,
@@ -853,8 +978,12 @@ def main():
                     e_[1] += ms
                     e_[2] = min(e_[2], ms)
                 if pk:
-                    d2 = max(pk.items(), key=lambda kv: kv[1][1])
+                    # dominant kernel and frac from UNCONTENDED durations: the parts' launches overlap on the chip, so summed
+                    # and average durations are shared time; the shortest launch in the timed region is
+                    # the kernel nearly on its own
+                    d2 = max(pk.items(), key=lambda kv: kv[1][2] * kv[1][0])
                     avg2 = d2[1][1] / d2[1][0] / 1e3
+                    min2 = d2[1][2] / 1e3
                     ppl2 = B / float(e2.S)
                     ba2 = b_alg_c2(H, W, int(round(float(nk.mean()))))
                     import glob as _glob
@@ -863,8 +992,11 @@ def main():
                         cands = sorted(_glob.glob(os.path.join(ROOT, "profiles", "*", "*" + pmc_tag + "*_pmc_hbm_per_kernel.csv")))
                         if cands:
                             tr2, src2 = pmc_traffic(d2[0], ppl2, cands[-1])
-                    rec2["roofline"] = {"bound": "hbm", "kernel": d2[0], "achieved": ba2 * ppl2 / avg2 / 1e9, "peak": HBM_PEAK_GBS,
-                                        "unit": "GB/s", "frac": ba2 * ppl2 / avg2 / 1e9 / HBM_PEAK_GBS, "traffic": tr2,
+                    rec2["roofline"] = {"bound": "hbm", "kernel": d2[0], "achieved": ba2 * ppl2 / min2 / 1e9, "peak": HBM_PEAK_GBS,
+                                        "unit": "GB/s", "frac": ba2 * ppl2 / min2 / 1e9 / HBM_PEAK_GBS,
+                                        "frac_basis": "min_launch_ms (shortest launch in the timed region; dominant = largest "
+                                                      "min x launches)",
+                                        "frac_avg_launch": ba2 * ppl2 / avg2 / 1e9 / HBM_PEAK_GBS, "traffic": tr2,
                                         "traffic_source": src2, "avg_launch_ms": avg2 * 1e3, "min_launch_ms": d2[1][2],
                                         "algorithmic_bytes_per_pair": ba2, "pairs_per_launch": ppl2}
                     rec2["kernels_ms_per_step"] = {k: v[1] / args.sub_steps for k, v in sorted(pk.items(), key=lambda kv: -kv[1][1])[:8]}
@@ -972,7 +1104,7 @@ def main():
         if sub_other:
             torch.cuda.synchronize()
             out.update(other_configs_subrecords())
-        print(json.dumps(out))
+        emit(out, args.detail_out)
     return
 
 

@@ -70,7 +70,9 @@ def kernel_table(prof, steps):
         e[0] += 1
         e[1] += ms
         e[2] = min(e[2], ms)
-    dom = max(per.items(), key=lambda kv: kv[1][1])
+    # dominant by UNCONTENDED time (shortest launch x launches): the parts' launches overlap on the chip, so the summed
+    # durations are shared time and would name whichever kernel waits most
+    dom = max(per.items(), key=lambda kv: kv[1][2] * kv[1][0])
     return per, dom
 
 
@@ -79,7 +81,8 @@ def roofline(per, dom, b_alg_unit, units_per_launch, cfg_tag):
     import csv
     import glob
     avg_s = dom[1][1] / dom[1][0] / 1e3
-    achieved = b_alg_unit * units_per_launch / avg_s / 1e9
+    min_s = dom[1][2] / 1e3
+    achieved = b_alg_unit * units_per_launch / min_s / 1e9
     label = dom[0].strip("()").split("<")[0]
     traffic, src = None, None
     for path in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*%s*pmc_hbm_per_kernel.csv" % cfg_tag)))):
@@ -91,6 +94,8 @@ def roofline(per, dom, b_alg_unit, units_per_launch, cfg_tag):
         if src:
             break
     return {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+            "frac_basis": "min_launch_ms (shortest launch in the timed region; dominant = largest min x launches)",
+            "frac_avg_launch": b_alg_unit * units_per_launch / avg_s / 1e9 / 8000.0,
             "traffic": traffic, "traffic_source": src, "avg_launch_ms": avg_s * 1e3, "min_launch_ms": dom[1][2],
             "launches": dom[1][0], "algorithmic_bytes_per_unit": b_alg_unit, "units_per_launch": units_per_launch,
             "note": "VALU / latency-bound integer and FP64 work: the HBM fraction is small by construction (SURVEY 8d); "
@@ -105,9 +110,11 @@ def main():
     ap.add_argument("--only", default="", help="C3 or C5: run just that configuration")
     ap.add_argument("--c3-streams", type=int, default=3, help="HIP streams the C3 batch is split over")
     ap.add_argument("--c5-streams", type=int, default=3, help="one-call RGB-D batches of --pairs pairs run side by side on this many HIP streams")
-    ap.add_argument("--c3-pano-width", type=int, default=2880,
-                    help="C3 panorama columns: 2880 x 292 gives the ~8000 keypoints per view the configuration names (2400 x 244, "
-                         "the reference default scaled by two, caps at ~7400 by GFT's minDistance and ORB.compute's border)")
+    ap.add_argument("--c3-pano-width", default="2400,2880",
+                    help="C3 panorama columns, comma-separated: 2400 x 244 is SURVEY 8(d)'s C3 (the reference default scaled by two, "
+                         "the geometry of tests/test_gpu_c3.py; GFT's minDistance and ORB.compute's border cap it at ~7400 keypoints "
+                         "per view) -> config \"C3\"; 2880 x 292 reaches the ~8000+ keypoints per view the configuration names -> "
+                         "config \"C3_2880\".  The same rendered omni frames serve every width")
     ap.add_argument("--render-workers", type=int, default=0, help="forked render processes (0 = auto; 1 under rocprofv3)")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--c5-algo", default="both", choices=["both", "EPNP", "KNEIP"])
@@ -119,9 +126,10 @@ def main():
     from vo_single_camera_sos_amd.omnistereo.gum import synthetic_gums
     from vo_single_camera_sos_amd.omnistereo.panorama import Panorama
     # ---- render on the host first (every C3 frame and every C5 pair its own room and noise)
+    widths = [int(w) for w in str(args.c3_pano_width).split(",") if w]
     gs = synthetic_gums(scale=2.0)
     for m in (gs.top_model, gs.bot_model):
-        m.panorama = Panorama(m, width=args.c3_pano_width)
+        m.panorama = Panorama(m, width=widths[0])
     gs.make_annulus_masks((960, 1280))
     omni3 = None
     B = args.pairs
@@ -150,7 +158,12 @@ def main():
     from vo_single_camera_sos_amd.frontend import DeviceImageModel, ImageFrontEnd
     from vo_single_camera_sos_amd.pipeline import FramePairPipeline, RGBDCamConfig, RGBDPairBatch, RigConfig
     ctx = Context(0)
-    if args.only != "C5":
+    for wi, width in enumerate(widths if args.only != "C5" else []):
+        if wi > 0:
+            gs = synthetic_gums(scale=2.0)
+            for m in (gs.top_model, gs.bot_model):
+                m.panorama = Panorama(m, width=width)
+            gs.make_annulus_masks((960, 1280))
         # ---- C3: the batch split over HIP streams (one libsosvo context each), as the C2 engine does: the latency-bound
         # stages of one part (corner selection, the per-bucket 2-NN matching) run under the VALU-bound median of another
         F = args.frames
@@ -200,11 +213,11 @@ def main():
         cap_hit = any(int(fe.n.max().item()) >= fe.kp_cap for _, _, fe, _, _ in parts)
         N = int(round(float(n_view)))
         b_alg = 960 * 1280 * 3 + N * 12 + N * 24   # one BGR frame in, match index + distance and XYZ out
-        print(json.dumps({"config": "C3", "metric": "frames/s (unwrap + median + GFT + ORB descriptors + 2-NN bucket matching + triangulation), 1280x960 omni",
-                          "value": F / dt, "ms_per_step": 1e3 * dt, "frames_per_step": F, "streams": len(parts),
+        print(json.dumps({"config": "C3" if width == 2400 else "C3_%d" % width, "metric": "frames/s (unwrap + median + GFT + ORB descriptors + 2-NN bucket matching + triangulation), 1280x960 omni",
+                          "value": F / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt, "frames_per_step": F, "streams": len(parts),
                           "panorama": "%d x %d" % (pano.cols, pano.rows), "keypoints_per_view": float(n_view),
                           "keypoint_capacity_hit": bool(cap_hit), "stereo_points_per_frame": float(M),
-                          "roofline": roofline(per, dom, b_alg, F // len(parts), "c3"),
+                          "roofline": roofline(per, dom, b_alg, F // len(parts), "c3" if width == 2880 else "c3w%d" % width),
                           "kernels_ms_per_step": {k: v[1] / args.steps for k, v in sorted(per.items(), key=lambda kv: -kv[1][1])},
                           "data": "synthetic (%d distinct frames)" % F}))
         for _, c, _, _, _ in parts:
@@ -245,7 +258,7 @@ def main():
         N = 2000
         b_alg = 2 * (480 * 640 * 3 + 480 * 640 * 2) + N * 12 + N + 96   # two BGR + u16 depth frames in; matches, mask, pose out
         print(json.dumps({"config": "C5", "metric": "frame-pairs/s (gray + GFT + ORB descriptors + back-projection + matching + central RANSAC 2000 it. + LM), 640x480 RGB-D",
-                          "algorithm": algo, "value": S5 * B / dt, "ms_per_step": 1e3 * dt, "pairs_per_step": S5 * B, "streams": S5,
+                          "algorithm": algo, "value": S5 * B / dt, "unit": "frame-pairs/s", "ms_per_step": 1e3 * dt, "pairs_per_step": S5 * B, "streams": S5,
                           "tracked_ok": int((rec[:, 14] == 0).sum()), "inliers_mean": float(rec[:, 12].mean()),
                           "correspondences_mean": float(rec[:, 13].mean()),
                           "roofline": roofline(per, dom, b_alg, B, "c5" + algo.lower()),
