@@ -17,7 +17,7 @@ export GPU_MAX_HW_QUEUES=32   # what the package asks for on import: under the p
 # render the frames ONCE, outside the profiler (forked workers), into the cache every pass below reads
 python3 bench.py --steps 1 --warmup 0 --no-cpu --no-h2d --no-isolated --no-sub --frames-cache $CACHE $EXTRA_ARGS > gpurun_out/${TAG}_plain.log 2>&1
 echo "frames rendered"
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$TAG --output-format csv -- python3 bench.py $ARGS > gpurun_out/prof_${TAG}_bench.log 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$TAG --output-format csv -- python3 bench.py $ARGS --detail-out gpurun_out/${TAG}_bench_detail_under_rocprof.json > gpurun_out/prof_${TAG}_bench.log 2>&1
 echo "stats pass done"
 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_${TAG}_fetch --output-format csv -- python3 bench.py $ARGS > gpurun_out/pmc_${TAG}_fetch.log 2>&1
 echo "fetch pass done"

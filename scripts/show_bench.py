@@ -1,8 +1,13 @@
-"""Prints the headline numbers of a bench.py JSON line (last line of the file): value, ms per step, per-kernel ms."""
+"""Prints the headline numbers of a bench.py record: the FULL record (bench_detail.json, which holds the per-kernel table)
+or a captured stdout whose last line is the compact line: value, ms per step, per-kernel ms."""
 import json
 import sys
 
-d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+text = open(sys.argv[1]).read().strip()
+try:
+    d = json.loads(text)
+except ValueError:
+    d = json.loads(text.splitlines()[-1])
 print("%.0f %s  %.3f ms/step  streams=%s B=%s" % (d["value"], d["unit"], d["ms_per_step"], d.get("streams"),
                                                    d["config"].get("pairs_per_gpu")))
 for k, v in sorted(d.get("kernels_ms_per_step", {}).items(), key=lambda kv: -kv[1]):
