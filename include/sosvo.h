@@ -560,7 +560,15 @@ int32_t sosvo_frame_pair_batch_streams(sosvo_ctx* ctx, const sosvo_rig* rig_host
  *   - hands every call inputs that are ready on the context's stream at the time of the call (as before),
  *   - alternates (at least) two `results` buffers if something still reads the previous call's records, and
  *   - calls ..._join(ctx) before reading records on the context's stream: it makes that stream wait for every part of
- *     the LATEST call (hence, in stream order, of all earlier ones).  The workspace may be the same for every call. */
+ *     the LATEST call (hence, in stream order, of all earlier ones), and
+ *   - treats the INPUTS like the records: until the join nothing orders the context's stream after the parts, so `omni`
+ *     (and the model tables) of an un-joined call must not be overwritten on the context's stream -- double-buffer the
+ *     frames or join first.
+ * The workspace may be the same for every call: part s of every call uses the same slice on the same internal stream.
+ * That holds only for the same split, so a call whose (n_pairs, n_streams) differ from the un-joined previous call's joins
+ * internally first (correct, but without the overlap).  A call made while the context's stream is being captured into a
+ * HIP graph fails with SOSVO_ERR_ARG while un-joined work is pending (join before capturing); after a join -- or after the
+ * joined form sosvo_frame_pair_batch_streams -- every call is self-contained and capturable. */
 int32_t sosvo_frame_pair_batch_streams_enqueue(sosvo_ctx* ctx, const sosvo_rig* rig_host, const sosvo_batch_cfg* cfg_host,
                                                int32_t n_streams, const uint8_t* omni, const uint32_t* unwrap_table,
                                                const uint32_t* mask_bits, const int8_t* pattern, void* workspace,

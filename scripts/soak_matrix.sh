@@ -3,7 +3,15 @@
 O=gpurun_out/soak_matrix.txt
 : > $O
 fail=0
-run() { echo "== $*" >> $O; timeout -k 10 500 python tests/soak_parity.py "$@" 2>&1 | grep -E "soak|Traceback|Error|differ" | tail -2 >> $O || true; echo "done: $*"; }
+# (the exit status is soak_parity's own -- not the grep's -- through a log file; a timeout counts as a failure too)
+run() {
+  echo "== $*" >> $O
+  local log=gpurun_out/soak_matrix_last.log rc=0
+  timeout -k 10 500 python tests/soak_parity.py "$@" > $log 2>&1 || rc=$?
+  grep -E "soak|Traceback|Error|differ" $log | tail -2 >> $O || true
+  if [ $rc -ne 0 ]; then echo "FAILED (exit $rc): $*" >> $O; fail=1; fi
+  echo "done (exit $rc): $*"
+}
 run --pairs 12 --workers 12 --seed 101 --pano-width 720 --features 100 --kp-cap 128 --iters 50 --median 3
 run --pairs 12 --workers 12 --seed 102 --pano-width 1200 --features 300 --kp-cap 512 --iters 300 --median 5
 run --pairs 12 --workers 12 --seed 103 --pano-width 1440 --features 1000 --kp-cap 512 --iters 2000 --median 0
@@ -17,3 +25,4 @@ run --pairs 12 --workers 12 --seed 110 --rgbd EPNP --features 300 --iters 100
 run --pairs 12 --workers 12 --seed 111 --rgbd KNEIP --features 3000 --iters 500
 run --pairs 12 --workers 12 --seed 112 --pano-width 1440 --features 1000 --kp-cap 512 --iters 500 --median 11 --solver GP3P
 cat $O
+exit $fail

@@ -109,6 +109,57 @@ def test_enqueue_without_join_overlaps_calls_and_keeps_the_records(ctx):
     assert torch.equal(got, want) and torch.equal(bufs[0], want)
 
 
+def test_multi_stream_c_call_is_capturable_after_eager_and_enqueued_calls():
+    """sosvo_frame_pair_batch_streams (n_streams > 1) captured into a HIP graph AFTER eager calls -- joined and
+    un-joined + join -- must not wait on a median event recorded outside the capture: the internal streams join the
+    capture through sub_begin, the token chain restarts, replays are bit-identical on poisoned outputs.  Capturing while
+    un-joined work is pending is refused (SOSVO_ERR_ARG), not silently mis-ordered; a different split behind an
+    un-joined call joins internally and still returns the right records."""
+    from vo_single_camera_sos_amd.device import Context, SosvoError
+    st = torch.cuda.Stream(torch.device("cuda", 0))
+    with torch.cuda.stream(st):
+        c = Context(0, st)
+        B, nfeat, cap = 5, 300, 320
+        model, rig, omni = _setup(c, B)
+        kw = dict(num_of_features=nfeat, kp_cap=cap, frame_cap=1024, max_iter=300, seed=11)
+        one = FramePairBatch(c, model, rig, B, **kw)
+        one.load_frames(omni)
+        want = one.step().clone()
+        multi = FramePairBatch(c, model, rig, B, n_streams=3, **kw)
+        multi.load_frames(omni)
+        other = torch.zeros_like(multi.out)
+        assert torch.equal(multi.step(), want)            # eager, joined: scratch reaches its final size
+        multi.enqueue(other)                              # eager, un-joined ...
+        st.synchronize()
+        # ... a capture now would depend on events from outside it: refused
+        g_bad = torch.cuda.CUDAGraph()
+        with pytest.raises(SosvoError):
+            with torch.cuda.graph(g_bad, stream=st):
+                multi.step()
+        multi.join()                                      # ... joined: self-contained again
+        st.synchronize()
+        assert torch.equal(other, want)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            multi.step()
+        st.synchronize()
+        for _ in range(4):
+            multi.out.fill_(float("nan"))
+            multi.workspace.fill_(0xFF)
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(multi.out, want), torch.nonzero(multi.out != want)[:8]
+        # a different split right behind an un-joined call: internal join, right records, same workspace
+        multi.enqueue(other)
+        two = FramePairBatch(c, model, rig, B, n_streams=2, **kw)
+        two.workspace = multi.workspace[: two.workspace.numel()]
+        two.load_frames(omni)
+        got = two.step()
+        st.synchronize()
+        assert torch.equal(got, want) and torch.equal(other, want)
+        c.close()
+
+
 def test_argument_errors(ctx):
     model, rig, omni = _setup(ctx, 1)
     batch = FramePairBatch(ctx, model, rig, 1, num_of_features=100, frame_cap=512, max_iter=50)

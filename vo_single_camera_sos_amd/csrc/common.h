@@ -34,7 +34,10 @@ struct sosvo_ctx {
   hipEvent_t sub_done[kSosvoMaxSubStreams], sub_median[kSosvoMaxSubStreams], sub_begin;
   int32_t n_sub;
   int32_t hint_shared_device;  // sosvo_set_hint(SOSVO_HINT_SHARED_DEVICE): other streams' kernels share the chip
-  int32_t sub_last;  // parts of the most recent sosvo_frame_pair_batch_streams[_enqueue] call (their medians' token chain goes on)
+  int32_t sub_last;  // parts of the most recent sosvo_frame_pair_batch_streams[_enqueue] call
+  // un-joined work of an ..._enqueue call is pending on the part streams: only then does the next call chain its first
+  // median behind the previous call's last one, and only then must its split (n_pairs, n_streams) equal the previous one
+  int32_t sub_pending, sub_last_pairs;
 };
 
 // Brackets the kernel launches of the enclosing scope with a HIP event pair when profiling is on.

@@ -645,8 +645,7 @@ __global__ __launch_bounds__(NT) void gft_select_kernel(const uint2* __restrict_
             uint32_t* c = &grid[((y / cell - cy0) * gw + (x / cell - cx0)) * 2];
             if (atomicCAS(&c[0], 0u, xy + 1u) != 0u && atomicCAS(&c[1], 0u, xy + 1u) != 0u) {  // third point of a cell
               const int o = atomicAdd(&s_ovf, 1);
-              if (o < limit_list) acc_list[o] = xy;
-              else stt |= 2;
+              if (o < limit_list) acc_list[o] = xy;  // (an overflow is reported once, after the loop, from s_ovf)
             }
           } else {
             acc_list[pos] = xy;
@@ -659,6 +658,7 @@ __global__ __launch_bounds__(NT) void gft_select_kernel(const uint2* __restrict_
   }
   __syncthreads();
   if (tid == 0) {
+    if (s_ovf > limit_list) stt |= 2;  // the overflowing lane is not tid 0 in general: decide from the shared counter
     n_out[p] = min(s_accepted, cap);
     if (status) status[p] = stt;
   }

@@ -544,12 +544,27 @@ static int32_t sosvo_frame_pair_batch_streams_impl(sosvo_ctx* ctx, const sosvo_r
     SOSVO_HIP(ctx, hipEventCreateWithFlags(&ctx->sub_median[i], hipEventDisableTiming));
     ctx->n_sub = i + 1;
   }
+  if (ctx->sub_pending) {
+    // un-joined parts of an earlier ..._enqueue call may still run.  A stream capture cannot depend on them (their events
+    // were recorded outside it), and a different split would lay this call's workspace slices over slices an earlier
+    // part still uses on ANOTHER stream (a slice is ordered by its own part stream only): join first in both cases.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    SOSVO_HIP(ctx, hipStreamIsCapturing(ctx->stream, &cap));
+    SOSVO_REQUIRE(ctx, cap == hipStreamCaptureStatusNone,
+                  "un-joined sosvo_frame_pair_batch_streams_enqueue work is pending: call ..._join before capturing");
+    if (ctx->sub_last != n_streams || ctx->sub_last_pairs != cfg->n_pairs) {
+      for (int s = 0; s < ctx->sub_last; ++s) SOSVO_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->sub_done[s], 0));
+      ctx->sub_pending = 0;
+    }
+  }
   // every part starts after the work already queued on the caller's stream ...
   SOSVO_HIP(ctx, hipEventRecord(ctx->sub_begin, ctx->stream));
   char* ws = reinterpret_cast<char*>(workspace);
-  // ... and the medians take turns: part s waits for the median of part s - 1, the first part for the LAST part of the
-  // previous call (its parts may still be running when calls are enqueued back to back, see ..._enqueue)
-  hipEvent_t token = ctx->sub_last > 0 ? ctx->sub_median[ctx->sub_last - 1] : nullptr;
+  // ... and the medians take turns: part s waits for the median of part s - 1; the first part waits for the LAST part of
+  // the previous call only while that call is un-joined (back-to-back ..._enqueue calls).  After a join the chain starts
+  // afresh: everything earlier is already ordered before sub_begin, and an event recorded before a stream capture began
+  // must not be waited on inside it.
+  hipEvent_t token = (ctx->sub_pending && ctx->sub_last > 0) ? ctx->sub_median[ctx->sub_last - 1] : nullptr;
   for (int s = 0; s < n_streams; ++s) {
     int lo, hi;
     part_range(cfg->n_pairs, s, n_streams, &lo, &hi);
@@ -566,6 +581,9 @@ static int32_t sosvo_frame_pair_batch_streams_impl(sosvo_ctx* ctx, const sosvo_r
       // not overtake them
       (void)hipEventRecord(ctx->sub_done[s], sc->stream);
       for (int k = 0; k <= s; ++k) (void)hipStreamWaitEvent(ctx->stream, ctx->sub_done[k], 0);
+      if (ctx->sub_pending)  // parts of the previous un-joined call beyond s: the caller's stream waits for them as well
+        for (int k = s + 1; k < ctx->sub_last; ++k) (void)hipStreamWaitEvent(ctx->stream, ctx->sub_done[k], 0);
+      ctx->sub_pending = 0;
       return sosvo_fail(ctx, rc, __func__, sc->err);
     }
     token = ctx->sub_median[s];
@@ -573,6 +591,8 @@ static int32_t sosvo_frame_pair_batch_streams_impl(sosvo_ctx* ctx, const sosvo_r
     ws += bytes;
   }
   ctx->sub_last = n_streams;
+  ctx->sub_last_pairs = cfg->n_pairs;
+  ctx->sub_pending = join ? 0 : 1;
   // ... and the caller's stream continues after all of them
   if (join)
     for (int s = 0; s < n_streams; ++s) SOSVO_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->sub_done[s], 0));
@@ -599,6 +619,7 @@ int32_t sosvo_frame_pair_batch_streams_enqueue(sosvo_ctx* ctx, const sosvo_rig* 
 int32_t sosvo_frame_pair_batch_streams_join(sosvo_ctx* ctx) {
   SOSVO_ENTER(ctx);
   for (int s = 0; s < ctx->sub_last; ++s) SOSVO_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->sub_done[s], 0));
+  ctx->sub_pending = 0;
   return SOSVO_OK;
 }
 
