@@ -884,13 +884,11 @@ def main():
                                         "solver and range bin -- the error does not depend on the points' range)"},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "frac_basis": "avg_launch_ms: HIP events around every launch inside the timed region (the contract's "
-                                       "figure; launches share the chip with the other streams' kernels); frac_isolated: the "
-                                       "kernel alone, measured right after the timed region",
+                         "frac_basis": "avg_launch_ms (HIP events in the timed region, chip shared with the other streams); "
+                                       "frac_isolated: the kernel alone",
                          "avg_launch_ms": dom_avg_s * 1e3, "min_launch_ms": dom[1][2], "launches": dom[1][0],
                          "pairs_per_launch": dom_pairs,
-                         "profile_events_in_timed_region": "on (two HIP events per launch; the un-profiled C entry runs at "
-                                                           "c_abi_streams.ratio_to_engine of this rate)",
+                         "profile_events_in_timed_region": "on; un-profiled C entry: sub.c_abi_streams.ratio_to_engine",
                          "isolated_launch_ms": iso_ms, "isolated_launch_ms_shared_hint": iso_hint_ms,
                          "achieved_isolated": b_alg * iso_pairs / (iso_ms * 1e-3) / 1e9 if iso_ms else None,
                          "frac_isolated": b_alg * iso_pairs / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if iso_ms else None,

@@ -48,9 +48,15 @@ __device__ __forceinline__ uint32_t hamming256(const uint4& a0, const uint4& a1,
 //     pitch 272 B: conflict-free ds_read_b128 across the 16-lane groups); B operands (queries): 32 VGPRs per 32-query tile.
 //   accumulator r of lane l is (train row 8 (r / 4) + 4 (l / 32) + r % 4, query column l % 32).
 // Built with -mllvm -amdgpu-mfma-vgpr-form (csrc/Makefile): the accumulators live in VGPRs, no v_accvgpr_read per element.
-// Keep the MFMA sequence branch-free: a first version with a wave-uniform `if` around every MFMA made the compiler
-// shuttle the accumulators between register files around each instruction, and under load (another stream's kernels on
-// the same CUs) ~8 % of the launches returned a wrong key (tests/test_gpu_batch_call.py holds the regression).
+// KEEP THE MFMA SEQUENCE BRANCH-FREE.  A first version with a wave-uniform `if` around every MFMA returned a wrong key in
+// ~8 % of launches under load.  Cause (found from the ISA in round 4): a result of the 8-pass
+// v_mfma_i32_32x32x32_i8 may not be touched by a VALU / LDS / VMEM instruction for 12 wait states, there is no hardware
+// interlock, and ROCm 7.2's hazard recogniser measures that distance wrongly across the if-diamonds conditional MFMAs
+// create (a block first reached through the longer path is not revisited through the shorter one): such forms compile to
+// paths with 6 - 10 wait states instead of 12, taken exactly when a wave's second query tile is dead.  Too few wait
+// states is a timing-dependent stale read -- hence "only under load".  scripts/check_mfma_hazards.py measures every path
+// of this file's ISA itself and tests/test_mfma_isa.py fails the CPU suite when an edit brings such a path (or
+// v_accvgpr moves, or a branch inside an accumulation chain) back.
 constexpr int kMmaTrainTile = 128;                  // trains per LDS tile
 constexpr int kMmaRowPitch = 272;                   // bytes per unpacked train row (256 + 16)
 constexpr int32_t kMmaInvalid7 = 1 << 24;           // base7 of a row without a train
