@@ -69,6 +69,79 @@ def test_annulus_masks_and_bucket_columns():
     assert pn.get_panorama_col_from_azimuth(2 * np.pi - 1e-9) in (0, 1)
 
 
+# ---- the distorted rig: the branches of the forward model the synthetic rig leaves at zero (a3 pinned on them) ----------
+def test_distorted_rig_lut_and_projection_bit_exact():
+    from distorted_rig import D, distorted_rig
+    gs = distorted_rig()
+    assert all(abs(v) > 0 for v in D["top_params"][[0, 1, 3, 4, 5, 8]]) and D["top_params"][6] != D["top_params"][7]
+    for name, m in (("top", gs.top_model), ("bot", gs.bot_model)):
+        pn = m.panorama
+        rows, cols, px, hmax, hmin, circ = D[name + "_pano"]
+        assert (pn.rows, pn.cols) == (int(rows), int(cols))
+        assert pn.pixel_size == px and pn.cyl_height_max == hmax and pn.z_height_min == hmin and pn.cyl_circumference == circ
+        assert np.array_equal([m.lowest_elevation_angle, m.highest_elevation_angle, m.globally_lowest_elevation_angle,
+                               m.globally_highest_elevation_angle], D[name + "_elev"])
+        sel = D[name + "_lut_rows"]
+        lx, ly = np.asarray(pn.world2cam_LUT_map_x), np.asarray(pn.world2cam_LUT_map_y)
+        assert np.array_equal(lx[sel], D[name + "_lut_x"], equal_nan=True)
+        assert np.array_equal(ly[sel], D[name + "_lut_y"], equal_nan=True)
+        assert int(np.isnan(lx).sum()) == int(D[name + "_lut_nan_count"][0])
+        assert np.array_equal(np.flatnonzero(np.isnan(lx).any(axis=1)), D[name + "_lut_nan_rows"])
+        for tag, arr in (("x", lx), ("y", ly)):      # EVERY entry of the float32 maps, through two sums
+            f32 = arr.astype(np.float32)
+            w = (np.arange(f32.size, dtype=np.float64).reshape(f32.shape) % 8191.0) + 1.0
+            assert np.nansum(f32, dtype=np.float64) == D[name + "_lut_%s_f32_sum" % tag][0]
+            assert np.nansum(f32.astype(np.float64) * w) == D[name + "_lut_%s_f32_wsum" % tag][0]
+        P = np.ones((1, D["proj_points_wrt_C"].shape[0], 4))
+        P[0, :, :3] = D["proj_points_wrt_C"]
+        u, v, _ = m.get_pixel_from_3D_point_wrt_C(P)
+        assert np.array_equal(np.stack([u.reshape(-1), v.reshape(-1)], axis=1), D["proj_uv_" + name])
+        assert np.array_equal(m.T_model_wrt_C, D[name + "_T_model_wrt_C"])
+    # the same arrays would NOT come out with the distortion-free model: the fixture does exercise the branch
+    m = gs.top_model
+    m.precalib_params.k1 = 0.0
+    u0, _, _ = m.get_pixel_from_3D_point_wrt_C(P)
+    assert np.abs(u0.reshape(-1) - D["proj_uv_top"][:, 0]).max() > 0.05
+
+
+def test_distorted_rig_angles_bearings_gates():
+    from distorted_rig import D, distorted_rig
+    from vo_single_camera_sos_amd.omnistereo.common_cv import filter_pixel_correspondences
+    gs = distorted_rig()
+    for name, m in (("top", gs.top_model), ("bot", gs.bot_model)):
+        az, el = m.panorama.get_direction_angles_from_pixel_pano(D["m_" + name], use_LUTs=False)
+        assert np.array_equal(az, D["az_" + name], equal_nan=True) and np.array_equal(el, D["el_" + name], equal_nan=True)
+        b = m.get_3D_point_from_angles_wrt_focus(azimuth=az, elevation=el)[0]
+        assert np.array_equal(b, D["bearing_" + name], equal_nan=True)
+    st = filter_pixel_correspondences(matched_points_top=D["m_top"][:, :2], matched_points_bot=D["m_bot"][:, :2],
+                                      min_rectified_disparity=1, max_horizontal_diff=2.5)
+    assert np.array_equal(st, D["gate_stereo"])
+
+
+def test_distorted_rig_masks_use_each_circle_s_own_centre_and_json_round_trip(tmp_path):
+    from distorted_rig import D, distorted_rig
+    from vo_single_camera_sos_amd.omnistereo.gum import GUM, load_gums_json, save_gums_json
+    gs = distorted_rig()
+    top, bot = gs.make_annulus_masks((480, 640))
+    t, b = gs.top_model, gs.bot_model
+    assert not np.array_equal(t.center_point_inner, t.center_point_outer)
+    want_top = GUM._disc((480, 640), t.center_point_outer, 226) & ~GUM._disc((480, 640), t.center_point_inner, 113) & \
+        ~GUM._disc((480, 640), b.center_point_outer, 101)
+    want_bot = GUM._disc((480, 640), b.center_point_outer, 101) & GUM._disc((480, 640), b.center_point_inner, 113) & \
+        ~GUM._disc((480, 640), b.center_point_inner, 50)
+    assert np.array_equal(top > 0, want_top) and np.array_equal(bot > 0, want_bot)
+    one_centre = GUM._disc((480, 640), t.center_point, 226) & ~GUM._disc((480, 640), t.center_point, 113)
+    assert not np.array_equal(top > 0, one_centre)
+    f = str(tmp_path / "rig.json")
+    save_gums_json(gs, f)
+    back = load_gums_json(f)
+    for a, c in ((gs.top_model, back.top_model), (gs.bot_model, back.bot_model)):
+        assert np.array_equal(a.center_point_inner, c.center_point_inner) and np.array_equal(a.center_point_outer, c.center_point_outer)
+        assert np.array_equal(a.panorama.world2cam_LUT_map_x, c.panorama.world2cam_LUT_map_x, equal_nan=True)
+    m2 = back.make_annulus_masks((480, 640))
+    assert np.array_equal(m2[0], top) and np.array_equal(m2[1], bot)
+
+
 # ---- the per-frame API mirrors (camera_models / common_cv / pose_est_tools / pyopengv) ---------------------
 def test_filter_pixel_correspondences_matches_reference_gates():
     from vo_single_camera_sos_amd.omnistereo.common_cv import filter_pixel_correspondences

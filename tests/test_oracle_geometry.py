@@ -113,3 +113,32 @@ def test_trig_core_against_the_host_math_library():
     for got, want in ((s, np.sin(x)), (c, np.cos(x)), (a, np.arctan(x))):
         assert np.all(np.abs(got - want) <= np.spacing(np.abs(want))), np.abs(got - want).max()
     assert s[-5] == np.sin(np.pi) and s[-4] == np.sin(2 * np.pi) and c[-3] == np.cos(np.pi / 2)
+
+
+def test_unwrap_lut_and_geometry_on_the_distorted_rig():
+    """tests/golden/geometry_distorted.npz (reference-generated): k1..k3, xi1, xi2, alpha_c non-zero, gamma1 != gamma2,
+    off-centre principal point -- the branch of orc_unwrap_lut the first fixture leaves at zero."""
+    D = np.load(os.path.join(os.path.dirname(__file__), "golden", "geometry_distorted.npz"))
+    for name in ("top", "bot"):
+        rows, cols, px, hmax, hmin, _ = D[name + "_pano"]
+        lo, hi = D[name + "_elev"][:2]
+        mx, my = oracle.unwrap_lut(D[name + "_params"], int(cols), int(rows), px, hmax, hmin, lo, hi)
+        sel = D[name + "_lut_rows"]
+        assert np.array_equal(np.isnan(mx[sel]), np.isnan(D[name + "_lut_x"]))
+        assert np.allclose(mx[sel], D[name + "_lut_x"], equal_nan=True, rtol=0, atol=1e-4)   # (float32 sinf / cosf, as above)
+        assert np.allclose(my[sel], D[name + "_lut_y"], equal_nan=True, rtol=0, atol=1e-4)
+        assert int(np.isnan(mx).sum()) == int(D[name + "_lut_nan_count"][0])
+        assert np.array_equal(np.flatnonzero(np.isnan(mx).any(axis=1)), D[name + "_lut_nan_rows"])
+        for tag, arr in (("x", mx), ("y", my)):
+            assert np.isclose(np.nansum(arr.astype(np.float32), dtype=np.float64), D[name + "_lut_%s_f32_sum" % tag][0], rtol=1e-7)
+        pano = (int(cols), int(rows), px, hmax)
+        az, el = oracle.pano_to_angles(D["m_" + name][:, 0], D["m_" + name][:, 1], *pano)
+        assert np.array_equal(np.isnan(az), np.isnan(D["az_" + name])) and np.array_equal(np.isnan(el), np.isnan(D["el_" + name]))
+        assert np.allclose(az, D["az_" + name], equal_nan=True, **RT) and np.allclose(el, D["el_" + name], equal_nan=True, **RT)
+        assert np.allclose(oracle.angles_to_bearing(az, el), D["bearing_" + name][:, :3], equal_nan=True, **RT)
+    X = oracle.triangulate_midpoint(D["az_top"], D["el_top"], D["az_bot"], D["el_bot"], D["top_F"], D["bot_F"])
+    want = D["tri_X_homo"]
+    assert np.array_equal(np.isnan(X).any(1), np.isnan(want[:, :3]).any(1))
+    assert np.allclose(X, want[:, :3], equal_nan=True, rtol=1e-9, atol=1e-7)
+    assert np.array_equal(oracle.range_filter_homo(X, 500.0, 7000.0), D["range_ok_500_7000"])
+    assert np.array_equal(oracle.pixel_gates(D["m_top"][:, :2], D["m_bot"][:, :2], 1, 2.5), D["gate_stereo"])

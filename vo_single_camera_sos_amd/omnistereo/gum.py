@@ -75,7 +75,11 @@ class GUM(object):
     mirror, -1 for the bottom one (gum.py:335-341)."""
 
     def __init__(self, params, z_axis, F, lowest_elevation_angle, highest_elevation_angle, inner_img_radius,
-                 outer_img_radius, center_point=None, image_size=(640, 480), mirror_name="", units="mm"):
+                 outer_img_radius, center_point=None, image_size=(640, 480), mirror_name="", units="mm",
+                 center_point_inner=None, center_point_outer=None):
+        """center_point: centre the radial limits were measured from (default: the principal point);
+        center_point_inner / center_point_outer: centres of the inner and the outer circle of the mirror's annulus mask
+        (camera_models.py:972-988, :1556-1557: a calibrated rig has one pair per mirror; default: center_point)."""
         self.precalib_params = params
         self.z_axis = float(z_axis)
         self.mirror_name = mirror_name or ("top" if z_axis > 0 else "bottom")
@@ -90,6 +94,9 @@ class GUM(object):
         self.inner_img_radius, self.outer_img_radius = inner_img_radius, outer_img_radius
         c = (params.u_center, params.v_center) if center_point is None else center_point
         self.center_point = np.asarray(c, dtype=np.float64)
+        self.center_point_inner = np.asarray(self.center_point if center_point_inner is None else center_point_inner, dtype=np.float64)
+        self.center_point_outer = np.asarray(self.center_point if center_point_outer is None else center_point_outer, dtype=np.float64)
+        params.center_point_inner, params.center_point_outer = self.center_point_inner, self.center_point_outer   # where the reference keeps them
         self.T_model_wrt_C = np.identity(4)
         self.T_C_wrt_model = np.identity(4)
         self.set_pose(self.F[:3, 0], np.identity(3))
@@ -179,9 +186,9 @@ class GUM(object):
     def make_mask(self, mask_shape, radius_pixel_shrinking=0):
         r_in = self.inner_img_radius + radius_pixel_shrinking
         r_out = self.outer_img_radius - radius_pixel_shrinking
-        m = self._disc(mask_shape, self.center_point, r_out)
+        m = self._disc(mask_shape, self.center_point_outer, r_out)     # camera_models.py:1556-1567
         if r_in > 0:
-            m &= ~self._disc(mask_shape, self.center_point, r_in)
+            m &= ~self._disc(mask_shape, self.center_point_inner, r_in)
         return m.astype(np.uint8) * 255
 
 
@@ -353,13 +360,14 @@ class GUMStereo(object):
         """camera_models.py:2944-2988: top = outer disc minus inner disc minus the bottom mirror's outer disc;
         bottom = its outer disc intersected with the top mirror's inner disc, minus its own inner disc."""
         t, b = self.top_model, self.bot_model
-        top = GUM._disc(shape, t.center_point, t.outer_img_radius)
+        # circle centres exactly as the reference picks them (:2946-2957, :2966-2983): each mirror's own inner / outer centre
+        top = GUM._disc(shape, t.center_point_outer, t.outer_img_radius)
         if t.inner_img_radius > 0:
-            top &= ~GUM._disc(shape, t.center_point, t.inner_img_radius)
+            top &= ~GUM._disc(shape, t.center_point_inner, t.inner_img_radius)
             if b.outer_img_radius > 0:
-                top &= ~GUM._disc(shape, b.center_point, b.outer_img_radius)
-        bot = GUM._disc(shape, b.center_point, b.outer_img_radius) & GUM._disc(shape, b.center_point, t.inner_img_radius)
-        bot &= ~GUM._disc(shape, b.center_point, b.inner_img_radius)
+                top &= ~GUM._disc(shape, b.center_point_outer, b.outer_img_radius)
+        bot = GUM._disc(shape, b.center_point_outer, b.outer_img_radius) & GUM._disc(shape, b.center_point_inner, t.inner_img_radius)
+        bot &= ~GUM._disc(shape, b.center_point_inner, b.inner_img_radius)
         t.mask, b.mask = top.astype(np.uint8) * 255, bot.astype(np.uint8) * 255
         self.construct_new_mask = False
         return t.mask, b.mask
@@ -395,7 +403,8 @@ def gums_to_dict(gums):
         d.update(z_axis=m.z_axis, F=[float(v) for v in m.F[:3, 0]], lowest_elevation_angle=m.lowest_elevation_angle,
                  highest_elevation_angle=m.highest_elevation_angle, inner_img_radius=float(m.inner_img_radius),
                  outer_img_radius=float(m.outer_img_radius), center_point=[float(v) for v in m.center_point],
-                 image_size=[int(v) for v in m.image_size])
+                 center_point_inner=[float(v) for v in m.center_point_inner],
+                 center_point_outer=[float(v) for v in m.center_point_outer], image_size=[int(v) for v in m.image_size])
         return d
     width = gums.top_model.panorama.cols if gums.top_model.panorama is not None else 1200
     return dict(format="sosvo-gums-1", units=gums.units, panorama_width=int(width), top=mirror(gums.top_model),
@@ -411,7 +420,8 @@ def gums_from_dict(d, with_panoramas=True):
         params = GUMParams(**{k: m[k] for k in _PARAM_FIELDS})
         return GUM(params, m["z_axis"], m["F"], m["lowest_elevation_angle"], m["highest_elevation_angle"],
                    m["inner_img_radius"], m["outer_img_radius"], center_point=m["center_point"],
-                   image_size=tuple(m["image_size"]), units=d["units"])
+                   image_size=tuple(m["image_size"]), units=d["units"], center_point_inner=m.get("center_point_inner"),
+                   center_point_outer=m.get("center_point_outer"))   # (optional keys: older documents have one centre)
     gums = GUMStereo(mirror(d["top"]), mirror(d["bottom"]), units=d["units"])
     if with_panoramas:
         for m in (gums.top_model, gums.bot_model):

@@ -8,13 +8,24 @@ import numpy as np
 
 
 def lift_pixels(model, u, v):
-    """Omni pixels -> unit viewing directions in the mirror frame (distortion-free GUM only).
-    Inverse of GUM.get_pixel_from_3D_point_wrt_M: q = Ps - Cp = lambda * (x, y, sigma), |Ps| = 1."""
+    """Omni pixels -> unit viewing directions in the mirror frame.
+    Inverse of GUM.get_pixel_from_3D_point_wrt_M: q = Ps - Cp = lambda * (x, y, sigma), |Ps| = 1; the radial polynomial
+    rho_d = rho_u (1 + k1 rho_u^2 + k2 rho_u^4 + k3 rho_u^6) is inverted by Newton's method (to 1e-15 in a few steps for
+    the mild distortions of a calibrated mirror)."""
     p = model.precalib_params
-    if p.use_distortion and (p.k1 or p.k2 or p.k3):
-        raise NotImplementedError("closed-form lifting needs k1 = k2 = k3 = 0")
     y = (v - p.v_center) / p.gamma2
     x = (u - p.u_center - p.gamma1 * p.alpha_c * y) / p.gamma1
+    if p.use_distortion and (p.k1 or p.k2 or p.k3):
+        rd = np.sqrt(x * x + y * y)
+        ru = rd.copy()
+        for _ in range(30):
+            r2 = ru * ru
+            f = ru * (1.0 + r2 * (p.k1 + r2 * (p.k2 + r2 * p.k3))) - rd
+            df = 1.0 + r2 * (3.0 * p.k1 + r2 * (5.0 * p.k2 + r2 * 7.0 * p.k3))
+            ru = ru - f / df
+        with np.errstate(divide="ignore", invalid="ignore"):
+            sc = np.where(rd > 0, ru / rd, 1.0)
+        x, y = x * sc, y * sc
     sigma = -1.0 if p.xi3 > 0 else 1.0  # sign of (Ps_z - xi3) for the visible half
     d = np.stack([x, y, np.full_like(x, sigma)], axis=-1)
     cp = np.array([p.xi1, p.xi2, p.xi3])
