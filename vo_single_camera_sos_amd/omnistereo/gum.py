@@ -96,7 +96,9 @@ class GUM(object):
         self.center_point = np.asarray(c, dtype=np.float64)
         self.center_point_inner = np.asarray(self.center_point if center_point_inner is None else center_point_inner, dtype=np.float64)
         self.center_point_outer = np.asarray(self.center_point if center_point_outer is None else center_point_outer, dtype=np.float64)
-        params.center_point_inner, params.center_point_outer = self.center_point_inner, self.center_point_outer   # where the reference keeps them
+        # (the reference keeps them on the parameter object, camera_models.py:972-988; plain tuples here)
+        params.center_point_inner = tuple(float(v) for v in self.center_point_inner)
+        params.center_point_outer = tuple(float(v) for v in self.center_point_outer)
         self.T_model_wrt_C = np.identity(4)
         self.T_C_wrt_model = np.identity(4)
         self.set_pose(self.F[:3, 0], np.identity(3))
