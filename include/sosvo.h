@@ -53,6 +53,14 @@ typedef enum {
 /* Version of this ABI (bumped on any signature change). */
 int32_t sosvo_abi_version(void);
 
+/* The descriptor test pattern cv2.ORB_create(...).compute uses (omnistereo/camera_models.py:1682, :1765;
+ * pose_est_tools.py:520, :553): OpenCV's learned table bit_pattern_31_, 256 tests x (x0, y0, x1, y1) = [512, 2] int8
+ * points, |coordinate| <= 13, written to HOST memory (1024 bytes).  It is the `pattern` argument of sosvo_describe_orb*,
+ * sosvo_detect_orb* and the batch entry points (which take it in device memory: copy it once).  Any other [512, 2] table
+ * with |coordinate| <= 16 is accepted there too (the Python package keeps a seeded one as `orb_pattern.seeded_pattern()`).
+ * No context needed. */
+int32_t sosvo_orb_bit_pattern_31(int8_t* pattern_host);
+
 /* Create a context on `device`; `stream` is a hipStream_t (0 = the null stream; pass
  * torch.cuda.current_stream().cuda_stream to order with torch work). */
 int32_t sosvo_create(sosvo_ctx** out, int32_t device, void* stream);

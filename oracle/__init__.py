@@ -425,6 +425,14 @@ def gauss7(gray):
 
 
 def orb_pattern():
+    """The default descriptor pattern: OpenCV's bit_pattern_31_ ([512, 2] int8, test t compares points 2t and 2t + 1)."""
+    pts = np.empty((512, 2), dtype=np.int8)
+    lib().orc_orb_pattern_opencv(_p(pts))
+    return pts
+
+
+def orb_pattern_seeded():
+    """The seeded pattern of rounds 1-3 (|coordinate| <= 12)."""
     pts = np.empty((512, 2), dtype=np.int8)
     lib().orc_orb_pattern(_p(pts))
     return pts

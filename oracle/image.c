@@ -22,8 +22,9 @@
  *          distance on a cell grid, stop at maxCorners;
  *   ORB.compute on provided keypoints: drop keypoints within 31 px of the border, 7x7 sigma=2 Gaussian,
  *          256 pair tests on offsets rotated by the keypoint angle and rounded, 8 tests per byte, LSB first.
- * Documented deviations (DESIGN.md "Image stages"): (1) OpenCV's learned 256-pair ORB pattern is data we
- * cannot obtain offline: the pattern here is our own seeded one (orc_orb_pattern).  (2) The float32
+ * Documented deviations (DESIGN.md "Image stages"): (1) closed in round 4: the default test pattern IS OpenCV's learned
+ * 256-pair table (orc_orb_pattern_opencv, oracle/orb_bit_pattern_31.h, generated from the data file the product ships);
+ * the seeded table of rounds 1-3 stays as orc_orb_pattern.  (2) The float32
  * evaluation order of the eigenvalue map and the 8.8 fixed-point Gaussian are OUR definitions (OpenCV's
  * differ in rounding details by version).  (3) The annulus masks are x^2 + y^2 <= r^2 discs built on the
  * host, not OpenCV's circle rasteriser.
@@ -297,7 +298,12 @@ void orc_gauss7(const uint8_t* gray, int32_t rows, int32_t cols, uint8_t* out) {
   free(tmp);
 }
 
-/* ---- K6b: the 256 test pairs (our own seeded pattern, see the header) -----------------------------
+/* ---- K6b: the 256 test pairs ----------------------------------------------------------------------
+ * default: OpenCV's bit_pattern_31_ */
+#include "orb_bit_pattern_31.h"
+void orc_orb_pattern_opencv(int8_t* pts /* [512][2] */) { memcpy(pts, orc_orb_bit_pattern_31, 1024); }
+
+/* the seeded pattern of rounds 1-3 (kept as an option) ------------------------------------------------
  * 512 points (x, y) as int8, |x|, |y| <= 12: sum of three uniform draws in [-4, 4] (bell-shaped, as the
  * BRIEF paper recommends), drawn from a splitmix64 stream with a fixed seed. */
 void orc_orb_pattern(int8_t* pts /* [512][2] */) {

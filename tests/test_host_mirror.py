@@ -52,7 +52,10 @@ def test_pixel_to_angles_bearings_and_projection():
 def test_product_orb_pattern_equals_oracle_pattern():
     import oracle
     from vo_single_camera_sos_amd import orb_pattern
-    assert np.array_equal(orb_pattern.orb_pattern(), oracle.orb_pattern())
+    assert np.array_equal(orb_pattern.orb_pattern(), oracle.orb_pattern())                 # OpenCV's table on both sides
+    assert np.array_equal(orb_pattern.seeded_pattern(), oracle.orb_pattern_seeded())
+    assert np.array_equal(orb_pattern.orb_pattern("seeded"), orb_pattern.seeded_pattern())
+    assert not np.array_equal(orb_pattern.orb_pattern(), orb_pattern.seeded_pattern())
     ca, sa = orb_pattern.angle_cos_sin(-1.0)
     assert ca.dtype == np.float32 and np.isclose(ca, np.cos(np.deg2rad(1.0))) and sa < 0
 

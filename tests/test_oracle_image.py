@@ -115,10 +115,17 @@ def test_gauss7_is_normalised_and_symmetric():
 
 
 def test_orb_pattern_and_descriptor_bits():
+    seeded = oracle.orb_pattern_seeded()
+    assert seeded.shape == (512, 2) and np.abs(seeded).max() <= 12
+    assert np.array_equal(seeded, oracle.orb_pattern_seeded())             # deterministic
+    sp = seeded.reshape(256, 4)
+    assert not np.any((sp[:, 0] == sp[:, 2]) & (sp[:, 1] == sp[:, 3]))
+    # the default: OpenCV's bit_pattern_31_ (known first / last rows of that table, |coordinate| <= 13)
     pat = oracle.orb_pattern()
-    assert pat.shape == (512, 2) and np.abs(pat).max() <= 12
-    assert np.array_equal(pat, oracle.orb_pattern())                       # deterministic
     pairs = pat.reshape(256, 4)
+    assert pat.shape == (512, 2) and pat.dtype == np.int8 and np.abs(pat).max() == 13
+    assert pairs[:4].tolist() == [[8, -3, 9, 5], [4, 2, 7, -12], [-11, 9, -8, 2], [7, -12, 12, -13]]
+    assert pairs[-1].tolist() == [-1, -6, 0, -11]
     assert not np.any((pairs[:, 0] == pairs[:, 2]) & (pairs[:, 1] == pairs[:, 3]))
     rng = np.random.default_rng(4)
     img = rng.integers(0, 256, (100, 120), dtype=np.uint8)

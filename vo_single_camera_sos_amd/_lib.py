@@ -34,6 +34,7 @@ class SosvoError(RuntimeError):
 # name -> (restype, argtypes); must list every function of include/sosvo.h (tested).
 SIGNATURES = {
     "sosvo_abi_version": (c_i32, []),
+    "sosvo_orb_bit_pattern_31": (c_i32, [c_p]),
     "sosvo_create": (c_i32, [ctypes.POINTER(c_p), c_i32, c_p]),
     "sosvo_destroy": (c_i32, [c_p]),
     "sosvo_set_stream": (c_i32, [c_p, c_p]),

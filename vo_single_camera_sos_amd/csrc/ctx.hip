@@ -1,11 +1,18 @@
 // Context, error reporting and the HIP-event timer of libsosvo.so.
 #include "common.h"
+#include "orb_bit_pattern_31.h"
 
 #include <stdlib.h>
 
 extern "C" {
 
 int32_t sosvo_abi_version(void) { return 1; }
+
+int32_t sosvo_orb_bit_pattern_31(int8_t* pattern_host) {
+  if (!pattern_host) return SOSVO_ERR_ARG;
+  memcpy(pattern_host, sosvo_orb_bit_pattern_31_table, 1024);
+  return SOSVO_OK;
+}
 
 int32_t sosvo_create(sosvo_ctx** out, int32_t device, void* stream) {
   if (!out) return SOSVO_ERR_ARG;

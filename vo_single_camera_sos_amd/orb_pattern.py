@@ -1,11 +1,15 @@
-"""The 256 BRIEF test pairs used by libsosvo's descriptor kernel (K6).
+"""The 256 BRIEF test pairs used by libsosvo's descriptor kernels (K6).
 
-OpenCV's ORB ships a learned 256-pair table (`bit_pattern_31_`); that table is data of a third-party
-library that is not in the reference tree and cannot be obtained offline, so this package defines its
-own fixed pattern: 512 points (x, y), each coordinate the sum of three uniform draws in [-4, 4]
-(bell-shaped as the BRIEF paper recommends, |coordinate| <= 12 so the patch rotated by any angle stays
-inside the 31-px border that ORB.compute enforces), drawn from a splitmix64 stream with a fixed seed.
-Descriptors are therefore comparable among themselves (all the VO path needs) but not with OpenCV's."""
+Default (round 4): OpenCV's learned table `bit_pattern_31_` -- what `cv2.ORB_create(...).compute` uses at the
+reference's call sites (omnistereo/camera_models.py:1682, :1765; pose_est_tools.py:520, :553).  It is third-party DATA
+(3-clause BSD), shipped as data/orb_bit_pattern_31.txt (taken from scikit-image's copy; the file's header says how) and
+also exported by the C ABI (`sosvo_orb_bit_pattern_31`).  |coordinate| <= 13: rotated by any angle a test point stays
+within 19 px of the keypoint, inside the 31-px border ORB.compute enforces.
+
+`seeded_pattern()` is the table rounds 1-3 used while OpenCV's was thought unobtainable: 512 points, each coordinate
+the sum of three uniform draws in [-4, 4] from a splitmix64 stream with a fixed seed (|coordinate| <= 12)."""
+import os
+
 import numpy as np
 
 _MASK = (1 << 64) - 1
@@ -24,8 +28,32 @@ def _splitmix_stream(seed):
         yield z
 
 
-def orb_pattern():
-    """-> int8 array [512, 2]: test t compares points 2t and 2t+1."""
+_OPENCV = None
+
+
+def opencv_pattern():
+    """-> int8 array [512, 2]: OpenCV's bit_pattern_31_; test t compares points 2t and 2t+1."""
+    global _OPENCV
+    if _OPENCV is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "orb_bit_pattern_31.txt")
+        rows = np.loadtxt(path, dtype=np.int64, comments="#")
+        if rows.shape != (256, 4) or np.abs(rows).max() > 13:
+            raise ValueError("%s: not the 256 x 4 table" % path)
+        _OPENCV = np.ascontiguousarray(rows.reshape(512, 2).astype(np.int8))
+    return _OPENCV.copy()
+
+
+def orb_pattern(kind="opencv"):
+    """The descriptor pattern the package hands to libsosvo: "opencv" (default) or "seeded"."""
+    if kind == "opencv":
+        return opencv_pattern()
+    if kind == "seeded":
+        return seeded_pattern()
+    raise ValueError("unknown pattern %r" % (kind,))
+
+
+def seeded_pattern():
+    """-> int8 array [512, 2]: the seeded table of rounds 1-3; test t compares points 2t and 2t+1."""
     gen = _splitmix_stream(0x0B5EED5EED5EED01)
     flat = np.empty(1024, dtype=np.int8)
     for i in range(1024):
