@@ -1,0 +1,93 @@
+"""GPU: the HIP path itself (through the C ABI), NOT the oracle, against independent third-party implementations on real
+photographs -- scikit-image 0.18.3 + scipy 1.7.1, fixtures tests/golden/thirdparty_*.npz written in the build container by
+tests/golden/make_thirdparty_fixtures.py.  Bit-exact on every byte / index:
+  sosvo_median_gray      == scipy.ndimage.median_filter per channel (replicated border) + the documented gray formula
+  sosvo_detect_fast      keypoints lie in skimage.feature.corner_fast's FAST-9 corner set and cover its components
+  sosvo_match_hamming    1-NN / 2-NN keys == skimage.feature.match_descriptors / scipy cdist on skimage ORB descriptors
+  sosvo_unwrap           == round-half-up of scipy's exact bilinear value on the 1/32-pixel grid, border taps 0
+These are not OpenCV binaries (K1-K7 stay "parity unpinned" against those)."""
+import numpy as np
+import pytest
+import torch
+
+import thirdparty as tp
+
+pytestmark = pytest.mark.gpu
+
+
+def _to(dev, *arrs):
+    return [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in arrs]
+
+
+def test_median_gray_equals_scipy_on_photographs(ctx):
+    for tag, k, img, want in tp.median_cases():
+        (t,) = _to(ctx.device, img[None])
+        got = ctx.median_gray(t, k)
+        ctx.synchronize()
+        assert np.array_equal(got.cpu().numpy()[0], want), (tag, k)
+
+
+def test_fused_unwrap_median_equals_scipy_chain(ctx):
+    """K1 + K2 + K3 in ONE kernel (the batched path's form) on a photograph: identity-like maps on the 1/32 grid, so the
+    expected panorama is scipy's rounded bilinear value and the expected gray scipy's median of it -- composed here from the
+    third-party pieces only."""
+    import scipy.ndimage as ndi
+    W = tp.load("warp")
+    img = W["img"]
+    H, Wd = img.shape[:2]
+    rows, cols = 64, 96
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    mx = (xx * 1.25 + 3.0 + (yy % 4) / 32.0).astype(np.float32)
+    my = (yy * 1.375 + 2.0 + (xx % 8) / 32.0).astype(np.float32)
+    assert mx.max() < Wd - 1 and my.max() < H - 1
+    pano = np.stack([np.floor(ndi.map_coordinates(img[..., c].astype(np.float64), [my.astype(np.float64), mx.astype(np.float64)],
+                                                  order=1, mode="nearest", prefilter=False) + 0.5) for c in range(3)], axis=-1).astype(np.uint8)
+    med = np.stack([ndi.median_filter(pano[..., c], size=11, mode="nearest") for c in range(3)], axis=-1)
+    want = tp.gray_of(med)
+    t_omni, t_mx, t_my = _to(ctx.device, img[None], np.stack([mx, mx]), np.stack([my, my]))
+    table = ctx.unwrap_prepare(None, t_mx, t_my, (H, Wd))
+    got = ctx.unwrap_median_gray(t_omni, table, 11)
+    ctx.synchronize()
+    got = got.cpu().numpy().reshape(2, rows, cols)
+    assert np.array_equal(got[0], want) and np.array_equal(got[1], want)
+
+
+@pytest.mark.parametrize("tag,thr,gray,corners", tp.fast_cases(), ids=lambda v: str(v) if isinstance(v, (str, int)) else "")
+def test_fast_keypoints_against_skimage_corner_set(ctx, tag, thr, gray, corners):
+    bits = np.ones((1,) + gray.shape, dtype=np.uint32)
+    t_gray, t_bits = _to(ctx.device, gray[None], bits)
+    kp, n, status = ctx.detect_fast(t_gray, t_bits, 1, 1, 16384, threshold=thr)
+    ctx.synchronize()
+    n = int(n.cpu().numpy()[0])
+    assert int(status.cpu().numpy()[0]) == 0 and n > 20
+    count, ncomp, empty = tp.check_fast_keypoints(kp.cpu().numpy()[0, :n], corners)
+    assert ncomp >= count * 0.5
+
+
+@pytest.mark.parametrize("tag,q,t,idx,dist", tp.hamming_cases(), ids=lambda v: v if isinstance(v, str) else "")
+def test_hamming_keys_equal_skimage_match_descriptors(ctx, tag, q, t, idx, dist):
+    from vo_single_camera_sos_amd import _lib
+    t_q, t_t = _to(ctx.device, q[None], t[None])
+    nq = torch.tensor([q.shape[0]], dtype=torch.int32, device=ctx.device)
+    nt = torch.tensor([t.shape[0]], dtype=torch.int32, device=ctx.device)
+    k1 = ctx.match_hamming(t_q, t_t, nq, nt, k=1)
+    k2 = ctx.match_hamming(t_q, t_t, nq, nt, k=2)
+    ctx.synchronize()
+    assert np.array_equal(k1.cpu().numpy()[0, :, 0], tp.keys_of(idx[:, 0], dist[:, 0], _lib.KEY_SHIFT))
+    assert np.array_equal(k2.cpu().numpy()[0], tp.keys_of(idx, dist, _lib.KEY_SHIFT))
+    # the stable sort by distance (sorted(matches, key=distance), camera_models.py:444) against numpy's stable argsort
+    order = ctx.sort_matches(k1, nq)
+    ctx.synchronize()
+    assert np.array_equal(order.cpu().numpy()[0, : q.shape[0]], np.argsort(dist[:, 0], kind="stable"))
+
+
+def test_unwrap_equals_scipy_bilinear_on_the_32nd_pixel_grid(ctx):
+    W = tp.load("warp")
+    img, mx, my = W["img"], W["map_x"], W["map_y"]
+    t_omni, t_mx, t_my = _to(ctx.device, img[None], np.stack([mx, mx[::-1]]), np.stack([my, my[::-1]]))   # two "views"
+    pano = ctx.unwrap(t_omni, None, t_mx, t_my)
+    table = ctx.unwrap_prepare(None, t_mx, t_my, img.shape[:2])
+    pano_t = ctx.unwrap_table(t_omni, table)
+    ctx.synchronize()
+    for got in (pano.cpu().numpy(), pano_t.cpu().numpy()):
+        assert np.array_equal(got[0, 0], W["bilinear_rounded"]) and np.array_equal(got[1, 0], W["bilinear_rounded"][::-1])

@@ -1,0 +1,45 @@
+"""CPU: the ORACLE's image / matching stages against independent third-party implementations on real photographs
+(scikit-image + scipy, tests/golden/thirdparty_*.npz; tests/golden/make_thirdparty_fixtures.py).  Until round 4 these
+stages were checked against hand-made known answers only; every expectation here comes from code that shares nothing with
+oracle/*.c.  (Not OpenCV binaries: K1-K7 stay "parity unpinned" against those; the semantics are OpenCV's documented ones.)"""
+import numpy as np
+import pytest
+
+import oracle
+import refflow
+import thirdparty as tp
+
+
+@pytest.mark.parametrize("tag,k,img,want", tp.median_cases(), ids=lambda v: str(v) if isinstance(v, (str, int)) else "")
+def test_median_gray_equals_scipy_median_filter(tag, k, img, want):
+    assert np.array_equal(oracle.median_gray(img, k), want)
+
+
+@pytest.mark.parametrize("tag,thr,gray,corners", tp.fast_cases(), ids=lambda v: str(v) if isinstance(v, (str, int)) else "")
+def test_fast9_corner_set_equals_skimage_corner_fast(tag, thr, gray, corners):
+    score = oracle.fast_score_map(gray, thr)
+    mine = score > 0
+    b = 3
+    assert np.array_equal(mine[b:-b, b:-b], corners[b:-b, b:-b])          # the corner SET, pixel for pixel
+    assert not mine[:b].any() and not mine[-b:].any() and not mine[:, :b].any() and not mine[:, -b:].any()
+    bits = np.ones(gray.shape, dtype=np.uint32)
+    kp = refflow.fast_keypoints(gray, bits, 0, thr)
+    n, ncomp, empty = tp.check_fast_keypoints(kp, corners, score=score)
+    assert n > 20 and ncomp >= n * 0.5
+
+
+@pytest.mark.parametrize("tag,q,t,idx,dist", tp.hamming_cases(), ids=lambda v: v if isinstance(v, str) else "")
+def test_hamming_nearest_neighbours_equal_skimage_and_scipy(tag, q, t, idx, dist):
+    assert q.shape[0] > 300 and t.shape[0] > 300
+    assert np.array_equal(oracle.match_hamming(q, t, k=1)[:, 0], tp.keys_of(idx[:, 0], dist[:, 0]))
+    assert np.array_equal(oracle.match_hamming(q, t, k=2), tp.keys_of(idx, dist))
+    assert (dist[:, 0] == dist[:, 1]).sum() >= 0 and dist.max() <= 256
+
+
+def test_remap_on_the_32nd_pixel_grid_equals_scipy_bilinear():
+    W = tp.load("warp")
+    img, mx, my = W["img"], W["map_x"], W["map_y"]
+    assert np.array_equal(mx * 32, np.rint(mx * 32)) and (~W["inside"]).sum() > 100
+    got = oracle.unwrap(img, None, mx, my)
+    assert np.array_equal(got, W["bilinear_rounded"])
+    assert np.abs(got.astype(np.float64) - W["bilinear_exact"]).max() <= 0.5
