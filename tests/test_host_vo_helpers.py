@@ -112,6 +112,96 @@ def test_rig_json_round_trip():
         gums_from_dict({"format": "pickle"})
 
 
+def _load_exporter():
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("export_reference_gums", os.path.join(root, "scripts", "export_reference_gums.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_reference_side_export_of_a_calibrated_rig(tmp_path):
+    """scripts/export_reference_gums.py (INTEGRATION.md "Bringing a calibrated rig over") on an object that carries the
+    REFERENCE's attribute names (gum.py:77-116, :169-214; camera_models.py:884-936, :972-988) with the numbers of the
+    reference-generated distorted rig: the JSON it writes loads into a rig whose unwrap LUT equals the reference's."""
+    import json
+    from types import SimpleNamespace as NS
+    from distorted_rig import D
+    from vo_single_camera_sos_amd.omnistereo.gum import load_gums_json
+    exp = _load_exporter()
+
+    def ref_like(name):
+        xi1, xi2, xi3, k1, k2, k3, g1, g2, alpha, uc, vc, z_axis, use_d = D[name + "_params"]
+        c, c_in, c_out = D[name + "_centers"]
+        pp = NS(xi1=xi1, xi2=xi2, xi3=xi3, k1=k1, k2=k2, k3=k3, p1=0.0, p2=0.0, gamma1=g1, gamma2=g2, alpha_c=alpha, u_center=uc,
+                v_center=vc, use_distortion=bool(use_d), center_point=np.array(c), center_point_inner=np.array(c_in),
+                center_point_outer=np.array(c_out), image_size=np.array([640, 480]))
+        F = np.ones((4, 1))
+        F[:3, 0] = D[name + "_F"]
+        return NS(precalib_params=pp, Cp_wrt_M=np.array([xi1, xi2, xi3]), z_axis=z_axis, F=F,
+                  lowest_elevation_angle=D[name + "_elev"][0], highest_elevation_angle=D[name + "_elev"][1],
+                  inner_img_radius=D[name + "_radii"][0], outer_img_radius=D[name + "_radii"][1],
+                  T_model_wrt_C=D[name + "_T_model_wrt_C"], panorama=NS(cols=int(D[name + "_pano"][1])))
+    gums = NS(top_model=ref_like("top"), bot_model=ref_like("bot"), units=str(D["units"][0]))
+    doc = exp.gums_to_sosvo_json(gums)
+    assert doc["format"] == "sosvo-gums-1" and doc["panorama_width"] == 1200 and "R_model_wrt_C" not in doc["top"]
+    f = str(tmp_path / "rig.json")
+    with open(f, "w") as fh:
+        json.dump(doc, fh)
+    rig = load_gums_json(f)
+    for name, m in (("top", rig.top_model), ("bot", rig.bot_model)):
+        sel = D[name + "_lut_rows"]
+        assert np.array_equal(np.asarray(m.panorama.world2cam_LUT_map_x)[sel], D[name + "_lut_x"], equal_nan=True)
+        assert np.array_equal(np.asarray(m.panorama.world2cam_LUT_map_y)[sel], D[name + "_lut_y"], equal_nan=True)
+        assert np.array_equal(m.center_point_outer, D[name + "_centers"][2]) and np.array_equal(m.F[:3, 0], D[name + "_F"])
+        assert [m.globally_lowest_elevation_angle, m.globally_highest_elevation_angle] == list(D[name + "_elev"][2:])
+    # a rotated mirror frame travels as R_model_wrt_C
+    a = np.deg2rad(1.5)
+    R = np.array([[np.cos(a), -np.sin(a), 0.0], [np.sin(a), np.cos(a), 0.0], [0.0, 0.0, 1.0]])
+    gums.bot_model.T_model_wrt_C = np.array(gums.bot_model.T_model_wrt_C)
+    gums.bot_model.T_model_wrt_C[:3, :3] = R
+    doc2 = exp.gums_to_sosvo_json(gums, panorama_width=900)
+    assert doc2["panorama_width"] == 900
+    from vo_single_camera_sos_amd.omnistereo.gum import gums_from_dict, gums_to_dict
+    rig2 = gums_from_dict(doc2, with_panoramas=False)
+    assert np.array_equal(rig2.bot_model.T_model_wrt_C[:3, :3], R) and np.array_equal(rig2.top_model.T_model_wrt_C[:3, :3], np.identity(3))
+    assert gums_to_dict(rig2)["bottom"]["R_model_wrt_C"] == doc2["bottom"]["R_model_wrt_C"]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/omnistereo"), reason="needs the reference tree (build container only)")
+def test_reference_side_export_on_a_live_reference_object(tmp_path):
+    """The same exporter on a LIVE GUMStereo of the imported reference (the object a user's pickle holds): every LUT entry of
+    the loaded rig equals the reference's own Panorama LUT.  Runs in a child interpreter (the reference needs placeholder
+    cv2 / pyopengv / vispy modules, tests/golden/make_fixtures.py) so that nothing leaks into this process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import json, sys, os
+import numpy as np
+sys.path.insert(0, os.path.join(%r, "tests", "golden")); sys.path.insert(0, os.path.join(%r, "scripts"))
+import make_fixtures as mf
+import export_reference_gums as exp
+gum, pano, cm, ccv, pet = mf.import_reference()
+gs, top, bot = mf.build_gums_distorted(gum, pano)
+json.dump(exp.gums_to_sosvo_json(gs), open(sys.argv[1], "w"))
+np.savez(sys.argv[2], tx=top.panorama.world2cam_LUT_map_x, ty=top.panorama.world2cam_LUT_map_y,
+         bx=bot.panorama.world2cam_LUT_map_x, by=bot.panorama.world2cam_LUT_map_y)
+""" % (root, root)
+    f, z = str(tmp_path / "rig.json"), str(tmp_path / "lut.npz")
+    env = dict(os.environ, PYTHONPATH="/root/reference", PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, "-c", code, f, z], capture_output=True, text=True, env=env, timeout=900,
+                       cwd=str(tmp_path))   # (not the repository root: its `omnistereo` alias package would shadow the reference's)
+    assert r.returncode == 0, r.stderr[-2000:]
+    from vo_single_camera_sos_amd.omnistereo.gum import load_gums_json
+    rig, L = load_gums_json(f), np.load(z)
+    for m, kx, ky in ((rig.top_model, "tx", "ty"), (rig.bot_model, "bx", "by")):
+        assert np.array_equal(np.asarray(m.panorama.world2cam_LUT_map_x), L[kx], equal_nan=True)
+        assert np.array_equal(np.asarray(m.panorama.world2cam_LUT_map_y), L[ky], equal_nan=True)
+
+
 def test_precalibration_bin_layout(tmp_path):
     """gum.py:216-272: the toolbox's .bin is a run of float64 -- xi (3 or 1), k1 k2 p1 p2 k3, gamma1 gamma2 u v alpha,
     ROI -- with the centre and ROI 1-based; checked against bytes packed by hand."""

@@ -402,6 +402,8 @@ _PARAM_FIELDS = ("xi1", "xi2", "xi3", "k1", "k2", "k3", "gamma1", "gamma2", "alp
 def gums_to_dict(gums):
     def mirror(m):
         d = {k: getattr(m.precalib_params, k) for k in _PARAM_FIELDS}
+        if not np.array_equal(m.T_model_wrt_C[:3, :3], np.identity(3)):
+            d["R_model_wrt_C"] = [[float(v) for v in row] for row in m.T_model_wrt_C[:3, :3]]
         d.update(z_axis=m.z_axis, F=[float(v) for v in m.F[:3, 0]], lowest_elevation_angle=m.lowest_elevation_angle,
                  highest_elevation_angle=m.highest_elevation_angle, inner_img_radius=float(m.inner_img_radius),
                  outer_img_radius=float(m.outer_img_radius), center_point=[float(v) for v in m.center_point],
@@ -420,10 +422,13 @@ def gums_from_dict(d, with_panoramas=True):
 
     def mirror(m):
         params = GUMParams(**{k: m[k] for k in _PARAM_FIELDS})
-        return GUM(params, m["z_axis"], m["F"], m["lowest_elevation_angle"], m["highest_elevation_angle"],
-                   m["inner_img_radius"], m["outer_img_radius"], center_point=m["center_point"],
-                   image_size=tuple(m["image_size"]), units=d["units"], center_point_inner=m.get("center_point_inner"),
-                   center_point_outer=m.get("center_point_outer"))   # (optional keys: older documents have one centre)
+        g = GUM(params, m["z_axis"], m["F"], m["lowest_elevation_angle"], m["highest_elevation_angle"],
+                m["inner_img_radius"], m["outer_img_radius"], center_point=m["center_point"],
+                image_size=tuple(m["image_size"]), units=d["units"], center_point_inner=m.get("center_point_inner"),
+                center_point_outer=m.get("center_point_outer"))   # (optional keys: older documents have one centre)
+        if m.get("R_model_wrt_C") is not None:   # orientation of the mirror frame wrt [C] (camera_models.py:955-962); default identity
+            g.set_pose(g.F[:3, 0], np.asarray(m["R_model_wrt_C"], dtype=np.float64))
+        return g
     gums = GUMStereo(mirror(d["top"]), mirror(d["bottom"]), units=d["units"])
     if with_panoramas:
         for m in (gums.top_model, gums.bot_model):
