@@ -9,9 +9,9 @@
 //   fast      FAST-9/16 score for every pyramid pixel in one launch (16 ring loads per lane from L1/L2);
 //   select    one workgroup per problem walks the levels: 3x3 NMS + 31-px border + mask -> candidates in LDS,
 //             keep the best 2 n_l by FAST score through a 256-bin LDS histogram (ties kept), Harris response
-//             per candidate, rank sort (response desc, then y, x), keep n_l (+ ties), intensity-centroid angle
-//             with one wave per keypoint (lanes = patch rows, shuffle reduction), fastAtan2 polynomial in
-//             float32 with a pinned operation order;
+//             per candidate (a LANE per candidate: separable Sobel on a three-row ring), rank sort (response desc,
+//             then y, x), keep n_l (+ ties), intensity-centroid angle (a lane per keypoint: v_dot4_u32_u8 with the
+//             disc as byte weights), fastAtan2 polynomial in float32 with a pinned operation order;
 //   describe  border rule on level-0 coordinates + stable compaction, then one wave per keypoint: the rotated
 //             offsets are evaluated per lane in float32, four 64-bit ballots are the 32 descriptor bytes.
 // Integer work except the Harris/angle float32 arithmetic, whose operation order is pinned -> bit-exact against
@@ -539,38 +539,46 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 
-// Harris response of the 7x7 block around (cx, cy), k = 0.04, by ONE WAVE.  The block's 3x3 Sobel pairs read the 9 x 9
-// pixels around the candidate; they arrive as 27 unaligned dwords (harris_fetch: lane t < 27 -> patch row t / 3, dword
-// t % 3; issued one candidate AHEAD of their use), go through a 108-byte LDS patch of the wave, and lane
-// (dy + 3) * 7 + (dx + 3) < 49 evaluates its pair from eight LDS bytes -- 27 global loads per candidate instead of 392 byte
-// loads.  (Candidates lie >= 31 px inside the level, so no tap leaves the image.)  The three sums of products are integer
-// wave reductions (exact, order-free), the float expression keeps the oracle's operation order.
-__device__ __forceinline__ uint32_t harris_fetch(const uint8_t* __restrict__ im, int w, int cx, int cy, int lane) {
-  const int t = lane < 27 ? lane : 0, r = t / 3, k = t - 3 * r;
-  return *reinterpret_cast<const u32_unaligned*>(im + (size_t)(cy - 4 + r) * w + (cx - 4) + 4 * k);
-}
-__device__ __forceinline__ float harris_response_wave(uint32_t fetched, volatile uint32_t* patch, int lane) {
-  __builtin_amdgcn_wave_barrier();  // (the previous candidate's reads of the patch are done: one wave, LDS in order)
-  if (lane < 27) patch[lane] = fetched;
-  __builtin_amdgcn_wave_barrier();
+// Harris response of the 7x7 block around (cx, cy), k = 0.04, by ONE LANE (round 4; rounds 1-3 spent a whole wave on a
+// candidate: 49 of 64 lanes busy, three 6-step cross-lane reductions and an LDS patch per candidate -- ~120 wave-instructions
+// each, the largest share of this VALU-bound kernel).  The block's 3x3 Sobel pairs read the 9 x 9 pixels around the
+// candidate: nine rows of three unaligned dwords (candidates lie >= 31 px inside the level, so no tap leaves the image),
+// Sobel taken apart into its row pass -- hd = p[x+1] - p[x-1], hs = p[x-1] + 2 p[x] + p[x+1] -- and its column pass
+// (Ix = hd above + 2 hd + hd below, Iy = hs below - hs above) on a three-row ring with compile-time slots: ~680
+// instructions for the 64 candidates of a wave.  The sums are integers (exact, order-free); the float expression keeps the
+// oracle's operation order.
+__device__ __forceinline__ float harris_response_lane(const uint8_t* __restrict__ im, int w, int cx, int cy) {
+  const uint8_t* p = im + (size_t)(cy - 4) * w + (cx - 4);
+  int hd[3][7], hs[3][7];
   int a = 0, b = 0, c = 0;
-  if (lane < 49) {
-    const int dy = lane / 7, dx = lane - dy * 7;  // pixel (dy + 1, dx + 1) of the 9 x 9 patch (12-byte rows)
-    const volatile uint8_t* q = reinterpret_cast<const volatile uint8_t*>(patch) + dy * 12 + dx;
-    const int p00 = q[0], p01 = q[1], p02 = q[2];
-    const int p10 = q[12], p12 = q[14];
-    const int p20 = q[24], p21 = q[25], p22 = q[26];
-    const int Ix = (p12 - p10) * 2 + (p02 - p00) + (p22 - p20);
-    const int Iy = (p21 - p01) * 2 + (p20 - p00) + (p22 - p02);
-    a = Ix * Ix;
-    b = Iy * Iy;
-    c = Ix * Iy;
-  }
+#pragma unroll 1
+  for (int r0 = 0; r0 < 9; r0 += 3) {  // three rows per trip: the ring slot of a row is compile-time; fully unrolled the 27
+                                       // loads are hoisted and the kernel spills at the 128 VGPRs four workgroups per CU leave
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    a += __shfl_xor(a, o);
-    b += __shfl_xor(b, o);
-    c += __shfl_xor(c, o);
+    for (int sl = 0; sl < 3; ++sl) {
+      const int r = r0 + sl;
+      const u32_unaligned* q = reinterpret_cast<const u32_unaligned*>(p + (size_t)r * w);
+      const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+      const int px[9] = {(int)(d0 & 255u), (int)((d0 >> 8) & 255u), (int)((d0 >> 16) & 255u), (int)(d0 >> 24),
+                         (int)(d1 & 255u), (int)((d1 >> 8) & 255u), (int)((d1 >> 16) & 255u), (int)(d1 >> 24), (int)(d2 & 255u)};
+#pragma unroll
+      for (int x = 0; x < 7; ++x) {
+        hd[sl][x] = px[x + 2] - px[x];
+        hs[sl][x] = px[x] + 2 * px[x + 1] + px[x + 2];
+      }
+      if (r >= 2) {  // (uniform) block row r - 2: rows r - 2 (above), r - 1, r (below) of the patch
+        constexpr int kAbove[3] = {1, 2, 0}, kMid[3] = {2, 0, 1};
+        const int t = kAbove[sl], m = kMid[sl];
+#pragma unroll
+        for (int x = 0; x < 7; ++x) {
+          const int Ix = hd[t][x] + 2 * hd[m][x] + hd[sl][x];
+          const int Iy = hs[sl][x] - hs[t][x];
+          a += Ix * Ix;
+          b += Iy * Iy;
+          c += Ix * Iy;
+        }
+      }
+    }
   }
   const float scale = 1.f / (4 * 7 * 255.f);
   const float s4 = (scale * scale) * (scale * scale);
@@ -578,43 +586,62 @@ __device__ __forceinline__ float harris_response_wave(uint32_t fetched, volatile
   return (((fa * fb) - (fc * fc)) - ((0.04f * (fa + fb)) * (fa + fb))) * s4;
 }
 
-// Intensity-centroid moments of the radius-15 disc around (cx, cy) by ONE WAVE: the 31 patch rows are 31 x 8 unaligned
-// dwords (columns cx - 15 .. cx + 16), four per lane; every lane adds its four pixels' u * I and (through its row's v) v * I
-// where |u| <= umax(|v|) (OpenCV's disc: 15 15 15 15 14 14 14 13 13 12 11 10 9 8 6 3, here as nibbles of one literal), and
-// two integer wave reductions finish m10 and m01 -- 4 dword loads per lane instead of 31 byte loads.
-__device__ __forceinline__ void ic_moments_wave(const uint8_t* __restrict__ im, int w, int cx, int cy, int lane, int& m10_out,
-                                                int& m01_out) {
-  constexpr unsigned long long kUmax = 0x3689ABCDDEEEFFFFULL;  // nibble |v| = umax(|v|)
-  int m10 = 0, m01 = 0;
-  uint32_t x[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int idx = min(q * 64 + lane, 247), r = idx >> 3, k = idx & 7;
-    x[q] = *reinterpret_cast<const u32_unaligned*>(im + (size_t)(cy - kHalfPatch + r) * w + (cx - kHalfPatch) + 4 * k);
-  }
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int idx = q * 64 + lane, r = idx >> 3, k = idx & 7, v = r - kHalfPatch;
-    if (idx < 248) {
-      const int d = (int)((kUmax >> (4 * (v < 0 ? -v : v))) & 15ULL);
-      int rs = 0;
-#pragma unroll
+// Intensity-centroid moments of the radius-15 disc around (cx, cy) by ONE LANE: patch row v = -15 .. 15 is eight unaligned
+// dwords (columns cx - 15 .. cx + 16), the disc |u| <= umax(|v|) (OpenCV's: 15 15 15 15 14 14 14 13 13 12 11 10 9 8 6 3)
+// becomes byte weights of v_dot4_u32_u8: 1 inside the disc for the row sum, u + 15 inside the disc for sum (u + 15) I -- two
+// dot instructions per dword, the weights a constant table read through the SCALAR unit (the row index is uniform), a
+// dword that misses the disc has weight 0.  m01 = sum v rowsum(v), m10 = sum (u + 15) I - 15 sum I.
+// ~750 instructions for 64 keypoints (a wave per keypoint took ~150 each).  A real loop over the rows (two per trip):
+// unrolled 31 times the 208 loads were all hoisted and the kernel ran at one wave per SIMD.
+struct IcWeights {
+  uint32_t w1[32][8], wu[32][8];  // (row 31: padding for the two-rows-per-trip loop, never read)
+};
+constexpr IcWeights make_ic_weights() {
+  IcWeights t{};
+  const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+  for (int r = 0; r < 31; ++r) {
+    const int v = r - 15, d = umax[v < 0 ? -v : v];
+    for (int k = 0; k < 8; ++k) {
+      uint32_t w1 = 0, wu = 0;
       for (int b = 0; b < 4; ++b) {
-        const int u = 4 * k + b - kHalfPatch, val = (int)((x[q] >> (8 * b)) & 255u);
+        const int u = 4 * k + b - 15;
         if ((u < 0 ? -u : u) <= d) {
-          m10 += u * val;
-          rs += val;
+          w1 |= 1u << (8 * b);
+          wu |= (uint32_t)(u + 15) << (8 * b);
         }
       }
-      m01 += v * rs;
+      t.w1[r][k] = w1;
+      t.wu[r][k] = wu;
     }
   }
+  return t;
+}
+__constant__ IcWeights kIcW = make_ic_weights();
+
+// rows first, first + step, ... of the patch (the workgroup's waves share a keypoint's 31 rows: four dependent load rounds
+// per wave instead of sixteen) -> partial sums: su = sum (u + 15) I, stot = sum I, m01 = sum v I over those rows
+__device__ __forceinline__ void ic_moments_rows(const uint8_t* __restrict__ im, int w, int cx, int cy, int first, int step,
+                                                uint32_t& su_out, uint32_t& stot_out, int& m01_out) {
+  const uint8_t* p = im + (size_t)(cy - kHalfPatch) * w + (cx - kHalfPatch);
+  uint32_t su = 0u, stot = 0u;
+  int m01 = 0;
+#pragma unroll 2
+  for (int r = first; r < 2 * kHalfPatch + 1; r += step) {
+    const u32_unaligned* q = reinterpret_cast<const u32_unaligned*>(p + (size_t)r * w);
+    uint32_t x[8];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    m10 += __shfl_xor(m10, o);
-    m01 += __shfl_xor(m01, o);
+    for (int k = 0; k < 8; ++k) x[k] = q[k];  // all eight in flight (a dword outside the disc has weight 0)
+    uint32_t rs = 0u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      rs = __builtin_amdgcn_udot4(x[k], kIcW.w1[r][k], rs, false);
+      su = __builtin_amdgcn_udot4(x[k], kIcW.wu[r][k], su, false);
+    }
+    m01 += (r - kHalfPatch) * (int)rs;
+    stot += rs;
   }
-  m10_out = m10;
+  su_out = su;
+  stot_out = stot;
   m01_out = m01;
 }
 
@@ -662,7 +689,7 @@ __global__ __launch_bounds__(kThreads) void orb_mask_bbox_kernel(const uint32_t*
 //   3. Harris response, one wave per candidate -> unique sort keys;  4. bitonic sort (response descending, then y, x);
 //   5. retainBest(quota) by response, ties kept (counted in parallel: the list is sorted);
 //   6. orientation, one wave per keypoint.
-__global__ __launch_bounds__(kThreads) void orb_select_kernel(LevelSrc S, const uint8_t* __restrict__ score,
+__global__ __launch_bounds__(kThreads, 4) void orb_select_kernel(LevelSrc S, const uint8_t* __restrict__ score,
                                                               const unsigned long long* __restrict__ flags,
                                                               const uint32_t* __restrict__ mask_pyr,
                                                               const uint32_t* __restrict__ bbox, Pyr P,
@@ -675,7 +702,7 @@ __global__ __launch_bounds__(kThreads) void orb_select_kernel(LevelSrc S, const 
   __shared__ unsigned long long ckey[kCandMax];  // ordered(harris) << 32 | (0xFFFFFFFF - linear index)
   __shared__ uint32_t kept[kCandMax];            // candidates that pass the FAST-score threshold (compacted)
   __shared__ int hist[256];
-  __shared__ uint32_t hpatch[kThreads / 64][28];  // the 9 x 12-byte Harris patch of each wave
+  __shared__ int ic_acc[192];                    // step 6: per keypoint of a 64-chunk, sum (u + 15) I | sum I | sum v I
   __shared__ int s_nc, s_thr, s_keep, s_nout, s_nk;
   const int tid = threadIdx.x, p = blockIdx.x, lane = tid & 63, wid = tid >> 6;
   const int img = p / nmask, m = p - img * nmask;
@@ -773,17 +800,13 @@ __global__ __launch_bounds__(kThreads) void orb_select_kernel(LevelSrc S, const 
     }
     __syncthreads();
     const int nc = min(s_nk, kCandMax);
-    // 3. Harris response of the survivors -> sort keys
-    uint32_t xy_next = wid < nc ? kept[wid] : 0u, fetched = 0u;
-    if (wid < nc) fetched = harris_fetch(im, w, (int)(xy_next & 0xFFFFu), (int)(xy_next >> 16), lane);
-    for (int j = wid; j < nc; j += kThreads / 64) {
-      const uint32_t xy = xy_next, cur = fetched;
-      if (j + kThreads / 64 < nc) {  // the next candidate's 27 dwords fly while this one is reduced
-        xy_next = kept[j + kThreads / 64];
-        fetched = harris_fetch(im, w, (int)(xy_next & 0xFFFFu), (int)(xy_next >> 16), lane);
-      }
-      const float r = harris_response_wave(cur, hpatch[wid], lane);
-      if (lane == 0) {
+    // 3. Harris response of the survivors -> sort keys: a lane per candidate, the candidates packed into as few waves as
+    // they fill (a wave's instruction count does not depend on how many of its lanes work)
+    for (int j0 = wid * 64; j0 < nc; j0 += kThreads) {
+      const int j = j0 + lane;
+      const uint32_t xy = kept[min(j, nc - 1)];
+      const float r = harris_response_lane(im, w, (int)(xy & 0xFFFFu), (int)(xy >> 16));
+      if (j < nc) {
         const uint32_t lin = (xy >> 16) * (uint32_t)w + (xy & 0xFFFFu);
         ckey[j] = ((unsigned long long)sosvo_float_ordered(r) << 32) | (0xFFFFFFFFu - lin);
       }
@@ -838,14 +861,24 @@ __global__ __launch_bounds__(kThreads) void orb_select_kernel(LevelSrc S, const 
     }
     __syncthreads();
     const int keep = nc > quota ? quota + s_keep : nc, base_out = s_nout;
-    // 6. orientation: one wave per keypoint, lanes 0..30 take the patch rows v = -15..15
-    for (int j = wid; j < keep && base_out + j < cap; j += kThreads / 64) {
-      const unsigned long long key = ckey[j];
+    // 6. orientation: a lane per keypoint, the 31 patch rows dealt over the workgroup's waves (partial sums meet in LDS)
+    const int nor = min(keep, cap - base_out);
+    for (int j0 = 0; j0 < nor; j0 += 64) {  // (uniform; one trip unless a level keeps more than 64)
+      if (tid < 192) ic_acc[tid] = 0;
+      __syncthreads();
+      const int j = j0 + lane;
+      const unsigned long long key = ckey[min(j, nor - 1)];
       const uint32_t lin = 0xFFFFFFFFu - (uint32_t)key;
       const int cy = (int)(lin / (uint32_t)w), cx = (int)(lin - (uint32_t)cy * (uint32_t)w);
-      int m10, m01;
-      ic_moments_wave(im, w, cx, cy, lane, m10, m01);
-      if (lane == 0) {
+      uint32_t su, stot;
+      int m01p;
+      ic_moments_rows(im, w, cx, cy, __builtin_amdgcn_readfirstlane(wid), kThreads / 64, su, stot, m01p);
+      atomicAdd(&ic_acc[lane], (int)su);
+      atomicAdd(&ic_acc[64 + lane], (int)stot);
+      atomicAdd(&ic_acc[128 + lane], m01p);
+      __syncthreads();
+      if (wid == 0 && j < nor) {
+        const int m10 = ic_acc[lane] - kHalfPatch * ic_acc[64 + lane], m01 = ic_acc[128 + lane];
         const size_t o = (size_t)p * cap + base_out + j;
         kp4[4 * o + 0] = (float)cx * P.scale[l];
         kp4[4 * o + 1] = (float)cy * P.scale[l];
@@ -853,6 +886,7 @@ __global__ __launch_bounds__(kThreads) void orb_select_kernel(LevelSrc S, const 
         kp4[4 * o + 3] = (float)l;
         resp_out[o] = sosvo_ordered_float((uint32_t)(key >> 32));
       }
+      __syncthreads();
     }
     __syncthreads();
     if (tid == 0) s_nout = min(cap, base_out + keep);
@@ -862,6 +896,14 @@ __global__ __launch_bounds__(kThreads) void orb_select_kernel(LevelSrc S, const 
 }
 
 // ---- descriptors of oriented multi-level keypoints ------------------------------------------------------------
+// The 512 test points of a keypoint are scattered bytes inside the (2R + 1)^2 patch around it (R = 19 for OpenCV's table at
+// any angle).  Read straight from the blurred level they are 8 gathers of 64 unrelated bytes per keypoint, which the
+// texture-address unit serialises lane by lane (measured, round 4: 1.67 ms per 256 pairs, the same before and after the
+// kernel's VALU instructions were halved).  So the patch goes through LDS: PR rows of pdw unaligned dwords (7 loads per lane
+// for R = 19, neighbouring lanes on neighbouring dwords), row pitch ODD in dwords so that the rows spread over all banks, and
+// the tests read LDS bytes.  Keypoints too close to their level's border for the patch (none the detector returns: it
+// keeps 31 px) take the direct path with reflected coordinates.
+constexpr int kDescPatchMaxR = 23, kDescPatchRows = 2 * kDescPatchMaxR + 1, kDescPatchPitch = 13, kDescPatchLoads = 9;
 __global__ __launch_bounds__(kThreads) void orb_describe_levels_kernel(const uint8_t* __restrict__ blur, Pyr P, int nlev_have,
                                                                        int rows, int cols, int nmask, int cap,
                                                                        float* __restrict__ kp4, int32_t* __restrict__ n_io,
@@ -869,8 +911,10 @@ __global__ __launch_bounds__(kThreads) void orb_describe_levels_kernel(const uin
                                                                        uint8_t* __restrict__ desc,
                                                                        float* __restrict__ kp_xy) {
   SOSVO_LATENCY_BOUND_PRIO();
-  extern __shared__ float lds_kp[];  // [cap][4]
+  extern __shared__ float lds_kp[];  // [cap][4] keypoints, then [cap][2] (cos, sin) of their angles
+  float* lds_cs = lds_kp + 4 * (size_t)cap;
   __shared__ int8_t spat[1024];
+  __shared__ uint32_t patch_lds[kThreads / 64][kDescPatchRows * kDescPatchPitch];
   __shared__ int wave_off[5];
   __shared__ int s_running;
   const int tid = threadIdx.x, p = blockIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -904,34 +948,92 @@ __global__ __launch_bounds__(kThreads) void orb_describe_levels_kernel(const uin
   __syncthreads();
   const int mkept = s_running;
   for (int i = tid; i < 4 * mkept; i += kThreads) kp4[(size_t)p * cap * 4 + i] = lds_kp[i];
+  // cos / sin of every kept keypoint's angle, a LANE per keypoint (trig_core.h's double-precision sincos, the oracle's bits,
+  // rounded once to float): evaluated by a whole wave per keypoint this was ~1/4 of the kernel's instructions
+  for (int i = tid; i < mkept; i += kThreads) {
+    float angle = lds_kp[4 * i + 2];
+    angle *= (float)(3.14159265358979323846 / 180.0);
+    double sd, cd;
+    sv_sincos((double)angle, &sd, &cd);
+    lds_cs[2 * i] = (float)cd;
+    lds_cs[2 * i + 1] = (float)sd;
+  }
+  __syncthreads();
   if (kp_xy)
     for (int i = tid; i < mkept; i += kThreads) {
       kp_xy[((size_t)p * cap + i) * 2] = lds_kp[4 * i];
       kp_xy[((size_t)p * cap + i) * 2 + 1] = lds_kp[4 * i + 1];
     }
   if (tid == 0) n_io[p] = mkept;
+  // this lane's four tests (lane, 64 + lane, 128 + lane, 192 + lane): their eight pattern points never change
+  float ppx[4][2], ppy[4][2];
+  int cmax = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int i = 2 * (64 * r + lane) + e;
+      const int ix = spat[2 * i], iy = spat[2 * i + 1];
+      ppx[r][e] = (float)ix;
+      ppy[r][e] = (float)iy;
+      cmax = max(cmax, max(abs(ix), abs(iy)));
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o));
+  const int margin = (int)((float)cmax * 1.4143f) + 2;  // a rotated, rounded test point stays within it (13 -> 20)
+  const int R = margin - 1, PR = 2 * R + 1, pdw = (PR + 3) >> 2, pstride = pdw | 1;
+  const bool patch_ok = R <= kDescPatchMaxR;  // (|coordinate| <= 16: R <= 23)
+  // this lane's dwords of a patch: item i = it * 64 + lane -> (row i / pdw, dword i % pdw); the same for every keypoint
+  int prow[kDescPatchLoads], pk[kDescPatchLoads];
+#pragma unroll
+  for (int it = 0; it < kDescPatchLoads; ++it) {
+    const int i = min(it * 64 + lane, PR * pdw - 1);  // (lanes past the end repeat the last item: same value, same word)
+    prow[it] = i / pdw;
+    pk[it] = i - prow[it] * pdw;
+  }
+  const int nit = patch_ok ? (PR * pdw + 63) >> 6 : 0;  // <= kDescPatchLoads
+  uint32_t* patch32 = patch_lds[wid];
+  const uint8_t* patch8 = reinterpret_cast<const uint8_t*>(patch32);
   for (int j = wid; j < mkept; j += kThreads / 64) {
     const int l = (int)lds_kp[4 * j + 3];
     const int hh = P.h[l], ww = P.w[l];
     const float inv = 1.f / P.scale[l];
-    float angle = lds_kp[4 * j + 2];
-    angle *= (float)(3.14159265358979323846 / 180.0);
-    double sd, cd;  // trig_core.h's sincos: the same bits as the oracle's, then one rounding to float on both sides
-    sv_sincos((double)angle, &sd, &cd);
-    const float ca = (float)cd, sa = (float)sd;
+    const float ca = lds_cs[2 * j], sa = lds_cs[2 * j + 1];
     const int cx = __float2int_rn(lds_kp[4 * j] * inv), cy = __float2int_rn(lds_kp[4 * j + 1] * inv);
     const uint8_t* im = blur + (size_t)img * P.total + P.off[l];
     unsigned long long* d = reinterpret_cast<unsigned long long*>(desc + ((size_t)p * cap + j) * 32);
+    // a keypoint at least `margin` px inside its level image (every keypoint the detector returns: it keeps 31 px, and
+    // OpenCV's table needs 20) needs no border reflection -- a wave-uniform test
+    const bool inside = cx >= margin && cy >= margin && cx < ww - margin && cy < hh - margin;
+    const uint8_t* ctr = im + (size_t)cy * ww + cx;
+    const bool staged = inside && patch_ok;  // wave-uniform
+    if (staged) {
+      uint32_t reg[kDescPatchLoads];
+#pragma unroll
+      for (int it = 0; it < kDescPatchLoads; ++it)
+        if (it < nit) reg[it] = *reinterpret_cast<const u32_unaligned*>(ctr + (prow[it] - R) * ww - R + 4 * pk[it]);
+      __builtin_amdgcn_wave_barrier();  // (the previous keypoint's reads of the patch are done: one wave, LDS in order)
+#pragma unroll
+      for (int it = 0; it < kDescPatchLoads; ++it)
+        if (it < nit) patch32[prow[it] * pstride + pk[it]] = reg[it];
+      __builtin_amdgcn_wave_barrier();
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int t = 64 * r + lane;
       int val[2];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const float px = (float)spat[2 * (2 * t + e)], py = (float)spat[2 * (2 * t + e) + 1];
+        const float px = ppx[r][e], py = ppy[r][e];
         const float xr = (px * ca) - (py * sa), yr = (px * sa) + (py * ca);
-        const int xx = refl101(cx + __float2int_rn(xr), ww), yy = refl101(cy + __float2int_rn(yr), hh);
-        val[e] = im[(size_t)yy * ww + xx];
+        const int dx = __float2int_rn(xr), dy = __float2int_rn(yr);
+        if (staged) {
+          val[e] = patch8[(dy + R) * (4 * pstride) + (dx + R)];
+        } else if (inside) {
+          val[e] = ctr[dy * ww + dx];
+        } else {
+          const int xx = refl101(cx + dx, ww), yy = refl101(cy + dy, hh);
+          val[e] = im[(size_t)yy * ww + xx];
+        }
       }
       const unsigned long long bal = __ballot(val[0] < val[1]);
       if (lane == 0) d[r] = bal;
@@ -1066,7 +1168,7 @@ int32_t run_orb_describe(sosvo_ctx* ctx, const uint8_t* gray, int nimg, int rows
     if (rc != SOSVO_OK) return rc;
   }
   SOSVO_LAUNCH(ctx, orb_describe_levels_kernel, dim3((unsigned)((size_t)nimg * nmask)), dim3(kThreads),
-               (size_t)cap * 4 * sizeof(float), ctx->stream, W.blur, P, nlev_have, rows, cols, nmask, cap, kp4, n, pattern, desc,
+               (size_t)cap * 6 * sizeof(float), ctx->stream, W.blur, P, nlev_have, rows, cols, nmask, cap, kp4, n, pattern, desc,
                kp_xy);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
