@@ -15,6 +15,9 @@ import csv, sys
 rows = list(csv.DictReader(open("gpurun_out/%s_kernel_stats.csv" % sys.argv[1])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 for r in rows[:16]:
-    name = r["Name"].split("(")[0].split("::")[-1][:34]
-    print("%-36s calls %4s  avg %8.1f us  min %8.1f us  %5.1f %%" % (name, r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
+    import re
+    m = re.search(r"(\w+_kernel|\w+Buffer\w*|elementwise\w*)", r["Name"])
+    name = m.group(1) if m else r["Name"][:34]
+    print("%-34s calls %4s  avg %8.1f us  min %8.1f us  per step %7.3f ms  %5.1f %%" % (name, r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["TotalDurationNs"]) / 8e6, 100 * float(r["TotalDurationNs"]) / tot))
+print("kernel time per step of 256 pairs: %.3f ms" % (tot / 8e6))
 PY

@@ -158,3 +158,6 @@ int32_t sosvo_launch_gauss7(sosvo_ctx* ctx, const uint8_t* in, long long img_str
 // ... with the output images out_stride bytes apart (level 0 of the ORB pyramid is read from the dense gray batch)
 int32_t sosvo_launch_gauss7_to(sosvo_ctx* ctx, const uint8_t* in, long long in_stride, int nimg, int rows, int cols,
                                uint8_t* out, long long out_stride);
+// ... restricted to the output rows [row_range[2 v], row_range[2 v + 1]) (device array; v = image / imgs_per_range)
+int32_t sosvo_launch_gauss7_rows(sosvo_ctx* ctx, const uint8_t* in, long long in_stride, int nimg, int rows, int cols,
+                                 uint8_t* out, long long out_stride, const int32_t* row_range, int imgs_per_range);

@@ -916,6 +916,10 @@ static int32_t launch_gauss7_rows(sosvo_ctx* ctx, const uint8_t* in, long long i
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
 }
+int32_t sosvo_launch_gauss7_rows(sosvo_ctx* ctx, const uint8_t* in, long long in_stride, int nimg, int rows, int cols,
+                                 uint8_t* out, long long out_stride, const int32_t* row_range, int imgs_per_range) {
+  return launch_gauss7_rows(ctx, in, in_stride, nimg, rows, cols, out, out_stride, row_range, imgs_per_range);
+}
 int32_t sosvo_launch_gauss7_to(sosvo_ctx* ctx, const uint8_t* in, long long in_stride, int nimg, int rows, int cols,
                                uint8_t* out, long long out_stride) {
   return launch_gauss7_rows(ctx, in, in_stride, nimg, rows, cols, out, out_stride, nullptr, 1);

@@ -26,7 +26,8 @@ constexpr int kLevels = 8;
 constexpr int kEdge = 31;
 constexpr int kHalfPatch = 15;
 constexpr int kFastThr = 20;
-constexpr int kCandMax = 2048;  // candidates per (problem, level) held in LDS
+constexpr int kCandMax = 1024;  // candidates per (problem, level) held in LDS (more: the threshold is still exact, a second walk
+                                // keeps the retained ones; 1024 instead of 2048 = 19 KB of LDS: five workgroups per CU, not four)
 
 struct Pyr {
   int h[kLevels], w[kLevels];
@@ -86,8 +87,27 @@ __device__ __forceinline__ ResizeTap resize_tap(int d, double scale, int n0) {
 
 // Tap table of the bilinear resizes (depends on the image size only): entry = i0 | w1 << 16 (i1 = min(i0 + 1, n0 - 1),
 // w0 = 2048 - w1), computed once per call instead of twice per output pixel (double-precision arithmetic).
-__global__ __launch_bounds__(kThreads) void resize_taps_kernel(Pyr P, uint32_t* __restrict__ taps) {
+__global__ __launch_bounds__(kThreads) void resize_taps_kernel(Pyr P, uint32_t* __restrict__ taps, int32_t* __restrict__ lvl_rows,
+                                                               const int8_t* __restrict__ pattern) {
   const int i = blockIdx.x * kThreads + threadIdx.x, l = blockIdx.y + 1;
+  // (piggy-backed: the rows of every level's BLURRED image a descriptor of a detected keypoint can read -- the detector keeps
+  // 31 px of border on the level, a rotated and rounded test point of THIS pattern stays within `reach` px, computed as
+  // orb_describe_levels_kernel computes its margin -- for the row-restricted blur)
+  if (lvl_rows && blockIdx.x == 0 && blockIdx.y == 0) {  // uniform per workgroup
+    __shared__ int s_cmax;
+    if (threadIdx.x == 0) s_cmax = 0;
+    __syncthreads();
+    int c = 0;
+    for (int k = threadIdx.x; k < 1024; k += kThreads) c = max(c, abs((int)pattern[k]));
+    atomicMax(&s_cmax, c);
+    __syncthreads();
+    const int reach = (int)((float)s_cmax * 1.4143f) + 2;
+    if (threadIdx.x < kLevels) {
+      const int t = threadIdx.x, hh = t < P.nlev ? P.h[t] : 0;
+      lvl_rows[2 * t] = min(max(kEdge - reach, 0), hh);
+      lvl_rows[2 * t + 1] = max(min(hh - kEdge + reach, hh), 0);
+    }
+  }
   if (l >= P.nlev || i >= P.w[l] + P.h[l]) return;
   const bool isx = i < P.w[l];
   const int d = isx ? i : i - P.w[l];
@@ -689,7 +709,7 @@ __global__ __launch_bounds__(kThreads) void orb_mask_bbox_kernel(const uint32_t*
 //   3. Harris response, one wave per candidate -> unique sort keys;  4. bitonic sort (response descending, then y, x);
 //   5. retainBest(quota) by response, ties kept (counted in parallel: the list is sorted);
 //   6. orientation, one wave per keypoint.
-__global__ __launch_bounds__(kThreads, 4) void orb_select_kernel(LevelSrc S, const uint8_t* __restrict__ score,
+__global__ __launch_bounds__(kThreads, 5) void orb_select_kernel(LevelSrc S, const uint8_t* __restrict__ score,
                                                               const unsigned long long* __restrict__ flags,
                                                               const uint32_t* __restrict__ mask_pyr,
                                                               const uint32_t* __restrict__ bbox, Pyr P,
@@ -1084,11 +1104,12 @@ Pyr make_pyr(int rows, int cols, int nfeatures) {
 
 // levels 1 .. nlev_build - 1 of every image into `pyr` (level 0 is `gray` itself); `taps`: P.ttotal words of scratch
 int32_t build_pyramid(sosvo_ctx* ctx, const uint8_t* gray, int nimg, int rows, int cols, const Pyr& P, int nlev_build,
-                      uint8_t* pyr, uint32_t* taps) {
+                      uint8_t* pyr, uint32_t* taps, int32_t* lvl_rows = nullptr, const int8_t* pattern = nullptr) {
   if (nlev_build <= 1) return SOSVO_OK;
   int tmax = 0;
   for (int l = 1; l < nlev_build; ++l) tmax = tmax > P.w[l] + P.h[l] ? tmax : P.w[l] + P.h[l];
-  SOSVO_LAUNCH(ctx, resize_taps_kernel, dim3(cdiv(tmax, kThreads), nlev_build - 1), dim3(kThreads), 0, ctx->stream, P, taps);
+  SOSVO_LAUNCH(ctx, resize_taps_kernel, dim3(cdiv(tmax, kThreads), nlev_build - 1), dim3(kThreads), 0, ctx->stream, P, taps,
+               pattern ? lvl_rows : nullptr, pattern);
   SOSVO_LAUNCH_CHECK(ctx);
   for (int l = 1; l < nlev_build; ++l) {
     const uint8_t* src = l == 1 ? gray : pyr + P.off[l - 1];
@@ -1110,6 +1131,7 @@ struct OrbScratch {
   uint8_t *pyr, *score, *blur;
   unsigned long long* flags;
   uint32_t *bbox, *taps;
+  int32_t* lvl_rows;  // [kLevels][2]: blurred rows a detected keypoint's descriptor can read (written with the taps)
   size_t bbox_bytes, bytes;
 };
 OrbScratch orb_scratch(const Pyr& P, int nimg, int nsets, bool detect, bool describe, char* base) {
@@ -1128,6 +1150,7 @@ OrbScratch orb_scratch(const Pyr& P, int nimg, int nsets, bool detect, bool desc
   o.bbox_bytes = detect ? (size_t)nsets * kLevels * 32 * 4 * sizeof(uint32_t) : 0;
   o.bbox = (uint32_t*)take(o.bbox_bytes);
   o.taps = (uint32_t*)take(sizeof(uint32_t) * (size_t)(P.ttotal > 0 ? P.ttotal : 1));
+  o.lvl_rows = (int32_t*)take(sizeof(int32_t) * 2 * kLevels);
   o.bytes = off;
   return o;
 }
@@ -1160,11 +1183,15 @@ int32_t run_orb_detect(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* mask
 // descriptors on a pyramid whose levels < nlev_have exist: blur those levels, border rule, rotated pattern
 int32_t run_orb_describe(sosvo_ctx* ctx, const uint8_t* gray, int nimg, int rows, int cols, int nmask, int cap, const Pyr& P,
                          int nlev_have, const OrbScratch& W, float* kp4, int32_t* n, const int8_t* pattern, uint8_t* desc,
-                         float* kp_xy) {
+                         float* kp_xy, bool detected_keypoints) {
+  // detected_keypoints: every keypoint keeps the detector's 31-px border ON ITS LEVEL, so only the rows W.lvl_rows names are
+  // ever read (keypoints handed in from outside keep that border in level-0 coordinates only: whole levels then)
+  const bool restrict_rows = detected_keypoints && nlev_have > 1;  // (lvl_rows is written with the resize taps)
   for (int l = 0; l < nlev_have; ++l) {  // the rolling strip kernel of detect.hip, level by level (same integer arithmetic)
-    const int32_t rc = l == 0 ? sosvo_launch_gauss7_to(ctx, gray, (long long)rows * cols, nimg, rows, cols, W.blur, P.total)
-                              : sosvo_launch_gauss7_to(ctx, W.pyr + P.off[l], P.total, nimg, P.h[l], P.w[l], W.blur + P.off[l],
-                                                       P.total);
+    const int32_t* rr = restrict_rows ? W.lvl_rows + 2 * l : nullptr;
+    const int32_t rc = l == 0 ? sosvo_launch_gauss7_rows(ctx, gray, (long long)rows * cols, nimg, rows, cols, W.blur, P.total, rr, nimg)
+                              : sosvo_launch_gauss7_rows(ctx, W.pyr + P.off[l], P.total, nimg, P.h[l], P.w[l], W.blur + P.off[l],
+                                                         P.total, rr, nimg);
     if (rc != SOSVO_OK) return rc;
   }
   SOSVO_LAUNCH(ctx, orb_describe_levels_kernel, dim3((unsigned)((size_t)nimg * nmask)), dim3(kThreads),
@@ -1238,7 +1265,7 @@ int32_t sosvo_describe_orb_levels(sosvo_ctx* ctx, const uint8_t* gray, int32_t n
   const OrbScratch W = orb_scratch(P, nimg, 1, false, true, (char*)ctx->ws);
   rc = build_pyramid(ctx, gray, nimg, rows, cols, P, P.nlev, W.pyr, W.taps);  // keypoints of any level: the whole pyramid
   if (rc != SOSVO_OK) return rc;
-  return run_orb_describe(ctx, gray, nimg, rows, cols, nmask, cap, P, P.nlev, W, kp4, n, pattern, desc, kp_xy);
+  return run_orb_describe(ctx, gray, nimg, rows, cols, nmask, cap, P, P.nlev, W, kp4, n, pattern, desc, kp_xy, false);
 }
 
 int32_t sosvo_detect_describe_orb(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* mask_pyr, int32_t nimg,
@@ -1258,11 +1285,11 @@ int32_t sosvo_detect_describe_orb(sosvo_ctx* ctx, const uint8_t* gray, const uin
   const OrbScratch W = orb_scratch(P, nimg, nsets, true, true, (char*)ctx->ws);
   // ONE pyramid for both halves, built only as far as a keypoint can come from (the levels with a quota and more than the
   // 31-px border): the detector's keypoints all lie on those levels
-  rc = build_pyramid(ctx, gray, nimg, rows, cols, P, P.ndet, W.pyr, W.taps);
+  rc = build_pyramid(ctx, gray, nimg, rows, cols, P, P.ndet, W.pyr, W.taps, W.lvl_rows, pattern);
   if (rc != SOSVO_OK) return rc;
   rc = run_orb_detect(ctx, gray, mask_pyr, nimg, images_per_maskset, rows, cols, nmask, cap, P, W, kp4, resp, n);
   if (rc != SOSVO_OK) return rc;
-  return run_orb_describe(ctx, gray, nimg, rows, cols, nmask, cap, P, P.ndet, W, kp4, n, pattern, desc, kp_xy);
+  return run_orb_describe(ctx, gray, nimg, rows, cols, nmask, cap, P, P.ndet, W, kp4, n, pattern, desc, kp_xy, true);
 }
 
 int32_t sosvo_detect_fast(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* mask_bits, int32_t nimg,
