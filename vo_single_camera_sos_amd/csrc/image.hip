@@ -223,22 +223,32 @@ __global__ __launch_bounds__(kThreads) void gray_kernel(const uint8_t* __restric
 // K1 + K3 without a median (median_win_size 0 / 1: the RGB-D frames' setting, and the setting under which the ORB detector
 // finds its quota on panoramas): every lane unwraps its pixel from the table and converts it to gray at once -- the colour
 // panoramas (2.5 MB per frame pair) are neither written nor read.  Same arithmetic as unwrap_lut_kernel + gray_kernel.
+// kUgPix pixels per thread (256 apart: every wave-load stays a run of 64 neighbouring pixels), their table entries and
+// gathers all in flight before the first blend: with one pixel per thread the kernel was a stream of 840 000 one-shot
+// workgroups per 256 frame pairs, bound by workgroup dispatch and by one exposed load latency each (round 4).
+constexpr int kUgPix = 4;
 __global__ __launch_bounds__(kThreads) void unwrap_gray_kernel(const uint8_t* __restrict__ omni, const uint2* __restrict__ table,
                                                                int nframes, int H, int W, int npix, uint8_t* __restrict__ gray) {
-  const int gx = (npix + kThreads - 1) / kThreads;   // XCD-aware 1-D grid as in unwrap_lut_kernel: one image on one XCD
+  const int gx = (npix + kThreads * kUgPix - 1) / (kThreads * kUgPix);   // XCD-aware 1-D grid as in unwrap_lut_kernel: one image on one XCD
   const int q = blockIdx.x >> 3;
   const int grp = q / gx, blk = q - grp * gx;
   const int img = grp * 8 + (blockIdx.x & 7);
   if (img >= 2 * nframes) return;  // uniform
-  const int pix = blk * kThreads + threadIdx.x;
-  if (pix >= npix) return;
   const int view = img / nframes, frame = img - view * nframes;
   const uint8_t* src = omni + (size_t)frame * H * W * 3;
-  const uint2 e = table[(size_t)view * npix + pix];
-  unsigned long long v[2];
-  unwrap_gather(src, H * W * 3, W, e, v);
-  const uint32_t bgr = unwrap_blend(H * W * 3, W, e, v);
-  gray[(size_t)img * npix + pix] = bgr2gray((int)(bgr & 255u), (int)((bgr >> 8) & 255u), (int)((bgr >> 16) & 255u));
+  const int pix0 = blk * kThreads * kUgPix + threadIdx.x;
+  uint2 e[kUgPix];
+  unsigned long long v[kUgPix][2];
+#pragma unroll
+  for (int k = 0; k < kUgPix; ++k) e[k] = table[(size_t)view * npix + min(pix0 + k * kThreads, npix - 1)];
+#pragma unroll
+  for (int k = 0; k < kUgPix; ++k) unwrap_gather(src, H * W * 3, W, e[k], v[k]);
+#pragma unroll
+  for (int k = 0; k < kUgPix; ++k) {
+    const int pix = pix0 + k * kThreads;
+    const uint32_t bgr = unwrap_blend(H * W * 3, W, e[k], v[k]);
+    if (pix < npix) gray[(size_t)img * npix + pix] = bgr2gray((int)(bgr & 255u), (int)((bgr >> 8) & 255u), (int)((bgr >> 16) & 255u));
+  }
 }
 
 // 64-bit wave ballot of "byte `byte` of x has its top bit set", as ONE SDWA compare (all lanes must be active).
@@ -619,7 +629,7 @@ int32_t sosvo_unwrap_median_gray_rows(sosvo_ctx* ctx, const uint8_t* omni, const
   if (nframes == 0) return SOSVO_OK;
   if (ksize <= 1) {  // no median: unwrap straight to gray (every row: nothing is skipped, row_range is not consulted)
     const int npix = rows * cols;
-    SOSVO_LAUNCH(ctx, unwrap_gray_kernel, dim3((unsigned)(cdiv(npix, kThreads) * 8 * cdiv(2 * nframes, 8))), dim3(kThreads), 0,
+    SOSVO_LAUNCH(ctx, unwrap_gray_kernel, dim3((unsigned)(cdiv(npix, kThreads * kUgPix) * 8 * cdiv(2 * nframes, 8))), dim3(kThreads), 0,
                  ctx->stream, omni, reinterpret_cast<const uint2*>(table), nframes, H, W, npix, gray);
     SOSVO_LAUNCH_CHECK(ctx);
     return SOSVO_OK;
