@@ -43,8 +43,11 @@ def opencv_pattern():
     return _OPENCV.copy()
 
 
-def orb_pattern(kind="opencv"):
-    """The descriptor pattern the package hands to libsosvo: "opencv" (default) or "seeded"."""
+def orb_pattern(kind=None):
+    """The descriptor pattern the package hands to libsosvo: "opencv" (default) or "seeded"; with kind None the environment
+    variable SOSVO_ORB_PATTERN chooses (unset: "opencv")."""
+    if kind is None:
+        kind = os.environ.get("SOSVO_ORB_PATTERN", "opencv")
     if kind == "opencv":
         return opencv_pattern()
     if kind == "seeded":
