@@ -54,6 +54,17 @@ __device__ __forceinline__ const uint8_t* level_image(const LevelSrc& S, const P
   return l == 0 ? S.gray + (size_t)img * S.npix0 : S.pyr + (size_t)img * S.total + P.off[l];
 }
 
+// Workgroup -> problem (image, mask), XCD-aware (as detect.hip's xcd_problem): workgroups are dealt round-robin over the 8
+// XCDs by linear id, so p = blockIdx.x spreads the 12 masks of one image over all eight L2s and every L2 fetches that
+// image's pyramid (round 3's PMC pass: 6.8 MB of fetches per frame pair in the selection alone).  Here XCD x takes the images
+// x, x + 8, ... with all their masks: grid = 8 * ceil(nimg / 8) * nmask, -1 for the padding ids.
+__device__ __forceinline__ int orb_xcd_problem(int nimg, int nmask) {
+  const int xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3);
+  const int img = (slot / nmask) * 8 + xcd, m = slot - (slot / nmask) * nmask;
+  return img < nimg ? img * nmask + m : -1;
+}
+inline unsigned orb_xcd_grid(int nimg, int nmask) { return (unsigned)(8 * ((nimg + 7) / 8) * nmask); }
+
 __device__ __forceinline__ int refl101(int i, int n) {
   if (n == 1) return 0;
   while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
@@ -715,7 +726,7 @@ __global__ __launch_bounds__(kThreads, 5) void orb_select_kernel(LevelSrc S, con
                                                               const uint32_t* __restrict__ bbox, Pyr P,
                                                               int images_per_maskset, int nmask, int cap,
                                                               float* __restrict__ kp4, float* __restrict__ resp_out,
-                                                              int32_t* __restrict__ n_out) {
+                                                              int32_t* __restrict__ n_out, int nimg_total) {
   SOSVO_LATENCY_BOUND_PRIO();
   __shared__ uint32_t cxy[kCandMax];            // (y << 16) | x; after the sort: the sorted positions
   __shared__ uint8_t cfast[kCandMax];
@@ -724,7 +735,9 @@ __global__ __launch_bounds__(kThreads, 5) void orb_select_kernel(LevelSrc S, con
   __shared__ int hist[256];
   __shared__ int ic_acc[192];                    // step 6: per keypoint of a 64-chunk, sum (u + 15) I | sum I | sum v I
   __shared__ int s_nc, s_thr, s_keep, s_nout, s_nk;
-  const int tid = threadIdx.x, p = blockIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int p = orb_xcd_problem(nimg_total, nmask);
+  if (p < 0) return;  // uniform (padding workgroup)
   const int img = p / nmask, m = p - img * nmask;
   if (tid == 0) s_nout = 0;
   __syncthreads();
@@ -929,7 +942,7 @@ __global__ __launch_bounds__(kThreads) void orb_describe_levels_kernel(const uin
                                                                        float* __restrict__ kp4, int32_t* __restrict__ n_io,
                                                                        const int8_t* __restrict__ pattern,
                                                                        uint8_t* __restrict__ desc,
-                                                                       float* __restrict__ kp_xy) {
+                                                                       float* __restrict__ kp_xy, int nimg_total) {
   SOSVO_LATENCY_BOUND_PRIO();
   extern __shared__ float lds_kp[];  // [cap][4] keypoints, then [cap][2] (cos, sin) of their angles
   float* lds_cs = lds_kp + 4 * (size_t)cap;
@@ -937,7 +950,9 @@ __global__ __launch_bounds__(kThreads) void orb_describe_levels_kernel(const uin
   __shared__ uint32_t patch_lds[kThreads / 64][kDescPatchRows * kDescPatchPitch];
   __shared__ int wave_off[5];
   __shared__ int s_running;
-  const int tid = threadIdx.x, p = blockIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int p = orb_xcd_problem(nimg_total, nmask);
+  if (p < 0) return;  // uniform (padding workgroup)
   const int img = p / nmask;
   const int n = min(n_io[p], cap);
   if (tid == 0) s_running = 0;
@@ -1174,8 +1189,8 @@ int32_t run_orb_detect(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* mask
     if (rc != SOSVO_OK) return rc;
   }
   LevelSrc S{gray, W.pyr, (long long)rows * cols, P.total};
-  SOSVO_LAUNCH(ctx, orb_select_kernel, dim3((unsigned)((size_t)nimg * nmask)), dim3(kThreads), 0, ctx->stream, S, W.score,
-               W.flags, mask_pyr, W.bbox, P, images_per_maskset, nmask, cap, kp4, resp, n);
+  SOSVO_LAUNCH(ctx, orb_select_kernel, dim3(orb_xcd_grid(nimg, nmask)), dim3(kThreads), 0, ctx->stream, S, W.score,
+               W.flags, mask_pyr, W.bbox, P, images_per_maskset, nmask, cap, kp4, resp, n, nimg);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
 }
@@ -1194,9 +1209,9 @@ int32_t run_orb_describe(sosvo_ctx* ctx, const uint8_t* gray, int nimg, int rows
                                                          P.total, rr, nimg);
     if (rc != SOSVO_OK) return rc;
   }
-  SOSVO_LAUNCH(ctx, orb_describe_levels_kernel, dim3((unsigned)((size_t)nimg * nmask)), dim3(kThreads),
+  SOSVO_LAUNCH(ctx, orb_describe_levels_kernel, dim3(orb_xcd_grid(nimg, nmask)), dim3(kThreads),
                (size_t)cap * 6 * sizeof(float), ctx->stream, W.blur, P, nlev_have, rows, cols, nmask, cap, kp4, n, pattern, desc,
-               kp_xy);
+               kp_xy, nimg);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
 }
