@@ -265,6 +265,9 @@ def sequence_subrecord(seq_omni, seq_poses, pano_width, mirror_frames=32):
     b = np.loadtxt(io.StringIO(texts["mirror_per_frame"]))
     out["mirror_max_abs_pose_difference"] = float(np.abs(a - b).max())
     out["value"], out["unit"] = out["frame_window_32"]["frames_per_s"], "frames/s"
+    hw = out["frame_window_32"].get("host_wall_s")
+    if hw:   # what the host spent WAITING for the GPU (front ends + speculative tracking of a window, serial tracking calls)
+        out["gpu_ms_per_frame"] = 1e3 * (hw["wait_and_readback"] + hw["serial_track"]) / out["frame_window_32"]["frames"]
     return out
 
 

@@ -1,0 +1,57 @@
+"""cProfile of run_VO in sequence mode (frame_window 32) on the bench's synthetic sequence: where the host spends a frame.
+    python scripts/profile_sequence.py [--frames 256] [--top 35]"""
+import argparse
+import contextlib
+import cProfile
+import io
+import os
+import pstats
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=256)
+    ap.add_argument("--top", type=int, default=35)
+    ap.add_argument("--window", type=int, default=32)
+    args = ap.parse_args()
+    from vo_single_camera_sos_amd import synthetic
+    from vo_single_camera_sos_amd.omnistereo.gum import synthetic_gums
+    from vo_single_camera_sos_amd.omnistereo.panorama import Panorama
+    gs = synthetic_gums()
+    for m in (gs.top_model, gs.bot_model):
+        m.panorama = Panorama(m, width=1440)
+    gs.make_annulus_masks((480, 640))
+    seq, _ = synthetic.make_sequence(gs, args.frames, seed=1241, workers=min(16, len(os.sched_getaffinity(0))))
+    import torch
+    from vo_single_camera_sos_amd.omnistereo.pose_est_tools import run_VO
+
+    def frames(n=args.frames):
+        for k in range(n):
+            yield k, seq[k], None
+    with tempfile.TemporaryDirectory() as d:
+        with contextlib.redirect_stdout(io.StringIO()):
+            run_VO(None, gs, results_path=d, _live_frames=lambda: frames(min(args.frames, 34)), frame_window=args.window)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = run_VO(None, gs, results_path=d, _live_frames=frames, frame_window=args.window)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            pr = cProfile.Profile()
+            pr.enable()
+            run_VO(None, gs, results_path=d, _live_frames=frames, frame_window=args.window)
+            torch.cuda.synchronize()
+            pr.disable()
+    print("unprofiled: %.1f frames/s, %.3f ms per frame; stages %s" % (args.frames / dt, 1e3 * dt / args.frames, r["sequence_mode"]["stage_s"]))
+    s = io.StringIO()
+    pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(args.top)
+    print(s.getvalue())
+
+
+if __name__ == "__main__":
+    main()

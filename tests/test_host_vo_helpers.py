@@ -265,3 +265,29 @@ def test_frame_source_thread_lockstep_and_free_running():
     t.quit_flag = True
     t.join()
     assert a is not None and b > a and t.current_frame is None
+
+
+def test_batched_quaternions_and_pose_line_formatting_equal_the_per_frame_forms():
+    """run_VO's sequence mode formats a window's pose lines at once: tr.quaternions_from_matrices must equal
+    quaternion_from_matrix row by row BIT FOR BIT, and repr() of the Python floats must print what print() prints for the
+    numpy scalars (the reference's `print(idx, t[0], ..., sep=" ")`, pose_est_tools.py:1611)."""
+    import io
+    from vo_single_camera_sos_amd.omnistereo import transformations as tr
+    rng = np.random.default_rng(3)
+    Ms = []
+    for k in range(300):
+        q = rng.normal(size=4)
+        T = tr.quaternion_matrix(q / np.linalg.norm(q))
+        if k % 3 == 0:
+            T[:3, :3] += rng.normal(scale=1e-9, size=(3, 3))     # slightly non-orthonormal, as chained poses are
+        T[:3, 3] = rng.normal(size=3) * 10.0 ** rng.integers(-7, 6)
+        Ms.append(T)
+    Ms += [np.identity(4), np.diag([1.0, -1.0, -1.0, 1.0]), np.diag([-1.0, -1.0, 1.0, 1.0])]
+    Ms = np.stack(Ms)
+    one = np.stack([tr.quaternion_from_matrix(M, isprecise=False) for M in Ms])
+    assert np.array_equal(tr.quaternions_from_matrices(Ms).view(np.uint64), one.view(np.uint64))
+    assert tr.quaternions_from_matrices(np.zeros((0, 4, 4))).shape == (0, 4)
+    vals = np.concatenate([Ms[:, :3, 3].ravel(), one.ravel(), [1e16, 1e-5, -0.0, 123456789012345680.0, 5e-324, np.nan, np.inf]])
+    buf = io.StringIO()
+    print(*vals, sep=" ", end="", file=buf)
+    assert buf.getvalue() == " ".join(repr(v) for v in vals.tolist())

@@ -128,6 +128,17 @@ class Panorama(object):
                                  stand_masks_width_in_degrees=1, show=False, omni_shape=None, unwrap_fn=None):
         """`unwrap_fn(omni_mask) -> pano_mask` overrides the GPU unwrap of the elevation mask (tests use it to
         build the masks without a GPU); default is self.get_panoramic_image."""
+        # the same request as last time (every tracker bootstrap asks again, pose_est_tools.py:870-878): the masks are a pure
+        # function of these arguments and of the model's annulus mask -- keep them (a GPU unwrap + twelve full-size images)
+        mm = getattr(self.model, "mask", None)
+        key = (float(azimuth_mask_degrees), float(overlap_degrees), bool(mask_also_on_elev), int(elev_mask_padding),
+               tuple(float(a) for a in stand_masks_azimuth_coord_in_degrees_list), float(stand_masks_width_in_degrees),
+               None if omni_shape is None else tuple(omni_shape), unwrap_fn is None, self.rows, self.cols,
+               None if mm is None else (mm.shape, int(np.count_nonzero(mm))),
+               tuple(float(v) for v in (self.model.inner_img_radius, self.model.outer_img_radius)))
+        if getattr(self, "_azimuthal_masks_key", None) == key and self.azimuthal_masks:
+            return self.azimuthal_masks
+        self._azimuthal_masks_key = None
         azimuth_mask_radians = np.deg2rad(azimuth_mask_degrees)
         overlap_radians = np.deg2rad(overlap_degrees)
         self.azimuthal_masks = []
@@ -168,6 +179,7 @@ class Panorama(object):
             if mask_for_stands is not None:
                 mask = np.where(mask > 0, mask & mask_for_stands, 0).astype(np.uint8)
             self.azimuthal_masks.append(mask)
+        self._azimuthal_masks_key = key
         return self.azimuthal_masks
 
     def mask_bits(self):

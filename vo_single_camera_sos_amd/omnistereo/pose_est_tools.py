@@ -31,6 +31,9 @@ from .camera_models import FeatureMatcher, KeyPoint, KeyPointAndDescriptor, Pano
 from .common_cv import filter_pixel_correspondences
 from .common_tools import copy_only_attributes, get_length_units_conversion_factor, make_sure_path_exists
 
+_IDENTITY4 = np.identity(4)
+_IDENTITY4.setflags(write=False)   # shared initial pose of device frames: replaced by the tracker, never written in place
+
 
 def normalized(v):
     return v / np.linalg.norm(v)
@@ -347,8 +350,11 @@ class TrackerStereoSE3(TrackerSE3):
         status) of the pair -- the speculative one when the reference is the frame's predecessor, one serial tracking
         call against the keyframe slot otherwise -- put through the same bookkeeping as above."""
         eng = current_frame.engine
-        if current_frame.spec_record is not None and getattr(reference_frame, "seq_index", None) == current_frame.seq_index - 1:
+        ref_seq = getattr(reference_frame, "seq_index", None)
+        if current_frame.spec_record is not None and ref_seq == current_frame.seq_index - 1:
             rec = current_frame.spec_record
+        elif current_frame.spec2_record is not None and ref_seq == current_frame.seq_index - 2:
+            rec = current_frame.spec2_record      # the frame in between was not promoted: tracked against t - 2 in the batch
         else:
             rec = eng.track(eng.key_slot, current_frame.slot, current_frame.seed)
         num_initial_matches = int(rec[13])
@@ -370,7 +376,10 @@ class StereoPanoramicKeyFrame(StereoPanoramicFrame):
     """pose_est_tools.py:625-632: a frame promoted to keyframe (a blind copy of its attributes)."""
 
     def __init__(self, frame, **kwargs):
-        copy_only_attributes(objfrom=frame, objto=self)
+        if isinstance(frame, DeviceStereoFrame):   # (plain instance attributes only: the same blind copy, without dir())
+            self.__dict__.update(frame.__dict__)
+        else:
+            copy_only_attributes(objfrom=frame, objto=self)
         self.children_ids = []
 
 
@@ -381,20 +390,20 @@ class DeviceStereoFrame(StereoPanoramicFrame):
     store while the frame's window is current; the keyframe slot once promoted)."""
 
     def __init__(self, engine, info, stereo_camera_model, frame_id, seq_index, **kwargs):
+        consts = getattr(engine, "_frame_consts", None)
+        if consts is None:   # the same for every frame of the engine (ctypes field reads are slow: once)
+            consts = engine._frame_consts = dict(
+                panoramic_image_top=None, panoramic_image_bottom=None, use_midpoint_triangulation=True,
+                use_opengv_triangulation=False, first_row_to_crop_bottom=0, total_time=0., pano_correspondences=None,
+                conversion_factor_length_to_m=get_length_units_conversion_factor(stereo_camera_model.units, "m"),
+                median_win_size=int(engine.cfg.median_ksize), min_disp=engine.rig_cfg.stereo_min_disp,
+                max_u_dist=engine.rig_cfg.stereo_max_hdiff, min_range=engine.rig_cfg.min_range, max_range=engine.rig_cfg.max_range)
+        self.__dict__.update(consts)
         self.frame_id = frame_id
         self.parent_id = kwargs.get("parent_id", -1)
-        self.T_frame_wrt_tracking_ref_frame = np.identity(4)
-        self.panoramic_image_top = self.panoramic_image_bottom = None
-        self.use_midpoint_triangulation, self.use_opengv_triangulation = True, False
-        self.conversion_factor_length_to_m = get_length_units_conversion_factor(stereo_camera_model.units, "m")
-        self.first_row_to_crop_bottom = 0
-        self.total_time = 0.
-        self.median_win_size = engine.cfg.median_ksize
-        self.min_disp, self.max_u_dist = engine.rig_cfg.stereo_min_disp, engine.rig_cfg.stereo_max_hdiff
-        self.min_range, self.max_range = engine.rig_cfg.min_range, engine.rig_cfg.max_range
-        self.pano_correspondences = None
+        self.T_frame_wrt_tracking_ref_frame = _IDENTITY4   # (replaced, never written in place, by the tracker)
         self.engine, self.slot, self.seq_index = engine, int(info["slot"]), int(seq_index)
-        self.seed, self.spec_record = int(info["seed"]), info["spec"]
+        self.seed, self.spec_record, self.spec2_record = int(info["seed"]), info["spec"], info.get("spec2")
         self.num_valid_keypoints = int(info["count"])
 
     def promote(self):
@@ -424,10 +433,22 @@ def sequence_engine_for(tracker, camera_model, first_image, window):
                     f2f_max_hdiff=tracker.max_horizontal_diff_f2f_matches, pct_good_matches=tracker.percentage_good_matches)
     nfeat = tracker.num_features_detection_for_static_stereo
     cap = int(min(4096, max(64, -(-int(nfeat) // 64) * 64)))      # as GUMStereo._front_end (the mirror path's capacity)
-    return SequenceEngine(om._context(), model, rig, window=window, num_of_features=nfeat, kp_cap=cap, frame_cap=4096,
-                          median_win_size=11, thr=tracker.backprojection_score_threshold_3D_to_2D,
-                          max_iter=tracker.max_ransac_iterations_3D_to_2D, adaptive=True, lm_iter=pyopengv.LM_MAX_ITERATIONS,
-                          ransac_solver="GP3P")
+    # an engine (frame store, pinned staging buffers, scratch) is kept with the rig and reused by later runs with the same
+    # settings: building one costs more than tracking a hundred frames
+    key = (int(window), int(nfeat), cap, float(tracker.backprojection_score_threshold_3D_to_2D),
+           int(tracker.max_ransac_iterations_3D_to_2D), float(tracker.max_horizontal_diff_f2f_matches),
+           float(tracker.percentage_good_matches), tuple(geo[0]), tuple(geo[1]), tuple(top.F[:3, 0]), tuple(bot.F[:3, 0]), id(model))
+    cache = om.__dict__.setdefault("_sequence_engines", {})
+    eng = cache.get(key)
+    if eng is None:
+        cache.clear()   # (one engine per rig: a new configuration replaces the old one's buffers)
+        eng = cache[key] = SequenceEngine(om._context(), model, rig, window=window, num_of_features=nfeat, kp_cap=cap,
+                                          frame_cap=4096, median_win_size=11, thr=tracker.backprojection_score_threshold_3D_to_2D,
+                                          max_iter=tracker.max_ransac_iterations_3D_to_2D, adaptive=True,
+                                          lm_iter=pyopengv.LM_MAX_ITERATIONS, ransac_solver="GP3P")
+    else:
+        eng.reset()
+    return eng
 
 
 class RGBDFrame(object):
@@ -495,7 +516,10 @@ class RGBDKeyFrame(RGBDFrame):
     """pose_est_tools.py:634-641"""
 
     def __init__(self, frame, **kwargs):
-        copy_only_attributes(objfrom=frame, objto=self)
+        if isinstance(frame, DeviceRGBDFrame):   # (plain instance attributes only: the same blind copy, without dir())
+            self.__dict__.update(frame.__dict__)
+        else:
+            copy_only_attributes(objfrom=frame, objto=self)
         self.children_ids = []
 
 
@@ -516,7 +540,7 @@ class DeviceRGBDFrame(RGBDFrame):
         self.rgb_img = self.depth_map = self.current_depth = None
         self.keypoints_and_descriptors = self.bearing_vectors = self.keypoints_3D_points = None
         self.engine, self.slot, self.seq_index = engine, int(info["slot"]), int(seq_index)
-        self.seed, self.spec_record = int(info["seed"]), info["spec"]
+        self.seed, self.spec_record, self.spec2_record = int(info["seed"]), info["spec"], info.get("spec2")
         self.num_valid_keypoints = int(info["count"])
 
     def promote(self):
@@ -602,8 +626,11 @@ def _rgbd_track_device_frame(self, reference_frame, current_frame):
     one when the reference is the frame's predecessor, one serial call against the keyframe slot otherwise) put through the
     bookkeeping of track_frame above."""
     eng = current_frame.engine
-    if current_frame.spec_record is not None and getattr(reference_frame, "seq_index", None) == current_frame.seq_index - 1:
+    ref_seq = getattr(reference_frame, "seq_index", None)
+    if current_frame.spec_record is not None and ref_seq == current_frame.seq_index - 1:
         rec = current_frame.spec_record
+    elif current_frame.spec2_record is not None and ref_seq == current_frame.seq_index - 2:
+        rec = current_frame.spec2_record
     else:
         rec = eng.track(eng.key_slot, current_frame.slot, current_frame.seed)
     num_initial_matches = int(rec[13])
@@ -657,10 +684,44 @@ def run_VO(visualizer_3D_VO, camera_model, gt_poses_filename=None, est_poses_fil
     results_path = os.path.realpath(os.path.expanduser(results_path))
     make_sure_path_exists(results_path)
     log = open(os.path.join(results_path, "printed_messages.log"), "w")
+    # Sequence mode keeps the per-frame host work small: messages and pose lines are collected and written once per window
+    # (same text, same order), the quaternions of a window's poses come from ONE batched eigen-decomposition
+    # (tr.quaternions_from_matrices: bit-identical rows).  The per-frame paths (frame_window 0, live sources) flush every frame.
+    out_msgs, log_only, pending = [], [], []    # stdout + log lines | (position in out_msgs, line) for the log only | poses
 
     def say(msg):
-        print(msg)
-        print(msg, file=log)
+        out_msgs.append(msg)
+
+    def flush_output():
+        if out_msgs or log_only:
+            if out_msgs:
+                print("\n".join(out_msgs))
+            lines, extra = list(out_msgs), sorted(log_only, key=lambda e: e[0], reverse=True)
+            for pos, line in extra:            # (a failure message goes to the log only, where it was said)
+                lines.insert(pos, line)
+            log.write("\n".join(lines) + "\n")
+            del out_msgs[:], log_only[:]
+        if pending:
+            idxs = [p_[0] for p_ in pending]
+            Te = np.stack([p_[1] for p_ in pending])
+            qe, te = tr.quaternions_from_matrices(Te).tolist(), Te[:, :3, 3].tolist()
+            est_file.write("".join("%d %s %s %s %s %s %s %s\n" % (i, repr(t[0]), repr(t[1]), repr(t[2]), repr(q[1]), repr(q[2]),
+                                                                     repr(q[3]), repr(q[0])) for i, t, q in zip(idxs, te, qe)))
+            gts = [p_[2] for p_ in pending]
+            uniq = {}
+            for g in gts:                        # (one shared identity for a run without ground truth: decomposed once)
+                uniq.setdefault(id(g), g)
+            keys = list(uniq)
+            Tg = np.stack([uniq[k_] for k_ in keys])
+            bad = np.isnan(Tg).any(axis=(1, 2))
+            qg = tr.quaternions_from_matrices(np.where(bad[:, None, None], np.identity(4), Tg)).tolist()
+            tg = Tg[:, :3, 3].tolist()
+            line_of = {}
+            for k_, b_, t, q in zip(keys, bad.tolist(), tg, qg):
+                line_of[k_] = " nan nan nan nan nan nan nan\n" if b_ else " %s %s %s %s %s %s %s\n" % (
+                    repr(t[0]), repr(t[1]), repr(t[2]), repr(q[1]), repr(q[2]), repr(q[3]), repr(q[0]))
+            gt_file.write("".join("%d%s" % (i, line_of[id(g)]) for i, g in zip(idxs, gts)))
+            del pending[:]
 
     pose_output_file_units = "m"
     zero_up_gt_wrt_origin = True
@@ -701,32 +762,75 @@ def run_VO(visualizer_3D_VO, camera_model, gt_poses_filename=None, est_poses_fil
         source = frames
 
         def frames():   # the same frames, `frame_window` at a time through the batched front end
+            import queue
+            W = int(frame_window)
             it = iter(source())
-            seq_index = 0
-            while True:
+
+            def next_chunk():
                 chunk = []
                 for item in it:
                     chunk.append(item)
-                    if len(chunk) >= int(frame_window):
+                    if len(chunk) >= W:
                         break
-                if not chunk:
-                    return
-                if not engine_state["tried"]:
-                    engine_state["tried"] = True
-                    engine_state["engine"] = (rgbd_sequence_engine_for if rgbd else sequence_engine_for)(
-                        tracker, camera_model, chunk[0][1], int(frame_window))
-                eng = engine_state["engine"]
-                if eng is None:          # no batched counterpart of this configuration: the per-frame path
+                return chunk
+            chunk = next_chunk()
+            if not chunk:
+                return
+            engine_state["tried"] = True
+            eng = engine_state["engine"] = (rgbd_sequence_engine_for if rgbd else sequence_engine_for)(
+                tracker, camera_model, chunk[0][1], W)
+            if eng is None:              # no batched counterpart of this configuration: the per-frame path
+                while chunk:
                     for item in chunk:
                         yield item
-                    continue
-                t0 = time.perf_counter()
-                infos = eng.push_window([(item[1], item[2]) if rgbd else item[1] for item in chunk])
-                engine_state["window_s"] += time.perf_counter() - t0
-                engine_state["windows"] += 1
-                for item, info in zip(chunk, infos):
-                    yield item[0], item[1], None, info, seq_index
-                    seq_index += 1
+                    chunk = next_chunk()
+                return
+            images_of = (lambda c: [(item[1], item[2]) for item in c]) if rgbd else (lambda c: [item[1] for item in c])
+            # a helper thread pulls the NEXT window from the source and copies it into the engine's other pinned buffer while
+            # this one is processed (the copy releases the GIL); a buffer returns to the thread after its upload was synchronised
+            free, ready = queue.Queue(), queue.Queue()
+            free.put(1)
+            stop = threading.Event()
+
+            def producer():
+                try:
+                    while not stop.is_set():
+                        c = next_chunk()
+                        if not c:
+                            break
+                        b = free.get()
+                        if b is None:
+                            return
+                        t0 = time.perf_counter()
+                        eng.stage_host(images_of(c), b)
+                        eng.stage_s["stage_to_pinned"] += time.perf_counter() - t0
+                        ready.put((c, b))
+                    ready.put((None, None))
+                except BaseException as e:   # handed to the consumer
+                    ready.put((e, None))
+            t0 = time.perf_counter()
+            eng.stage_host(images_of(chunk), 0)
+            eng.stage_s["stage_to_pinned"] += time.perf_counter() - t0
+            worker = threading.Thread(target=producer, name="sosvo-stage", daemon=True)
+            worker.start()
+            seq_index, buf = 0, 0
+            try:
+                while chunk:
+                    t0 = time.perf_counter()
+                    infos = eng.push_staged(buf, len(chunk))     # (synchronises: the upload from `buf` is complete)
+                    engine_state["window_s"] += time.perf_counter() - t0
+                    engine_state["windows"] += 1
+                    free.put(buf)
+                    flush_output()                               # the previous window's lines, off the per-frame path
+                    for item, info in zip(chunk, infos):
+                        yield item[0], item[1], None, info, seq_index
+                        seq_index += 1
+                    chunk, buf = ready.get()
+                    if isinstance(chunk, BaseException):
+                        raise chunk
+            finally:
+                stop.set()
+                free.put(None)
     if gt_poses_filename is None or not os.path.exists(gt_poses_filename):
         n_gt = max(len(img_indices), img_indices[-1] + 1)
         gt_list = n_gt * [np.identity(4)]   # (a live run has no ground truth: identity for every frame, as :1012)
@@ -760,19 +864,22 @@ def run_VO(visualizer_3D_VO, camera_model, gt_poses_filename=None, est_poses_fil
     n_done = 0
     frame_iter = iter(frames())
     img_index_number = -1
+    batched_output = False       # sequence mode: lines are written once per window (flush_output in the window generator)
+    kf_lines = []
     while True:
-        t_frame = time.process_time()
-        t0 = time.process_time()
+        t_frame = t0 = time.process_time()
         try:
             item = next(frame_iter)
         except StopIteration:
             break
         idx, img, depth_map = item[:3]
         dev_info = item[3] if len(item) > 3 else None
+        batched_output = dev_info is not None
         img_index_number += 1
+        t1 = time.process_time()
         if img_index_number > 0:
-            acc["read"] += time.process_time() - t0
-        t0 = time.process_time()
+            acc["read"] += t1 - t0
+        t0 = t1
         if dev_info is not None:
             current_frame = (DeviceRGBDFrame if rgbd else DeviceStereoFrame)(
                 engine_state["engine"], dev_info, camera_model, frame_id=idx, seq_index=item[4], parent_id=current_keyframe_id)
@@ -782,16 +889,17 @@ def run_VO(visualizer_3D_VO, camera_model, gt_poses_filename=None, est_poses_fil
         else:
             camera_model.set_current_omni_image(img, generate_panoramas=False, view=False, apply_mask=True, mask_RGB=(0, 0, 0))
             current_frame = StereoPanoramicFrame(stereo_camera_model=camera_model, frame_id=idx, parent_id=current_keyframe_id)
+        t1 = time.process_time()
         if img_index_number > 0:
-            acc["setup"] += time.process_time() - t0
+            acc["setup"] += t1 - t0
         T_gt = gt_list[idx] if idx < len(gt_list) else (np.identity(4) if _live_frames is not None else np.full((4, 4), np.nan))
         if T_Rgt_wrt_S is not None:
             T_gt = tr.concatenate_matrices(T_Rgt_wrt_S, T_gt, T_S_wrt_Rgt)   # :1472
         if img_index_number > 0:
-            t0 = time.process_time()
+            t0 = t1
             ok, msg = tracker.track_frame(reference_frame=reference_frame, current_frame=current_frame)
             if not ok:
-                print(msg, file=log)
+                log_only.append((len(out_msgs), msg))
                 warn("%sWarning failed: %s" % (prefix, msg))
                 break
             reference_frame.children_ids.append(current_frame.frame_id)
@@ -833,7 +941,7 @@ def run_VO(visualizer_3D_VO, camera_model, gt_poses_filename=None, est_poses_fil
             if dev_info is not None:
                 current_frame.promote()   # the frame's record moves to the store's keyframe slot
             current_keyframe_id = reference_frame.frame_id
-            print(current_keyframe_id, file=kf_file)
+            kf_lines.append("%d\n" % current_keyframe_id)
             keyframe_ids.append(current_keyframe_id)
             if len(tracker.T_Ckey_wrt_S_est_list) > 0:
                 T_key = tr.concatenate_matrices(tracker.T_Ckey_wrt_S_est_list[-1], reference_frame.T_frame_wrt_tracking_ref_frame)
@@ -842,21 +950,20 @@ def run_VO(visualizer_3D_VO, camera_model, gt_poses_filename=None, est_poses_fil
             tracker.T_Ckey_wrt_S_est_list.append(T_key)
             create_keyframe = False
             number_of_keyframes += 1
-        # TUM lines: idx tx ty tz qx qy qz qw (:1611-1621)
-        q = tr.quaternion_from_matrix(matrix=tracker.T_C_curr_frame_wrt_S_est, isprecise=False)
-        t = tr.translation_from_matrix(matrix=tracker.T_C_curr_frame_wrt_S_est)
-        print(idx, t[0], t[1], t[2], q[1], q[2], q[3], q[0], sep=" ", end="\n", file=est_file)
-        if np.any(np.isnan(T_gt)):
-            qg, tg = 4 * [np.nan], 3 * [np.nan]
-        else:
-            qg, tg = tr.quaternion_from_matrix(matrix=T_gt, isprecise=False), tr.translation_from_matrix(matrix=T_gt)
-        print(idx, tg[0], tg[1], tg[2], qg[1], qg[2], qg[3], qg[0], sep=" ", end="\n", file=gt_file)
-        poses_out.append((idx, np.array(tracker.T_C_curr_frame_wrt_S_est, copy=True)))
+        # TUM lines: idx tx ty tz qx qy qz qw (:1611-1621), quaternion_from_matrix(isprecise=False) of the pose -- formatted by
+        # flush_output (a window at a time in sequence mode)
+        T_now = np.array(tracker.T_C_curr_frame_wrt_S_est, copy=True)
+        pending.append((idx, T_now, T_gt))
+        poses_out.append((idx, T_now))
         if img_index_number > 0:
             acc["vo"] += time.process_time() - t_frame
         n_done = img_index_number
         say("%sDONE with F[%d] (Parent K[%d]). C.M.Avg. RANSAC inlier ratio = %.3f"
             % (prefix, current_frame.frame_id, current_frame.parent_id, inlier_ratio_cma))
+        if not batched_output:
+            flush_output()
+    flush_output()
+    kf_file.write("".join(kf_lines))
     d = float(max(n_done, 1))
     summary = "\n".join([
         "%sVO done with %d keyframes" % (prefix, number_of_keyframes),
@@ -870,6 +977,7 @@ def run_VO(visualizer_3D_VO, camera_model, gt_poses_filename=None, est_poses_fil
         "Estimated poses in TUM format SAVED as " + est_path,
         "Keyframes (indices) SAVED as " + kf_path])
     say(summary)
+    flush_output()
     for f in (est_file, gt_file, kf_file, log):
         f.close()
     out = dict(poses=poses_out, keyframe_ids=keyframe_ids, tracked=n_done, message=summary)

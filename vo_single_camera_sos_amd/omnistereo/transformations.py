@@ -95,6 +95,30 @@ def quaternion_from_matrix(matrix, isprecise=False):
     return -q if q[0] < 0.0 else q
 
 
+def quaternions_from_matrices(matrices):
+    """quaternion_from_matrix for a stack [n, 4, 4] (or [n, 3, 3]) -> [n, 4] rows [w, x, y, z]: the same float64 operations
+    element by element and the same LAPACK call per matrix (numpy's eigh loops over the stack), so every row equals the
+    one-at-a-time result bit for bit (tests/test_host_vo_helpers.py) -- run_VO formats a window's pose lines with it."""
+    M = np.asarray(matrices, dtype=np.float64)
+    n = M.shape[0]
+    if n == 0:
+        return np.zeros((0, 4))
+    R = M[:, :3, :3]
+    K = np.empty((n, 4, 4))
+    K[:, :3, :3] = R + R.transpose(0, 2, 1)
+    for i in range(3):
+        j, k = (i + 1) % 3, (i + 2) % 3
+        K[:, i, i] = R[:, i, i] - R[:, j, j] - R[:, k, k]
+    z = np.stack([R[:, 2, 1] - R[:, 1, 2], R[:, 0, 2] - R[:, 2, 0], R[:, 1, 0] - R[:, 0, 1]], axis=1)
+    K[:, 3, :3] = z
+    K[:, :3, 3] = z
+    K[:, 3, 3] = R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2]
+    evals, evecs = np.linalg.eigh(K / 3.0)
+    v = evecs[np.arange(n), :, np.argmax(evals, axis=1)]        # [n, 4] = (x, y, z, w)
+    q = v[:, [3, 0, 1, 2]]
+    return np.where(q[:, :1] < 0.0, -q, q)
+
+
 def quaternion_multiply(q1, q0):
     """Hamilton product q1 * q0 of two [w, x, y, z] quaternions (the rotation q0 followed by q1)."""
     w0, x0, y0, z0 = q0

@@ -384,10 +384,17 @@ class _SequenceBase(object):
     def _init_windows(self, window):
         self.W = max(1, int(window))
         self.slots, self.key_slot = 2 * self.W + 1, 2 * self.W
+        self.reset()
+
+    def reset(self):
+        """Forget the sequence (an engine is reused from run to run: its buffers -- pinned host memory among them -- are the
+        expensive part of its construction)."""
         self.half = 1            # the half the NEXT window goes to is 1 - half
         self.last_slot = None    # slot of the newest frame of the sequence
+        self.last2_slot = None   # ... and of the one before it
         self.frames_seen = 0     # frames pushed so far (frame t of the sequence is tracked with seed t - 1)
         self.serial_calls = 0    # tracking calls the speculation did not cover
+        self._key_src = None     # slot of a promoted frame whose record has not been copied to the keyframe slot yet
         self.stage_s = dict(stage_to_pinned=0.0, enqueue=0.0, wait_and_readback=0.0, serial_track=0.0)   # host wall clock
 
     def push_window(self, images):
@@ -401,10 +408,28 @@ class _SequenceBase(object):
         if n > self.W:
             raise ValueError("more frames than the window holds")
         t0 = time.perf_counter()
-        self._stage(images)
+        self.stage_host(images, 0)
+        self.stage_s["stage_to_pinned"] += time.perf_counter() - t0
+        return self.push_staged(0, n)
+
+    def stage_host(self, images, buf):
+        """Copies the frames into pinned host buffer `buf` (0 / 1).  Touches nothing else: a helper thread may stage the NEXT
+        window into the other buffer while this one is processed (numpy's copy releases the GIL) -- run_VO does."""
+        self._stage_host(images, int(buf))
+
+    def push_staged(self, buf, n):
+        """push_window for n frames already staged in pinned buffer `buf`."""
+        import time
+        if n == 0:
+            return []
+        if n > self.W:
+            raise ValueError("more frames than the window holds")
         t1 = time.perf_counter()
         self.half = 1 - self.half
         first = self.half * self.W
+        if self._key_src is not None and first <= self._key_src < first + self.W:
+            self._flush_promotion()   # the promoted frame's record is about to be overwritten
+        self._upload(int(buf), n)
         self._front_end(n, first)
         # speculative tracking: frame i of the window against its predecessor (the first one against the previous
         # window's last frame; the very first frame of the sequence has nothing to track against)
@@ -414,11 +439,23 @@ class _SequenceBase(object):
         seed0 = self.frames_seen - 1 if self.last_slot is not None else 0   # frame t tracks with seed t - 1
         if cur:
             self._track(prev, cur, seed0, self.spec)
+        # second guess: frame t against frame t - 2 -- the reference whenever frame t - 1 was NOT promoted to keyframe (then
+        # the keyframe usually is t - 2: a frame is passed over when it has moved too little, rarely twice in a row).  Same
+        # seeds (t - 1), so these are the records the serial call would return; what neither guess covers stays serial.
+        # (a frame of the previous window is still in the store unless its slot lies in the half being refilled: window 1)
+        alive = lambda s_: s_ is not None and not (first <= s_ < first + self.W)  # noqa: E731
+        older = ([self.last2_slot] if alive(self.last2_slot) and alive(self.last_slot) else []) + \
+            ([self.last_slot] if alive(self.last_slot) else []) + slots                       # frames ... t0-2, t0-1, t0, ...
+        k0 = len(older) - n                                     # position of the window's first frame in `older`
+        cur2 = [slots[i] for i in range(n) if k0 + i - 2 >= 0]
+        prev2 = [older[k0 + i - 2] for i in range(n) if k0 + i - 2 >= 0]
+        if cur2:
+            self._track(prev2, cur2, self.frames_seen + (n - len(cur2)) - 1, self.spec2)
         t2 = time.perf_counter()
         counts = self._counts(first, n)   # synchronises
         spec = self.spec[:len(cur)].cpu().numpy() if cur else np.zeros((0, 16))
+        spec2 = self.spec2[:len(cur2)].cpu().numpy() if cur2 else np.zeros((0, 16))
         t3 = time.perf_counter()
-        self.stage_s["stage_to_pinned"] += t1 - t0
         self.stage_s["enqueue"] += t2 - t1
         self.stage_s["wait_and_readback"] += t3 - t2
         out = []
@@ -426,9 +463,11 @@ class _SequenceBase(object):
             t = self.frames_seen + i            # index of the frame in the sequence
             j = i if self.last_slot is not None else i - 1
             has = j >= 0 and len(cur) > 0
+            j2 = i - (n - len(cur2))
             out.append(dict(slot=slots[i], count=counts[i], seed=max(t - 1, 0), spec_ref=prev[j] if has else None,
-                            spec=spec[j].copy() if has else None))
+                            spec=spec[j].copy() if has else None, spec2=spec2[j2].copy() if j2 >= 0 else None))
         self.frames_seen += n
+        self.last2_slot = slots[-2] if n >= 2 else self.last_slot
         self.last_slot = slots[-1]
         return out
 
@@ -437,14 +476,23 @@ class _SequenceBase(object):
         import time
         t0 = time.perf_counter()
         self.serial_calls += 1
+        if int(ref_slot) == self.key_slot:
+            self._flush_promotion()
         self._track([int(ref_slot)], [int(cur_slot)], int(seed), self.one)
         rec = self.one.cpu().numpy()[0]
         self.stage_s["serial_track"] += time.perf_counter() - t0
         return rec
 
     def promote(self, slot):
-        """The frame in `slot` becomes the keyframe: its record is copied to the keyframe slot (asynchronous)."""
-        self._copy(int(slot), self.key_slot)
+        """The frame in `slot` becomes the keyframe.  Its record moves to the keyframe slot LAZILY: when a serial tracking call
+        reads that slot, or when the window half the frame lives in is about to be refilled -- most keyframes are replaced
+        by the next one before either happens (242 of 256 frames of the bench sequence are promoted, 14 copies are made)."""
+        self._key_src = int(slot)
+
+    def _flush_promotion(self):
+        if self._key_src is not None:
+            self._copy(self._key_src, self.key_slot)
+            self._key_src = None
 
 
 class SequenceEngine(_SequenceBase):
@@ -484,17 +532,19 @@ class SequenceEngine(_SequenceBase):
         dev = ctx.device
         self.workspace = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
         self.omni = torch.zeros((self.W, model.H, model.W, 3), dtype=torch.uint8, device=dev)
-        self._host = torch.zeros((self.W, model.H, model.W, 3), dtype=torch.uint8).pin_memory()
-        self._host_np = self._host.numpy()
+        self._host = [torch.zeros((self.W, model.H, model.W, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self._host_np = [h.numpy() for h in self._host]
         self.spec = torch.zeros((self.W, 16), dtype=torch.float64, device=dev)
+        self.spec2 = torch.zeros((self.W, 16), dtype=torch.float64, device=dev)
         self.one = torch.zeros((1, 16), dtype=torch.float64, device=dev)
 
-    def _stage(self, images):
-        n = len(images)
-        for i in range(n):
-            np.copyto(self._host_np[i], images[i])
-        self.omni[:n].copy_(self._host[:n], non_blocking=True)
-        self._n = n
+    def _stage_host(self, images, buf):
+        dst = self._host_np[buf]
+        for i in range(len(images)):
+            np.copyto(dst[i], images[i])
+
+    def _upload(self, buf, n):
+        self.omni[:n].copy_(self._host[buf][:n], non_blocking=True)
 
     def _front_end(self, n, first):
         m = self.model
@@ -753,19 +803,21 @@ class RGBDSequenceEngine(_SequenceBase):
         self.workspace = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
         self.bgr = torch.zeros((self.W, rows, cols, 3), dtype=torch.uint8, device=dev)
         self.depth = torch.zeros((self.W, rows, cols), dtype=torch.float32, device=dev)
-        self._host_bgr = torch.zeros((self.W, rows, cols, 3), dtype=torch.uint8).pin_memory()
-        self._host_depth = torch.zeros((self.W, rows, cols), dtype=torch.float32).pin_memory()
-        self._np_bgr, self._np_depth = self._host_bgr.numpy(), self._host_depth.numpy()
+        self._host_bgr = [torch.zeros((self.W, rows, cols, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self._host_depth = [torch.zeros((self.W, rows, cols), dtype=torch.float32).pin_memory() for _ in range(2)]
+        self._np_bgr, self._np_depth = [h.numpy() for h in self._host_bgr], [h.numpy() for h in self._host_depth]
         self.spec = torch.zeros((self.W, 16), dtype=torch.float64, device=dev)
+        self.spec2 = torch.zeros((self.W, 16), dtype=torch.float64, device=dev)
         self.one = torch.zeros((1, 16), dtype=torch.float64, device=dev)
 
-    def _stage(self, images):
-        n = len(images)
+    def _stage_host(self, images, buf):
         for i, (bgr, depth) in enumerate(images):
-            np.copyto(self._np_bgr[i], bgr)
-            np.copyto(self._np_depth[i], np.asarray(depth, dtype=np.float32))
-        self.bgr[:n].copy_(self._host_bgr[:n], non_blocking=True)
-        self.depth[:n].copy_(self._host_depth[:n], non_blocking=True)
+            np.copyto(self._np_bgr[buf][i], bgr)
+            np.copyto(self._np_depth[buf][i], np.asarray(depth, dtype=np.float32))
+
+    def _upload(self, buf, n):
+        self.bgr[:n].copy_(self._host_bgr[buf][:n], non_blocking=True)
+        self.depth[:n].copy_(self._host_depth[buf][:n], non_blocking=True)
 
     def _front_end(self, n, first):
         self.ctx.rgbd_sequence_front_end(self.cam, self.cfg, self.W, self.slots, self.bgr[:n], self.depth[:n], first,
