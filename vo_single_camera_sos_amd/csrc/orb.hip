@@ -213,28 +213,64 @@ __device__ __forceinline__ uint32_t max16(uint32_t a, uint32_t b) { return (uint
 
 // e[k] = 256 + circle pixel k - centre pixel (1 .. 511, so that 16-bit UNSIGNED minima / maxima -- the fast-rate VALU
 // forms -- order them) -> corner score: the largest threshold for which the pixel is still a FAST-9 corner, minus 1
-// (0: not a corner at `thr`).  Over the 16 arcs of 9 consecutive circle pixels: A = max of the arcs' minima (brighter),
-// B = min of the arcs' maxima (darker), by doubling (windows of 2, 4, 8, then 9); best = max(A - 256, 256 - B).
-__device__ __forceinline__ int fast_score_from_biased(const uint32_t (&e)[16], int thr) {
-  uint32_t lo2[16], hi2[16], lo4[16], hi4[16];
+// (0: not a corner at `thr`): best = max(A - 256, 256 - B) with A = max over the 16 arcs of 9 consecutive circle pixels of
+// the arc's minimum (brighter), B = min over the arcs of the arc's maximum (darker).
+//
+// max over the arcs of the arc's minimum, van Herk's way: the circle is two blocks of eight; an arc that starts at k inside
+// a block is the block's suffix from k plus the k + 1 first values of the other block, so 4 x 7 running minima (two
+// suffix, two prefix chains) + 16 + 15 instructions serve all 16 arcs (59; a doubling network needs 80).
+__device__ __forceinline__ uint32_t fast_arc_max_of_min(const uint32_t (&g)[16]) {
+  uint32_t suf0[8], pre1[8], suf1[8], pre0[8];
+  suf0[7] = g[7];
+  pre1[0] = g[8];
+  suf1[7] = g[15];
+  pre0[0] = g[0];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    lo2[k] = min16(e[k], e[(k + 1) & 15]);
-    hi2[k] = max16(e[k], e[(k + 1) & 15]);
+  for (int k = 6; k >= 0; --k) {
+    suf0[k] = min16(g[k], suf0[k + 1]);
+    suf1[k] = min16(g[8 + k], suf1[k + 1]);
   }
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    lo4[k] = min16(lo2[k], lo2[(k + 2) & 15]);
-    hi4[k] = max16(hi2[k], hi2[(k + 2) & 15]);
+  for (int j = 1; j < 8; ++j) {
+    pre1[j] = min16(g[8 + j], pre1[j - 1]);
+    pre0[j] = min16(g[j], pre0[j - 1]);
   }
-  uint32_t A = 0u, B = 0xFFFFu;
+  uint32_t A = min16(suf0[0], pre1[0]);
+  A = max16(A, min16(suf1[0], pre0[0]));
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    A = max16(A, min16(min16(lo4[k], lo4[(k + 4) & 15]), e[(k + 8) & 15]));
-    B = min16(B, max16(max16(hi4[k], hi4[(k + 4) & 15]), e[(k + 8) & 15]));
+  for (int k = 1; k < 8; ++k) {
+    A = max16(A, min16(suf0[k], pre1[k]));
+    A = max16(A, min16(suf1[k], pre0[k]));
   }
-  const int best = max((int)A - 256, 256 - (int)B);
-  return best > thr ? best - 1 : 0;
+  return A;
+}
+
+// ONE polarity per lane, on the RAW circle values (round 4; rounds 1-3 biased all 16 values by 256 - centre and ran a brighter
+// and a darker network on every pixel: 16 + 160 instructions).  Minima / maxima commute with the bias, so the network runs on
+// the pixel values themselves and the centre is subtracted once at the end.  Any arc of 9 holds at least two of the four compass
+// pixels (0, 4, 8, 12), so a pixel can only be a brighter corner at `thr` when the SECOND LARGEST of them exceeds centre + thr
+// (cb) and a darker one when the second smallest is below centre - thr (cd) -- both from one 8-instruction sorting step; a side
+// that cannot be a corner scores <= thr and never decides the result.  Darker lanes run the same network on 255 - v = v ^ 0xFF:
+// best = A' - centre (brighter), A' - (255 - centre) (darker), i.e. A' - (centre ^ mask).  Lanes with BOTH (0.3 % of the pixels
+// of a noisy panorama, some lane in ~12 % of a wave's rows) take a second pass with the other polarity, decided per wave.
+// Equality with the two-sided network on biased values: scratch-checked on 24 M circles, and by every detector test.
+// v[k]: circle pixel k (0 .. 255), c: the centre; valid: the lane's pixel can be a corner at all (interior column).
+__device__ __forceinline__ int fast_score_raw(const uint32_t (&v)[16], int c, int thr, bool valid) {
+  const uint32_t hiA = max16(v[0], v[4]), loA = min16(v[0], v[4]), hiB = max16(v[8], v[12]), loB = min16(v[8], v[12]);
+  const uint32_t X = min16(hiA, hiB), Y = max16(loA, loB);
+  const bool cb = valid && (int)max16(X, Y) > c + thr, cd = valid && (int)min16(X, Y) < c - thr;
+  if (__ballot(cb || cd) == 0ULL) return 0;  // uniform: no lane of the wave can hold a corner (most rows of a blurred panorama)
+  const uint32_t mm = (cd && !cb) ? 0xFFu : 0u;
+  uint32_t g[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) g[k] = v[k] ^ mm;
+  int best = (int)fast_arc_max_of_min(g) - (int)((uint32_t)c ^ mm);
+  if (__ballot(cb && cd) != 0ULL) {  // uniform
+#pragma unroll
+    for (int k = 0; k < 16; ++k) g[k] = v[k] ^ 0xFFu;
+    best = max(best, (int)fast_arc_max_of_min(g) - (int)((uint32_t)c ^ 0xFFu));
+  }
+  return ((cb || cd) && best > thr) ? best - 1 : 0;
 }
 
 // FAST-9/16 score map of nimg images that lie img_stride bytes apart (a dense batch, or one pyramid level), rows
@@ -294,31 +330,25 @@ __global__ __launch_bounds__(kThreads) void fast_score_rolling_kernel(const uint
       // row y + dy lives in slot (P + 4 + dy) mod 7; circle pixel k = (rx[k], ry[k]) as in OpenCV's table
       constexpr int s3 = (P + 7) % 7, s2 = (P + 6) % 7, s1 = (P + 5) % 7, s0 = (P + 4) % 7, m1 = (P + 3) % 7, m2 = (P + 2) % 7,
                     m3 = (P + 1) % 7;
-      const uint32_t base = 256u - (uint32_t)vc[s0];
-      uint32_t e[16];
-      e[0] = (uint32_t)vc[s3] + base;    // ( 0,  3)
-      e[1] = (uint32_t)vr1[s3] + base;   // ( 1,  3)
-      e[2] = (uint32_t)vr2[s2] + base;   // ( 2,  2)
-      e[3] = (uint32_t)vr3[s1] + base;   // ( 3,  1)
-      e[4] = (uint32_t)vr3[s0] + base;   // ( 3,  0)
-      e[5] = (uint32_t)vr3[m1] + base;   // ( 3, -1)
-      e[6] = (uint32_t)vr2[m2] + base;   // ( 2, -2)
-      e[7] = (uint32_t)vr1[m3] + base;   // ( 1, -3)
-      e[8] = (uint32_t)vc[m3] + base;    // ( 0, -3)
-      e[9] = (uint32_t)vl1[m3] + base;   // (-1, -3)
-      e[10] = (uint32_t)vl2[m2] + base;  // (-2, -2)
-      e[11] = (uint32_t)vl3[m1] + base;  // (-3, -1)
-      e[12] = (uint32_t)vl3[s0] + base;  // (-3,  0)
-      e[13] = (uint32_t)vl3[s1] + base;  // (-3,  1)
-      e[14] = (uint32_t)vl2[s2] + base;  // (-2,  2)
-      e[15] = (uint32_t)vl1[s3] + base;  // (-1,  3)
-      // Any arc of 9 consecutive circle pixels holds at least two of the four compass pixels (0, 4, 8, 12), so a corner
-      // at `thr` needs two of them brighter than centre + thr or two darker than centre - thr.  When no lane of the wave
-      // passes that test (most row segments of a blurred panorama) the min / max network is skipped: all scores are 0.
-      const uint32_t hi_t = 256u + (uint32_t)thr, lo_t = 256u - (uint32_t)thr;
-      const int nb = (int)(e[0] > hi_t) + (int)(e[4] > hi_t) + (int)(e[8] > hi_t) + (int)(e[12] > hi_t);
-      const int nd = (int)(e[0] < lo_t) + (int)(e[4] < lo_t) + (int)(e[8] < lo_t) + (int)(e[12] < lo_t);
-      if (__ballot(interior_x && (nb >= 2 || nd >= 2)) != 0ULL) s = interior_x ? fast_score_from_biased(e, thr) : 0;
+      const uint32_t v[16] = {
+          (uint32_t)vc[s3],   // ( 0,  3)
+          (uint32_t)vr1[s3],  // ( 1,  3)
+          (uint32_t)vr2[s2],  // ( 2,  2)
+          (uint32_t)vr3[s1],  // ( 3,  1)
+          (uint32_t)vr3[s0],  // ( 3,  0)
+          (uint32_t)vr3[m1],  // ( 3, -1)
+          (uint32_t)vr2[m2],  // ( 2, -2)
+          (uint32_t)vr1[m3],  // ( 1, -3)
+          (uint32_t)vc[m3],   // ( 0, -3)
+          (uint32_t)vl1[m3],  // (-1, -3)
+          (uint32_t)vl2[m2],  // (-2, -2)
+          (uint32_t)vl3[m1],  // (-3, -1)
+          (uint32_t)vl3[s0],  // (-3,  0)
+          (uint32_t)vl3[s1],  // (-3,  1)
+          (uint32_t)vl2[s2],  // (-2,  2)
+          (uint32_t)vl1[s3],  // (-1,  3)
+      };
+      s = fast_score_raw(v, vc[s0], thr, interior_x);
     }
     if (out_lane) o[(uint32_t)(y * cols) + (uint32_t)xc] = (uint8_t)s;
     if (fo) {  // uniform
@@ -354,6 +384,269 @@ static int32_t launch_fast_score(sosvo_ctx* ctx, const uint8_t* in, long long im
                img_stride, nimg, rows, cols, strips, thr, r0, r1, out, out_stride, flags, flags_stride);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
+}
+
+// ---- one pass over a pyramid level: FAST flags + blur + next level (round 4) ---------------------------------------
+// Rounds 1-3 read every level three times (resize -> HBM -> FAST score -> HBM, and again for the 7x7 blur) in 4 + 5 + 5
+// launches per call; the three consumers want the same thing -- the last seven rows of a column strip and the three
+// neighbours to each side -- which the FAST kernel's register ring already holds.  Here the wave that walks a 64-column
+// strip (56 owned columns, halo 4) of level l down its rows produces, from ONE read of the level:
+//   * FAST-9 score -> 3x3 local-maximum flags (as fast_score_rolling_kernel), the score stored ONLY at the flagged pixels
+//     (the selection reads nothing else of the map);
+//   * the 7x7 Gaussian of the rows a descriptor can read (gauss7_kernel's integer arithmetic: a ring of horizontal sums;
+//     mirrored columns through lane reads in the two edge strips, mirrored rows by walking the reflected row indices);
+//   * level l + 1 (resize_level_kernel's arithmetic): output row dy is due when its lower source row arrives; output column
+//     dx belongs to the strip that owns its left tap x0(dx), lane j of the wave takes dx = dx_first + j (<= 56 columns a
+//     strip) and fetches its two taps of both source rows from the owning lanes with two ds_bpermute of the packed rows.
+// What a row t of the walk (t = -3 .. rows + 2: three mirrored rows each side for the blur) has to do is the same for every
+// wave of the launch, so it comes from a table written once per call (orb_rowtab_kernel) and fetched one row ahead next to
+// the pixel: the first version evaluated ~100 scalar instructions of row-range tests per row and stalled on a dependent
+// load of the next y tap after every output row -- as many issue slots as the arithmetic.
+constexpr uint32_t kRtEmit = 1u << 31, kRtTopSelf = 1u << 28;  // word 0: dy | wy1 << 16 | flags
+constexpr uint32_t kRtHsum = 1u, kRtBlurOut = 2u, kRtFastRow = 4u, kRtScore = 8u, kRtFlagRow = 16u;  // word 1
+struct LevelPass {
+  const uint8_t* in;  // level l of image i at in + i * in_stride
+  long long in_stride;
+  int nimg, rows, cols, strips, thr;
+  const uint2* rowtab;  // [rows + 6]: entry t + 3 for row t of the walk
+  uint8_t* score;
+  long long score_stride;
+  unsigned long long* flags;
+  long long flags_stride;
+  uint8_t* blur;  // (rows per the table)
+  long long blur_stride;
+  uint8_t* next;  // level l + 1 (null: none), h1 x w1; xtaps = its w1 x taps
+  long long next_stride;
+  int w1;
+  const uint32_t* xtaps;
+};
+
+__device__ __forceinline__ uint32_t orb_mad24(uint32_t k, uint32_t x, uint32_t acc) {  // (detect.hip's mad24)
+  uint32_t r;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(k), "v"(acc));
+  return r;
+}
+__device__ __forceinline__ uint32_t orb_mul24(uint32_t a, uint32_t b) {  // a, b < 2^24, product < 2^32: full-rate multiply
+  uint32_t r;
+  asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// The walk's row table of every detection level.  grid = (cdiv(rows0 + 6, kThreads), ndet).  Per level l: entry t + 3,
+//   word 0: the output row dy of level l + 1 whose LOWER source row is t (resize_tap: y1 = min(y0 + 1, h - 1); distinct for
+//           distinct dy because h[l] > h[l + 1], which the host checks): kRtEmit | dy | wy1 << 16, kRtTopSelf when y0 == t;
+//   word 1: kRtHsum (row t enters a blurred row), kRtBlurOut (blurred row t - 3 is due), kRtFastRow (FAST row y = t - 3 in
+//           [fr0, fr1)), kRtScore (y has its 3-px border), kRtFlagRow (flags of row y - 1 are due).
+// Blurred rows: all when `pattern` is given and restrict_rows is 0, run_orb_describe's lvl_rows when it is 1 (also written
+// here), none without a pattern.
+__global__ __launch_bounds__(kThreads) void orb_rowtab_kernel(Pyr P, const int8_t* __restrict__ pattern, int restrict_rows,
+                                                              int tab_stride, uint2* __restrict__ rowtab,
+                                                              int32_t* __restrict__ lvl_rows) {
+  __shared__ int s_cmax;
+  const int l = blockIdx.y, idx = blockIdx.x * kThreads + threadIdx.x;
+  const int h = P.h[l];
+  int br0 = 0, br1 = 0;
+  if (pattern) {  // uniform
+    if (threadIdx.x == 0) s_cmax = 0;
+    __syncthreads();
+    int c = 0;
+    for (int k = threadIdx.x; k < 1024; k += kThreads) c = max(c, abs((int)pattern[k]));
+    atomicMax(&s_cmax, c);
+    __syncthreads();
+    const int reach = (int)((float)s_cmax * 1.4143f) + 2;  // (as resize_taps_kernel / orb_describe_levels_kernel)
+    br0 = restrict_rows ? min(max(kEdge - reach, 0), h) : 0;
+    br1 = restrict_rows ? max(min(h - kEdge + reach, h), 0) : h;
+    if (lvl_rows && blockIdx.x == 0 && threadIdx.x == 0) {
+      lvl_rows[2 * l] = br0;
+      lvl_rows[2 * l + 1] = br1;
+    }
+  }
+  if (idx >= h + 6) return;
+  const int t = idx - 3;
+  const int fr0 = P.det[l] ? kEdge - 1 : 0, fr1 = P.det[l] ? h - kEdge + 1 : 0;
+  uint32_t w0 = 0u, w1 = 0u;
+  if (l + 1 < P.ndet && t >= 0 && t < h) {
+    const int h1 = P.h[l + 1];
+    const double scale = (double)h / h1;
+    int dy = max((int)((double)(t - 2) / scale) - 1, 0);
+    for (int k = 0; k < 8 && dy < h1; ++k, ++dy) {
+      const ResizeTap tp = resize_tap(dy, scale, h);
+      if (tp.i1 == t) {
+        w0 = kRtEmit | (uint32_t)dy | ((uint32_t)tp.w1 << 16) | (tp.i0 == t ? kRtTopSelf : 0u);
+        break;
+      }
+      if (tp.i1 > t) break;
+    }
+  }
+  if (br1 > br0 && t >= br0 - 3 && t <= br1 + 2) w1 |= kRtHsum;
+  if (br1 > br0 && t - 3 >= br0 && t - 3 < br1) w1 |= kRtBlurOut;
+  const int y = t - 3;
+  if (fr1 > fr0 && y >= fr0 && y < fr1) {
+    w1 |= kRtFastRow;
+    if (y >= 3 && y < h - 3) w1 |= kRtScore;
+    if (y - 1 > fr0 && y - 1 < fr1 - 1) w1 |= kRtFlagRow;
+  }
+  rowtab[(size_t)l * tab_stride + idx] = make_uint2(w0, w1);
+}
+
+__global__ __launch_bounds__(kThreads) void orb_level_pass_kernel(const LevelPass A) {
+  SOSVO_STREAMING_PRIO();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * kThreads + threadIdx.x) >> 6));
+  if (wave >= A.nimg * A.strips) return;  // wave-uniform
+  const int rows = A.rows, cols = A.cols, strips = A.strips, thr = A.thr;
+  const int img = wave / strips, strip = wave - img * strips;
+  const int xb = strip * kFsStripW - kFsHalo;
+  const int xc = xb + lane;
+  const int xs = min(max(xc, 0), cols - 1);
+  const bool out_lane = lane >= kFsHalo && lane < 64 - kFsHalo && xc < cols;
+  const bool interior_x = xc >= 3 && xc < cols - 3;
+  const uint8_t* g = A.in + (size_t)img * A.in_stride;
+  uint8_t* sc = A.score + (size_t)img * A.score_stride;
+  unsigned long long* fo = A.flags + (size_t)img * A.flags_stride;
+  uint8_t* bo = A.blur + (size_t)img * A.blur_stride;
+  uint8_t* no = A.next + (size_t)img * A.next_stride;
+  // blur: lanes of the mirrored neighbours (edge strips only)
+  int src[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) src[k] = min(max(refl101(xs + k - 3, cols) - xb, 0), 63);
+  const bool edge_strip = xb < 3 || xb + 64 > cols - 3;  // wave-uniform: some lane's x-3 .. x+3 are mirrored columns
+  // next level: this lane's output column and its taps' lanes
+  const int w1 = A.w1;
+  int dx = 0, la = 0, lb = 0;
+  uint32_t wx1 = 0u;
+  bool rz_lane = false;
+  if (A.next) {  // uniform
+    const int xlo = strip * kFsStripW;
+    // first output column whose left tap x0 (non-decreasing in dx, ~ dx * cols / w1) lies at or beyond xlo: start a little
+    // below the estimate and walk up (scalar, at most a few steps)
+    int d0 = max((int)((long long)xlo * w1 / cols) - 2, 0);
+    while (d0 < w1 && (int)(A.xtaps[d0] & 0xFFFFu) < xlo) ++d0;
+    dx = d0 + lane;
+    const uint32_t tx = A.xtaps[min(dx, w1 - 1)];
+    const int x0 = (int)(tx & 0xFFFFu), x1 = x0 + 1 < cols ? x0 + 1 : cols - 1;
+    rz_lane = dx < w1 && x0 < xlo + kFsStripW;
+    la = 4 * min(max(x0 - xb, 0), 63);
+    lb = 4 * min(max(x1 - xb, 0), 63);
+    wx1 = tx >> 16;
+  }
+  const uint32_t wx0 = 2048u - wx1;
+  // ring slot = (t + 3) mod 7, compile-time after unrolling; per slot the centre value and its six shifted copies
+  int vc[7], vl1[7], vl2[7], vl3[7], vr1[7], vr2[7], vr3[7];
+  uint32_t hs[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    vc[k] = vl1[k] = vl2[k] = vl3[k] = vr1[k] = vr2[k] = vr3[k] = 0;
+    hs[k] = 0u;
+  }
+  int hm_a = 0, hm_b = 0, s_b = 0, lr_b = 0;  // NMS state: hm = max over (x-1, x, x+1) of rows y-2 / y-1, s / lr of row y-1
+  const int t_last = rows + 2;
+  // row t's pixel and table entry are requested one step ahead (mirrored rows: |t| and 2 (rows - 1) - t, rows > 6)
+  auto src_row = [&](int t) { return min(abs(t), 2 * (rows - 1) - abs(t)); };
+  int c_next = (int)g[(uint32_t)(src_row(-3) * cols) + (uint32_t)xs];
+  uint2 e_next = A.rowtab[0];
+  auto step = [&](auto phase_tag, auto edge_tag, const int t) __attribute__((always_inline)) {
+    constexpr int P = decltype(phase_tag)::value;
+    constexpr bool EDGE = decltype(edge_tag)::value;
+    if (t > t_last) return;  // uniform
+    const uint32_t e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e_next.x);
+    const uint32_t e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e_next.y);
+    {
+      const int c = c_next;  // row t
+      const int tn = min(t + 1, t_last);
+      c_next = (int)g[(uint32_t)(src_row(tn) * cols) + (uint32_t)xs];
+      e_next = A.rowtab[tn + 3];
+      vc[P] = c;
+      vr1[P] = fs_from_right(c);
+      vr2[P] = fs_from_right(vr1[P]);
+      vr3[P] = fs_from_right(vr2[P]);
+      vl1[P] = fs_from_left(c);
+      vl2[P] = fs_from_left(vl1[P]);
+      vl3[P] = fs_from_left(vl2[P]);
+    }
+    // ---- next level: the output row whose lower source row is t ----
+    if (e0 & kRtEmit) {  // uniform
+      const uint32_t top = (uint32_t)((e0 & kRtTopSelf) ? vc[P] : vc[(P + 6) % 7]);  // (y0 == y1 only past the last row pair)
+      const uint32_t pk = top | ((uint32_t)vc[P] << 16);
+      const uint32_t va = (uint32_t)__builtin_amdgcn_ds_bpermute(la, (int)pk);
+      const uint32_t vb = (uint32_t)__builtin_amdgcn_ds_bpermute(lb, (int)pk);
+      const uint32_t wy1 = (e0 >> 16) & 0xFFFu, wy0 = 2048u - wy1, dy = e0 & 0xFFFFu;
+      const uint32_t a0 = va & 0xFFFFu, b0 = va >> 16, a1 = vb & 0xFFFFu, b1 = vb >> 16;
+      // (wy0 * top + wy1 * bot + 2^21) >> 22 with top, bot <= 2048 * 255 < 2^24: 24-bit multiplies, 32-bit sums, exact
+      const uint32_t ht = orb_mad24(wx1, a1, orb_mul24(wx0, a0)), hb = orb_mad24(wx1, b1, orb_mul24(wx0, b0));
+      const uint32_t res = (orb_mul24(wy0, ht) + orb_mul24(wy1, hb) + (1u << 21)) >> 22;
+      if (rz_lane) no[dy * (uint32_t)w1 + (uint32_t)dx] = (uint8_t)res;
+    }
+    // ---- blur: horizontal sum of row t, then output row t - 3 ----
+    if (e1 & kRtHsum) {  // uniform
+      const int c = vc[P];
+      int l1, l2, l3, r1, r2, r3;
+      if (EDGE) {
+        l3 = __shfl(c, src[0]); l2 = __shfl(c, src[1]); l1 = __shfl(c, src[2]);
+        r1 = __shfl(c, src[4]); r2 = __shfl(c, src[5]); r3 = __shfl(c, src[6]);
+      } else {
+        l1 = vl1[P]; l2 = vl2[P]; l3 = vl3[P];
+        r1 = vr1[P]; r2 = vr2[P]; r3 = vr3[P];
+      }
+      hs[P] = orb_mad24(18u, (uint32_t)(l3 + r3), orb_mad24(34u, (uint32_t)(l2 + r2), orb_mad24(49u, (uint32_t)(l1 + r1), orb_mul24(54u, (uint32_t)c))));
+      if (e1 & kRtBlurOut) {  // uniform; rows t-6 .. t live in slots P+1 .. P+7 (mod 7)
+        const uint32_t vsum = orb_mad24(18u, hs[(P + 1) % 7] + hs[P], orb_mad24(34u, hs[(P + 2) % 7] + hs[(P + 6) % 7],
+                                        orb_mad24(49u, hs[(P + 3) % 7] + hs[(P + 5) % 7], orb_mul24(54u, hs[(P + 4) % 7]))));
+        if (out_lane) bo[(uint32_t)((t - 3) * cols) + (uint32_t)xc] = (uint8_t)((vsum + 32768u) >> 16);
+      }
+    }
+    // ---- FAST score of row y = t - 3, flags (and the flagged pixels' scores) of row y - 1 ----
+    if (!(e1 & kRtFastRow)) return;  // uniform
+    const int y = t - 3;
+    int s = 0;
+    if (e1 & kRtScore) {  // uniform
+      // row y + dy lives in slot (P + 4 + dy) mod 7; circle pixel k = (rx[k], ry[k]) as in OpenCV's table
+      constexpr int s3 = (P + 7) % 7, s2 = (P + 6) % 7, s1 = (P + 5) % 7, s0 = (P + 4) % 7, m1 = (P + 3) % 7, m2 = (P + 2) % 7,
+                    m3 = (P + 1) % 7;
+      const uint32_t v[16] = {
+          (uint32_t)vc[s3],   // ( 0,  3)
+          (uint32_t)vr1[s3],  // ( 1,  3)
+          (uint32_t)vr2[s2],  // ( 2,  2)
+          (uint32_t)vr3[s1],  // ( 3,  1)
+          (uint32_t)vr3[s0],  // ( 3,  0)
+          (uint32_t)vr3[m1],  // ( 3, -1)
+          (uint32_t)vr2[m2],  // ( 2, -2)
+          (uint32_t)vr1[m3],  // ( 1, -3)
+          (uint32_t)vc[m3],   // ( 0, -3)
+          (uint32_t)vl1[m3],  // (-1, -3)
+          (uint32_t)vl2[m2],  // (-2, -2)
+          (uint32_t)vl3[m1],  // (-3, -1)
+          (uint32_t)vl3[s0],  // (-3,  0)
+          (uint32_t)vl3[s1],  // (-3,  1)
+          (uint32_t)vl2[s2],  // (-2,  2)
+          (uint32_t)vl1[s3],  // (-1,  3)
+      };
+      s = fast_score_raw(v, vc[s0], thr, interior_x);
+    }
+    const int lr = max(fs_from_left(s), fs_from_right(s)), hm = max(lr, s);
+    if (e1 & kRtFlagRow) {  // flag row y - 1 (uniform)
+      const bool is_max = out_lane && s_b > 0 && s_b > lr_b && s_b > hm_a && s_b > hm;
+      const unsigned long long bal = __ballot(is_max);
+      if (lane == 0) fo[(uint32_t)((y - 1) * strips + strip)] = bal;
+      if (is_max) sc[(uint32_t)((y - 1) * cols) + (uint32_t)xc] = (uint8_t)s_b;
+    }
+    hm_a = hm_b;
+    hm_b = hm;
+    s_b = s;
+    lr_b = lr;
+  };
+  auto run = [&](auto edge_tag) __attribute__((always_inline)) {
+    for (int t = -3; t <= t_last; t += 7) {
+      step(std::integral_constant<int, 0>{}, edge_tag, t);
+      step(std::integral_constant<int, 1>{}, edge_tag, t + 1);
+      step(std::integral_constant<int, 2>{}, edge_tag, t + 2);
+      step(std::integral_constant<int, 3>{}, edge_tag, t + 3);
+      step(std::integral_constant<int, 4>{}, edge_tag, t + 4);
+      step(std::integral_constant<int, 5>{}, edge_tag, t + 5);
+      step(std::integral_constant<int, 6>{}, edge_tag, t + 6);
+    }
+  };
+  if (edge_strip && A.blur) run(std::true_type{}); else run(std::false_type{});
 }
 
 // ---- FAST as a detector of its own (feature_detection_method "FAST") ------------------------------------------
@@ -1147,6 +1440,8 @@ struct OrbScratch {
   unsigned long long* flags;
   uint32_t *bbox, *taps;
   int32_t* lvl_rows;  // [kLevels][2]: blurred rows a detected keypoint's descriptor can read (written with the taps)
+  uint2* rowtab;      // [kLevels][rowtab_stride]: orb_level_pass_kernel's row tables
+  int rowtab_stride;
   size_t bbox_bytes, bytes;
 };
 OrbScratch orb_scratch(const Pyr& P, int nimg, int nsets, bool detect, bool describe, char* base) {
@@ -1166,6 +1461,8 @@ OrbScratch orb_scratch(const Pyr& P, int nimg, int nsets, bool detect, bool desc
   o.bbox = (uint32_t*)take(o.bbox_bytes);
   o.taps = (uint32_t*)take(sizeof(uint32_t) * (size_t)(P.ttotal > 0 ? P.ttotal : 1));
   o.lvl_rows = (int32_t*)take(sizeof(int32_t) * 2 * kLevels);
+  o.rowtab_stride = P.h[0] + 6;
+  o.rowtab = (uint2*)take(detect ? sizeof(uint2) * (size_t)kLevels * o.rowtab_stride : 0);
   o.bytes = off;
   return o;
 }
@@ -1173,14 +1470,15 @@ OrbScratch orb_scratch(const Pyr& P, int nimg, int nsets, bool detect, bool desc
 // detection on a pyramid whose levels < P.ndet exist: mask bounding boxes, FAST scores + flags of the detection levels
 // (only the rows inside the 31-px border matter: candidates in [31, h - 31), their neighbours one row further), selection
 int32_t run_orb_detect(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* mask_pyr, int nimg, int images_per_maskset, int rows,
-                       int cols, int nmask, int cap, const Pyr& P, const OrbScratch& W, float* kp4, float* resp, int32_t* n) {
+                       int cols, int nmask, int cap, const Pyr& P, const OrbScratch& W, float* kp4, float* resp, int32_t* n,
+                       bool have_flags = false) {
   const int nsets = cdiv(nimg, images_per_maskset);
   SOSVO_HIP(ctx, hipMemsetAsync(W.bbox, 0, W.bbox_bytes, ctx->stream));
   int total_rows = 0;
   for (int l = 0; l < P.nlev; ++l) total_rows += P.h[l];
   SOSVO_LAUNCH(ctx, orb_mask_bbox_kernel, dim3(total_rows, nsets), dim3(kThreads), 0, ctx->stream, mask_pyr, P, nmask, W.bbox);
   SOSVO_LAUNCH_CHECK(ctx);
-  for (int l = 0; l < P.ndet; ++l) {
+  for (int l = 0; l < P.ndet && !have_flags; ++l) {  // (have_flags: run_orb_level_passes wrote flags and scores)
     if (!P.det[l]) continue;
     const uint8_t* in = l == 0 ? gray : W.pyr + P.off[l];
     const long long in_stride = l == 0 ? (long long)rows * cols : P.total;
@@ -1195,14 +1493,65 @@ int32_t run_orb_detect(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* mask
   return SOSVO_OK;
 }
 
+// The detection levels in ONE pass each (orb_level_pass_kernel): flags + flagged scores of level l, its blur (describe), and
+// level l + 1 -- instead of build_pyramid + the FAST launches of run_orb_detect + the blur launches of run_orb_describe.
+// Needs what every real image has (a detection level is more than 62 px high and wide, and strictly higher than the next one).
+bool orb_level_passes_ok(const Pyr& P) {
+  if (P.ndet < 1) return false;
+  for (int l = 0; l < P.ndet; ++l) {
+    if (P.h[l] < 8 || P.w[l] < 8) return false;
+    if (l + 1 < P.ndet && !(P.h[l] > P.h[l + 1] && P.w[l] >= P.w[l + 1])) return false;
+  }
+  return true;
+}
+int32_t run_orb_level_passes(sosvo_ctx* ctx, const uint8_t* gray, int nimg, int rows, int cols, const Pyr& P, const OrbScratch& W,
+                             bool describe, const int8_t* pattern) {
+  const bool restrict_rows = describe && P.ndet > 1;  // (as run_orb_describe)
+  if (P.ndet > 1) {
+    int tmax = 0;
+    for (int l = 1; l < P.ndet; ++l) tmax = tmax > P.w[l] + P.h[l] ? tmax : P.w[l] + P.h[l];
+    SOSVO_LAUNCH(ctx, resize_taps_kernel, dim3(cdiv(tmax, kThreads), P.ndet - 1), dim3(kThreads), 0, ctx->stream, P, W.taps,
+                 (int32_t*)nullptr, (const int8_t*)nullptr);
+    SOSVO_LAUNCH_CHECK(ctx);
+  }
+  SOSVO_LAUNCH(ctx, orb_rowtab_kernel, dim3(cdiv(P.h[0] + 6, kThreads), P.ndet), dim3(kThreads), 0, ctx->stream, P,
+               describe ? pattern : (const int8_t*)nullptr, restrict_rows ? 1 : 0, W.rowtab_stride, W.rowtab, W.lvl_rows);
+  SOSVO_LAUNCH_CHECK(ctx);
+  for (int l = 0; l < P.ndet; ++l) {
+    LevelPass A;
+    A.in = l == 0 ? gray : W.pyr + P.off[l];
+    A.in_stride = l == 0 ? (long long)rows * cols : P.total;
+    A.nimg = nimg;
+    A.rows = P.h[l];
+    A.cols = P.w[l];
+    A.strips = P.fstrips[l];
+    A.thr = kFastThr;
+    A.rowtab = W.rowtab + (size_t)l * W.rowtab_stride;
+    A.score = W.score + P.off[l];
+    A.score_stride = P.total;
+    A.flags = W.flags + P.foff[l];
+    A.flags_stride = P.ftotal;
+    A.blur = describe ? W.blur + P.off[l] : nullptr;
+    A.blur_stride = P.total;
+    const bool next = l + 1 < P.ndet;
+    A.next = next ? W.pyr + P.off[l + 1] : nullptr;
+    A.next_stride = P.total;
+    A.w1 = next ? P.w[l + 1] : 0;
+    A.xtaps = next ? W.taps + P.toff[l + 1] : nullptr;
+    SOSVO_LAUNCH(ctx, orb_level_pass_kernel, dim3(cdiv(nimg * A.strips, kThreads / 64)), dim3(kThreads), 0, ctx->stream, A);
+    SOSVO_LAUNCH_CHECK(ctx);
+  }
+  return SOSVO_OK;
+}
+
 // descriptors on a pyramid whose levels < nlev_have exist: blur those levels, border rule, rotated pattern
 int32_t run_orb_describe(sosvo_ctx* ctx, const uint8_t* gray, int nimg, int rows, int cols, int nmask, int cap, const Pyr& P,
                          int nlev_have, const OrbScratch& W, float* kp4, int32_t* n, const int8_t* pattern, uint8_t* desc,
-                         float* kp_xy, bool detected_keypoints) {
+                         float* kp_xy, bool detected_keypoints, bool have_blur = false) {
   // detected_keypoints: every keypoint keeps the detector's 31-px border ON ITS LEVEL, so only the rows W.lvl_rows names are
   // ever read (keypoints handed in from outside keep that border in level-0 coordinates only: whole levels then)
   const bool restrict_rows = detected_keypoints && nlev_have > 1;  // (lvl_rows is written with the resize taps)
-  for (int l = 0; l < nlev_have; ++l) {  // the rolling strip kernel of detect.hip, level by level (same integer arithmetic)
+  for (int l = 0; l < nlev_have && !have_blur; ++l) {  // the rolling strip kernel of detect.hip, level by level (same integer arithmetic)
     const int32_t* rr = restrict_rows ? W.lvl_rows + 2 * l : nullptr;
     const int32_t rc = l == 0 ? sosvo_launch_gauss7_rows(ctx, gray, (long long)rows * cols, nimg, rows, cols, W.blur, P.total, rr, nimg)
                               : sosvo_launch_gauss7_rows(ctx, W.pyr + P.off[l], P.total, nimg, P.h[l], P.w[l], W.blur + P.off[l],
@@ -1259,9 +1608,11 @@ int32_t sosvo_detect_orb(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* ma
   int32_t rc = sosvo_ws_reserve(ctx, orb_scratch(P, nimg, nsets, true, false, nullptr).bytes);
   if (rc != SOSVO_OK) return rc;
   const OrbScratch W = orb_scratch(P, nimg, nsets, true, false, (char*)ctx->ws);
-  rc = build_pyramid(ctx, gray, nimg, rows, cols, P, P.ndet, W.pyr, W.taps);
+  const bool fused = orb_level_passes_ok(P);
+  rc = fused ? run_orb_level_passes(ctx, gray, nimg, rows, cols, P, W, false, nullptr)
+             : build_pyramid(ctx, gray, nimg, rows, cols, P, P.ndet, W.pyr, W.taps);
   if (rc != SOSVO_OK) return rc;
-  return run_orb_detect(ctx, gray, mask_pyr, nimg, images_per_maskset, rows, cols, nmask, cap, P, W, kp4, resp, n);
+  return run_orb_detect(ctx, gray, mask_pyr, nimg, images_per_maskset, rows, cols, nmask, cap, P, W, kp4, resp, n, fused);
 }
 
 int32_t sosvo_describe_orb_levels(sosvo_ctx* ctx, const uint8_t* gray, int32_t nimg, int32_t rows, int32_t cols,
@@ -1300,11 +1651,13 @@ int32_t sosvo_detect_describe_orb(sosvo_ctx* ctx, const uint8_t* gray, const uin
   const OrbScratch W = orb_scratch(P, nimg, nsets, true, true, (char*)ctx->ws);
   // ONE pyramid for both halves, built only as far as a keypoint can come from (the levels with a quota and more than the
   // 31-px border): the detector's keypoints all lie on those levels
-  rc = build_pyramid(ctx, gray, nimg, rows, cols, P, P.ndet, W.pyr, W.taps, W.lvl_rows, pattern);
+  const bool fused = orb_level_passes_ok(P);
+  rc = fused ? run_orb_level_passes(ctx, gray, nimg, rows, cols, P, W, true, pattern)
+             : build_pyramid(ctx, gray, nimg, rows, cols, P, P.ndet, W.pyr, W.taps, W.lvl_rows, pattern);
   if (rc != SOSVO_OK) return rc;
-  rc = run_orb_detect(ctx, gray, mask_pyr, nimg, images_per_maskset, rows, cols, nmask, cap, P, W, kp4, resp, n);
+  rc = run_orb_detect(ctx, gray, mask_pyr, nimg, images_per_maskset, rows, cols, nmask, cap, P, W, kp4, resp, n, fused);
   if (rc != SOSVO_OK) return rc;
-  return run_orb_describe(ctx, gray, nimg, rows, cols, nmask, cap, P, P.ndet, W, kp4, n, pattern, desc, kp_xy, true);
+  return run_orb_describe(ctx, gray, nimg, rows, cols, nmask, cap, P, P.ndet, W, kp4, n, pattern, desc, kp_xy, true, fused);
 }
 
 int32_t sosvo_detect_fast(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* mask_bits, int32_t nimg,
