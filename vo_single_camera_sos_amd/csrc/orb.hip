@@ -1250,6 +1250,16 @@ __global__ __launch_bounds__(kThreads) void orb_describe_levels_kernel(const uin
   const int n = min(n_io[p], cap);
   if (tid == 0) s_running = 0;
   for (int i = tid; i < 1024; i += kThreads) spat[i] = pattern[i];
+  // the levels' geometry in LDS: indexed by a keypoint's level inside the descriptor loop, where a look-up in the by-value
+  // struct is a global load from the kernel arguments whose wait would drain the patch loads in flight
+  __shared__ int s_lh[kLevels], s_lw[kLevels], s_loff[kLevels];
+  __shared__ float s_linv[kLevels];
+  if (tid < kLevels) {
+    s_lh[tid] = P.h[tid];
+    s_lw[tid] = P.w[tid];
+    s_loff[tid] = (int)P.off[tid];  // (< 2^28 * 3: rows * cols < 2^28)
+    s_linv[tid] = 1.f / P.scale[tid];
+  }
   __syncthreads();
   for (int i0 = 0; i0 < n; i0 += kThreads) {
     const int i = i0 + tid;
@@ -1322,45 +1332,107 @@ __global__ __launch_bounds__(kThreads) void orb_describe_levels_kernel(const uin
   const int nit = patch_ok ? (PR * pdw + 63) >> 6 : 0;  // <= kDescPatchLoads
   uint32_t* patch32 = patch_lds[wid];
   const uint8_t* patch8 = reinterpret_cast<const uint8_t*>(patch32);
-  for (int j = wid; j < mkept; j += kThreads / 64) {
-    const int l = (int)lds_kp[4 * j + 3];
-    const int hh = P.h[l], ww = P.w[l];
-    const float inv = 1.f / P.scale[l];
-    const float ca = lds_cs[2 * j], sa = lds_cs[2 * j + 1];
-    const int cx = __float2int_rn(lds_kp[4 * j] * inv), cy = __float2int_rn(lds_kp[4 * j + 1] * inv);
-    const uint8_t* im = blur + (size_t)img * P.total + P.off[l];
-    unsigned long long* d = reinterpret_cast<unsigned long long*>(desc + ((size_t)p * cap + j) * 32);
+  // A keypoint's state: where its patch lies and the patch dwords themselves, REQUESTED ONE KEYPOINT AHEAD: a wave used to
+  // load, wait a full memory round trip, stage and test one keypoint after the other (round 4's stats pass: 2.8 us per keypoint
+  // and wave for ~150 instructions); now the next keypoint's loads fly while this one's tests run.  For the waits to count
+  // loads instead of draining them, the staged loop holds no other global load and a fixed number of patch loads per keypoint
+  // (NIT = 7 for OpenCV's table, 9 at most; a keypoint that is not staged -- none the detector returns -- loads a patch that
+  // certainly exists, the top-left corner of its image's level 0, and is described by the second loop below).
+  struct KpState {
+    int cx, cy, hh, ww;
+    float ca, sa;
+    bool staged;
+  };
+  // (a keypoint belongs to a WAVE: its level, centre and image pointers are told to be scalars, so that the patch loads take a
+  // scalar base plus one 32-bit offset per lane instead of seven 64-bit address chains)
+  const int wid_s = __builtin_amdgcn_readfirstlane(wid);
+  auto locate = [&](int j, const uint8_t*& im, const uint8_t*& ctr, bool& inside) __attribute__((always_inline)) {
+    KpState k;
+    const int l = __builtin_amdgcn_readfirstlane((int)lds_kp[4 * j + 3]);
+    k.hh = __builtin_amdgcn_readfirstlane(s_lh[l]);
+    k.ww = __builtin_amdgcn_readfirstlane(s_lw[l]);
+    const float inv = s_linv[l];
+    k.ca = lds_cs[2 * j];
+    k.sa = lds_cs[2 * j + 1];
+    k.cx = __builtin_amdgcn_readfirstlane(__float2int_rn(lds_kp[4 * j] * inv));
+    k.cy = __builtin_amdgcn_readfirstlane(__float2int_rn(lds_kp[4 * j + 1] * inv));
+    im = blur + (size_t)img * P.total + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane(s_loff[l]);
     // a keypoint at least `margin` px inside its level image (every keypoint the detector returns: it keeps 31 px, and
     // OpenCV's table needs 20) needs no border reflection -- a wave-uniform test
-    const bool inside = cx >= margin && cy >= margin && cx < ww - margin && cy < hh - margin;
-    const uint8_t* ctr = im + (size_t)cy * ww + cx;
-    const bool staged = inside && patch_ok;  // wave-uniform
-    if (staged) {
-      uint32_t reg[kDescPatchLoads];
+    inside = k.cx >= margin && k.cy >= margin && k.cx < k.ww - margin && k.cy < k.hh - margin;
+    ctr = im + (size_t)k.cy * k.ww + k.cx;
+    k.staged = inside && patch_ok;  // wave-uniform
+    return k;
+  };
+  auto staged_loop = [&](auto nit_tag) __attribute__((always_inline)) {
+    constexpr int NIT = decltype(nit_tag)::value;
+    // (a kept keypoint lies >= 31 px inside level 0, so level 0 holds a (2 R + 1)-row patch with its centre at (R, R))
+    const uint8_t* safe = blur + (size_t)img * P.total + (size_t)R * P.w[0] + R;
+    auto fetch = [&](int j, uint32_t (&reg)[NIT]) __attribute__((always_inline)) {
+      const uint8_t *im, *ctr;
+      bool inside;
+      const KpState k = locate(j, im, ctr, inside);
+      const int pitch = k.staged ? k.ww : P.w[0];
+      const uint8_t* c = (k.staged ? ctr : safe) - (size_t)(R * pitch + R);  // the patch's first byte (scalar)
 #pragma unroll
-      for (int it = 0; it < kDescPatchLoads; ++it)
-        if (it < nit) reg[it] = *reinterpret_cast<const u32_unaligned*>(ctr + (prow[it] - R) * ww - R + 4 * pk[it]);
+      for (int it = 0; it < NIT; ++it)
+        reg[it] = *reinterpret_cast<const u32_unaligned*>(c + orb_mad24((uint32_t)prow[it], (uint32_t)pitch, (uint32_t)(4 * pk[it])));
+      return k;
+    };
+    uint32_t reg_n[NIT];
+    KpState nxt;
+    if (wid_s < mkept) nxt = fetch(wid_s, reg_n);
+    for (int j = wid_s; j < mkept; j += kThreads / 64) {
+      const KpState k = nxt;
+      uint32_t reg[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) reg[it] = reg_n[it];
+      if (j + kThreads / 64 < mkept) nxt = fetch(j + kThreads / 64, reg_n);
+      if (!k.staged) continue;  // (uniform; the second loop's)
+      unsigned long long* d = reinterpret_cast<unsigned long long*>(desc + ((size_t)p * cap + j) * 32);
       __builtin_amdgcn_wave_barrier();  // (the previous keypoint's reads of the patch are done: one wave, LDS in order)
 #pragma unroll
-      for (int it = 0; it < kDescPatchLoads; ++it)
-        if (it < nit) patch32[prow[it] * pstride + pk[it]] = reg[it];
+      for (int it = 0; it < NIT; ++it) patch32[prow[it] * pstride + pk[it]] = reg[it];
       __builtin_amdgcn_wave_barrier();
-    }
 #pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int val[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float px = ppx[r][e], py = ppy[r][e];
+          const float xr = (px * k.ca) - (py * k.sa), yr = (px * k.sa) + (py * k.ca);
+          const int dx = __float2int_rn(xr), dy = __float2int_rn(yr);
+          val[e] = patch8[orb_mad24((uint32_t)(dy + R), (uint32_t)(4 * pstride), (uint32_t)(dx + R))];
+        }
+        const unsigned long long bal = __ballot(val[0] < val[1]);
+        if (lane == 0) d[r] = bal;
+      }
+    }
+  };
+  if (patch_ok) {  // uniform
+    if (nit <= 7) staged_loop(std::integral_constant<int, 7>{}); else staged_loop(std::integral_constant<int, kDescPatchLoads>{});
+  }
+  // keypoints too close to their level's border for the patch, or a pattern beyond the staged radius: straight from memory
+  for (int j = wid_s; j < mkept; j += kThreads / 64) {
+    const uint8_t *im, *ctr;
+    bool inside;
+    const KpState k = locate(j, im, ctr, inside);
+    if (k.staged) continue;  // uniform
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(desc + ((size_t)p * cap + j) * 32);
+#pragma unroll 1
     for (int r = 0; r < 4; ++r) {
       int val[2];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const float px = ppx[r][e], py = ppy[r][e];
-        const float xr = (px * ca) - (py * sa), yr = (px * sa) + (py * ca);
+        const int i = 2 * (64 * r + lane) + e;
+        const float px = (float)spat[2 * i], py = (float)spat[2 * i + 1];
+        const float xr = (px * k.ca) - (py * k.sa), yr = (px * k.sa) + (py * k.ca);
         const int dx = __float2int_rn(xr), dy = __float2int_rn(yr);
-        if (staged) {
-          val[e] = patch8[(dy + R) * (4 * pstride) + (dx + R)];
-        } else if (inside) {
-          val[e] = ctr[dy * ww + dx];
+        if (inside) {
+          val[e] = ctr[dy * k.ww + dx];
         } else {
-          const int xx = refl101(cx + dx, ww), yy = refl101(cy + dy, hh);
-          val[e] = im[(size_t)yy * ww + xx];
+          const int xx = refl101(k.cx + dx, k.ww), yy = refl101(k.cy + dy, k.hh);
+          val[e] = im[(size_t)yy * k.ww + xx];
         }
       }
       const unsigned long long bal = __ballot(val[0] < val[1]);
