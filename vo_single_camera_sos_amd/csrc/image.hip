@@ -226,7 +226,7 @@ __global__ __launch_bounds__(kThreads) void gray_kernel(const uint8_t* __restric
 // kUgPix pixels per thread (256 apart: every wave-load stays a run of 64 neighbouring pixels), their table entries and
 // gathers all in flight before the first blend: with one pixel per thread the kernel was a stream of 840 000 one-shot
 // workgroups per 256 frame pairs, bound by workgroup dispatch and by one exposed load latency each (round 4).
-constexpr int kUgPix = 4;
+constexpr int kUgPix = 8;
 __global__ __launch_bounds__(kThreads) void unwrap_gray_kernel(const uint8_t* __restrict__ omni, const uint2* __restrict__ table,
                                                                int nframes, int H, int W, int npix, uint8_t* __restrict__ gray) {
   const int gx = (npix + kThreads * kUgPix - 1) / (kThreads * kUgPix);   // XCD-aware 1-D grid as in unwrap_lut_kernel: one image on one XCD

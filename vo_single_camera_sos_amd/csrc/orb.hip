@@ -489,12 +489,16 @@ __global__ __launch_bounds__(kThreads) void orb_rowtab_kernel(Pyr P, const int8_
   rowtab[(size_t)l * tab_stride + idx] = make_uint2(w0, w1);
 }
 
+constexpr int kRowTabLds = 1024;  // rows + 6 entries of the level's table in LDS (higher images take the separate kernels)
 __global__ __launch_bounds__(kThreads) void orb_level_pass_kernel(const LevelPass A) {
   SOSVO_STREAMING_PRIO();
+  __shared__ uint2 s_tab[kRowTabLds];
+  const int rows = A.rows, cols = A.cols, strips = A.strips, thr = A.thr;
+  for (int i = threadIdx.x; i < rows + 6; i += kThreads) s_tab[i] = A.rowtab[i];  // (rows + 6 <= kRowTabLds: the host checks)
+  __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * kThreads + threadIdx.x) >> 6));
-  if (wave >= A.nimg * A.strips) return;  // wave-uniform
-  const int rows = A.rows, cols = A.cols, strips = A.strips, thr = A.thr;
+  if (wave >= A.nimg * A.strips) return;  // wave-uniform (after the workgroup's only barrier)
   const int img = wave / strips, strip = wave - img * strips;
   const int xb = strip * kFsStripW - kFsHalo;
   const int xc = xb + lane;
@@ -540,11 +544,24 @@ __global__ __launch_bounds__(kThreads) void orb_level_pass_kernel(const LevelPas
     hs[k] = 0u;
   }
   int hm_a = 0, hm_b = 0, s_b = 0, lr_b = 0;  // NMS state: hm = max over (x-1, x, x+1) of rows y-2 / y-1, s / lr of row y-1
+  uint32_t hx_prev = 0u;                      // next level: the previous row, interpolated at this lane's output column
   const int t_last = rows + 2;
-  // row t's pixel and table entry are requested one step ahead (mirrored rows: |t| and 2 (rows - 1) - t, rows > 6)
+  // A wave's rows come SEVEN AT A TIME, one ring revolution ahead (mirrored rows: |t| and 2 (rows - 1) - t, rows > 6): with
+  // row t + 1 requested at step t -- ~0.6 us of the SIMD's other waves' work -- a load that misses the L2 (a wave's rows are
+  // `cols` bytes apart: another line every step) was not covered, with one load in flight per wave the chip held a third of
+  // the bytes in flight its bandwidth needs, and the kernel ran at the speed of its loads, not of its arithmetic.  (Requested
+  // in one batch the compiler counts the loads down -- s_waitcnt vmcnt(13), (12), ... -- ; a rolling request per step between
+  // the conditional stores ends in vmcnt(0) everywhere.)  The table entry comes from LDS one step ahead: a table load from
+  // memory inside the loop would turn every wait for it into a wait for all the rows in flight (one in-order counter).
   auto src_row = [&](int t) { return min(abs(t), 2 * (rows - 1) - abs(t)); };
-  int c_next = (int)g[(uint32_t)(src_row(-3) * cols) + (uint32_t)xs];
-  uint2 e_next = A.rowtab[0];
+  auto tab = [&](int i) { return s_tab[i]; };  // (LDS only: a table load from memory inside the loop would make every wait for it a wait for the rows in flight)
+  int c_cur[7], c_pre[7];
+  auto request = [&](int t0) __attribute__((always_inline)) {  // rows t0 .. t0 + 6 -> c_pre
+#pragma unroll
+    for (int k = 0; k < 7; ++k) c_pre[k] = (int)g[(uint32_t)(src_row(min(t0 + k, t_last)) * cols) + (uint32_t)xs];
+  };
+  request(-3);
+  uint2 e_next = tab(0);
   auto step = [&](auto phase_tag, auto edge_tag, const int t) __attribute__((always_inline)) {
     constexpr int P = decltype(phase_tag)::value;
     constexpr bool EDGE = decltype(edge_tag)::value;
@@ -552,10 +569,8 @@ __global__ __launch_bounds__(kThreads) void orb_level_pass_kernel(const LevelPas
     const uint32_t e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e_next.x);
     const uint32_t e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e_next.y);
     {
-      const int c = c_next;  // row t
-      const int tn = min(t + 1, t_last);
-      c_next = (int)g[(uint32_t)(src_row(tn) * cols) + (uint32_t)xs];
-      e_next = A.rowtab[tn + 3];
+      const int c = c_cur[P];  // row t
+      e_next = tab(min(t + 1, t_last) + 3);
       vc[P] = c;
       vr1[P] = fs_from_right(c);
       vr2[P] = fs_from_right(vr1[P]);
@@ -564,18 +579,19 @@ __global__ __launch_bounds__(kThreads) void orb_level_pass_kernel(const LevelPas
       vl2[P] = fs_from_left(vl1[P]);
       vl3[P] = fs_from_left(vl2[P]);
     }
-    // ---- next level: the output row whose lower source row is t ----
-    if (e0 & kRtEmit) {  // uniform
-      const uint32_t top = (uint32_t)((e0 & kRtTopSelf) ? vc[P] : vc[(P + 6) % 7]);  // (y0 == y1 only past the last row pair)
-      const uint32_t pk = top | ((uint32_t)vc[P] << 16);
-      const uint32_t va = (uint32_t)__builtin_amdgcn_ds_bpermute(la, (int)pk);
-      const uint32_t vb = (uint32_t)__builtin_amdgcn_ds_bpermute(lb, (int)pk);
-      const uint32_t wy1 = (e0 >> 16) & 0xFFFu, wy0 = 2048u - wy1, dy = e0 & 0xFFFFu;
-      const uint32_t a0 = va & 0xFFFFu, b0 = va >> 16, a1 = vb & 0xFFFFu, b1 = vb >> 16;
-      // (wy0 * top + wy1 * bot + 2^21) >> 22 with top, bot <= 2048 * 255 < 2^24: 24-bit multiplies, 32-bit sums, exact
-      const uint32_t ht = orb_mad24(wx1, a1, orb_mul24(wx0, a0)), hb = orb_mad24(wx1, b1, orb_mul24(wx0, b0));
-      const uint32_t res = (orb_mul24(wy0, ht) + orb_mul24(wy1, hb) + (1u << 21)) >> 22;
-      if (rz_lane) no[dy * (uint32_t)w1 + (uint32_t)dx] = (uint8_t)res;
+    // ---- next level: row t interpolated horizontally at this lane's output column (once per source row: the row is the
+    // lower tap of one output row and, four times out of five, the upper tap of the next), then the output row due at t ----
+    if (A.next) {  // uniform
+      const uint32_t a0 = (uint32_t)__builtin_amdgcn_ds_bpermute(la, vc[P]), a1 = (uint32_t)__builtin_amdgcn_ds_bpermute(lb, vc[P]);
+      const uint32_t hx = orb_mad24(wx1, a1, orb_mul24(wx0, a0));  // <= 2048 * 255 < 2^24
+      if (e0 & kRtEmit) {  // uniform
+        const uint32_t top = (e0 & kRtTopSelf) ? hx : hx_prev;  // (y0 == y1 only past the last row pair)
+        const uint32_t wy1 = (e0 >> 16) & 0xFFFu, wy0 = 2048u - wy1, dy = e0 & 0xFFFFu;
+        // (wy0 * top + wy1 * bot + 2^21) >> 22: 24-bit multiplies, 32-bit sums, exact
+        const uint32_t res = (orb_mul24(wy0, top) + orb_mul24(wy1, hx) + (1u << 21)) >> 22;
+        if (rz_lane) no[dy * (uint32_t)w1 + (uint32_t)dx] = (uint8_t)res;
+      }
+      hx_prev = hx;
     }
     // ---- blur: horizontal sum of row t, then output row t - 3 ----
     if (e1 & kRtHsum) {  // uniform
@@ -637,6 +653,9 @@ __global__ __launch_bounds__(kThreads) void orb_level_pass_kernel(const LevelPas
   };
   auto run = [&](auto edge_tag) __attribute__((always_inline)) {
     for (int t = -3; t <= t_last; t += 7) {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) c_cur[k] = c_pre[k];
+      request(min(t + 7, t_last));
       step(std::integral_constant<int, 0>{}, edge_tag, t);
       step(std::integral_constant<int, 1>{}, edge_tag, t + 1);
       step(std::integral_constant<int, 2>{}, edge_tag, t + 2);
@@ -1013,7 +1032,7 @@ __global__ __launch_bounds__(kThreads) void orb_mask_bbox_kernel(const uint32_t*
 //   3. Harris response, one wave per candidate -> unique sort keys;  4. bitonic sort (response descending, then y, x);
 //   5. retainBest(quota) by response, ties kept (counted in parallel: the list is sorted);
 //   6. orientation, one wave per keypoint.
-__global__ __launch_bounds__(kThreads, 5) void orb_select_kernel(LevelSrc S, const uint8_t* __restrict__ score,
+__global__ __launch_bounds__(kThreads, 6) void orb_select_kernel(LevelSrc S, const uint8_t* __restrict__ score,
                                                               const unsigned long long* __restrict__ flags,
                                                               const uint32_t* __restrict__ mask_pyr,
                                                               const uint32_t* __restrict__ bbox, Pyr P,
@@ -1569,7 +1588,7 @@ int32_t run_orb_detect(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* mask
 // level l + 1 -- instead of build_pyramid + the FAST launches of run_orb_detect + the blur launches of run_orb_describe.
 // Needs what every real image has (a detection level is more than 62 px high and wide, and strictly higher than the next one).
 bool orb_level_passes_ok(const Pyr& P) {
-  if (P.ndet < 1) return false;
+  if (P.ndet < 1 || P.h[0] + 6 > kRowTabLds) return false;
   for (int l = 0; l < P.ndet; ++l) {
     if (P.h[l] < 8 || P.w[l] < 8) return false;
     if (l + 1 < P.ndet && !(P.h[l] > P.h[l + 1] && P.w[l] >= P.w[l + 1])) return false;
