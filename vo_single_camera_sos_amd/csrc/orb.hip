@@ -394,7 +394,7 @@ static int32_t launch_fast_score(sosvo_ctx* ctx, const uint8_t* in, long long im
 //   * FAST-9 score -> 3x3 local-maximum flags (as fast_score_rolling_kernel), the score stored ONLY at the flagged pixels
 //     (the selection reads nothing else of the map);
 //   * the 7x7 Gaussian of the rows a descriptor can read (gauss7_kernel's integer arithmetic: a ring of horizontal sums;
-//     mirrored columns through lane reads in the two edge strips, mirrored rows by walking the reflected row indices);
+//     mirrored columns in the halo lanes of the two edge strips, mirrored rows by walking the reflected row indices);
 //   * level l + 1 (resize_level_kernel's arithmetic): output row dy is due when its lower source row arrives; output column
 //     dx belongs to the strip that owns its left tap x0(dx), lane j of the wave takes dx = dx_first + j (<= 56 columns a
 //     strip) and fetches its two taps of both source rows from the owning lanes with two ds_bpermute of the packed rows.
@@ -502,7 +502,9 @@ __global__ __launch_bounds__(kThreads) void orb_level_pass_kernel(const LevelPas
   const int img = wave / strips, strip = wave - img * strips;
   const int xb = strip * kFsStripW - kFsHalo;
   const int xc = xb + lane;
-  const int xs = min(max(xc, 0), cols - 1);
+  // (halo lanes beyond the image's sides hold the MIRRORED columns -- reflect-101, what the blur wants there; FAST and the next
+  // level never look at them -- so the blur's neighbours are the ring's shifted copies in the edge strips too)
+  const int xs = min(max(xc < 0 ? -xc : (xc >= cols ? 2 * (cols - 1) - xc : xc), 0), cols - 1);
   const bool out_lane = lane >= kFsHalo && lane < 64 - kFsHalo && xc < cols;
   const bool interior_x = xc >= 3 && xc < cols - 3;
   const uint8_t* g = A.in + (size_t)img * A.in_stride;
@@ -510,11 +512,6 @@ __global__ __launch_bounds__(kThreads) void orb_level_pass_kernel(const LevelPas
   unsigned long long* fo = A.flags + (size_t)img * A.flags_stride;
   uint8_t* bo = A.blur + (size_t)img * A.blur_stride;
   uint8_t* no = A.next + (size_t)img * A.next_stride;
-  // blur: lanes of the mirrored neighbours (edge strips only)
-  int src[7];
-#pragma unroll
-  for (int k = 0; k < 7; ++k) src[k] = min(max(refl101(xs + k - 3, cols) - xb, 0), 63);
-  const bool edge_strip = xb < 3 || xb + 64 > cols - 3;  // wave-uniform: some lane's x-3 .. x+3 are mirrored columns
   // next level: this lane's output column and its taps' lanes
   const int w1 = A.w1;
   int dx = 0, la = 0, lb = 0;
@@ -550,26 +547,26 @@ __global__ __launch_bounds__(kThreads) void orb_level_pass_kernel(const LevelPas
   // row t + 1 requested at step t -- ~0.6 us of the SIMD's other waves' work -- a load that misses the L2 (a wave's rows are
   // `cols` bytes apart: another line every step) was not covered, with one load in flight per wave the chip held a third of
   // the bytes in flight its bandwidth needs, and the kernel ran at the speed of its loads, not of its arithmetic.  (Requested
-  // in one batch the compiler counts the loads down -- s_waitcnt vmcnt(13), (12), ... -- ; a rolling request per step between
+  // in batches the compiler counts the loads down -- s_waitcnt vmcnt(6), (5), ... -- ; a rolling request per step between
   // the conditional stores ends in vmcnt(0) everywhere.)  The table entry comes from LDS one step ahead: a table load from
   // memory inside the loop would turn every wait for it into a wait for all the rows in flight (one in-order counter).
   auto src_row = [&](int t) { return min(abs(t), 2 * (rows - 1) - abs(t)); };
   auto tab = [&](int i) { return s_tab[i]; };  // (LDS only: a table load from memory inside the loop would make every wait for it a wait for the rows in flight)
-  int c_cur[7], c_pre[7];
-  auto request = [&](int t0) __attribute__((always_inline)) {  // rows t0 .. t0 + 6 -> c_pre
+  int c_pre[7];
+  auto request = [&](int t0, int k0, int k1) __attribute__((always_inline)) {  // rows t0 + k0 .. t0 + k1 - 1 -> their slots
 #pragma unroll
-    for (int k = 0; k < 7; ++k) c_pre[k] = (int)g[(uint32_t)(src_row(min(t0 + k, t_last)) * cols) + (uint32_t)xs];
+    for (int k = 0; k < 7; ++k)
+      if (k >= k0 && k < k1) c_pre[k] = (int)g[(uint32_t)(src_row(min(t0 + k, t_last)) * cols) + (uint32_t)xs];
   };
-  request(-3);
+  request(-3, 0, 7);
   uint2 e_next = tab(0);
-  auto step = [&](auto phase_tag, auto edge_tag, const int t) __attribute__((always_inline)) {
+  auto step = [&](auto phase_tag, const int t) __attribute__((always_inline)) {
     constexpr int P = decltype(phase_tag)::value;
-    constexpr bool EDGE = decltype(edge_tag)::value;
     if (t > t_last) return;  // uniform
     const uint32_t e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e_next.x);
     const uint32_t e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e_next.y);
     {
-      const int c = c_cur[P];  // row t
+      const int c = c_pre[P];  // row t
       e_next = tab(min(t + 1, t_last) + 3);
       vc[P] = c;
       vr1[P] = fs_from_right(c);
@@ -595,16 +592,8 @@ __global__ __launch_bounds__(kThreads) void orb_level_pass_kernel(const LevelPas
     }
     // ---- blur: horizontal sum of row t, then output row t - 3 ----
     if (e1 & kRtHsum) {  // uniform
-      const int c = vc[P];
-      int l1, l2, l3, r1, r2, r3;
-      if (EDGE) {
-        l3 = __shfl(c, src[0]); l2 = __shfl(c, src[1]); l1 = __shfl(c, src[2]);
-        r1 = __shfl(c, src[4]); r2 = __shfl(c, src[5]); r3 = __shfl(c, src[6]);
-      } else {
-        l1 = vl1[P]; l2 = vl2[P]; l3 = vl3[P];
-        r1 = vr1[P]; r2 = vr2[P]; r3 = vr3[P];
-      }
-      hs[P] = orb_mad24(18u, (uint32_t)(l3 + r3), orb_mad24(34u, (uint32_t)(l2 + r2), orb_mad24(49u, (uint32_t)(l1 + r1), orb_mul24(54u, (uint32_t)c))));
+      hs[P] = orb_mad24(18u, (uint32_t)(vl3[P] + vr3[P]), orb_mad24(34u, (uint32_t)(vl2[P] + vr2[P]),
+                        orb_mad24(49u, (uint32_t)(vl1[P] + vr1[P]), orb_mul24(54u, (uint32_t)vc[P]))));
       if (e1 & kRtBlurOut) {  // uniform; rows t-6 .. t live in slots P+1 .. P+7 (mod 7)
         const uint32_t vsum = orb_mad24(18u, hs[(P + 1) % 7] + hs[P], orb_mad24(34u, hs[(P + 2) % 7] + hs[(P + 6) % 7],
                                         orb_mad24(49u, hs[(P + 3) % 7] + hs[(P + 5) % 7], orb_mul24(54u, hs[(P + 4) % 7]))));
@@ -651,21 +640,19 @@ __global__ __launch_bounds__(kThreads) void orb_level_pass_kernel(const LevelPas
     s_b = s;
     lr_b = lr;
   };
-  auto run = [&](auto edge_tag) __attribute__((always_inline)) {
-    for (int t = -3; t <= t_last; t += 7) {
-#pragma unroll
-      for (int k = 0; k < 7; ++k) c_cur[k] = c_pre[k];
-      request(min(t + 7, t_last));
-      step(std::integral_constant<int, 0>{}, edge_tag, t);
-      step(std::integral_constant<int, 1>{}, edge_tag, t + 1);
-      step(std::integral_constant<int, 2>{}, edge_tag, t + 2);
-      step(std::integral_constant<int, 3>{}, edge_tag, t + 3);
-      step(std::integral_constant<int, 4>{}, edge_tag, t + 4);
-      step(std::integral_constant<int, 5>{}, edge_tag, t + 5);
-      step(std::integral_constant<int, 6>{}, edge_tag, t + 6);
-    }
-  };
-  if (edge_strip && A.blur) run(std::true_type{}); else run(std::false_type{});
+  // (the next revolution's rows in two half-batches into the slots just emptied: slots 0 .. 3 after step 3, 4 .. 6 after step 6
+  // -- three to six steps ahead of their use, and seven registers instead of fourteen)
+  for (int t = -3; t <= t_last; t += 7) {
+    step(std::integral_constant<int, 0>{}, t);
+    step(std::integral_constant<int, 1>{}, t + 1);
+    step(std::integral_constant<int, 2>{}, t + 2);
+    step(std::integral_constant<int, 3>{}, t + 3);
+    request(t + 7, 0, 4);
+    step(std::integral_constant<int, 4>{}, t + 4);
+    step(std::integral_constant<int, 5>{}, t + 5);
+    step(std::integral_constant<int, 6>{}, t + 6);
+    request(t + 7, 4, 7);
+  }
 }
 
 // ---- FAST as a detector of its own (feature_detection_method "FAST") ------------------------------------------
