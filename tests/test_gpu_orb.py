@@ -180,3 +180,61 @@ def test_detect_orb_on_noise_with_more_local_maxima_than_the_candidate_list(ctx)
             p = i * 2 + m
             assert n[p] == len(wkp) and len(wkp) > 100
             assert np.array_equal(kp4[p, :n[p]], wkp) and np.array_equal(resp[p, :n[p]], wresp), (i, m)
+
+
+def test_detect_describe_orb_on_an_image_too_tall_for_the_level_passes(ctx):
+    """orb_level_pass_kernel keeps a level's row table in LDS (1018 rows); a taller image takes the separate resize / FAST /
+    blur kernels.  Both routes must give the oracle's keypoints and descriptors."""
+    rng = np.random.default_rng(77)
+    shape, nmask, nfeatures, cap = (1100, 150), 2, 120, 256
+    imgs = np.stack([_contrast(rng, shape) for _ in range(2)])
+    bits = _sector_masks(shape[0], shape[1], nmask, rng)[None]
+    t_img, t_bits, t_pat = _to(ctx.device, imgs, bits, orb_pattern.orb_pattern())
+    mask_pyr = ctx.orb_mask_pyramid(t_bits, nmask)
+    P = 2 * nmask
+    z = lambda shp, dt: torch.full(shp, 7, dtype=dt, device=ctx.device)  # noqa: E731
+    kp4, resp, n = z((P, cap, 4), torch.float32), z((P, cap), torch.float32), z((P,), torch.int32)
+    desc, kp_xy = z((P, cap, 32), torch.uint8), z((P, cap, 2), torch.float32)
+    ctx.detect_describe_orb(t_img, mask_pyr, 2, nmask, nfeatures, t_pat, kp4, resp, n, desc, kp_xy=kp_xy)
+    ctx.synchronize()
+    nn = n.cpu().numpy()
+    for i in range(2):
+        want = oracle.orb_detect(imgs[i], bits[0], nmask, nfeatures, cap)
+        for m in range(nmask):
+            p = i * nmask + m
+            wk, wr = want[m]
+            want_d, kept = oracle.orb_describe_levels(imgs[i], wk)
+            assert nn[p] == len(kept) and len(kept) > 20, (p, nn[p], len(kept))
+            assert np.array_equal(kp4[p, : nn[p]].cpu().numpy(), wk[kept]), p
+            assert np.array_equal(desc[p, : nn[p]].cpu().numpy(), want_d), p
+
+
+def test_detect_describe_orb_with_a_pattern_that_reaches_the_image_border(ctx):
+    """A test pattern with coordinates up to +-24 reaches further than the detector's 31-px border leaves room for on a level:
+    descriptors then read mirrored pixels of the blurred levels -- in the level passes the blur's mirrored columns are the
+    halo lanes of the two edge strips, its mirrored rows the walk's first and last three."""
+    rng = np.random.default_rng(78)
+    shape, nmask, nfeatures, cap = (130, 420), 3, 150, 256
+    imgs = np.stack([_contrast(rng, shape) for _ in range(2)])
+    bits = _sector_masks(shape[0], shape[1], nmask, rng)[None]
+    pat = rng.integers(-24, 25, size=(512, 2)).astype(np.int8)
+    t_img, t_bits, t_pat = _to(ctx.device, imgs, bits, pat)
+    mask_pyr = ctx.orb_mask_pyramid(t_bits, nmask)
+    P = 2 * nmask
+    z = lambda shp, dt: torch.full(shp, 7, dtype=dt, device=ctx.device)  # noqa: E731
+    kp4, resp, n = z((P, cap, 4), torch.float32), z((P, cap), torch.float32), z((P,), torch.int32)
+    desc, kp_xy = z((P, cap, 32), torch.uint8), z((P, cap, 2), torch.float32)
+    ctx.detect_describe_orb(t_img, mask_pyr, 2, nmask, nfeatures, t_pat, kp4, resp, n, desc, kp_xy=kp_xy)
+    ctx.synchronize()
+    nn = n.cpu().numpy()
+    total = 0
+    for i in range(2):
+        want = oracle.orb_detect(imgs[i], bits[0], nmask, nfeatures, cap)
+        for m in range(nmask):
+            p = i * nmask + m
+            wk, wr = want[m]
+            want_d, kept = oracle.orb_describe_levels(imgs[i], wk, pat)
+            assert nn[p] == len(kept), (p, nn[p], len(kept))
+            assert np.array_equal(desc[p, : nn[p]].cpu().numpy(), want_d), p
+            total += len(kept)
+    assert total > 100
