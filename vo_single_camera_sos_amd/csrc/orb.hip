@@ -868,6 +868,8 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 }
 
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+typedef uint32_t u32x3_unaligned __attribute__((ext_vector_type(3), aligned(1)));
+typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
 
 // Harris response of the 7x7 block around (cx, cy), k = 0.04, by ONE LANE (round 4; rounds 1-3 spent a whole wave on a
 // candidate: 49 of 64 lanes busy, three 6-step cross-lane reductions and an LDS patch per candidate -- ~120 wave-instructions
@@ -887,8 +889,10 @@ __device__ __forceinline__ float harris_response_lane(const uint8_t* __restrict_
 #pragma unroll
     for (int sl = 0; sl < 3; ++sl) {
       const int r = r0 + sl;
-      const u32_unaligned* q = reinterpret_cast<const u32_unaligned*>(p + (size_t)r * w);
-      const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+      // (ONE 12-byte load per row: every lane has its own candidate, i.e. its own cache line, and the texture addresser takes a
+      // wave-load's lines one per clock -- three dword loads per row were three such walks)
+      const u32x3_unaligned q = *reinterpret_cast<const u32x3_unaligned*>(p + (size_t)r * w);
+      const uint32_t d0 = q.x, d1 = q.y, d2 = q.z;
       const int px[9] = {(int)(d0 & 255u), (int)((d0 >> 8) & 255u), (int)((d0 >> 16) & 255u), (int)(d0 >> 24),
                          (int)(d1 & 255u), (int)((d1 >> 8) & 255u), (int)((d1 >> 16) & 255u), (int)(d1 >> 24), (int)(d2 & 255u)};
 #pragma unroll
@@ -957,10 +961,11 @@ __device__ __forceinline__ void ic_moments_rows(const uint8_t* __restrict__ im, 
   int m01 = 0;
 #pragma unroll 2
   for (int r = first; r < 2 * kHalfPatch + 1; r += step) {
-    const u32_unaligned* q = reinterpret_cast<const u32_unaligned*>(p + (size_t)r * w);
-    uint32_t x[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) x[k] = q[k];  // all eight in flight (a dword outside the disc has weight 0)
+    // (two 16-byte loads per row instead of eight dword loads: fewer requests; the time is the L2's -- every 32-byte row
+    // segment of a patch pulls its own 128-byte line: 2 M keypoints x ~40 lines per launch)
+    const u32x4_unaligned qa = *reinterpret_cast<const u32x4_unaligned*>(p + (size_t)r * w);
+    const u32x4_unaligned qb = *reinterpret_cast<const u32x4_unaligned*>(p + (size_t)r * w + 16);
+    const uint32_t x[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};  // (a dword outside the disc has weight 0)
     uint32_t rs = 0u;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -1012,6 +1017,21 @@ __global__ __launch_bounds__(kThreads) void orb_mask_bbox_kernel(const uint32_t*
   }
 }
 
+#ifdef SOSVO_DEBUG_TIMING
+// (debug build only, `make EXTRA=-DSOSVO_DEBUG_TIMING`: phase clocks of orb_select_kernel, 100 MHz ticks summed over workgroups)
+__device__ unsigned long long g_sel_ticks[8];
+#define SEL_TICK(k)                                                                      \
+  do {                                                                                   \
+    __syncthreads();                                                                     \
+    if (tid == 0) {                                                                      \
+      const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();                  \
+      atomicAdd(&g_sel_ticks[k], now_ - t_prev_);                                        \
+      t_prev_ = now_;                                                                    \
+    }                                                                                    \
+  } while (0)
+#else
+#define SEL_TICK(k) do { } while (0)
+#endif
 // One workgroup per problem (image, mask) walks the detection levels.  Per level:
 //   1. candidates: the local-maximum flags of the FAST score map (one u64 per row and 56-column strip, written by the
 //      score kernel) inside the mask's bounding box and the 31-px border, mask bit set -> (position, score) in LDS;
@@ -1040,6 +1060,9 @@ __global__ __launch_bounds__(kThreads, 6) void orb_select_kernel(LevelSrc S, con
   const int img = p / nmask, m = p - img * nmask;
   if (tid == 0) s_nout = 0;
   __syncthreads();
+#ifdef SOSVO_DEBUG_TIMING
+  unsigned long long t_prev_ = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int l = 0; l < P.ndet; ++l) {
     if (!P.det[l]) continue;  // uniform
     const int h = P.h[l], w = P.w[l], quota = P.quota[l];
@@ -1061,23 +1084,50 @@ __global__ __launch_bounds__(kThreads, 6) void orb_select_kernel(LevelSrc S, con
     const int bx1 = min(w - kEdge, (int)bb[2]), by1 = min(h - kEdge, (int)bb[3]);  // exclusive
     const int rw = bb[2] ? max(0, bx1 - bx0) : 0, rh = bb[2] ? max(0, by1 - by0) : 0;
     // (the walk over the flag words; visit(x, y, FAST score) for every local maximum inside the mask)
+    // Memory round trips are what this phase costs (a level's flag words, mask words and scores come from HBM: 128 images
+    // of 577 KB share one XCD's 4 MB L2, ~2 - 3 us each under load), so the walk keeps as few of them in series as the data
+    // allows: the flag words of TWO trips are requested together, and inside a word the mask word and the score of the NEXT
+    // set bit are requested (both at once: neither needs the other) before the current bit's are looked at -- two loads deep
+    // per word instead of flag -> mask -> score per bit, one word after the other.
     auto walk = [&](auto visit) {
       if (rw <= 0 || rh <= 0) return;
-      const int st0 = bx0 / kFsStripW, ns = (bx1 - 1) / kFsStripW - st0 + 1;
-      for (int i = tid; i < ns * rh; i += kThreads) {
-        const int ry = i / ns, sidx = st0 + (i - ry * ns), y = by0 + ry;
-        const int xbase = sidx * kFsStripW - kFsHalo;  // column of bit 0
+      const int st0 = bx0 / kFsStripW, ns = (bx1 - 1) / kFsStripW - st0 + 1, nw = ns * rh;
+      auto word = [&](int i, int& y, int& xbase) -> unsigned long long {
+        const int ry = i / ns, sidx = st0 + (i - ry * ns);
+        y = by0 + ry;
+        xbase = sidx * kFsStripW - kFsHalo;  // column of bit 0
         unsigned long long wd = fl[(size_t)y * strips + sidx];
-        {  // keep the bits whose column lies inside [bx0, bx1)
-          const int l_lo = max(0, bx0 - xbase), l_hi = min(63, bx1 - 1 - xbase);
-          wd = l_hi >= l_lo ? (wd >> l_lo << l_lo) & (~0ULL >> (63 - l_hi)) : 0ULL;
+        // keep the bits whose column lies inside [bx0, bx1)
+        const int l_lo = max(0, bx0 - xbase), l_hi = min(63, bx1 - 1 - xbase);
+        return l_hi >= l_lo ? (wd >> l_lo << l_lo) & (~0ULL >> (63 - l_hi)) : 0ULL;
+      };
+      auto bits = [&](unsigned long long wd, int y, int xbase) __attribute__((always_inline)) {
+        if (!wd) return;
+        const uint32_t row = (uint32_t)y * (uint32_t)w;
+        int x = xbase + __ffsll((long long)wd) - 1;
+        wd &= wd - 1ULL;
+        uint32_t mword = mk[row + (uint32_t)x];
+        int sval = (int)sc[row + (uint32_t)x];
+        for (;;) {
+          const int xc = x, sc_c = sval;
+          const uint32_t mc = mword;
+          const bool more = wd != 0ULL;
+          if (more) {
+            x = xbase + __ffsll((long long)wd) - 1;
+            wd &= wd - 1ULL;
+            mword = mk[row + (uint32_t)x];
+            sval = (int)sc[row + (uint32_t)x];
+          }
+          if ((mc >> m) & 1u) visit(xc, y, sc_c);
+          if (!more) break;
         }
-        while (wd) {
-          const int x = xbase + __ffsll((long long)wd) - 1;
-          wd &= wd - 1ULL;
-          if (!((mk[(size_t)y * w + x] >> m) & 1u)) continue;
-          visit(x, y, (int)sc[(size_t)y * w + x]);
-        }
+      };
+      for (int i = tid; i < nw; i += 2 * kThreads) {
+        int y0 = 0, xb0 = 0, y1 = 0, xb1 = 0;
+        const unsigned long long w0 = word(i, y0, xb0);
+        const unsigned long long w1 = i + kThreads < nw ? word(i + kThreads, y1, xb1) : 0ULL;
+        bits(w0, y0, xb0);
+        bits(w1, y1, xb1);
       }
     };
     walk([&](int x, int y, int sv) {
@@ -1089,6 +1139,7 @@ __global__ __launch_bounds__(kThreads, 6) void orb_select_kernel(LevelSrc S, con
       }
     });
     __syncthreads();
+    SEL_TICK(0);
     const int nc_all = s_nc;
     if (nc_all == 0) continue;  // uniform: nothing on this level (s_nc is re-initialised behind the barrier of the next level's step 1)
     // 2. retainBest(2 * quota) by FAST score, ties kept: the largest score t with #(score >= t) >= 2 quota
@@ -1131,6 +1182,7 @@ __global__ __launch_bounds__(kThreads, 6) void orb_select_kernel(LevelSrc S, con
       });
     }
     __syncthreads();
+    SEL_TICK(1);
     const int nc = min(s_nk, kCandMax);
     // 3. Harris response of the survivors -> sort keys: a lane per candidate, the candidates packed into as few waves as
     // they fill (a wave's instruction count does not depend on how many of its lanes work)
@@ -1146,6 +1198,7 @@ __global__ __launch_bounds__(kThreads, 6) void orb_select_kernel(LevelSrc S, con
     // 4. sort, descending: response, then (y, x) ascending (keys are unique; padding sorts last).  Up to 64 keys (the usual
     // case on a blurred panorama): one wave, in registers, no barriers; more: bitonic sort in LDS by the workgroup.
     __syncthreads();
+    SEL_TICK(2);
     if (nc <= 64) {
       if (wid == 0) {
         unsigned long long key = lane < nc ? ckey[lane] : 0ULL;
@@ -1183,6 +1236,7 @@ __global__ __launch_bounds__(kThreads, 6) void orb_select_kernel(LevelSrc S, con
         }
       }
     }
+    SEL_TICK(3);
     // 5. retainBest(quota) by Harris response, ties kept: quota + the following entries that equal the quota-th response
     if (nc > quota) {  // uniform
       const uint32_t amb = (uint32_t)(ckey[quota - 1] >> 32);  // ordered(float): same order as the responses
@@ -1223,6 +1277,7 @@ __global__ __launch_bounds__(kThreads, 6) void orb_select_kernel(LevelSrc S, con
     __syncthreads();
     if (tid == 0) s_nout = min(cap, base_out + keep);
     __syncthreads();
+    SEL_TICK(4);
   }
   if (tid == 0) n_out[p] = s_nout;
 }
@@ -1236,6 +1291,7 @@ __global__ __launch_bounds__(kThreads, 6) void orb_select_kernel(LevelSrc S, con
 // the tests read LDS bytes.  Keypoints too close to their level's border for the patch (none the detector returns: it
 // keeps 31 px) take the direct path with reflected coordinates.
 constexpr int kDescPatchMaxR = 23, kDescPatchRows = 2 * kDescPatchMaxR + 1, kDescPatchPitch = 13, kDescPatchLoads = 9;
+constexpr int kDescRegionBytes = 24 * 1024;
 __global__ __launch_bounds__(kThreads) void orb_describe_levels_kernel(const uint8_t* __restrict__ blur, Pyr P, int nlev_have,
                                                                        int rows, int cols, int nmask, int cap,
                                                                        float* __restrict__ kp4, int32_t* __restrict__ n_io,
@@ -1246,7 +1302,13 @@ __global__ __launch_bounds__(kThreads) void orb_describe_levels_kernel(const uin
   extern __shared__ float lds_kp[];  // [cap][4] keypoints, then [cap][2] (cos, sin) of their angles
   float* lds_cs = lds_kp + 4 * (size_t)cap;
   __shared__ int8_t spat[1024];
-  __shared__ uint32_t patch_lds[kThreads / 64][kDescPatchRows * kDescPatchPitch];
+  // one LDS area, two uses: the REGION of a level's blurred image under all of this problem's keypoints of that level (the
+  // usual case, below), or the four waves' per-keypoint patches (keypoints whose region does not fit)
+  __shared__ uint32_t region32[kDescRegionBytes / 4];
+  static_assert(kDescRegionBytes >= (int)sizeof(uint32_t) * (kThreads / 64) * kDescPatchRows * kDescPatchPitch, "patches fit");
+  __shared__ int s_bb[kLevels][6];  // per level, over its keypoints with a whole patch: xmin, ymin, xmax, ymax (level px), first / last index
+  __shared__ int s_mode[kLevels];   // 1: the level's keypoints are described from the region
+  __shared__ int s_rest;            // keypoints that are not (1: the per-keypoint paths have work)
   __shared__ int wave_off[5];
   __shared__ int s_running;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1336,7 +1398,7 @@ __global__ __launch_bounds__(kThreads) void orb_describe_levels_kernel(const uin
     pk[it] = i - prow[it] * pdw;
   }
   const int nit = patch_ok ? (PR * pdw + 63) >> 6 : 0;  // <= kDescPatchLoads
-  uint32_t* patch32 = patch_lds[wid];
+  uint32_t* patch32 = region32 + wid * (kDescPatchRows * kDescPatchPitch);
   const uint8_t* patch8 = reinterpret_cast<const uint8_t*>(patch32);
   // A keypoint's state: where its patch lies and the patch dwords themselves, REQUESTED ONE KEYPOINT AHEAD: a wave used to
   // load, wait a full memory round trip, stage and test one keypoint after the other (round 4's stats pass: 2.8 us per keypoint
@@ -1345,9 +1407,9 @@ __global__ __launch_bounds__(kThreads) void orb_describe_levels_kernel(const uin
   // (NIT = 7 for OpenCV's table, 9 at most; a keypoint that is not staged -- none the detector returns -- loads a patch that
   // certainly exists, the top-left corner of its image's level 0, and is described by the second loop below).
   struct KpState {
-    int cx, cy, hh, ww;
+    int cx, cy, hh, ww, l;
     float ca, sa;
-    bool staged;
+    bool staged, region;
   };
   // (a keypoint belongs to a WAVE: its level, centre and image pointers are told to be scalars, so that the patch loads take a
   // scalar base plus one 32-bit offset per lane instead of seven 64-bit address chains)
@@ -1367,9 +1429,86 @@ __global__ __launch_bounds__(kThreads) void orb_describe_levels_kernel(const uin
     // OpenCV's table needs 20) needs no border reflection -- a wave-uniform test
     inside = k.cx >= margin && k.cy >= margin && k.cx < k.ww - margin && k.cy < k.hh - margin;
     ctr = im + (size_t)k.cy * k.ww + k.cx;
-    k.staged = inside && patch_ok;  // wave-uniform
+    k.l = l;
+    k.region = inside && s_mode[l] != 0;              // wave-uniform
+    k.staged = inside && patch_ok && !k.region;       // wave-uniform
     return k;
   };
+  // ---- the usual case: a level's keypoints from ONE staged region ------------------------------------------------------
+  // Round 4's counters: every 40-byte row of a keypoint's patch pulls its own 128-byte line through the L2 (~45 lines, 6 KB per
+  // keypoint, 12 GB per 256 frame pairs: the kernel ran at the L2's line rate, not at its 150 instructions per keypoint) -- and
+  // the ~165 keypoints of a mask lie so close together that their patches cover the same pixels nine times over.  So: per
+  // level, the bounding box of the problem's keypoints grown by the pattern's reach goes to LDS once (coalesced dword loads,
+  // ~20 KB for a 120-column mask of a 146-row panorama) and every test of every keypoint of that level is an LDS byte read.
+  // A level whose region exceeds the LDS area (one mask over a whole wide image) keeps the per-keypoint patches below.
+  if (tid < kLevels) {
+    s_bb[tid][0] = s_bb[tid][1] = s_bb[tid][4] = 0x7FFFFFFF;
+    s_bb[tid][2] = s_bb[tid][3] = s_bb[tid][5] = -1;
+    s_mode[tid] = 0;
+  }
+  if (tid == 0) s_rest = 0;
+  __syncthreads();
+  for (int i = tid; i < mkept; i += kThreads) {
+    const int l = (int)lds_kp[4 * i + 3];
+    const int cx = __float2int_rn(lds_kp[4 * i] * s_linv[l]), cy = __float2int_rn(lds_kp[4 * i + 1] * s_linv[l]);
+    if (cx >= margin && cy >= margin && cx < s_lw[l] - margin && cy < s_lh[l] - margin) {
+      atomicMin(&s_bb[l][0], cx);
+      atomicMin(&s_bb[l][1], cy);
+      atomicMax(&s_bb[l][2], cx);
+      atomicMax(&s_bb[l][3], cy);
+      atomicMin(&s_bb[l][4], i);
+      atomicMax(&s_bb[l][5], i);
+    } else {
+      s_rest = 1;
+    }
+  }
+  __syncthreads();
+  const uint8_t* region8 = reinterpret_cast<const uint8_t*>(region32);
+  for (int l = 0; l < nlev_have; ++l) {  // (uniform)
+    const int xmin = s_bb[l][0], ymin = s_bb[l][1], xmax = s_bb[l][2], ymax = s_bb[l][3], jlo = s_bb[l][4], jhi = s_bb[l][5];
+    if (xmax < 0) continue;  // no keypoint with a whole patch on this level
+    const int rx0 = xmin - R, ry0 = ymin - R, rw = xmax - xmin + 2 * R + 1, rh = ymax - ymin + 2 * R + 1;
+    const int ldw = (rw + 3) >> 2, pitch_dw = ldw | 1;  // (an odd pitch in dwords: a patch column spreads over the banks)
+    if (pitch_dw * 4 * rh > kDescRegionBytes) {
+      if (tid == 0) s_rest = 1;
+      continue;
+    }
+    const uint8_t* im = blur + (size_t)img * P.total + (size_t)(uint32_t)s_loff[l];
+    const int ww = s_lw[l];
+    __syncthreads();  // (the previous level's tests are done with the area)
+    for (int i = tid; i < rh * ldw; i += kThreads) {
+      const int ry = i / ldw, k = i - ry * ldw;
+      region32[ry * pitch_dw + k] = *reinterpret_cast<const u32_unaligned*>(im + (size_t)(ry0 + ry) * ww + rx0 + 4 * k);
+    }
+    if (tid == 0) s_mode[l] = 1;
+    __syncthreads();
+    const uint32_t pitch_b = 4u * (uint32_t)pitch_dw;
+    for (int j = jlo + wid_s; j <= jhi; j += kThreads / 64) {
+      if (__builtin_amdgcn_readfirstlane((int)lds_kp[4 * j + 3]) != l) continue;  // (keypoints handed in out of level order)
+      const float inv = s_linv[l];
+      const int cx = __builtin_amdgcn_readfirstlane(__float2int_rn(lds_kp[4 * j] * inv));
+      const int cy = __builtin_amdgcn_readfirstlane(__float2int_rn(lds_kp[4 * j + 1] * inv));
+      if (!(cx >= margin && cy >= margin && cx < ww - margin && cy < s_lh[l] - margin)) continue;  // uniform: the border loop's
+      const float ca = lds_cs[2 * j], sa = lds_cs[2 * j + 1];
+      const uint32_t org = (uint32_t)(cy - ry0) * pitch_b + (uint32_t)(cx - rx0);
+      unsigned long long* d = reinterpret_cast<unsigned long long*>(desc + ((size_t)p * cap + j) * 32);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int val[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float px = ppx[r][e], py = ppy[r][e];
+          const float xr = (px * ca) - (py * sa), yr = (px * sa) + (py * ca);
+          const int dx = __float2int_rn(xr), dy = __float2int_rn(yr);
+          val[e] = region8[org + (uint32_t)(dy * (int)pitch_b + dx)];
+        }
+        const unsigned long long bal = __ballot(val[0] < val[1]);
+        if (lane == 0) d[r] = bal;
+      }
+    }
+  }
+  __syncthreads();  // (s_mode / s_rest complete; the area is free for the per-keypoint patches)
+  if (!s_rest) return;  // uniform: every keypoint came from a region
   auto staged_loop = [&](auto nit_tag) __attribute__((always_inline)) {
     constexpr int NIT = decltype(nit_tag)::value;
     // (a kept keypoint lies >= 31 px inside level 0, so level 0 holds a (2 R + 1)-row patch with its centre at (R, R))
@@ -1423,7 +1562,7 @@ __global__ __launch_bounds__(kThreads) void orb_describe_levels_kernel(const uin
     const uint8_t *im, *ctr;
     bool inside;
     const KpState k = locate(j, im, ctr, inside);
-    if (k.staged) continue;  // uniform
+    if (k.staged || k.region) continue;  // uniform
     unsigned long long* d = reinterpret_cast<unsigned long long*>(desc + ((size_t)p * cap + j) * 32);
 #pragma unroll 1
     for (int r = 0; r < 4; ++r) {
@@ -1646,6 +1785,17 @@ int32_t run_orb_describe(sosvo_ctx* ctx, const uint8_t* gray, int nimg, int rows
 }  // namespace
 
 extern "C" {
+
+#ifdef SOSVO_DEBUG_TIMING
+int32_t sosvo_debug_orb_select_ticks(unsigned long long* out8, int32_t reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_sel_ticks), sizeof(unsigned long long) * 8) != hipSuccess) return SOSVO_ERR_HIP;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_sel_ticks), z, sizeof(z)) != hipSuccess) return SOSVO_ERR_HIP;
+  }
+  return SOSVO_OK;
+}
+#endif
 
 int64_t sosvo_orb_pyramid_pixels(int32_t rows, int32_t cols) {
   if (rows < 1 || cols < 1) return 0;
