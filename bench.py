@@ -508,8 +508,8 @@ def compose_headline(out, detail_path=None):
     line["bounds"] = extra
     # one number (and its unit's worth of context) per sub-record; errors as short strings
     sub = {}
-    for key in ("pcie_inclusive", "c_abi_streams", "orb_detector", "orb_detector_median11", "gp3p", "pano_1200", "c3", "c3_2880",
-                "c5_epnp", "c5_kneip", "sequence", "sequence_rgbd"):
+    for key in ("pcie_inclusive", "c_abi_streams", "orb_detector", "orb_detector_median11", "gp3p", "seeded_pattern", "pano_1200", "c3",
+                "c3_2880", "c5_epnp", "c5_kneip", "sequence", "sequence_rgbd"):
         d = out.get(key)
         if not isinstance(d, dict):
             continue
@@ -523,7 +523,8 @@ def compose_headline(out, detail_path=None):
         if isinstance(r2, dict):
             e["frac"] = _sig(r2.get("frac"), 3)
             e["kernel"] = _clip(str(r2.get("kernel", "")).strip("()").split("<")[0], 32)
-        for k in ("keypoints_per_view_mean", "keypoints_per_view", "ratio_to_engine", "h2d_GBps", "same_results", "gpu_ms_per_frame"):
+        for k in ("keypoints_per_view_mean", "keypoints_per_view", "inliers_per_pair_mean", "ratio_to_engine", "h2d_GBps", "same_results",
+                  "gpu_ms_per_frame"):
             if k in d:
                 e[k] = _sig(d[k], 4)
         sub[key] = e
@@ -1068,6 +1069,16 @@ def main():
                     out["orb_detector_median11"] = sub_engine(detection_method="ORB", ransac_solver=args.ransac_solver)
                 if args.ransac_solver != "GP3P":
                     out["gp3p"] = sub_engine(detection_method=args.detector, ransac_solver="GP3P", pmc_tag="gp3p")
+                if os.environ.get("SOSVO_ORB_PATTERN", "opencv") != "seeded":
+                    # the SAME step with the seeded BRIEF table rounds 1-3 ran (round 4's default is OpenCV's learned table, whose
+                    # descriptors match 1.67 x as many points on these frames: everything behind the matcher carries more work
+                    # per pair).  Same build, same frames: the headline of rounds 1-3 and this round's compare through this record.
+                    os.environ["SOSVO_ORB_PATTERN"] = "seeded"
+                    try:
+                        out["seeded_pattern"] = sub_engine(detection_method=args.detector, ransac_solver=args.ransac_solver)
+                        out["seeded_pattern"]["note"] = "rounds 1-3's workload: seeded BRIEF table instead of OpenCV's bit_pattern_31_"
+                    finally:
+                        del os.environ["SOSVO_ORB_PATTERN"]
                 if args.pano_width != 1200:
                     # the reference's default panorama width (demo_vo_sos.py: 1200 columns -> 1200 x 122 panoramas, fewer
                     # keypoints per view than the 2000 BASELINE's metric names) on the same omni frames

@@ -223,31 +223,57 @@ __global__ __launch_bounds__(kThreads) void gray_kernel(const uint8_t* __restric
 // K1 + K3 without a median (median_win_size 0 / 1: the RGB-D frames' setting, and the setting under which the ORB detector
 // finds its quota on panoramas): every lane unwraps its pixel from the table and converts it to gray at once -- the colour
 // panoramas (2.5 MB per frame pair) are neither written nor read.  Same arithmetic as unwrap_lut_kernel + gray_kernel.
-// kUgPix pixels per thread (256 apart: every wave-load stays a run of 64 neighbouring pixels), their table entries and
-// gathers all in flight before the first blend: with one pixel per thread the kernel was a stream of 840 000 one-shot
-// workgroups per 256 frame pairs, bound by workgroup dispatch and by one exposed load latency each (round 4).
-constexpr int kUgPix = 8;
+// NK pixels per thread, their table entries and gathers all in flight before the first blend: with one pixel per thread the
+// kernel was a stream of 840 000 one-shot workgroups per 256 frame pairs, bound by workgroup dispatch and by one exposed load
+// latency each (round 4).  A wave gathers a 16 x 4 TILE of the panorama per load, not 64 pixels of one row: 64 neighbouring
+// columns lie on a ~40-px arc of the omni frame that crosses up to ~40 image rows -- every few lanes another 128-byte line
+// through the L2 for 8 useful bytes each -- while a 16 x 4 tile lands in a ~10 x 3 px patch of the frame (the kernel moves
+// ~0.5 GB through HBM per 256 pairs and ran at 0.83 ms: at the L2's line rate, not at HBM's).  The gray bytes of the
+// workgroup's 64 x (4 NK) tile meet in LDS and leave as 64-byte row segments (the tile mapping on its own -- 16-byte pieces
+// of four rows per store -- was no faster than the row mapping).  NK = 4 or 2: the tile height that wastes fewer rows.
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned_img;
+template <int NK>
 __global__ __launch_bounds__(kThreads) void unwrap_gray_kernel(const uint8_t* __restrict__ omni, const uint2* __restrict__ table,
-                                                               int nframes, int H, int W, int npix, uint8_t* __restrict__ gray) {
-  const int gx = (npix + kThreads * kUgPix - 1) / (kThreads * kUgPix);   // XCD-aware 1-D grid as in unwrap_lut_kernel: one image on one XCD
+                                                               int nframes, int H, int W, int rows, int cols, uint8_t* __restrict__ gray) {
+  constexpr int TW = 64, TH = 4 * NK;
+  __shared__ uint32_t tile[TH][TW / 4];
+  const int nbx = (cols + TW - 1) / TW, nby = (rows + TH - 1) / TH;
+  const int gx = nbx * nby, npix = rows * cols;   // XCD-aware 1-D grid as in unwrap_lut_kernel: one image on one XCD
   const int q = blockIdx.x >> 3;
   const int grp = q / gx, blk = q - grp * gx;
   const int img = grp * 8 + (blockIdx.x & 7);
   if (img >= 2 * nframes) return;  // uniform
   const int view = img / nframes, frame = img - view * nframes;
   const uint8_t* src = omni + (size_t)frame * H * W * 3;
-  const int pix0 = blk * kThreads * kUgPix + threadIdx.x;
-  uint2 e[kUgPix];
-  unsigned long long v[kUgPix][2];
+  const int by = blk / nbx, bx = blk - by * nbx;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lx = wid * 16 + (lane & 15), ly = lane >> 4;  // this thread's column and first row inside the tile
+  const int col = min(bx * TW + lx, cols - 1), row0 = by * TH + ly;
+  uint2 e[NK];
+  unsigned long long v[NK][2];
 #pragma unroll
-  for (int k = 0; k < kUgPix; ++k) e[k] = table[(size_t)view * npix + min(pix0 + k * kThreads, npix - 1)];
+  for (int k = 0; k < NK; ++k) e[k] = table[(size_t)view * npix + (size_t)min(row0 + 4 * k, rows - 1) * cols + col];
 #pragma unroll
-  for (int k = 0; k < kUgPix; ++k) unwrap_gather(src, H * W * 3, W, e[k], v[k]);
+  for (int k = 0; k < NK; ++k) unwrap_gather(src, H * W * 3, W, e[k], v[k]);
+  uint8_t* tile8 = reinterpret_cast<uint8_t*>(&tile[0][0]);
 #pragma unroll
-  for (int k = 0; k < kUgPix; ++k) {
-    const int pix = pix0 + k * kThreads;
+  for (int k = 0; k < NK; ++k) {
     const uint32_t bgr = unwrap_blend(H * W * 3, W, e[k], v[k]);
-    if (pix < npix) gray[(size_t)img * npix + pix] = bgr2gray((int)(bgr & 255u), (int)((bgr >> 8) & 255u), (int)((bgr >> 16) & 255u));
+    tile8[(ly + 4 * k) * TW + lx] = bgr2gray((int)(bgr & 255u), (int)((bgr >> 8) & 255u), (int)((bgr >> 16) & 255u));
+  }
+  __syncthreads();
+  // TH rows x 16 dwords: a wave stores whole 64-byte row segments
+  for (int i = threadIdx.x; i < TH * (TW / 4); i += kThreads) {
+    const int r = i / (TW / 4), c4 = i - r * (TW / 4);
+    const int row = by * TH + r, c = bx * TW + 4 * c4;
+    if (row >= rows || c >= cols) continue;
+    uint8_t* o = gray + (size_t)img * npix + (size_t)row * cols + c;
+    const uint32_t w4 = tile[r][c4];
+    if (c + 3 < cols) {
+      *reinterpret_cast<u32_unaligned_img*>(o) = w4;
+    } else {
+      for (int b = 0; c + b < cols; ++b) o[b] = (uint8_t)(w4 >> (8 * b));
+    }
   }
 }
 
@@ -628,9 +654,16 @@ int32_t sosvo_unwrap_median_gray_rows(sosvo_ctx* ctx, const uint8_t* omni, const
   SOSVO_REQUIRE(ctx, ksize == 0 || ksize == 1 || ksize == 3 || ksize == 5 || ksize == 11, "ksize must be 0/1 (no median), 3, 5 or 11");
   if (nframes == 0) return SOSVO_OK;
   if (ksize <= 1) {  // no median: unwrap straight to gray (every row: nothing is skipped, row_range is not consulted)
-    const int npix = rows * cols;
-    SOSVO_LAUNCH(ctx, unwrap_gray_kernel, dim3((unsigned)(cdiv(npix, kThreads * kUgPix) * 8 * cdiv(2 * nframes, 8))), dim3(kThreads), 0,
-                 ctx->stream, omni, reinterpret_cast<const uint2*>(table), nframes, H, W, npix, gray);
+    // (tile height 16 or 8: the one that covers the rows with less padding)
+    const bool th16 = cdiv(rows, 16) * 16 <= cdiv(rows, 8) * 8;
+    const int nblk = cdiv(cols, 64) * cdiv(rows, th16 ? 16 : 8);
+    const dim3 grid((unsigned)(nblk * 8 * cdiv(2 * nframes, 8)));
+    if (th16)
+      SOSVO_LAUNCH(ctx, unwrap_gray_kernel<4>, grid, dim3(kThreads), 0, ctx->stream, omni, reinterpret_cast<const uint2*>(table),
+                   nframes, H, W, rows, cols, gray);
+    else
+      SOSVO_LAUNCH(ctx, unwrap_gray_kernel<2>, grid, dim3(kThreads), 0, ctx->stream, omni, reinterpret_cast<const uint2*>(table),
+                   nframes, H, W, rows, cols, gray);
     SOSVO_LAUNCH_CHECK(ctx);
     return SOSVO_OK;
   }
