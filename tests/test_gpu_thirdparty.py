@@ -91,3 +91,15 @@ def test_unwrap_equals_scipy_bilinear_on_the_32nd_pixel_grid(ctx):
     ctx.synchronize()
     for got in (pano.cpu().numpy(), pano_t.cpu().numpy()):
         assert np.array_equal(got[0, 0], W["bilinear_rounded"]) and np.array_equal(got[1, 0], W["bilinear_rounded"][::-1])
+
+
+@pytest.mark.parametrize("tag,gray,xy,angle", tp.orientation_cases(), ids=lambda v: v if isinstance(v, str) else "")
+def test_orb_orientation_agrees_with_skimage_corner_orientations(ctx, tag, gray, xy, angle):
+    """sosvo_detect_orb on a photograph: the level-0 keypoints' angles (orb_select_kernel's integer moments + fastAtan2
+    polynomial) within 0.02 degrees of scikit-image's corner_orientations at the same positions."""
+    t_img, t_bits = _to(ctx.device, gray[None], np.ones((1,) + gray.shape, np.uint32))
+    pyr = ctx.orb_mask_pyramid(t_bits, 1)
+    kp4, resp, n = ctx.detect_orb(t_img, pyr, 1, 1, 500, 1024)
+    ctx.synchronize()
+    k = int(n.cpu().numpy()[0])
+    tp.check_orientations(kp4[0, :k].cpu().numpy(), xy, angle)

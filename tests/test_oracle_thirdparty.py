@@ -43,3 +43,11 @@ def test_remap_on_the_32nd_pixel_grid_equals_scipy_bilinear():
     got = oracle.unwrap(img, None, mx, my)
     assert np.array_equal(got, W["bilinear_rounded"])
     assert np.abs(got.astype(np.float64) - W["bilinear_exact"]).max() <= 0.5
+
+
+@pytest.mark.parametrize("tag,gray,xy,angle", tp.orientation_cases(), ids=lambda v: v if isinstance(v, str) else "")
+def test_orb_orientation_agrees_with_skimage_corner_orientations(tag, gray, xy, angle):
+    """The intensity-centroid angle of every level-0 ORB keypoint against scikit-image's atan2(m01, m10) over OFAST_MASK."""
+    kp4, _ = oracle.orb_detect(gray, np.ones(gray.shape, np.uint32), 1, 500, 1024)[0]
+    worst = tp.check_orientations(kp4, xy, angle)
+    assert worst > 0.0   # (a polynomial arctangent: not the same bits as numpy's)
