@@ -14,6 +14,7 @@ import os
 import sys
 
 import numpy as np
+import scipy.ndimage as ndi
 import skimage
 import skimage.data
 import skimage.io
@@ -48,6 +49,21 @@ def main():
         out[tag + "_gray"] = g
         out[tag + "_xy"] = xy.astype(np.int32)
         out[tag + "_angle_deg"] = np.mod(np.degrees(ang), 360.0)
+        # Harris response of the 7 x 7 block around each keypoint, k = 0.04, gradients by the 3 x 3 Sobel pair, scaled by
+        # (1 / (4 * 7 * 255))^4 -- ORB's HarrisResponses -- with scipy's correlate and plain float64 sums
+        gi = g.astype(np.float64)
+        sx = np.array([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]], dtype=np.float64)
+        ix, iy = ndi.correlate(gi, sx, mode="mirror"), ndi.correlate(gi, sx.T, mode="mirror")
+        box = np.ones((7, 7))
+        a, b, c = (ndi.correlate(v, box, mode="constant") for v in (ix * ix, iy * iy, ix * iy))
+        sc4 = (1.0 / (4 * 7 * 255.0)) ** 4
+        r = ((a * b - c * c) - 0.04 * (a + b) ** 2) * sc4
+        out[tag + "_harris"] = r[xy[:, 1], xy[:, 0]]
+        # 7 x 7 Gaussian in 8.8 fixed point (taps 18 34 49 54 49 34 18 / 256 per axis, reflect-101 border, one rounding at the
+        # end): scipy's correlate1d on integers with mode 'mirror'
+        taps = np.array([18, 34, 49, 54, 49, 34, 18], dtype=np.int64)
+        v = ndi.correlate1d(ndi.correlate1d(g.astype(np.int64), taps, axis=1, mode="mirror"), taps, axis=0, mode="mirror")
+        out[tag + "_gauss7"] = ((v + 32768) >> 16).astype(np.uint8)
         print(tag, g.shape, "level-0 keypoints", len(xy))
     p = os.path.join(HERE, "thirdparty_orientation.npz")
     np.savez_compressed(p, **out)

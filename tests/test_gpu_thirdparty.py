@@ -103,3 +103,5 @@ def test_orb_orientation_agrees_with_skimage_corner_orientations(ctx, tag, gray,
     ctx.synchronize()
     k = int(n.cpu().numpy()[0])
     tp.check_orientations(kp4[0, :k].cpu().numpy(), xy, angle)
+    harris = dict((t, h) for t, _, _, h in tp.harris_cases())[tag]   # the same run's Harris responses against scipy's
+    tp.check_harris(kp4[0, :k].cpu().numpy(), resp[0, :k].cpu().numpy(), xy, harris)

@@ -51,3 +51,15 @@ def test_orb_orientation_agrees_with_skimage_corner_orientations(tag, gray, xy, 
     kp4, _ = oracle.orb_detect(gray, np.ones(gray.shape, np.uint32), 1, 500, 1024)[0]
     worst = tp.check_orientations(kp4, xy, angle)
     assert worst > 0.0   # (a polynomial arctangent: not the same bits as numpy's)
+
+
+@pytest.mark.parametrize("tag,gray,xy,harris", tp.harris_cases(), ids=lambda v: v if isinstance(v, str) else "")
+def test_orb_harris_response_agrees_with_scipy(tag, gray, xy, harris):
+    """float32 with a pinned operation order against float64 sums by scipy.ndimage: 3e-7 relative measured."""
+    kp4, resp = oracle.orb_detect(gray, np.ones(gray.shape, np.uint32), 1, 500, 1024)[0]
+    tp.check_harris(kp4, resp, xy, harris)
+
+
+@pytest.mark.parametrize("tag,gray,want", tp.gauss7_cases(), ids=lambda v: v if isinstance(v, str) else "")
+def test_gauss7_equals_scipy_integer_correlation(tag, gray, want):
+    assert np.array_equal(oracle.gauss7(gray), want)

@@ -102,6 +102,29 @@ def orientation_cases():
     return [(tag, O[tag + "_gray"], O[tag + "_xy"], O[tag + "_angle_deg"]) for tag in ("camera", "astronaut", "coffee")]
 
 
+def harris_cases():
+    """-> list of (tag, gray u8, xy [n, 2], harris [n] float64): ORB's 7 x 7 Harris response at the level-0 keypoints by
+    scipy.ndimage (Sobel pair, box sums, float64)."""
+    O = load("orientation")
+    return [(tag, O[tag + "_gray"], O[tag + "_xy"], O[tag + "_harris"]) for tag in ("camera", "astronaut", "coffee")]
+
+
+def gauss7_cases():
+    """-> list of (tag, gray u8, blurred u8): the 7 x 7 fixed-point Gaussian (taps 18 34 49 54 49 34 18 / 256 per axis,
+    reflect-101 border, one rounding) by scipy.ndimage.correlate1d on integers."""
+    O = load("orientation")
+    return [(tag, O[tag + "_gray"], O[tag + "_gauss7"]) for tag in ("camera", "astronaut", "coffee")]
+
+
+def check_harris(kp4, resp, xy, harris, rtol=2e-6):
+    l0 = kp4[:, 3] == 0
+    assert int(l0.sum()) == xy.shape[0] and np.array_equal(kp4[l0][:, :2].astype(np.int32), xy)
+    r = resp[l0].astype(np.float64)
+    rel = np.abs(r - harris) / np.abs(harris)
+    assert rel.max() <= rtol, float(rel.max())
+    return float(rel.max())
+
+
 def check_orientations(kp4, xy, angle_deg, tol_deg=0.02):
     """kp4 [n, 4] (x, y, angle, level) of a detector run on the fixture's image: its level-0 keypoints are the fixture's, in
     order, and their angles agree with the third-party atan2(m01, m10) within `tol_deg` on the circle (cv2's fastAtan2, which
