@@ -177,7 +177,7 @@ def sequence_rgbd_subrecord(bgr, depth, mirror_frames=32):
                 run_VO(None, cam, results_path=d, _live_frames=lambda: frames(min(N, 34)), frame_window=32)
                 torch.cuda.synchronize()
             dts = []
-            for _ in range(3 if label == "frame_window_32" else 1):   # (host-clocked, ~0.1 s: the median of three runs)
+            for _ in range(7 if label == "frame_window_32" else 1):   # (host-clocked, ~0.03 s a run: the median of seven)
                 t0 = time.perf_counter()
                 r = run_VO(None, cam, results_path=d, _live_frames=frames, frame_window=window)
                 torch.cuda.synchronize()
@@ -230,7 +230,7 @@ def sequence_subrecord(seq_omni, seq_poses, pano_width, mirror_frames=32):
                 run_VO(None, gs, results_path=d, _live_frames=lambda: frames(min(N, 34)), frame_window=32)
                 torch.cuda.synchronize()
             dts = []
-            for _ in range(3 if label == "frame_window_32" else 1):   # (host-clocked, ~0.1 s: the median of three runs)
+            for _ in range(7 if label == "frame_window_32" else 1):   # (host-clocked, ~0.03 s a run: the median of seven)
                 t0 = time.perf_counter()
                 r = run_VO(None, gs, results_path=d, _live_frames=frames, frame_window=window)
                 torch.cuda.synchronize()

@@ -557,10 +557,25 @@ def rgbd_sequence_engine_for(tracker, camera_model, first_rgb, window):
     cm = camera_model
     cam = RGBDCamConfig(cm.fx, cm.fy, cm.center_x, cm.center_y, cm.focal_length_m, cm.depth_is_Z, 0.8, 7.0,
                         f2f_max_hdiff=tracker.max_horizontal_diff_f2f_matches, pct_good_matches=tracker.percentage_good_matches)
-    return RGBDSequenceEngine(cm._context(), cam, window=window, image_shape=np.asarray(first_rgb).shape[:2],
-                              num_of_features=tracker.num_features_detection_for_motion, median_win_size=0,
-                              thr=tracker.backprojection_score_threshold_3D_to_2D, max_iter=tracker.max_ransac_iterations_3D_to_2D,
-                              adaptive=True, lm_iter=pyopengv.LM_MAX_ITERATIONS, pose_est_algorithm=tracker.pose_est_algorithm)
+    shape = tuple(int(v) for v in np.asarray(first_rgb).shape[:2])
+    # (as sequence_engine_for: the engine -- frame store, 136 MB of pinned staging buffers, scratch -- stays with the camera
+    # model and serves later runs with the same settings; building one costs 15 ms, a 128-frame run 45)
+    key = (int(window), shape, int(tracker.num_features_detection_for_motion), float(tracker.backprojection_score_threshold_3D_to_2D),
+           int(tracker.max_ransac_iterations_3D_to_2D), float(tracker.max_horizontal_diff_f2f_matches),
+           float(tracker.percentage_good_matches), str(tracker.pose_est_algorithm), float(cm.fx), float(cm.fy), float(cm.center_x),
+           float(cm.center_y), float(cm.focal_length_m), bool(cm.depth_is_Z))
+    cache = cm.__dict__.setdefault("_sequence_engines", {})
+    eng = cache.get(key)
+    if eng is None:
+        cache.clear()
+        eng = cache[key] = RGBDSequenceEngine(cm._context(), cam, window=window, image_shape=shape,
+                                              num_of_features=tracker.num_features_detection_for_motion, median_win_size=0,
+                                              thr=tracker.backprojection_score_threshold_3D_to_2D,
+                                              max_iter=tracker.max_ransac_iterations_3D_to_2D, adaptive=True,
+                                              lm_iter=pyopengv.LM_MAX_ITERATIONS, pose_est_algorithm=tracker.pose_est_algorithm)
+    else:
+        eng.reset()
+    return eng
 
 
 class TrackerRGBDSE3(TrackerSE3):
