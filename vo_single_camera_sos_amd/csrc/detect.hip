@@ -164,6 +164,14 @@ __global__ __launch_bounds__(kThreads) void min_eigen_kernel(const uint8_t* __re
 
   // interior strips: the columns x-1 / x+1 of every lane that matters live in lanes -1 / +1
   const bool edge_strip = xb < 1 || xb + 64 > cols - 1;  // wave-uniform
+  // The gray rows come three at a time, one ring revolution ahead (round 4, as orb_level_pass_kernel: a wave's rows are `cols`
+  // bytes apart -- another cache line every step -- and a load used in the step that issues it leaves the step's whole
+  // latency to the other waves of the SIMD).
+  int c_cur[3] = {0, 0, 0}, c_pre[3] = {0, 0, 0};
+  auto request = [&](int t0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c_pre[k] = (int)g[(uint32_t)(refl101(min(t0 + k, t_last), rows) * cols) + (uint32_t)xs];
+  };
   auto step = [&](auto phase_tag, auto edge_tag, const int t) __attribute__((always_inline)) {
     constexpr int P = decltype(phase_tag)::value;
     constexpr bool EDGE = decltype(edge_tag)::value;
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(kThreads) void min_eigen_kernel(const uint8_t* __re
     const uint32_t o_pre = (uint32_t)(max(y_pre, 0) * cols) + (uint32_t)xc;
     const uint32_t mb_pre = y_out ? mb[o_pre] : 0u;
     {
-      const int c = (int)g[(uint32_t)(refl101(t, rows) * cols) + (uint32_t)xs];  // rows * cols < 2^28
+      const int c = c_cur[P];  // gray row t (requested a ring revolution ahead: rows * cols < 2^28)
       const int l = left(c), r = right(c);
       hd[i2] = r - l;
       hs[i2] = (l + 2 * c) + r;
@@ -231,7 +239,11 @@ __global__ __launch_bounds__(kThreads) void min_eigen_kernel(const uint8_t* __re
     }
   };
   auto run = [&](auto edge_tag) __attribute__((always_inline)) {
+    request(t_first);
     for (int t = t_first; t <= t_last; t += 3) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) c_cur[k] = c_pre[k];
+      request(t + 3);
       step(std::integral_constant<int, 0>{}, edge_tag, t);
       step(std::integral_constant<int, 1>{}, edge_tag, t + 1);
       step(std::integral_constant<int, 2>{}, edge_tag, t + 2);
@@ -708,13 +720,20 @@ __global__ __launch_bounds__(kThreads) void gauss7_kernel(const uint8_t* __restr
   uint32_t h[7] = {0, 0, 0, 0, 0, 0, 0};
   const bool edge_strip = xb < 3 || xb + 64 > cols - 3;  // wave-uniform: some lane's x-3 .. x+3 are mirrored columns
   const int t_first = ys - 3, t_last = ye + 2;
-  int c_next = (int)g[(uint32_t)(refl101(t_first, rows) * cols) + (uint32_t)xs];
+  // gray rows in two half-batches into the ring slots just emptied, three to six steps ahead of their use (round 4, as
+  // orb_level_pass_kernel: one row ahead does not cover a load that misses the L2)
+  int c_pre[7];
+  auto request = [&](int t0, int k0, int k1) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+      if (k >= k0 && k < k1) c_pre[k] = (int)g[(uint32_t)(refl101(min(t0 + k, t_last), rows) * cols) + (uint32_t)xs];
+  };
+  request(t_first, 0, 7);
   auto step = [&](auto phase_tag, auto edge_tag, const int t) __attribute__((always_inline)) {
     constexpr int P = decltype(phase_tag)::value;
     constexpr bool EDGE = decltype(edge_tag)::value;
     if (t > t_last) return;  // uniform
-    const int c = c_next;  // gray row t, requested one step ago; row t + 1 is requested now
-    c_next = (int)g[(uint32_t)(refl101(min(t + 1, t_last), rows) * cols) + (uint32_t)xs];
+    const int c = c_pre[P];  // gray row t
     int l1, l2, l3, r1, r2, r3;
     if (EDGE) {
       l3 = __shfl(c, src[0]); l2 = __shfl(c, src[1]); l1 = __shfl(c, src[2]);
@@ -739,9 +758,11 @@ __global__ __launch_bounds__(kThreads) void gauss7_kernel(const uint8_t* __restr
       step(std::integral_constant<int, 1>{}, edge_tag, t + 1);
       step(std::integral_constant<int, 2>{}, edge_tag, t + 2);
       step(std::integral_constant<int, 3>{}, edge_tag, t + 3);
+      request(t + 7, 0, 4);
       step(std::integral_constant<int, 4>{}, edge_tag, t + 4);
       step(std::integral_constant<int, 5>{}, edge_tag, t + 5);
       step(std::integral_constant<int, 6>{}, edge_tag, t + 6);
+      request(t + 7, 4, 7);
     }
   };
   if (edge_strip) run(std::true_type{}); else run(std::false_type{});
