@@ -308,13 +308,19 @@ __global__ __launch_bounds__(kThreads) void fast_score_rolling_kernel(const uint
   int hm_a = 0, hm_b = 0, s_b = 0, lr_b = 0;  // NMS state: hm = max over (x-1, x, x+1) of rows y-2 / y-1, s / lr of row y-1
   const int t_first = r0 - 3, t_last = r1 - 1 + 3;
   auto src_row = [&](int t) { return min(max(t, 0), rows - 1); };  // clamped rows are never used as circle pixels
-  int c_next = (int)g[(uint32_t)(src_row(t_first) * cols) + (uint32_t)xs];
+  // rows in two half-batches into the slots just emptied, three to six steps ahead of their use (as orb_level_pass_kernel)
+  int c_pre[7];
+  auto request = [&](int t0, int k0, int k1) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+      if (k >= k0 && k < k1) c_pre[k] = (int)g[(uint32_t)(src_row(min(t0 + k, t_last)) * cols) + (uint32_t)xs];
+  };
+  request(t_first, 0, 7);
   auto step = [&](auto phase_tag, const int t) __attribute__((always_inline)) {
     constexpr int P = decltype(phase_tag)::value;
     if (t > t_last) return;  // uniform
     {
-      const int c = c_next;  // row t
-      c_next = (int)g[(uint32_t)(src_row(t + 1) * cols) + (uint32_t)xs];
+      const int c = c_pre[P];  // row t
       vc[P] = c;
       vr1[P] = fs_from_right(c);
       vr2[P] = fs_from_right(vr1[P]);
@@ -369,9 +375,11 @@ __global__ __launch_bounds__(kThreads) void fast_score_rolling_kernel(const uint
     step(std::integral_constant<int, 1>{}, t + 1);
     step(std::integral_constant<int, 2>{}, t + 2);
     step(std::integral_constant<int, 3>{}, t + 3);
+    request(t + 7, 0, 4);
     step(std::integral_constant<int, 4>{}, t + 4);
     step(std::integral_constant<int, 5>{}, t + 5);
     step(std::integral_constant<int, 6>{}, t + 6);
+    request(t + 7, 4, 7);
   }
 }
 
