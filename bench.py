@@ -616,6 +616,9 @@ def parse():
                     help="ORB_create(nfeatures) per azimuthal mask of the orb_detector sub-record (12 masks x 230: ~2000 per view)")
     ap.add_argument("--sequence-frames", type=int, default=256,
                     help="frames of the synthetic sequence of the `sequence` sub-record (run_VO in sequence mode); 0 = skip")
+    ap.add_argument("--sequence-child", action="store_true",
+                    help="(internal) render the sequences, run the two sequence sub-records in THIS fresh process and print them "
+                         "as one JSON line: a process that has created the batch engines loses ~15 % on the host-bound VO loop")
     ap.add_argument("--detail-out", default=os.path.join(ROOT, "bench_detail.json"),
                     help="file the FULL record goes to (per-kernel tables, notes, sub-records); stdout carries the compact line")
     ap.add_argument("--dump-records", default=None,
@@ -672,6 +675,46 @@ def cpu_baseline_all_cores(omni, im_kw, rig_kw, thr, iters, seed, cores, pairs_p
     return n / dt, dt, n
 
 
+def sequence_child(args):
+    """`bench.py --sequence-child`: the two sequence sub-records in a fresh process (sequences rendered by forked workers
+    before the GPU is touched), printed as one JSON line."""
+    from vo_single_camera_sos_amd import synthetic
+    from vo_single_camera_sos_amd.omnistereo.gum import synthetic_gums
+    from vo_single_camera_sos_amd.omnistereo.panorama import Panorama
+    gs = synthetic_gums()
+    for m in (gs.top_model, gs.bot_model):
+        m.panorama = Panorama(m, width=args.pano_width)
+    gs.make_annulus_masks((480, 640))
+    workers = args.render_workers if args.render_workers > 0 else max(1, min(16, host_cores()))
+    seq_omni, seq_poses = synthetic.make_sequence(gs, args.sequence_frames, seed=args.seed + 7, workers=workers)
+    seq_bgr, seq_depth, _ = synthetic.make_rgbd_sequence(min(128, args.sequence_frames), seed=args.seed + 9, workers=workers)
+    out = {}
+    try:
+        out["sequence"] = sequence_subrecord(seq_omni, seq_poses, args.pano_width)
+    except Exception as e:  # the headline number does not depend on it
+        out["sequence"] = {"error": repr(e)}
+    try:
+        out["sequence_rgbd"] = sequence_rgbd_subrecord(seq_bgr, seq_depth)
+    except Exception as e:
+        out["sequence_rgbd"] = {"error": repr(e)}
+    print(json.dumps(out), flush=True)
+    return 0
+
+
+def sequence_subrecords_child(args, timeout_s=300):
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--sequence-child", "--sequence-frames", str(args.sequence_frames),
+           "--pano-width", str(args.pano_width), "--seed", str(args.seed), "--render-workers", str(args.render_workers)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+        for line in reversed(r.stdout.splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"sequence": {"error": (r.stderr or "no output")[-300:]}}
+    except Exception as e:
+        return {"sequence": {"error": repr(e)}}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -687,6 +730,8 @@ def main():
     from vo_single_camera_sos_amd.parallel import gather_records, max_over_ranks
     from vo_single_camera_sos_amd.pipeline import OverlappedFramePairs, RigConfig
 
+    if args.sequence_child:
+        sys.exit(sequence_child(args))
     B = args.pairs_per_gpu
     H, W = 480, 640
     RUN_CFG.update(detector=args.detector, ransac_solver=args.ransac_solver, pano_width=args.pano_width)
@@ -715,9 +760,7 @@ def main():
             np.savez(cache, omni=omni, R=np.stack([p_[0] for p_ in poses]), t=np.stack([p_[1] for p_ in poses]), seed=args.seed,
                      pano_width=args.pano_width)
     seq_omni = None
-    if world == 1 and not args.no_sub and args.sequence_frames > 0:   # (rendered here: forked workers, before any GPU call)
-        seq_omni, seq_poses = synthetic.make_sequence(gs, args.sequence_frames, seed=args.seed + 7, workers=workers)
-        seq_bgr, seq_depth, _ = synthetic.make_rgbd_sequence(min(128, args.sequence_frames), seed=args.seed + 9, workers=workers)
+    want_sequence = world == 1 and not args.no_sub and args.sequence_frames > 0   # (a child process renders and runs them)
     dist = None
     # (SOSVO_BENCH_FORCE_DIST=1: a launcher-started single rank also goes through init_process_group + the RCCL
     # gather -- tests/test_gpu_bench_rccl.py rehearses the N > 1 code path on the one-GPU box that way)
@@ -1104,15 +1147,9 @@ def main():
         dist.destroy_process_group()
     eng.close()
     if rank == 0:
-        if sub_other and seq_omni is not None:
-            try:
-                out["sequence"] = sequence_subrecord(seq_omni, seq_poses, args.pano_width)
-            except Exception as e:  # the headline number does not depend on it
-                out["sequence"] = {"error": repr(e)}
-            try:
-                out["sequence_rgbd"] = sequence_rgbd_subrecord(seq_bgr, seq_depth)
-            except Exception as e:
-                out["sequence_rgbd"] = {"error": repr(e)}
+        if sub_other and want_sequence:
+            torch.cuda.synchronize()
+            out.update(sequence_subrecords_child(args))
         if sub_other:
             torch.cuda.synchronize()
             out.update(other_configs_subrecords())
