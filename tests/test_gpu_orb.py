@@ -238,3 +238,29 @@ def test_detect_describe_orb_with_a_pattern_that_reaches_the_image_border(ctx):
             assert np.array_equal(desc[p, : nn[p]].cpu().numpy(), want_d), p
             total += len(kept)
     assert total > 100
+
+
+def test_detect_orb_with_a_mask_that_has_no_row_inside_the_border(ctx):
+    """A mask whose pixels all lie within 31 px of the top edge has columns but no rows a keypoint could come from: the
+    selection must neither stage a region for it nor read through an empty row range (a GPU memory fault in round 4's first
+    region-staging form, found by scripts/fuzz_parity.py)."""
+    rng = np.random.default_rng(91)
+    shape = (120, 300)
+    imgs = np.stack([_contrast(rng, shape) for _ in range(2)])
+    bits = np.zeros((1,) + shape, np.uint32)
+    bits[0, :25, 40:260] |= 1          # mask 0: only border rows
+    bits[0, :, 100:220] |= 2           # mask 1: a normal sector
+    bits[0, 50:70, :20] |= 4           # mask 2: only border columns
+    t_img, t_bits = _to(ctx.device, imgs, bits)
+    pyr = ctx.orb_mask_pyramid(t_bits, 3)
+    kp4, resp, n = ctx.detect_orb(t_img, pyr, 2, 3, 150, 256)
+    ctx.synchronize()
+    kp4, resp, n = kp4.cpu().numpy(), resp.cpu().numpy(), n.cpu().numpy()
+    for i in range(2):
+        want = oracle.orb_detect(imgs[i], bits[0], 3, 150, 256)
+        for m in range(3):
+            p = i * 3 + m
+            wk, wr = want[m]
+            assert n[p] == len(wk), (i, m, n[p], len(wk))
+            assert np.array_equal(kp4[p, : n[p]], wk) and np.array_equal(resp[p, : n[p]], wr), (i, m)
+        assert n[i * 3] == 0 and n[i * 3 + 2] == 0 and n[i * 3 + 1] > 10

@@ -1047,7 +1047,8 @@ __device__ unsigned long long g_sel_ticks[8];
 //   3. Harris response, one wave per candidate -> unique sort keys;  4. bitonic sort (response descending, then y, x);
 //   5. retainBest(quota) by response, ties kept (counted in parallel: the list is sorted);
 //   6. orientation, one wave per keypoint.
-__global__ __launch_bounds__(kThreads, 6) void orb_select_kernel(LevelSrc S, const uint8_t* __restrict__ score,
+constexpr int kSelRegionBytes = 20 * 1024;
+__global__ __launch_bounds__(kThreads, 4) void orb_select_kernel(LevelSrc S, const uint8_t* __restrict__ score,
                                                               const unsigned long long* __restrict__ flags,
                                                               const uint32_t* __restrict__ mask_pyr,
                                                               const uint32_t* __restrict__ bbox, Pyr P,
@@ -1061,6 +1062,7 @@ __global__ __launch_bounds__(kThreads, 6) void orb_select_kernel(LevelSrc S, con
   __shared__ uint32_t kept[kCandMax];            // candidates that pass the FAST-score threshold (compacted)
   __shared__ int hist[256];
   __shared__ int ic_acc[192];                    // step 6: per keypoint of a 64-chunk, sum (u + 15) I | sum I | sum v I
+  __shared__ uint32_t region32[kSelRegionBytes / 4];  // the level's pixels under the mask's candidates (steps 3 and 6)
   __shared__ int s_nc, s_thr, s_keep, s_nout, s_nk;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int p = orb_xcd_problem(nimg_total, nmask);
@@ -1091,6 +1093,35 @@ __global__ __launch_bounds__(kThreads, 6) void orb_select_kernel(LevelSrc S, con
     const int bx0 = max(kEdge, (int)(0xFFFFFFFFu - bb[0])), by0 = max(kEdge, (int)(0xFFFFFFFFu - bb[1]));
     const int bx1 = min(w - kEdge, (int)bb[2]), by1 = min(h - kEdge, (int)bb[3]);  // exclusive
     const int rw = bb[2] ? max(0, bx1 - bx0) : 0, rh = bb[2] ? max(0, by1 - by0) : 0;
+    // The rectangle of the level every Harris block and every orientation patch of this mask lies in -- the candidates keep to
+    // [bx0, bx1) x [by0, by1), a patch reaches 15 px (16 to the right: rows are read as 32 bytes) -- is requested NOW, into
+    // registers (<= 20 dwords a thread, coalesced), and goes to LDS behind step 2: steps 3 and 6 then read LDS instead of
+    // sending 27 + 248 scattered dwords per candidate / keypoint through the texture addresser (70 % + 21 % of the kernel's
+    // 702 M accesses, round 4's counter pass).  A rectangle beyond the LDS area (one mask over a wide image): memory, as before.
+    constexpr int kRegPer = kSelRegionBytes / 4 / kThreads;
+    const int gx0 = bx0 - kHalfPatch, gy0 = by0 - kHalfPatch;
+    const int gw = rw > 0 ? rw + 2 * kHalfPatch + 1 : 0, gh = rh > 0 ? rh + 2 * kHalfPatch : 0;
+    const int gldw = (gw + 3) >> 2, gpitch_dw = gldw | 1, gpitch_b = 4 * gpitch_dw;
+    const bool staged = gw > 0 && gh > 0 && gpitch_b * gh <= kSelRegionBytes;  // uniform (a mask without rows inside the border: gh 0)
+    uint32_t rv[kRegPer];
+    int rdst[kRegPer];
+    if (staged) {
+      const int step_r = kThreads / gldw, step_k = kThreads - step_r * gldw;
+      int ry = tid / gldw, k = tid - ry * gldw;
+      const uint8_t* org = im + (size_t)gy0 * w + gx0;
+#pragma unroll
+      for (int u = 0; u < kRegPer; ++u) {
+        rdst[u] = ry < gh ? ry * gpitch_dw + k : -1;
+        rv[u] = *reinterpret_cast<const u32_unaligned*>(org + (uint32_t)(min(ry, gh - 1) * w + 4 * k));
+        k += step_k;
+        ry += step_r;
+        if (k >= gldw) {
+          k -= gldw;
+          ++ry;
+        }
+      }
+    }
+    const uint8_t* region8 = reinterpret_cast<const uint8_t*>(region32);
     // (the walk over the flag words; visit(x, y, FAST score) for every local maximum inside the mask)
     // Memory round trips are what this phase costs (a level's flag words, mask words and scores come from HBM: 128 images
     // of 577 KB share one XCD's 4 MB L2, ~2 - 3 us each under load), so the walk keeps as few of them in series as the data
@@ -1189,6 +1220,11 @@ __global__ __launch_bounds__(kThreads, 6) void orb_select_kernel(LevelSrc S, con
         }
       });
     }
+    if (staged) {
+#pragma unroll
+      for (int u = 0; u < kRegPer; ++u)
+        if (rdst[u] >= 0) region32[rdst[u]] = rv[u];
+    }
     __syncthreads();
     SEL_TICK(1);
     const int nc = min(s_nk, kCandMax);
@@ -1197,7 +1233,8 @@ __global__ __launch_bounds__(kThreads, 6) void orb_select_kernel(LevelSrc S, con
     for (int j0 = wid * 64; j0 < nc; j0 += kThreads) {
       const int j = j0 + lane;
       const uint32_t xy = kept[min(j, nc - 1)];
-      const float r = harris_response_lane(im, w, (int)(xy & 0xFFFFu), (int)(xy >> 16));
+      const float r = staged ? harris_response_lane(region8, gpitch_b, (int)(xy & 0xFFFFu) - gx0, (int)(xy >> 16) - gy0)
+                             : harris_response_lane(im, w, (int)(xy & 0xFFFFu), (int)(xy >> 16));
       if (j < nc) {
         const uint32_t lin = (xy >> 16) * (uint32_t)w + (xy & 0xFFFFu);
         ckey[j] = ((unsigned long long)sosvo_float_ordered(r) << 32) | (0xFFFFFFFFu - lin);
@@ -1266,7 +1303,10 @@ __global__ __launch_bounds__(kThreads, 6) void orb_select_kernel(LevelSrc S, con
       const int cy = (int)(lin / (uint32_t)w), cx = (int)(lin - (uint32_t)cy * (uint32_t)w);
       uint32_t su, stot;
       int m01p;
-      ic_moments_rows(im, w, cx, cy, __builtin_amdgcn_readfirstlane(wid), kThreads / 64, su, stot, m01p);
+      if (staged)
+        ic_moments_rows(region8, gpitch_b, cx - gx0, cy - gy0, __builtin_amdgcn_readfirstlane(wid), kThreads / 64, su, stot, m01p);
+      else
+        ic_moments_rows(im, w, cx, cy, __builtin_amdgcn_readfirstlane(wid), kThreads / 64, su, stot, m01p);
       atomicAdd(&ic_acc[lane], (int)su);
       atomicAdd(&ic_acc[64 + lane], (int)stot);
       atomicAdd(&ic_acc[128 + lane], m01p);
