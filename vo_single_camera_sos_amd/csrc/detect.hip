@@ -770,6 +770,7 @@ __global__ __launch_bounds__(kThreads) void gauss7_kernel(const uint8_t* __restr
 
 // ---- K6b: border rule + descriptors ---------------------------------------------------------------------
 constexpr int kPatchMaxR = 23, kPatchRows = 48, kPatchStride = 64;
+constexpr int kDescRegionBytesGft = 24 * 1024;
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 // (NT threads: a problem's keypoints are shared by NT / 64 waves, one keypoint per wave and step -- 256 for the C2 batch of
 // 4096 problems, 512 when a launch has few problems, 1024 for the whole-image problems of up to 4096 keypoints)
@@ -784,9 +785,14 @@ __global__ __launch_bounds__(NT) void orb_describe_kernel(const uint8_t* __restr
   extern __shared__ float lds_kp[];  // [cap][2] compacted keypoints
   __shared__ int off[512];
   __shared__ uint16_t poff[512];
-  __shared__ uint32_t patch_lds[NT / 64][kPatchRows * kPatchStride / 4];
+  // one LDS area, two uses (NT = 256, the batch of (image, mask) problems): the REGION of the blurred image under all of the
+  // problem's keypoints (below), or the waves' per-keypoint patches; the larger workgroups keep the patches only
+  constexpr int kPatchWords = (NT / 64) * (kPatchRows * kPatchStride / 4);
+  constexpr int kRegionWords = NT == 256 ? kDescRegionBytesGft / 4 : 0;
+  __shared__ uint32_t patch_area[kPatchWords > kRegionWords ? kPatchWords : kRegionWords];
   __shared__ int wave_off[NT / 64 + 1];
   __shared__ int s_running, s_R;
+  __shared__ int s_bb[4];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int p = xcd_problem(nimg_total, nmask);
   if (p < 0) return;  // uniform (padding workgroup)
@@ -853,8 +859,83 @@ __global__ __launch_bounds__(NT) void orb_describe_kernel(const uint8_t* __restr
   for (int i = tid; i < 2 * m; i += NT) kp[(size_t)p * cap * 2 + i] = lds_kp[i];
   if (tid == 0) n_io[p] = m;
   const uint8_t* im = blurred + (size_t)img * rows * cols;
+  // ---- the usual case of the (image, mask) batch: every keypoint from ONE staged region (round 4) -------------------------
+  // The ~165 keypoints of an azimuthal mask lie so close together that their (2R + 1)^2 patches cover the same pixels about
+  // nine times over, and fetched per keypoint they are 390 scattered dwords each through the texture addresser (0.8 G dword
+  // accesses per 256 frame pairs: more than any other kernel of the step).  The bounding box of the problem's keypoints grown
+  // by R goes to LDS once (coalesced dword loads, ~20 KB for a 120-column mask of a 146-row panorama); the tests read it.
+  if constexpr (NT == 256) {
+    if (patch_ok && m > 0) {  // uniform
+      if (tid < 4) s_bb[tid] = tid < 2 ? 0x7FFFFFFF : -1;
+      __syncthreads();
+      for (int i = tid; i < m; i += NT) {
+        const int cx = __float2int_rn(lds_kp[2 * i]), cy = __float2int_rn(lds_kp[2 * i + 1]);
+        atomicMin(&s_bb[0], cx);
+        atomicMin(&s_bb[1], cy);
+        atomicMax(&s_bb[2], cx);
+        atomicMax(&s_bb[3], cy);
+      }
+      __syncthreads();
+      const int rx0 = s_bb[0] - R, ry0 = s_bb[1] - R, rw = s_bb[2] - s_bb[0] + PR, rh = s_bb[3] - s_bb[1] + PR;
+      const int ldw = (rw + 3) >> 2, pitch_dw = ldw | 1, pitch_b = 4 * pitch_dw;
+      if (pitch_b * rh <= kDescRegionBytesGft) {  // uniform
+        {  // eight requests in flight per thread, the position advanced without a division
+          const int step_r = NT / ldw, step_k = NT - step_r * ldw;
+          int ry = tid / ldw, k = tid - ry * ldw;
+          const uint8_t* org = im + (size_t)ry0 * cols + rx0;
+          while (__any(ry < rh)) {
+            uint32_t v[8];
+            int dst[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              dst[u] = ry < rh ? ry * pitch_dw + k : -1;
+              v[u] = *reinterpret_cast<const u32_unaligned*>(org + (uint32_t)(min(ry, rh - 1) * cols + 4 * k));
+              k += step_k;
+              ry += step_r;
+              if (k >= ldw) {
+                k -= ldw;
+                ++ry;
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (dst[u] >= 0) patch_area[dst[u]] = v[u];
+          }
+        }
+        // this lane's eight test points as offsets inside the region (tests lane, 64 + lane, 128 + lane, 192 + lane)
+        int ra[4], rb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int o = off[2 * (64 * r + lane) + e];
+            const int dy = (o + R * cols + R) / cols - R, dx = o - dy * cols;  // recover (dx, dy): |dx| <= R < cols
+            (e ? rb[r] : ra[r]) = dy * pitch_b + dx;
+          }
+        }
+        __syncthreads();
+        const uint8_t* region8 = reinterpret_cast<const uint8_t*>(patch_area);
+        const int wid_s = __builtin_amdgcn_readfirstlane(wid);
+        for (int j = wid_s; j < m; j += NT / 64) {
+          const int cx = __builtin_amdgcn_readfirstlane(__float2int_rn(lds_kp[2 * j]));
+          const int cy = __builtin_amdgcn_readfirstlane(__float2int_rn(lds_kp[2 * j + 1]));
+          const int org = (cy - ry0) * pitch_b + (cx - rx0);
+          unsigned long long* d = reinterpret_cast<unsigned long long*>(desc + ((size_t)p * cap + j) * 32);
+          unsigned long long mine = 0ULL;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const unsigned long long bal = __ballot(region8[org + ra[r]] < region8[org + rb[r]]);
+            if (lane == r) mine = bal;
+          }
+          if (lane < 4) d[lane] = mine;  // one 32-byte store
+        }
+        return;
+      }
+      __syncthreads();  // (the per-keypoint patches below reuse the area)
+    }
+  }
   if (patch_ok) {
-    uint32_t* patch32 = patch_lds[wid];
+    uint32_t* patch32 = patch_area + wid * (kPatchRows * kPatchStride / 4);
     const uint8_t* patch = reinterpret_cast<const uint8_t*>(patch32);
     // 8 lanes (dwords) per patch row and 8 rows per round while a row fits 32 bytes, else 16 lanes x 4 rows.  Lanes
     // past the row's last dword / rows past the patch repeat the last one (same value to the same LDS word), so the
