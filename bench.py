@@ -1102,16 +1102,6 @@ def main():
             except Exception as e:
                 out["c_abi_streams"] = {"error": repr(e)}
             try:
-                if args.detector != "ORB":
-                    # the ORB detector AT THE METRIC'S LOAD (~2000 keypoints per view): without the median blur (the RGB-D
-                    # frames' setting, pose_est_tools.py:427) and with the per-mask quota that yields that count; on the
-                    # 11x11-median-blurred panoramas (the SOS frames' setting) FAST finds ~150 corners per view
-                    out["orb_detector"] = sub_engine(detection_method="ORB", ransac_solver=args.ransac_solver, median_win_size=0,
-                                                     num_of_features=args.orb_features_per_mask, pmc_tag="orb")
-                    out["orb_detector"]["setting"] = "ORB_create(%d).detect per mask + compute, median_win_size 0" % args.orb_features_per_mask
-                    out["orb_detector_median11"] = sub_engine(detection_method="ORB", ransac_solver=args.ransac_solver)
-                if args.ransac_solver != "GP3P":
-                    out["gp3p"] = sub_engine(detection_method=args.detector, ransac_solver="GP3P", pmc_tag="gp3p")
                 if os.environ.get("SOSVO_ORB_PATTERN", "opencv") != "seeded":
                     # the SAME step with the seeded BRIEF table rounds 1-3 ran (round 4's default is OpenCV's learned table, whose
                     # descriptors match 1.67 x as many points on these frames: everything behind the matcher carries more work
@@ -1122,6 +1112,16 @@ def main():
                         out["seeded_pattern"]["note"] = "rounds 1-3's workload: seeded BRIEF table instead of OpenCV's bit_pattern_31_"
                     finally:
                         del os.environ["SOSVO_ORB_PATTERN"]
+                if args.detector != "ORB":
+                    # the ORB detector AT THE METRIC'S LOAD (~2000 keypoints per view): without the median blur (the RGB-D
+                    # frames' setting, pose_est_tools.py:427) and with the per-mask quota that yields that count; on the
+                    # 11x11-median-blurred panoramas (the SOS frames' setting) FAST finds ~150 corners per view
+                    out["orb_detector"] = sub_engine(detection_method="ORB", ransac_solver=args.ransac_solver, median_win_size=0,
+                                                     num_of_features=args.orb_features_per_mask, pmc_tag="orb")
+                    out["orb_detector"]["setting"] = "ORB_create(%d).detect per mask + compute, median_win_size 0" % args.orb_features_per_mask
+                    out["orb_detector_median11"] = sub_engine(detection_method="ORB", ransac_solver=args.ransac_solver)
+                if args.ransac_solver != "GP3P":
+                    out["gp3p"] = sub_engine(detection_method=args.detector, ransac_solver="GP3P", pmc_tag="gp3p")
                 if args.pano_width != 1200:
                     # the reference's default panorama width (demo_vo_sos.py: 1200 columns -> 1200 x 122 panoramas, fewer
                     # keypoints per view than the 2000 BASELINE's metric names) on the same omni frames

@@ -264,3 +264,24 @@ def test_detect_orb_with_a_mask_that_has_no_row_inside_the_border(ctx):
             assert n[p] == len(wk), (i, m, n[p], len(wk))
             assert np.array_equal(kp4[p, : n[p]], wk) and np.array_equal(resp[p, : n[p]], wr), (i, m)
         assert n[i * 3] == 0 and n[i * 3 + 2] == 0 and n[i * 3 + 1] > 10
+
+
+def test_detect_describe_orb_at_the_largest_keypoint_capacity(ctx):
+    """cap = 2048 (the ABI's limit for descriptors): the descriptor kernel's LDS is then 48 KB of keypoints beside its 24 KB
+    staging area."""
+    rng = np.random.default_rng(93)
+    shape, nmask, nfeatures, cap = (146, 700), 1, 2000, 2048
+    imgs = np.stack([_contrast(rng, shape)])
+    bits = np.ones((1,) + shape, np.uint32)
+    t_img, t_bits, t_pat = _to(ctx.device, imgs, bits, orb_pattern.orb_pattern())
+    mask_pyr = ctx.orb_mask_pyramid(t_bits, nmask)
+    z = lambda shp, dt: torch.full(shp, 7, dtype=dt, device=ctx.device)  # noqa: E731
+    kp4, resp, n = z((1, cap, 4), torch.float32), z((1, cap), torch.float32), z((1,), torch.int32)
+    desc, kp_xy = z((1, cap, 32), torch.uint8), z((1, cap, 2), torch.float32)
+    ctx.detect_describe_orb(t_img, mask_pyr, 1, nmask, nfeatures, t_pat, kp4, resp, n, desc, kp_xy=kp_xy)
+    ctx.synchronize()
+    k = int(n.cpu().numpy()[0])
+    wk, wr = oracle.orb_detect(imgs[0], bits[0], nmask, nfeatures, cap)[0]
+    want_d, kept = oracle.orb_describe_levels(imgs[0], wk)
+    assert k == len(kept) and k > 500, (k, len(kept))
+    assert np.array_equal(kp4[0, :k].cpu().numpy(), wk[kept]) and np.array_equal(desc[0, :k].cpu().numpy(), want_d)
