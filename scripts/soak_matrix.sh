@@ -16,7 +16,7 @@ run --pairs 12 --workers 12 --seed 101 --pano-width 720 --features 100 --kp-cap 
 run --pairs 12 --workers 12 --seed 102 --pano-width 1200 --features 300 --kp-cap 512 --iters 300 --median 5
 run --pairs 12 --workers 12 --seed 103 --pano-width 1440 --features 1000 --kp-cap 512 --iters 2000 --median 0
 run --pairs 12 --workers 12 --seed 104 --pano-width 960 --features 50 --kp-cap 64 --iters 17 --median 11 --solver GP3P
-run --pairs 12 --workers 12 --seed 105 --pano-width 2880 --features 1000 --kp-cap 1024 --iters 100 --median 11
+run --pairs 12 --workers 12 --seed 105 --pano-width 2880 --features 1000 --kp-cap 1024 --iters 100 --median 11 --frame-cap 8192
 run --pairs 12 --workers 12 --seed 106 --detector ORB --median 0 --features 60 --kp-cap 256 --iters 200
 run --pairs 12 --workers 12 --seed 107 --detector ORB --median 3 --features 500 --kp-cap 1280 --iters 200 --pano-width 1200
 run --pairs 12 --workers 12 --seed 108 --detector FAST --kp-cap 256 --median 0 --iters 100

@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--pano-width", type=int, default=1440)
     ap.add_argument("--detector", default="GFT", choices=["GFT", "ORB", "FAST", "AGAST"])
     ap.add_argument("--kp-cap", type=int, default=512, help="keypoint capacity per (frame, mirror, mask)")
+    ap.add_argument("--frame-cap", type=int, default=2048,
+                    help="stereo points per frame / correspondences per pair the engine holds (the oracle has no such limit: a "
+                         "configuration that exceeds it differs by construction -- wide panoramas with OpenCV's BRIEF table do)")
     ap.add_argument("--median", type=int, default=11, help="median window (11 = the SOS frames' setting; 0 = none)")
     ap.add_argument("--features", type=int, default=1000, help="detector budget per azimuthal mask")
     ap.add_argument("--solver", default="P3P", choices=["P3P", "GP3P"],
@@ -54,7 +57,7 @@ def main():
     import torch
     from vo_single_camera_sos_amd.pipeline import OverlappedFramePairs, RigConfig
     eng = OverlappedFramePairs(0, gs, (480, 640), RigConfig(**rig_kw), B, n_streams=2, num_of_features=args.features, kp_cap=args.kp_cap,
-                               frame_cap=2048, max_iter=args.iters, adaptive=False, seed=args.seed, detection_method=args.detector,
+                               frame_cap=args.frame_cap, max_iter=args.iters, adaptive=False, seed=args.seed, detection_method=args.detector,
                                ransac_solver=args.solver, median_win_size=args.median)
     assert not any(int(p.fe.status.max().item()) for p in eng.parts) or args.detector != "GFT"
     eng.load_frames(omni)
