@@ -701,6 +701,30 @@ def sequence_child(args):
     return 0
 
 
+def child_bench_subrecord(args, extra, env=None, timeout_s=240):
+    """A variant of the headline step as a sub-record, measured by THIS program in a fresh child process (`--no-sub`): an
+    engine created late in a process that has already built several measures 5 - 8 % low (the ORB-detector path 45.8 k as the
+    fifth engine of the parent, 49.5 k on its own), and these records are the ones compared from round to round."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--no-sub", "--no-cpu", "--no-h2d", "--no-isolated", "--steps", str(args.sub_steps),
+           "--warmup", "2", "--pairs-per-gpu", str(args.pairs_per_gpu), "--streams", str(args.streams), "--iters", str(args.iters),
+           "--seed", str(args.seed), "--pano-width", str(args.pano_width), "--render-workers", str(args.render_workers),
+           "--detail-out", os.path.join("/tmp", "sosvo_bench_child_%d.json" % os.getpid())] + list(extra)
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT, env=dict(os.environ, **(env or {})))
+        for line in reversed(r.stdout.splitlines()):
+            if line.startswith("{"):
+                d = json.loads(line)
+                cfg = d.get("config", {})
+                return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                        "pairs_per_step": cfg.get("global_pairs_per_step"), "keypoints_per_view_mean": cfg.get("keypoints_per_view_mean"),
+                        "tracked_ok": cfg.get("tracked_ok"), "inliers_per_pair_mean": cfg.get("inliers_per_pair_mean"),
+                        "roofline": d.get("roofline"), "process": "child (fresh interpreter, python bench.py --no-sub ...)"}
+        return {"error": (r.stderr or "no output")[-300:]}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def sequence_subrecords_child(args, timeout_s=300):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--sequence-child", "--sequence-frames", str(args.sequence_frames),
@@ -1106,22 +1130,23 @@ def main():
                     # the SAME step with the seeded BRIEF table rounds 1-3 ran (round 4's default is OpenCV's learned table, whose
                     # descriptors match 1.67 x as many points on these frames: everything behind the matcher carries more work
                     # per pair).  Same build, same frames: the headline of rounds 1-3 and this round's compare through this record.
-                    os.environ["SOSVO_ORB_PATTERN"] = "seeded"
-                    try:
-                        out["seeded_pattern"] = sub_engine(detection_method=args.detector, ransac_solver=args.ransac_solver)
-                        out["seeded_pattern"]["note"] = "rounds 1-3's workload: seeded BRIEF table instead of OpenCV's bit_pattern_31_"
-                    finally:
-                        del os.environ["SOSVO_ORB_PATTERN"]
+                    out["seeded_pattern"] = child_bench_subrecord(args, ["--detector", args.detector, "--ransac-solver", args.ransac_solver,
+                                                                         "--features-per-mask", str(args.features_per_mask),
+                                                                         "--median-win-size", str(args.median_win_size)],
+                                                                  env={"SOSVO_ORB_PATTERN": "seeded"})
+                    out["seeded_pattern"]["note"] = "rounds 1-3's workload: seeded BRIEF table instead of OpenCV's bit_pattern_31_"
                 if args.detector != "ORB":
                     # the ORB detector AT THE METRIC'S LOAD (~2000 keypoints per view): without the median blur (the RGB-D
                     # frames' setting, pose_est_tools.py:427) and with the per-mask quota that yields that count; on the
                     # 11x11-median-blurred panoramas (the SOS frames' setting) FAST finds ~150 corners per view
-                    out["orb_detector"] = sub_engine(detection_method="ORB", ransac_solver=args.ransac_solver, median_win_size=0,
-                                                     num_of_features=args.orb_features_per_mask, pmc_tag="orb")
+                    out["orb_detector"] = child_bench_subrecord(args, ["--detector", "ORB", "--ransac-solver", args.ransac_solver,
+                                                                       "--median-win-size", "0", "--features-per-mask",
+                                                                       str(args.orb_features_per_mask)])
                     out["orb_detector"]["setting"] = "ORB_create(%d).detect per mask + compute, median_win_size 0" % args.orb_features_per_mask
                     out["orb_detector_median11"] = sub_engine(detection_method="ORB", ransac_solver=args.ransac_solver)
                 if args.ransac_solver != "GP3P":
-                    out["gp3p"] = sub_engine(detection_method=args.detector, ransac_solver="GP3P", pmc_tag="gp3p")
+                    out["gp3p"] = child_bench_subrecord(args, ["--detector", args.detector, "--ransac-solver", "GP3P", "--features-per-mask",
+                                                               str(args.features_per_mask), "--median-win-size", str(args.median_win_size)])
                 if args.pano_width != 1200:
                     # the reference's default panorama width (demo_vo_sos.py: 1200 columns -> 1200 x 122 panoramas, fewer
                     # keypoints per view than the 2000 BASELINE's metric names) on the same omni frames
