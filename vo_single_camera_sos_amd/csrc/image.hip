@@ -225,12 +225,16 @@ __global__ __launch_bounds__(kThreads) void gray_kernel(const uint8_t* __restric
 // panoramas (2.5 MB per frame pair) are neither written nor read.  Same arithmetic as unwrap_lut_kernel + gray_kernel.
 // NK pixels per thread, their table entries and gathers all in flight before the first blend: with one pixel per thread the
 // kernel was a stream of 840 000 one-shot workgroups per 256 frame pairs, bound by workgroup dispatch and by one exposed load
-// latency each (round 4).  A wave gathers a 16 x 4 TILE of the panorama per load, not 64 pixels of one row: 64 neighbouring
-// columns lie on a ~40-px arc of the omni frame that crosses up to ~40 image rows -- every few lanes another 128-byte line
-// through the L2 for 8 useful bytes each -- while a 16 x 4 tile lands in a ~10 x 3 px patch of the frame (the kernel moves
-// ~0.5 GB through HBM per 256 pairs and ran at 0.83 ms: at the L2's line rate, not at HBM's).  The gray bytes of the
-// workgroup's 64 x (4 NK) tile meet in LDS and leave as 64-byte row segments (the tile mapping on its own -- 16-byte pieces
-// of four rows per store -- was no faster than the row mapping).  NK = 4 or 2: the tile height that wastes fewer rows.
+// latency each (round 4).  What bounds it now is the texture addresser (round 4's counter pass: busy 80 % of the kernel's
+// cycles, ~1.1 cache accesses per lane and gather -- one per DISTINCT dword a wave asks for; neighbouring lanes' taps overlap
+// and are merged): a bilinear tap pair of BGR bytes per output pixel is what it is.  A wave gathers a 16 x 4 TILE of the
+// panorama per load rather than 64 pixels of one row (64 neighbouring columns lie on a ~40-px arc of the omni frame that
+// crosses up to ~40 image rows; the tile lands in a ~10 x 3 px patch: a third of the cache lines), and the gray bytes of the
+// workgroup's 64 x (4 NK) tile meet in LDS and leave as 64-byte row segments.  Measured on its own the three mappings are
+// within 2 % of each other (row 0.83 ms, tile with row-piece stores 0.87, tile + LDS 0.85 per 256 pairs): the dword count
+// does not depend on the mapping -- but the STEP does: with three streams sharing the chip the tile + LDS form gives 49.5 k
+// pairs/s against 48.1 k for the row form (A/B, same build otherwise): a third of the lines through the L2 leaves more of it to
+// the other streams' kernels.  NK = 4 or 2: the tile height that wastes fewer rows.
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned_img;
 template <int NK>
 __global__ __launch_bounds__(kThreads) void unwrap_gray_kernel(const uint8_t* __restrict__ omni, const uint2* __restrict__ table,

@@ -4,16 +4,22 @@
 //   .compute(pano, keypoints)                        camera_models.py:1765; pose_est_tools.py:553
 //
 // Batched over images (view-major) x azimuthal masks; problem p = image * nmask + mask.
-//   pyramid   8 levels x 1.2, each level bilinear (11-bit fixed point) from the previous one; all levels of one
-//             image live back to back in one workspace row (level offsets in a by-value struct);
-//   fast      FAST-9/16 score for every pyramid pixel in one launch (16 ring loads per lane from L1/L2);
-//   select    one workgroup per problem walks the levels: 3x3 NMS + 31-px border + mask -> candidates in LDS,
-//             keep the best 2 n_l by FAST score through a 256-bin LDS histogram (ties kept), Harris response
-//             per candidate (a LANE per candidate: separable Sobel on a three-row ring), rank sort (response desc,
-//             then y, x), keep n_l (+ ties), intensity-centroid angle (a lane per keypoint: v_dot4_u32_u8 with the
-//             disc as byte weights), fastAtan2 polynomial in float32 with a pinned operation order;
-//   describe  border rule on level-0 coordinates + stable compaction, then one wave per keypoint: the rotated
-//             offsets are evaluated per lane in float32, four 64-bit ballots are the 32 descriptor bytes.
+//   levels    8 levels x 1.2, each level bilinear (11-bit fixed point) from the previous one; all levels of one image live
+//             back to back in one workspace row (level offsets in a by-value struct).  ONE launch per level
+//             (orb_level_pass_kernel, round 4): a wave walks a 64-column strip of level l down its rows and produces, from one
+//             read of the level, the FAST-9/16 local-maximum flags (+ the flagged pixels' scores), the 7x7 blur of the rows a
+//             descriptor can read, and level l + 1.  FAST score: one polarity per lane on raw pixel values, van Herk arc network.
+//             (Images taller than the row table's LDS area, and keypoints handed in from outside, take the separate
+//             resize / FAST / blur kernels.)
+//   select    one workgroup per problem walks the levels: flags + 31-px border + mask -> candidates in LDS, keep the best
+//             2 n_l by FAST score through a 256-bin LDS histogram (ties kept), Harris response per candidate (a LANE per
+//             candidate: separable Sobel on a three-row ring), rank sort (response desc, then y, x), keep n_l (+ ties),
+//             intensity-centroid angle (a lane per keypoint: v_dot4_u32_u8 with the disc as byte weights), fastAtan2 polynomial
+//             in float32 with a pinned operation order.  The rectangle of the level under the mask's candidates is staged in
+//             LDS: the Harris blocks and orientation patches read it instead of memory;
+//   describe  border rule on level-0 coordinates + stable compaction, then one wave per keypoint: the rotated offsets are
+//             evaluated per lane in float32, four 64-bit ballots are the 32 descriptor bytes.  Per level the bounding box of
+//             the problem's keypoints grown by the pattern's reach is staged in LDS once; every test is an LDS byte read.
 // Integer work except the Harris/angle float32 arithmetic, whose operation order is pinned -> bit-exact against
 // the oracle (cos/sin of the angle are double-precision library calls rounded to float32 on both sides).
 #include "common.h"
@@ -253,7 +259,8 @@ __device__ __forceinline__ uint32_t fast_arc_max_of_min(const uint32_t (&g)[16])
 // that cannot be a corner scores <= thr and never decides the result.  Darker lanes run the same network on 255 - v = v ^ 0xFF:
 // best = A' - centre (brighter), A' - (255 - centre) (darker), i.e. A' - (centre ^ mask).  Lanes with BOTH (0.3 % of the pixels
 // of a noisy panorama, some lane in ~12 % of a wave's rows) take a second pass with the other polarity, decided per wave.
-// Equality with the two-sided network on biased values: scratch-checked on 24 M circles, and by every detector test.
+// Equality with the two-sided network on biased values: tests/fast_network_check.cpp (plain C++, in the CPU suite) on random
+// and adversarial circles, and every detector test.
 // v[k]: circle pixel k (0 .. 255), c: the centre; valid: the lane's pixel can be a corner at all (interior column).
 __device__ __forceinline__ int fast_score_raw(const uint32_t (&v)[16], int c, int thr, bool valid) {
   const uint32_t hiA = max16(v[0], v[4]), loA = min16(v[0], v[4]), hiB = max16(v[8], v[12]), loB = min16(v[8], v[12]);
