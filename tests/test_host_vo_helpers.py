@@ -291,3 +291,19 @@ def test_batched_quaternions_and_pose_line_formatting_equal_the_per_frame_forms(
     buf = io.StringIO()
     print(*vals, sep=" ", end="", file=buf)
     assert buf.getvalue() == " ".join(repr(v) for v in vals.tolist())
+
+
+def test_window_staging_copies_every_frame_with_and_without_the_pool():
+    """pipeline._stage_rows: frames of a window into the (pinned) staging array -- one by one for short windows, four numpy
+    copies at a time otherwise; casting copies (a float64 depth map into a float32 buffer) included."""
+    from vo_single_camera_sos_amd.pipeline import _stage_rows
+    rng = np.random.default_rng(5)
+    for n in (1, 3, 4, 9):
+        frames = [rng.integers(0, 255, (6, 8, 3), dtype=np.uint8) for _ in range(n)]
+        dst = np.zeros((12, 6, 8, 3), np.uint8)
+        _stage_rows(dst, frames)
+        assert all(np.array_equal(dst[i], frames[i]) for i in range(n)) and not dst[n:].any()
+    depth = [rng.random((6, 8)) for _ in range(5)]
+    dst = np.zeros((5, 6, 8), np.float32)
+    _stage_rows(dst, depth)
+    assert all(np.array_equal(dst[i], depth[i].astype(np.float32)) for i in range(5))
