@@ -1055,6 +1055,7 @@ __device__ unsigned long long g_sel_ticks[8];
 //   5. retainBest(quota) by response, ties kept (counted in parallel: the list is sorted);
 //   6. orientation, one wave per keypoint.
 constexpr int kSelRegionBytes = 20 * 1024;
+constexpr int kRankSortMax = 192;  // <= kThreads (one key per thread) and <= kCandMax / 2 (the sorted copy lives in `kept`)
 __global__ __launch_bounds__(kThreads, 4) void orb_select_kernel(LevelSrc S, const uint8_t* __restrict__ score,
                                                               const unsigned long long* __restrict__ flags,
                                                               const uint32_t* __restrict__ mask_pyr,
@@ -1267,6 +1268,20 @@ __global__ __launch_bounds__(kThreads, 4) void orb_select_kernel(LevelSrc S, con
         }
         ckey[lane] = key;
       }
+      __syncthreads();
+    } else if (nc <= kRankSortMax) {
+      // up to 192 keys (the usual case on the three largest levels: 2 n_l = 70 .. 100 candidates + ties): every thread RANKS
+      // its key against all the others (broadcast LDS reads, unique keys -> the ranks are a permutation) and writes it to its
+      // place -- three barriers instead of the bitonic network's 28 (a level's sort was ~8 us of barriers with one key per
+      // two threads: variants of the kernel without the phases behind the walk showed the selection spending 2/3 of its time
+      // in these low-parallelism phases, not in memory)
+      unsigned long long* tmp = reinterpret_cast<unsigned long long*>(kept);  // (the candidate list is dead behind step 3)
+      const unsigned long long mine = tid < nc ? ckey[tid] : 0ULL;
+      int rank = 0;
+      for (int i = 0; i < nc; ++i) rank += ckey[i] > mine ? 1 : 0;
+      if (tid < nc) tmp[rank] = mine;
+      __syncthreads();
+      if (tid < nc) ckey[tid] = tmp[tid];
       __syncthreads();
     } else {
       int N = 128;
