@@ -45,8 +45,9 @@ struct Pyr {
   // detection: levels that can hold a keypoint (a quota and more than the 31-px border); local-maximum flags of their
   // FAST score maps, one u64 per (row, 56-column strip): foff = first word of a level inside an image's ftotal words
   int det[kLevels], ndet;  // ndet = 1 + the highest such level (the pyramid is only built that far for detection)
-  int fstrips[kLevels];
-  long long foff[kLevels], ftotal;
+  int fstrips[kLevels];    // 56-column strips of a level (fast_score_rolling_kernel / orb_level_pass_kernel: one flag word each)
+  int fstrips2[kLevels];   // 120-column strips (orb_level_pass2_kernel: TWO flag words each, even and odd columns)
+  long long foff[kLevels], ftotal;  // (a level's rows hold max(fstrips, 2 fstrips2) words: either layout fits)
   int toff[kLevels], ttotal;  // resize tap table: level l >= 1 holds w[l] x taps, then h[l] y taps, at toff[l]
 };
 
@@ -289,6 +290,7 @@ __device__ __forceinline__ int fast_score_raw(const uint32_t (&v)[16], int c, in
 // non-maximum suppression of the detectors), for rows (r0, r1 - 1); the halo of 4 makes the scores of an output lane's
 // neighbours exact.
 constexpr int kFsHalo = 4, kFsStripW = 64 - 2 * kFsHalo;
+constexpr int kLp2Halo = 4, kLp2StripW = 128 - 2 * kLp2Halo;  // two pixels per lane (orb_level_pass2_kernel)
 __global__ __launch_bounds__(kThreads) void fast_score_rolling_kernel(const uint8_t* __restrict__ in, long long img_stride,
                                                                       int nimg, int rows, int cols, int strips, int thr,
                                                                       int r0, int r1, uint8_t* __restrict__ out,
@@ -504,6 +506,10 @@ __global__ __launch_bounds__(kThreads) void orb_rowtab_kernel(Pyr P, const int8_
   rowtab[(size_t)l * tab_stride + idx] = make_uint2(w0, w1);
 }
 
+#ifndef SOSVO_ORB_TWO_PIXEL_LANES
+#define SOSVO_ORB_TWO_PIXEL_LANES 1
+#endif
+constexpr bool kOrbTwoPixelLanes = SOSVO_ORB_TWO_PIXEL_LANES != 0;  // which level pass the ORB path launches (A/B: -DSOSVO_ORB_TWO_PIXEL_LANES=0)
 constexpr int kRowTabLds = 1024;  // rows + 6 entries of the level's table in LDS (higher images take the separate kernels)
 __global__ __launch_bounds__(kThreads) void orb_level_pass_kernel(const LevelPass A) {
   SOSVO_STREAMING_PRIO();
@@ -657,6 +663,254 @@ __global__ __launch_bounds__(kThreads) void orb_level_pass_kernel(const LevelPas
   };
   // (the next revolution's rows in two half-batches into the slots just emptied: slots 0 .. 3 after step 3, 4 .. 6 after step 6
   // -- three to six steps ahead of their use, and seven registers instead of fourteen)
+  for (int t = -3; t <= t_last; t += 7) {
+    step(std::integral_constant<int, 0>{}, t);
+    step(std::integral_constant<int, 1>{}, t + 1);
+    step(std::integral_constant<int, 2>{}, t + 2);
+    step(std::integral_constant<int, 3>{}, t + 3);
+    request(t + 7, 0, 4);
+    step(std::integral_constant<int, 4>{}, t + 4);
+    step(std::integral_constant<int, 5>{}, t + 5);
+    step(std::integral_constant<int, 6>{}, t + 6);
+    request(t + 7, 4, 7);
+  }
+}
+
+// ---- the level pass with TWO pixels per lane (round 4) --------------------------------------------------------------------
+// The one-pixel form above is priced per wave-instruction (issue-bound at four waves per SIMD) and per byte-wide memory
+// instruction; taken apart, its floor is the walk itself.  Here a lane owns the pixel PAIR (x, x + 1) as two 16-bit halves of one
+// register: the FAST network runs on v_pk_min_u16 / v_pk_max_u16 (the same ~140 instructions per wave and row now cover 120
+// owned columns instead of 56), the polarity mask is one 32-bit xor for both halves, predicates are saturating packed
+// subtractions (nonzero half = true), loads and blur stores are 16 bits wide.  Strip = 128 columns (120 owned, halo 4);
+// shifted copies of a row: the neighbour lanes' pairs by DPP, the odd shifts by v_alignbit of two of them.  Flags: TWO words
+// per (row, strip) -- bit b of word h is column strip * 120 - 4 + 2 b + h.  Everything else (row table, rows seven ahead,
+// mirrored halo columns, arithmetic) as orb_level_pass_kernel; results identical.
+typedef unsigned short orb_us2 __attribute__((ext_vector_type(2)));
+typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
+__device__ __forceinline__ orb_us2 pk_u(uint32_t x) { return __builtin_bit_cast(orb_us2, x); }
+__device__ __forceinline__ uint32_t pk_w(orb_us2 x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) { return pk_w(__builtin_elementwise_min(pk_u(a), pk_u(b))); }
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return pk_w(__builtin_elementwise_max(pk_u(a), pk_u(b))); }
+__device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) { return pk_w(__builtin_elementwise_sub_sat(pk_u(a), pk_u(b))); }
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return pk_w(pk_u(a) + pk_u(b)); }
+__device__ __forceinline__ uint32_t pk_mul(uint32_t a, uint32_t b) { return pk_w(pk_u(a) * pk_u(b)); }
+// nonzero half -> 0x00FF, zero half -> 0
+__device__ __forceinline__ uint32_t pk_mask8(uint32_t d) { return pk_mul(pk_min(d, 0x00010001u), 0x00FF00FFu); }
+
+__device__ __forceinline__ uint32_t fast_arc_max_of_min_pk(const uint32_t (&g)[16]) {  // fast_arc_max_of_min on both halves
+  uint32_t suf0[8], pre1[8], suf1[8], pre0[8];
+  suf0[7] = g[7];
+  pre1[0] = g[8];
+  suf1[7] = g[15];
+  pre0[0] = g[0];
+#pragma unroll
+  for (int k = 6; k >= 0; --k) {
+    suf0[k] = pk_min(g[k], suf0[k + 1]);
+    suf1[k] = pk_min(g[8 + k], suf1[k + 1]);
+  }
+#pragma unroll
+  for (int j = 1; j < 8; ++j) {
+    pre1[j] = pk_min(g[8 + j], pre1[j - 1]);
+    pre0[j] = pk_min(g[j], pre0[j - 1]);
+  }
+  uint32_t A = pk_min(suf0[0], pre1[0]);
+  A = pk_max(A, pk_min(suf1[0], pre0[0]));
+#pragma unroll
+  for (int k = 1; k < 8; ++k) {
+    A = pk_max(A, pk_min(suf0[k], pre1[k]));
+    A = pk_max(A, pk_min(suf1[k], pre0[k]));
+  }
+  return A;
+}
+
+// fast_score_raw on both halves: v[k], c: packed pixel pairs (0 .. 255 per half); thr_pk = thr | thr << 16 (thr <= 254),
+// thrm1_pk likewise for thr - 1; valid_pk: 0x00FF per half whose pixel can be a corner.  -> packed scores.
+__device__ __forceinline__ uint32_t fast_score_pk(const uint32_t (&v)[16], uint32_t c, uint32_t thr_pk, uint32_t thrm1_pk,
+                                                  uint32_t valid_pk) {
+  const uint32_t hiA = pk_max(v[0], v[4]), loA = pk_min(v[0], v[4]), hiB = pk_max(v[8], v[12]), loB = pk_min(v[8], v[12]);
+  const uint32_t X = pk_min(hiA, hiB), Y = pk_max(loA, loB);
+  // second largest compass pixel > c + thr / second smallest < c - thr, as saturating differences (nonzero = true)
+  const uint32_t mB = pk_mask8(pk_subs(pk_max(X, Y), pk_add(c, thr_pk))) & valid_pk;
+  const uint32_t mD = pk_mask8(pk_subs(c, pk_add(pk_min(X, Y), thr_pk))) & valid_pk;
+  if (__ballot((mB | mD) != 0u) == 0ULL) return 0u;  // uniform
+  const uint32_t mm = mD & ~mB;
+  uint32_t g[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) g[k] = v[k] ^ mm;
+  uint32_t t = pk_subs(fast_arc_max_of_min_pk(g), pk_add(c ^ mm, thr_pk));                 // best - thr where positive
+  uint32_t s = pk_add(t, pk_mul(pk_min(t, 0x00010001u), thrm1_pk)) & (mB | mD);             // best - 1 where best > thr
+  if (__ballot((mB & mD) != 0u) != 0ULL) {  // uniform: some half has two brighter AND two darker compass pixels
+#pragma unroll
+    for (int k = 0; k < 16; ++k) g[k] = v[k] ^ mD;   // the darker polarity wherever it can hold a corner
+    t = pk_subs(fast_arc_max_of_min_pk(g), pk_add(c ^ mD, thr_pk));
+    s = pk_max(s, pk_add(t, pk_mul(pk_min(t, 0x00010001u), thrm1_pk)) & mD);
+  }
+  return s;
+}
+
+__global__ __launch_bounds__(kThreads) void orb_level_pass2_kernel(const LevelPass A) {
+  SOSVO_STREAMING_PRIO();
+  __shared__ uint2 s_tab[kRowTabLds];
+  const int rows = A.rows, cols = A.cols, strips = A.strips;
+  for (int i = threadIdx.x; i < rows + 6; i += kThreads) s_tab[i] = A.rowtab[i];  // (rows + 6 <= kRowTabLds: the host checks)
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * kThreads + threadIdx.x) >> 6));
+  if (wave >= A.nimg * strips) return;  // wave-uniform (after the workgroup's only barrier)
+  const int img = wave / strips, strip = wave - img * strips;
+  const int xb = strip * kLp2StripW - kLp2Halo;
+  const int x_lo = xb + 2 * lane, x_hi = x_lo + 1;
+  // the pair's source: mirrored columns (reflect-101) are consecutive too, in descending order -> one 16-bit load, halves swapped
+  auto mirror = [&](int x) { return min(max(x < 0 ? -x : (x >= cols ? 2 * (cols - 1) - x : x), 0), cols - 1); };
+  const int m_lo = mirror(x_lo), m_hi = mirror(x_hi);
+  const bool swapped = m_hi < m_lo;
+  const int src_col = min(min(m_lo, m_hi), cols - 2);
+  const uint32_t unpack_sel = swapped ? 0x0C000C01u : 0x0C010C00u;  // v_perm_b32: bytes (b0, 0, b1, 0) / (b1, 0, b0, 0)
+  const bool own = lane >= kLp2Halo / 2 && lane < 64 - kLp2Halo / 2;
+  const bool out_lo = own && x_lo < cols, out_hi = own && x_hi < cols;
+  const uint32_t out_pk = (out_lo ? 0x0000FFFFu : 0u) | (out_hi ? 0xFFFF0000u : 0u);
+  const uint32_t valid_pk = ((x_lo >= 3 && x_lo < cols - 3) ? 0x000000FFu : 0u) | ((x_hi >= 3 && x_hi < cols - 3) ? 0x00FF0000u : 0u);
+  const uint32_t thr_pk = (uint32_t)A.thr * 0x00010001u, thrm1_pk = (uint32_t)(A.thr - 1) * 0x00010001u;
+  const uint8_t* g = A.in + (size_t)img * A.in_stride;
+  uint8_t* sc = A.score + (size_t)img * A.score_stride;
+  unsigned long long* fo = A.flags + (size_t)img * A.flags_stride;
+  uint8_t* bo = A.blur + (size_t)img * A.blur_stride;
+  uint8_t* no = A.next + (size_t)img * A.next_stride;
+  // next level: up to two output columns per lane (a strip's 120 columns map to <= 120 outputs: j = lane, 64 + lane)
+  const int w1 = A.w1;
+  int dxo[2] = {0, 0}, la[2] = {0, 0}, sh[2] = {0, 0};
+  uint32_t wx1[2] = {0u, 0u};
+  bool rz[2] = {false, false};
+  if (A.next) {  // uniform
+    const int xlo = strip * kLp2StripW;
+    int d0 = max((int)((long long)xlo * w1 / cols) - 2, 0);
+    while (d0 < w1 && (int)(A.xtaps[d0] & 0xFFFFu) < xlo) ++d0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      dxo[q] = d0 + 64 * q + lane;
+      const uint32_t tx = A.xtaps[min(dxo[q], w1 - 1)];
+      const int x0 = (int)(tx & 0xFFFFu);
+      rz[q] = dxo[q] < w1 && x0 < xlo + kLp2StripW;
+      const int rel = min(max(x0 - xb, 0), 125);
+      la[q] = 4 * (rel >> 1);    // lane that holds the pair with x0
+      sh[q] = 16 * (rel & 1);    // x0 is that pair's high half: the window (pair, next pair) >> 16
+      wx1[q] = tx >> 16;
+    }
+  }
+  // ring slot = (t + 3) mod 7; per slot the centre pair and its six shifted copies (packed)
+  uint32_t vc[7], vl1[7], vl2[7], vl3[7], vr1[7], vr2[7], vr3[7];
+  uint32_t hsl[7], hsh[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    vc[k] = vl1[k] = vl2[k] = vl3[k] = vr1[k] = vr2[k] = vr3[k] = 0u;
+    hsl[k] = hsh[k] = 0u;
+  }
+  uint32_t hm_a = 0u, hm_b = 0u, s_b = 0u, lr_b = 0u;  // NMS state (packed), as the one-pixel form's
+  uint32_t hx_prev[2] = {0u, 0u};
+  const int t_last = rows + 2;
+  auto src_row = [&](int t) { return min(abs(t), 2 * (rows - 1) - abs(t)); };
+  uint32_t c_pre[7];
+  auto request = [&](int t0, int k0, int k1) __attribute__((always_inline)) {  // rows t0 + k0 .. t0 + k1 - 1 -> their slots
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+      if (k >= k0 && k < k1)
+        c_pre[k] = (uint32_t)*reinterpret_cast<const u16_unaligned*>(g + (uint32_t)(src_row(min(t0 + k, t_last)) * cols) + (uint32_t)src_col);
+  };
+  request(-3, 0, 7);
+  uint2 e_next = s_tab[0];
+  auto step = [&](auto phase_tag, const int t) __attribute__((always_inline)) {
+    constexpr int P = decltype(phase_tag)::value;
+    if (t > t_last) return;  // uniform
+    const uint32_t e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e_next.x);
+    const uint32_t e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e_next.y);
+    {
+      const uint32_t c = __builtin_amdgcn_perm(0u, c_pre[P], unpack_sel);  // row t: (x, x + 1) as 16-bit halves
+      e_next = s_tab[min(t + 1, t_last) + 3];
+      const uint32_t nx = (uint32_t)fs_from_right((int)c), nx2 = (uint32_t)fs_from_right((int)nx);   // (x+2, x+3), (x+4, x+5)
+      const uint32_t pv = (uint32_t)fs_from_left((int)c), pv2 = (uint32_t)fs_from_left((int)pv);     // (x-2, x-1), (x-4, x-3)
+      vc[P] = c;
+      vr1[P] = __builtin_amdgcn_alignbit(nx, c, 16);    // (x+1, x+2)
+      vr2[P] = nx;
+      vr3[P] = __builtin_amdgcn_alignbit(nx2, nx, 16);  // (x+3, x+4)
+      vl1[P] = __builtin_amdgcn_alignbit(c, pv, 16);    // (x-1, x)
+      vl2[P] = pv;
+      vl3[P] = __builtin_amdgcn_alignbit(pv, pv2, 16);  // (x-3, x-2)
+    }
+    // ---- next level ----
+    if (A.next) {  // uniform
+      uint32_t hx[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const uint32_t q0 = (uint32_t)__builtin_amdgcn_ds_bpermute(la[q], (int)vc[P]);
+        const uint32_t q1 = (uint32_t)__builtin_amdgcn_ds_bpermute(la[q], (int)vr2[P]);
+        const uint32_t win = __builtin_amdgcn_alignbit(q1, q0, (uint32_t)sh[q]);  // (pixel x0, pixel x0 + 1)
+        hx[q] = orb_mad24(wx1[q], win >> 16, orb_mul24(2048u - wx1[q], win & 0xFFFFu));
+      }
+      if (e0 & kRtEmit) {  // uniform
+        const uint32_t wy1 = (e0 >> 16) & 0xFFFu, wy0 = 2048u - wy1, dy = e0 & 0xFFFFu;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const uint32_t top = (e0 & kRtTopSelf) ? hx[q] : hx_prev[q];
+          const uint32_t res = (orb_mul24(wy0, top) + orb_mul24(wy1, hx[q]) + (1u << 21)) >> 22;
+          if (rz[q]) no[dy * (uint32_t)w1 + (uint32_t)dxo[q]] = (uint8_t)res;
+        }
+      }
+      hx_prev[0] = hx[0];
+      hx_prev[1] = hx[1];
+    }
+    // ---- blur ----
+    if (e1 & kRtHsum) {  // uniform
+      // horizontal sums fit 16 bits (255 * 256): packed multiply-adds
+      const orb_us2 hp = pk_u(vc[P]) * (unsigned short)54 + (pk_u(vl1[P]) + pk_u(vr1[P])) * (unsigned short)49 +
+                         (pk_u(vl2[P]) + pk_u(vr2[P])) * (unsigned short)34 + (pk_u(vl3[P]) + pk_u(vr3[P])) * (unsigned short)18;
+      const uint32_t hpw = pk_w(hp);
+      hsl[P] = hpw & 0xFFFFu;
+      hsh[P] = hpw >> 16;
+      if (e1 & kRtBlurOut) {  // uniform; rows t-6 .. t live in slots P+1 .. P+7 (mod 7)
+        const uint32_t vl = orb_mad24(18u, hsl[(P + 1) % 7] + hsl[P], orb_mad24(34u, hsl[(P + 2) % 7] + hsl[(P + 6) % 7],
+                                      orb_mad24(49u, hsl[(P + 3) % 7] + hsl[(P + 5) % 7], orb_mul24(54u, hsl[(P + 4) % 7]))));
+        const uint32_t vh = orb_mad24(18u, hsh[(P + 1) % 7] + hsh[P], orb_mad24(34u, hsh[(P + 2) % 7] + hsh[(P + 6) % 7],
+                                      orb_mad24(49u, hsh[(P + 3) % 7] + hsh[(P + 5) % 7], orb_mul24(54u, hsh[(P + 4) % 7]))));
+        const uint32_t bl = (vl + 32768u) >> 16, bh = (vh + 32768u) >> 16;
+        uint8_t* o = bo + (uint32_t)((t - 3) * cols) + (uint32_t)x_lo;
+        if (out_hi) {
+          *reinterpret_cast<u16_unaligned*>(o) = (uint16_t)(bl | (bh << 8));
+        } else if (out_lo) {
+          *o = (uint8_t)bl;
+        }
+      }
+    }
+    // ---- FAST score of row y = t - 3, flags (and the flagged pixels' scores) of row y - 1 ----
+    if (!(e1 & kRtFastRow)) return;  // uniform
+    const int y = t - 3;
+    uint32_t s = 0u;
+    if (e1 & kRtScore) {  // uniform
+      constexpr int s3 = (P + 7) % 7, s2 = (P + 6) % 7, s1 = (P + 5) % 7, s0 = (P + 4) % 7, m1 = (P + 3) % 7, m2 = (P + 2) % 7,
+                    m3 = (P + 1) % 7;
+      const uint32_t v[16] = {vc[s3],  vr1[s3], vr2[s2], vr3[s1], vr3[s0], vr3[m1], vr2[m2], vr1[m3],
+                              vc[m3],  vl1[m3], vl2[m2], vl3[m1], vl3[s0], vl3[s1], vl2[s2], vl1[s3]};
+      s = fast_score_pk(v, vc[s0], thr_pk, thrm1_pk, valid_pk);
+    }
+    // packed scores of the left / right neighbours: (x-1, x) and (x+1, x+2)
+    const uint32_t sn = (uint32_t)fs_from_right((int)s), sp = (uint32_t)fs_from_left((int)s);
+    const uint32_t lr = pk_max(__builtin_amdgcn_alignbit(s, sp, 16), __builtin_amdgcn_alignbit(sn, s, 16)), hm = pk_max(lr, s);
+    if (e1 & kRtFlagRow) {  // flag row y - 1 (uniform)
+      // strictly greater than the eight neighbours (and hence > 0): saturating difference to their maximum, nonzero = flagged
+      const uint32_t f = pk_subs(s_b, pk_max(pk_max(lr_b, hm_a), hm)) & out_pk;
+      const bool f_lo = (f & 0xFFFFu) != 0u, f_hi = (f >> 16) != 0u;
+      const unsigned long long bal_lo = __ballot(f_lo), bal_hi = __ballot(f_hi);
+      if (lane == 0) {
+        fo[(uint32_t)(((y - 1) * strips + strip) * 2)] = bal_lo;
+        fo[(uint32_t)(((y - 1) * strips + strip) * 2 + 1)] = bal_hi;
+      }
+      if (f_lo) sc[(uint32_t)((y - 1) * cols) + (uint32_t)x_lo] = (uint8_t)s_b;
+      if (f_hi) sc[(uint32_t)((y - 1) * cols) + (uint32_t)x_hi] = (uint8_t)(s_b >> 16);
+    }
+    hm_a = hm_b;
+    hm_b = hm;
+    s_b = s;
+    lr_b = lr;
+  };
   for (int t = -3; t <= t_last; t += 7) {
     step(std::integral_constant<int, 0>{}, t);
     step(std::integral_constant<int, 1>{}, t + 1);
@@ -1062,7 +1316,7 @@ __global__ __launch_bounds__(kThreads, 4) void orb_select_kernel(LevelSrc S, con
                                                               const uint32_t* __restrict__ bbox, Pyr P,
                                                               int images_per_maskset, int nmask, int cap,
                                                               float* __restrict__ kp4, float* __restrict__ resp_out,
-                                                              int32_t* __restrict__ n_out, int nimg_total) {
+                                                              int32_t* __restrict__ n_out, int nimg_total, int flags2) {
   SOSVO_LATENCY_BOUND_PRIO();
   __shared__ uint32_t cxy[kCandMax];            // (y << 16) | x; after the sort: the sorted positions
   __shared__ uint8_t cfast[kCandMax];
@@ -1088,7 +1342,9 @@ __global__ __launch_bounds__(kThreads, 4) void orb_select_kernel(LevelSrc S, con
     const uint8_t* sc = score + (size_t)img * P.total + P.off[l];
     const uint32_t* mk = mask_pyr + (size_t)(img / images_per_maskset) * P.total + P.off[l];
     const unsigned long long* fl = flags + (size_t)img * P.ftotal + P.foff[l];
-    const int strips = P.fstrips[l];
+    // flag words of a row: one per 56-column strip (bit b = column 56 s - 4 + b), or -- flags2, orb_level_pass2_kernel's --
+    // two per 120-column strip (bit b of word h = column 120 s - 4 + 2 b + h)
+    const int strips = flags2 ? 2 * P.fstrips2[l] : P.fstrips[l];
     if (tid == 0) {
       s_nc = 0;
       s_nk = 0;
@@ -1138,20 +1394,22 @@ __global__ __launch_bounds__(kThreads, 4) void orb_select_kernel(LevelSrc S, con
     // per word instead of flag -> mask -> score per bit, one word after the other.
     auto walk = [&](auto visit) {
       if (rw <= 0 || rh <= 0) return;
-      const int st0 = bx0 / kFsStripW, ns = (bx1 - 1) / kFsStripW - st0 + 1, nw = ns * rh;
+      // (word index inside a row: strip for the one-word layout, 2 strip + half for the two-word one; xstep = columns per bit)
+      const int xstep = flags2 ? 2 : 1, sw = flags2 ? kLp2StripW : kFsStripW;
+      const int st0 = (bx0 / sw) * xstep, ns = ((bx1 - 1) / sw) * xstep + (xstep - 1) - st0 + 1, nw = ns * rh;
       auto word = [&](int i, int& y, int& xbase) -> unsigned long long {
         const int ry = i / ns, sidx = st0 + (i - ry * ns);
         y = by0 + ry;
-        xbase = sidx * kFsStripW - kFsHalo;  // column of bit 0
+        xbase = flags2 ? (sidx >> 1) * kLp2StripW - kLp2Halo + (sidx & 1) : sidx * kFsStripW - kFsHalo;  // column of bit 0
         unsigned long long wd = fl[(size_t)y * strips + sidx];
-        // keep the bits whose column lies inside [bx0, bx1)
-        const int l_lo = max(0, bx0 - xbase), l_hi = min(63, bx1 - 1 - xbase);
+        // keep the bits whose column xbase + xstep b lies inside [bx0, bx1)
+        const int l_lo = max(0, (bx0 - xbase + xstep - 1) / xstep), l_hi = min(63, (bx1 - 1 - xbase) >= 0 ? (bx1 - 1 - xbase) / xstep : -1);
         return l_hi >= l_lo ? (wd >> l_lo << l_lo) & (~0ULL >> (63 - l_hi)) : 0ULL;
       };
       auto bits = [&](unsigned long long wd, int y, int xbase) __attribute__((always_inline)) {
         if (!wd) return;
         const uint32_t row = (uint32_t)y * (uint32_t)w;
-        int x = xbase + __ffsll((long long)wd) - 1;
+        int x = xbase + xstep * (__ffsll((long long)wd) - 1);
         wd &= wd - 1ULL;
         uint32_t mword = mk[row + (uint32_t)x];
         int sval = (int)sc[row + (uint32_t)x];
@@ -1160,7 +1418,7 @@ __global__ __launch_bounds__(kThreads, 4) void orb_select_kernel(LevelSrc S, con
           const uint32_t mc = mword;
           const bool more = wd != 0ULL;
           if (more) {
-            x = xbase + __ffsll((long long)wd) - 1;
+            x = xbase + xstep * (__ffsll((long long)wd) - 1);
             wd &= wd - 1ULL;
             mword = mk[row + (uint32_t)x];
             sval = (int)sc[row + (uint32_t)x];
@@ -1708,8 +1966,9 @@ Pyr make_pyr(int rows, int cols, int nfeatures) {
     P.det[l] = P.quota[l] > 0 && P.h[l] > 2 * kEdge && P.w[l] > 2 * kEdge;
     if (P.det[l]) P.ndet = l + 1;
     P.fstrips[l] = cdiv(P.w[l], kFsStripW);
+    P.fstrips2[l] = cdiv(P.w[l], kLp2StripW);
     P.foff[l] = foff;
-    foff += (long long)P.h[l] * P.fstrips[l];
+    foff += (long long)P.h[l] * (P.fstrips[l] > 2 * P.fstrips2[l] ? P.fstrips[l] : 2 * P.fstrips2[l]);
     P.toff[l] = toff;
     if (l >= 1) toff += P.w[l] + P.h[l];
   }
@@ -1796,7 +2055,8 @@ int32_t run_orb_detect(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* mask
   }
   LevelSrc S{gray, W.pyr, (long long)rows * cols, P.total};
   SOSVO_LAUNCH(ctx, orb_select_kernel, dim3(orb_xcd_grid(nimg, nmask)), dim3(kThreads), 0, ctx->stream, S, W.score,
-               W.flags, mask_pyr, W.bbox, P, images_per_maskset, nmask, cap, kp4, resp, n, nimg);
+               W.flags, mask_pyr, W.bbox, P, images_per_maskset, nmask, cap, kp4, resp, n, nimg,
+               (have_flags && kOrbTwoPixelLanes) ? 1 : 0);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
 }
@@ -1832,7 +2092,7 @@ int32_t run_orb_level_passes(sosvo_ctx* ctx, const uint8_t* gray, int nimg, int 
     A.nimg = nimg;
     A.rows = P.h[l];
     A.cols = P.w[l];
-    A.strips = P.fstrips[l];
+    A.strips = kOrbTwoPixelLanes ? P.fstrips2[l] : P.fstrips[l];
     A.thr = kFastThr;
     A.rowtab = W.rowtab + (size_t)l * W.rowtab_stride;
     A.score = W.score + P.off[l];
@@ -1846,7 +2106,10 @@ int32_t run_orb_level_passes(sosvo_ctx* ctx, const uint8_t* gray, int nimg, int 
     A.next_stride = P.total;
     A.w1 = next ? P.w[l + 1] : 0;
     A.xtaps = next ? W.taps + P.toff[l + 1] : nullptr;
-    SOSVO_LAUNCH(ctx, orb_level_pass_kernel, dim3(cdiv(nimg * A.strips, kThreads / 64)), dim3(kThreads), 0, ctx->stream, A);
+    if (kOrbTwoPixelLanes)
+      SOSVO_LAUNCH(ctx, orb_level_pass2_kernel, dim3(cdiv(nimg * A.strips, kThreads / 64)), dim3(kThreads), 0, ctx->stream, A);
+    else
+      SOSVO_LAUNCH(ctx, orb_level_pass_kernel, dim3(cdiv(nimg * A.strips, kThreads / 64)), dim3(kThreads), 0, ctx->stream, A);
     SOSVO_LAUNCH_CHECK(ctx);
   }
   return SOSVO_OK;
