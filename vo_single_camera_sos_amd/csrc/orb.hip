@@ -6,7 +6,7 @@
 // Batched over images (view-major) x azimuthal masks; problem p = image * nmask + mask.
 //   levels    8 levels x 1.2, each level bilinear (11-bit fixed point) from the previous one; all levels of one image live
 //             back to back in one workspace row (level offsets in a by-value struct).  ONE launch per level
-//             (orb_level_pass_kernel, round 4): a wave walks a 64-column strip of level l down its rows and produces, from one
+//             (orb_level_pass_kernel, round 4): a wave walks a 128-column strip of level l (two pixels per lane) down its rows and produces, from one
 //             read of the level, the FAST-9/16 local-maximum flags (+ the flagged pixels' scores), the 7x7 blur of the rows a
 //             descriptor can read, and level l + 1.  FAST score: one polarity per lane on raw pixel values, van Herk arc network.
 //             (Images taller than the row table's LDS area, and keypoints handed in from outside, take the separate
@@ -45,8 +45,8 @@ struct Pyr {
   // detection: levels that can hold a keypoint (a quota and more than the 31-px border); local-maximum flags of their
   // FAST score maps, one u64 per (row, 56-column strip): foff = first word of a level inside an image's ftotal words
   int det[kLevels], ndet;  // ndet = 1 + the highest such level (the pyramid is only built that far for detection)
-  int fstrips[kLevels];    // 56-column strips of a level (fast_score_rolling_kernel / orb_level_pass_kernel: one flag word each)
-  int fstrips2[kLevels];   // 120-column strips (orb_level_pass2_kernel: TWO flag words each, even and odd columns)
+  int fstrips[kLevels];    // 56-column strips of a level (fast_score_rolling_kernel: one flag word each)
+  int fstrips2[kLevels];   // 120-column strips (orb_level_pass_kernel: TWO flag words each, even and odd columns)
   long long foff[kLevels], ftotal;  // (a level's rows hold max(fstrips, 2 fstrips2) words: either layout fits)
   int toff[kLevels], ttotal;  // resize tap table: level l >= 1 holds w[l] x taps, then h[l] y taps, at toff[l]
 };
@@ -290,7 +290,7 @@ __device__ __forceinline__ int fast_score_raw(const uint32_t (&v)[16], int c, in
 // non-maximum suppression of the detectors), for rows (r0, r1 - 1); the halo of 4 makes the scores of an output lane's
 // neighbours exact.
 constexpr int kFsHalo = 4, kFsStripW = 64 - 2 * kFsHalo;
-constexpr int kLp2Halo = 4, kLp2StripW = 128 - 2 * kLp2Halo;  // two pixels per lane (orb_level_pass2_kernel)
+constexpr int kLp2Halo = 4, kLp2StripW = 128 - 2 * kLp2Halo;  // two pixels per lane (orb_level_pass_kernel)
 __global__ __launch_bounds__(kThreads) void fast_score_rolling_kernel(const uint8_t* __restrict__ in, long long img_stride,
                                                                       int nimg, int rows, int cols, int strips, int thr,
                                                                       int r0, int r1, uint8_t* __restrict__ out,
@@ -406,19 +406,21 @@ static int32_t launch_fast_score(sosvo_ctx* ctx, const uint8_t* in, long long im
 // ---- one pass over a pyramid level: FAST flags + blur + next level (round 4) ---------------------------------------
 // Rounds 1-3 read every level three times (resize -> HBM -> FAST score -> HBM, and again for the 7x7 blur) in 4 + 5 + 5
 // launches per call; the three consumers want the same thing -- the last seven rows of a column strip and the three
-// neighbours to each side -- which the FAST kernel's register ring already holds.  Here the wave that walks a 64-column
-// strip (56 owned columns, halo 4) of level l down its rows produces, from ONE read of the level:
+// neighbours to each side -- which a rolling FAST kernel's register ring already holds.  Here the wave that walks a
+// column strip of level l down its rows produces, from ONE read of the level:
 //   * FAST-9 score -> 3x3 local-maximum flags (as fast_score_rolling_kernel), the score stored ONLY at the flagged pixels
 //     (the selection reads nothing else of the map);
 //   * the 7x7 Gaussian of the rows a descriptor can read (gauss7_kernel's integer arithmetic: a ring of horizontal sums;
 //     mirrored columns in the halo lanes of the two edge strips, mirrored rows by walking the reflected row indices);
-//   * level l + 1 (resize_level_kernel's arithmetic): output row dy is due when its lower source row arrives; output column
-//     dx belongs to the strip that owns its left tap x0(dx), lane j of the wave takes dx = dx_first + j (<= 56 columns a
-//     strip) and fetches its two taps of both source rows from the owning lanes with two ds_bpermute of the packed rows.
+//   * level l + 1 (resize_level_kernel's arithmetic): output row dy is due when its lower source row arrives; an output
+//     column belongs to the strip that owns its left tap x0(dx) and fetches its taps from the owning lanes (ds_bpermute).
 // What a row t of the walk (t = -3 .. rows + 2: three mirrored rows each side for the blur) has to do is the same for every
-// wave of the launch, so it comes from a table written once per call (orb_rowtab_kernel) and fetched one row ahead next to
-// the pixel: the first version evaluated ~100 scalar instructions of row-range tests per row and stalled on a dependent
-// load of the next y tap after every output row -- as many issue slots as the arithmetic.
+// wave of the launch, so it comes from a table written once per call (orb_rowtab_kernel), held in LDS and read one row
+// ahead: the first version evaluated ~100 scalar instructions of row-range tests per row and stalled on a dependent load of
+// the next y tap after every output row -- as many issue slots as the arithmetic.  Steps of the kernel's history (ms per 256
+// frame pairs, all five levels): separate kernels 3.23; one pass, one pixel per lane 3.02; row table 2.32; rows requested
+// seven ahead 2.14; mirrored halo lanes instead of an edge-strip variant (113 VGPRs: four waves per SIMD) 1.84; TWO pixels
+// per lane (below) 1.40.
 constexpr uint32_t kRtEmit = 1u << 31, kRtTopSelf = 1u << 28;  // word 0: dy | wy1 << 16 | flags
 constexpr uint32_t kRtHsum = 1u, kRtBlurOut = 2u, kRtFastRow = 4u, kRtScore = 8u, kRtFlagRow = 16u;  // word 1
 struct LevelPass {
@@ -506,185 +508,17 @@ __global__ __launch_bounds__(kThreads) void orb_rowtab_kernel(Pyr P, const int8_
   rowtab[(size_t)l * tab_stride + idx] = make_uint2(w0, w1);
 }
 
-#ifndef SOSVO_ORB_TWO_PIXEL_LANES
-#define SOSVO_ORB_TWO_PIXEL_LANES 1
-#endif
-constexpr bool kOrbTwoPixelLanes = SOSVO_ORB_TWO_PIXEL_LANES != 0;  // which level pass the ORB path launches (A/B: -DSOSVO_ORB_TWO_PIXEL_LANES=0)
 constexpr int kRowTabLds = 1024;  // rows + 6 entries of the level's table in LDS (higher images take the separate kernels)
-__global__ __launch_bounds__(kThreads) void orb_level_pass_kernel(const LevelPass A) {
-  SOSVO_STREAMING_PRIO();
-  __shared__ uint2 s_tab[kRowTabLds];
-  const int rows = A.rows, cols = A.cols, strips = A.strips, thr = A.thr;
-  for (int i = threadIdx.x; i < rows + 6; i += kThreads) s_tab[i] = A.rowtab[i];  // (rows + 6 <= kRowTabLds: the host checks)
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * kThreads + threadIdx.x) >> 6));
-  if (wave >= A.nimg * A.strips) return;  // wave-uniform (after the workgroup's only barrier)
-  const int img = wave / strips, strip = wave - img * strips;
-  const int xb = strip * kFsStripW - kFsHalo;
-  const int xc = xb + lane;
-  // (halo lanes beyond the image's sides hold the MIRRORED columns -- reflect-101, what the blur wants there; FAST and the next
-  // level never look at them -- so the blur's neighbours are the ring's shifted copies in the edge strips too)
-  const int xs = min(max(xc < 0 ? -xc : (xc >= cols ? 2 * (cols - 1) - xc : xc), 0), cols - 1);
-  const bool out_lane = lane >= kFsHalo && lane < 64 - kFsHalo && xc < cols;
-  const bool interior_x = xc >= 3 && xc < cols - 3;
-  const uint8_t* g = A.in + (size_t)img * A.in_stride;
-  uint8_t* sc = A.score + (size_t)img * A.score_stride;
-  unsigned long long* fo = A.flags + (size_t)img * A.flags_stride;
-  uint8_t* bo = A.blur + (size_t)img * A.blur_stride;
-  uint8_t* no = A.next + (size_t)img * A.next_stride;
-  // next level: this lane's output column and its taps' lanes
-  const int w1 = A.w1;
-  int dx = 0, la = 0, lb = 0;
-  uint32_t wx1 = 0u;
-  bool rz_lane = false;
-  if (A.next) {  // uniform
-    const int xlo = strip * kFsStripW;
-    // first output column whose left tap x0 (non-decreasing in dx, ~ dx * cols / w1) lies at or beyond xlo: start a little
-    // below the estimate and walk up (scalar, at most a few steps)
-    int d0 = max((int)((long long)xlo * w1 / cols) - 2, 0);
-    while (d0 < w1 && (int)(A.xtaps[d0] & 0xFFFFu) < xlo) ++d0;
-    dx = d0 + lane;
-    const uint32_t tx = A.xtaps[min(dx, w1 - 1)];
-    const int x0 = (int)(tx & 0xFFFFu), x1 = x0 + 1 < cols ? x0 + 1 : cols - 1;
-    rz_lane = dx < w1 && x0 < xlo + kFsStripW;
-    la = 4 * min(max(x0 - xb, 0), 63);
-    lb = 4 * min(max(x1 - xb, 0), 63);
-    wx1 = tx >> 16;
-  }
-  const uint32_t wx0 = 2048u - wx1;
-  // ring slot = (t + 3) mod 7, compile-time after unrolling; per slot the centre value and its six shifted copies
-  int vc[7], vl1[7], vl2[7], vl3[7], vr1[7], vr2[7], vr3[7];
-  uint32_t hs[7];
-#pragma unroll
-  for (int k = 0; k < 7; ++k) {
-    vc[k] = vl1[k] = vl2[k] = vl3[k] = vr1[k] = vr2[k] = vr3[k] = 0;
-    hs[k] = 0u;
-  }
-  int hm_a = 0, hm_b = 0, s_b = 0, lr_b = 0;  // NMS state: hm = max over (x-1, x, x+1) of rows y-2 / y-1, s / lr of row y-1
-  uint32_t hx_prev = 0u;                      // next level: the previous row, interpolated at this lane's output column
-  const int t_last = rows + 2;
-  // A wave's rows come SEVEN AT A TIME, one ring revolution ahead (mirrored rows: |t| and 2 (rows - 1) - t, rows > 6): with
-  // row t + 1 requested at step t -- ~0.6 us of the SIMD's other waves' work -- a load that misses the L2 (a wave's rows are
-  // `cols` bytes apart: another line every step) was not covered, with one load in flight per wave the chip held a third of
-  // the bytes in flight its bandwidth needs, and the kernel ran at the speed of its loads, not of its arithmetic.  (Requested
-  // in batches the compiler counts the loads down -- s_waitcnt vmcnt(6), (5), ... -- ; a rolling request per step between
-  // the conditional stores ends in vmcnt(0) everywhere.)  The table entry comes from LDS one step ahead: a table load from
-  // memory inside the loop would turn every wait for it into a wait for all the rows in flight (one in-order counter).
-  auto src_row = [&](int t) { return min(abs(t), 2 * (rows - 1) - abs(t)); };
-  auto tab = [&](int i) { return s_tab[i]; };  // (LDS only: a table load from memory inside the loop would make every wait for it a wait for the rows in flight)
-  int c_pre[7];
-  auto request = [&](int t0, int k0, int k1) __attribute__((always_inline)) {  // rows t0 + k0 .. t0 + k1 - 1 -> their slots
-#pragma unroll
-    for (int k = 0; k < 7; ++k)
-      if (k >= k0 && k < k1) c_pre[k] = (int)g[(uint32_t)(src_row(min(t0 + k, t_last)) * cols) + (uint32_t)xs];
-  };
-  request(-3, 0, 7);
-  uint2 e_next = tab(0);
-  auto step = [&](auto phase_tag, const int t) __attribute__((always_inline)) {
-    constexpr int P = decltype(phase_tag)::value;
-    if (t > t_last) return;  // uniform
-    const uint32_t e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e_next.x);
-    const uint32_t e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e_next.y);
-    {
-      const int c = c_pre[P];  // row t
-      e_next = tab(min(t + 1, t_last) + 3);
-      vc[P] = c;
-      vr1[P] = fs_from_right(c);
-      vr2[P] = fs_from_right(vr1[P]);
-      vr3[P] = fs_from_right(vr2[P]);
-      vl1[P] = fs_from_left(c);
-      vl2[P] = fs_from_left(vl1[P]);
-      vl3[P] = fs_from_left(vl2[P]);
-    }
-    // ---- next level: row t interpolated horizontally at this lane's output column (once per source row: the row is the
-    // lower tap of one output row and, four times out of five, the upper tap of the next), then the output row due at t ----
-    if (A.next) {  // uniform
-      const uint32_t a0 = (uint32_t)__builtin_amdgcn_ds_bpermute(la, vc[P]), a1 = (uint32_t)__builtin_amdgcn_ds_bpermute(lb, vc[P]);
-      const uint32_t hx = orb_mad24(wx1, a1, orb_mul24(wx0, a0));  // <= 2048 * 255 < 2^24
-      if (e0 & kRtEmit) {  // uniform
-        const uint32_t top = (e0 & kRtTopSelf) ? hx : hx_prev;  // (y0 == y1 only past the last row pair)
-        const uint32_t wy1 = (e0 >> 16) & 0xFFFu, wy0 = 2048u - wy1, dy = e0 & 0xFFFFu;
-        // (wy0 * top + wy1 * bot + 2^21) >> 22: 24-bit multiplies, 32-bit sums, exact
-        const uint32_t res = (orb_mul24(wy0, top) + orb_mul24(wy1, hx) + (1u << 21)) >> 22;
-        if (rz_lane) no[dy * (uint32_t)w1 + (uint32_t)dx] = (uint8_t)res;
-      }
-      hx_prev = hx;
-    }
-    // ---- blur: horizontal sum of row t, then output row t - 3 ----
-    if (e1 & kRtHsum) {  // uniform
-      hs[P] = orb_mad24(18u, (uint32_t)(vl3[P] + vr3[P]), orb_mad24(34u, (uint32_t)(vl2[P] + vr2[P]),
-                        orb_mad24(49u, (uint32_t)(vl1[P] + vr1[P]), orb_mul24(54u, (uint32_t)vc[P]))));
-      if (e1 & kRtBlurOut) {  // uniform; rows t-6 .. t live in slots P+1 .. P+7 (mod 7)
-        const uint32_t vsum = orb_mad24(18u, hs[(P + 1) % 7] + hs[P], orb_mad24(34u, hs[(P + 2) % 7] + hs[(P + 6) % 7],
-                                        orb_mad24(49u, hs[(P + 3) % 7] + hs[(P + 5) % 7], orb_mul24(54u, hs[(P + 4) % 7]))));
-        if (out_lane) bo[(uint32_t)((t - 3) * cols) + (uint32_t)xc] = (uint8_t)((vsum + 32768u) >> 16);
-      }
-    }
-    // ---- FAST score of row y = t - 3, flags (and the flagged pixels' scores) of row y - 1 ----
-    if (!(e1 & kRtFastRow)) return;  // uniform
-    const int y = t - 3;
-    int s = 0;
-    if (e1 & kRtScore) {  // uniform
-      // row y + dy lives in slot (P + 4 + dy) mod 7; circle pixel k = (rx[k], ry[k]) as in OpenCV's table
-      constexpr int s3 = (P + 7) % 7, s2 = (P + 6) % 7, s1 = (P + 5) % 7, s0 = (P + 4) % 7, m1 = (P + 3) % 7, m2 = (P + 2) % 7,
-                    m3 = (P + 1) % 7;
-      const uint32_t v[16] = {
-          (uint32_t)vc[s3],   // ( 0,  3)
-          (uint32_t)vr1[s3],  // ( 1,  3)
-          (uint32_t)vr2[s2],  // ( 2,  2)
-          (uint32_t)vr3[s1],  // ( 3,  1)
-          (uint32_t)vr3[s0],  // ( 3,  0)
-          (uint32_t)vr3[m1],  // ( 3, -1)
-          (uint32_t)vr2[m2],  // ( 2, -2)
-          (uint32_t)vr1[m3],  // ( 1, -3)
-          (uint32_t)vc[m3],   // ( 0, -3)
-          (uint32_t)vl1[m3],  // (-1, -3)
-          (uint32_t)vl2[m2],  // (-2, -2)
-          (uint32_t)vl3[m1],  // (-3, -1)
-          (uint32_t)vl3[s0],  // (-3,  0)
-          (uint32_t)vl3[s1],  // (-3,  1)
-          (uint32_t)vl2[s2],  // (-2,  2)
-          (uint32_t)vl1[s3],  // (-1,  3)
-      };
-      s = fast_score_raw(v, vc[s0], thr, interior_x);
-    }
-    const int lr = max(fs_from_left(s), fs_from_right(s)), hm = max(lr, s);
-    if (e1 & kRtFlagRow) {  // flag row y - 1 (uniform)
-      const bool is_max = out_lane && s_b > 0 && s_b > lr_b && s_b > hm_a && s_b > hm;
-      const unsigned long long bal = __ballot(is_max);
-      if (lane == 0) fo[(uint32_t)((y - 1) * strips + strip)] = bal;
-      if (is_max) sc[(uint32_t)((y - 1) * cols) + (uint32_t)xc] = (uint8_t)s_b;
-    }
-    hm_a = hm_b;
-    hm_b = hm;
-    s_b = s;
-    lr_b = lr;
-  };
-  // (the next revolution's rows in two half-batches into the slots just emptied: slots 0 .. 3 after step 3, 4 .. 6 after step 6
-  // -- three to six steps ahead of their use, and seven registers instead of fourteen)
-  for (int t = -3; t <= t_last; t += 7) {
-    step(std::integral_constant<int, 0>{}, t);
-    step(std::integral_constant<int, 1>{}, t + 1);
-    step(std::integral_constant<int, 2>{}, t + 2);
-    step(std::integral_constant<int, 3>{}, t + 3);
-    request(t + 7, 0, 4);
-    step(std::integral_constant<int, 4>{}, t + 4);
-    step(std::integral_constant<int, 5>{}, t + 5);
-    step(std::integral_constant<int, 6>{}, t + 6);
-    request(t + 7, 4, 7);
-  }
-}
-
-// ---- the level pass with TWO pixels per lane (round 4) --------------------------------------------------------------------
-// The one-pixel form above is priced per wave-instruction (issue-bound at four waves per SIMD) and per byte-wide memory
-// instruction; taken apart, its floor is the walk itself.  Here a lane owns the pixel PAIR (x, x + 1) as two 16-bit halves of one
-// register: the FAST network runs on v_pk_min_u16 / v_pk_max_u16 (the same ~140 instructions per wave and row now cover 120
-// owned columns instead of 56), the polarity mask is one 32-bit xor for both halves, predicates are saturating packed
-// subtractions (nonzero half = true), loads and blur stores are 16 bits wide.  Strip = 128 columns (120 owned, halo 4);
-// shifted copies of a row: the neighbour lanes' pairs by DPP, the odd shifts by v_alignbit of two of them.  Flags: TWO words
-// per (row, strip) -- bit b of word h is column strip * 120 - 4 + 2 b + h.  Everything else (row table, rows seven ahead,
-// mirrored halo columns, arithmetic) as orb_level_pass_kernel; results identical.
+// ---- two pixels per lane ---------------------------------------------------------------------------------------------------
+// With one pixel per lane the pass was priced per wave-instruction (issue-bound at four waves per SIMD) and per byte-wide
+// memory instruction: taken apart (compile-time variants), FAST alone cost 0.91 ms, blur + next level alone 0.79, of which the
+// walk itself -- a byte load, six lane moves, byte stores per row -- ~0.4 each.  So a lane owns the pixel PAIR (x, x + 1) as the
+// two 16-bit halves of one register: the FAST network runs on v_pk_min_u16 / v_pk_max_u16 (about the same instruction count per
+// wave and row now covers 120 owned columns instead of 56), the polarity mask is one 32-bit xor for both halves, predicates
+// are saturating packed subtractions (nonzero half = true), loads and blur stores are 16 bits wide.  Strip = 128 columns (120
+// owned, halo 4); shifted copies of a row: the neighbour lanes' pairs by DPP, the odd shifts by v_alignbit of two of them.
+// Flags: TWO words per (row, strip) -- bit b of word h is column strip * 120 - 4 + 2 b + h.  144 VGPRs (three waves per SIMD;
+// forced to 128 it spills 17 and runs 36 % slower).
 typedef unsigned short orb_us2 __attribute__((ext_vector_type(2)));
 typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
 __device__ __forceinline__ orb_us2 pk_u(uint32_t x) { return __builtin_bit_cast(orb_us2, x); }
@@ -748,7 +582,7 @@ __device__ __forceinline__ uint32_t fast_score_pk(const uint32_t (&v)[16], uint3
   return s;
 }
 
-__global__ __launch_bounds__(kThreads) void orb_level_pass2_kernel(const LevelPass A) {
+__global__ __launch_bounds__(kThreads) void orb_level_pass_kernel(const LevelPass A) {
   SOSVO_STREAMING_PRIO();
   __shared__ uint2 s_tab[kRowTabLds];
   const int rows = A.rows, cols = A.cols, strips = A.strips;
@@ -1342,7 +1176,7 @@ __global__ __launch_bounds__(kThreads, 4) void orb_select_kernel(LevelSrc S, con
     const uint8_t* sc = score + (size_t)img * P.total + P.off[l];
     const uint32_t* mk = mask_pyr + (size_t)(img / images_per_maskset) * P.total + P.off[l];
     const unsigned long long* fl = flags + (size_t)img * P.ftotal + P.foff[l];
-    // flag words of a row: one per 56-column strip (bit b = column 56 s - 4 + b), or -- flags2, orb_level_pass2_kernel's --
+    // flag words of a row: one per 56-column strip (bit b = column 56 s - 4 + b), or -- flags2, orb_level_pass_kernel's --
     // two per 120-column strip (bit b of word h = column 120 s - 4 + 2 b + h)
     const int strips = flags2 ? 2 * P.fstrips2[l] : P.fstrips[l];
     if (tid == 0) {
@@ -2056,7 +1890,7 @@ int32_t run_orb_detect(sosvo_ctx* ctx, const uint8_t* gray, const uint32_t* mask
   LevelSrc S{gray, W.pyr, (long long)rows * cols, P.total};
   SOSVO_LAUNCH(ctx, orb_select_kernel, dim3(orb_xcd_grid(nimg, nmask)), dim3(kThreads), 0, ctx->stream, S, W.score,
                W.flags, mask_pyr, W.bbox, P, images_per_maskset, nmask, cap, kp4, resp, n, nimg,
-               (have_flags && kOrbTwoPixelLanes) ? 1 : 0);
+               have_flags ? 1 : 0);
   SOSVO_LAUNCH_CHECK(ctx);
   return SOSVO_OK;
 }
@@ -2092,7 +1926,7 @@ int32_t run_orb_level_passes(sosvo_ctx* ctx, const uint8_t* gray, int nimg, int 
     A.nimg = nimg;
     A.rows = P.h[l];
     A.cols = P.w[l];
-    A.strips = kOrbTwoPixelLanes ? P.fstrips2[l] : P.fstrips[l];
+    A.strips = P.fstrips2[l];
     A.thr = kFastThr;
     A.rowtab = W.rowtab + (size_t)l * W.rowtab_stride;
     A.score = W.score + P.off[l];
@@ -2106,10 +1940,7 @@ int32_t run_orb_level_passes(sosvo_ctx* ctx, const uint8_t* gray, int nimg, int 
     A.next_stride = P.total;
     A.w1 = next ? P.w[l + 1] : 0;
     A.xtaps = next ? W.taps + P.toff[l + 1] : nullptr;
-    if (kOrbTwoPixelLanes)
-      SOSVO_LAUNCH(ctx, orb_level_pass2_kernel, dim3(cdiv(nimg * A.strips, kThreads / 64)), dim3(kThreads), 0, ctx->stream, A);
-    else
-      SOSVO_LAUNCH(ctx, orb_level_pass_kernel, dim3(cdiv(nimg * A.strips, kThreads / 64)), dim3(kThreads), 0, ctx->stream, A);
+    SOSVO_LAUNCH(ctx, orb_level_pass_kernel, dim3(cdiv(nimg * A.strips, kThreads / 64)), dim3(kThreads), 0, ctx->stream, A);
     SOSVO_LAUNCH_CHECK(ctx);
   }
   return SOSVO_OK;
