@@ -420,7 +420,7 @@ static int32_t launch_fast_score(sosvo_ctx* ctx, const uint8_t* in, long long im
 // the next y tap after every output row -- as many issue slots as the arithmetic.  Steps of the kernel's history (ms per 256
 // frame pairs, all five levels): separate kernels 3.23; one pass, one pixel per lane 3.02; row table 2.32; rows requested
 // seven ahead 2.14; mirrored halo lanes instead of an edge-strip variant (113 VGPRs: four waves per SIMD) 1.84; TWO pixels
-// per lane (below) 1.40.
+// per lane (below) 1.40, at four waves per SIMD 1.33.
 constexpr uint32_t kRtEmit = 1u << 31, kRtTopSelf = 1u << 28;  // word 0: dy | wy1 << 16 | flags
 constexpr uint32_t kRtHsum = 1u, kRtBlurOut = 2u, kRtFastRow = 4u, kRtScore = 8u, kRtFlagRow = 16u;  // word 1
 struct LevelPass {
@@ -517,8 +517,9 @@ constexpr int kRowTabLds = 1024;  // rows + 6 entries of the level's table in LD
 // wave and row now covers 120 owned columns instead of 56), the polarity mask is one 32-bit xor for both halves, predicates
 // are saturating packed subtractions (nonzero half = true), loads and blur stores are 16 bits wide.  Strip = 128 columns (120
 // owned, halo 4); shifted copies of a row: the neighbour lanes' pairs by DPP, the odd shifts by v_alignbit of two of them.
-// Flags: TWO words per (row, strip) -- bit b of word h is column strip * 120 - 4 + 2 b + h.  144 VGPRs (three waves per SIMD;
-// forced to 128 it spills 17 and runs 36 % slower).
+// Flags: TWO words per (row, strip) -- bit b of word h is column strip * 120 - 4 + 2 b + h.  127 VGPRs: four waves per SIMD
+// (with all seven shifted copies in rings and an unpacked ring of horizontal sums it was 144 and three waves: 1.40 ms against
+// 1.33; forced to 128 by the compiler that form spilled 17 registers and ran 36 % slower).
 typedef unsigned short orb_us2 __attribute__((ext_vector_type(2)));
 typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
 __device__ __forceinline__ orb_us2 pk_u(uint32_t x) { return __builtin_bit_cast(orb_us2, x); }
@@ -632,12 +633,14 @@ __global__ __launch_bounds__(kThreads) void orb_level_pass_kernel(const LevelPas
     }
   }
   // ring slot = (t + 3) mod 7; per slot the centre pair and its six shifted copies (packed)
-  uint32_t vc[7], vl1[7], vl2[7], vl3[7], vr1[7], vr2[7], vr3[7];
-  uint32_t hsl[7], hsh[7];
+  // (the even shifts -- the neighbour lanes' pairs themselves -- are NOT kept: one lane move from vc where FAST needs them, and
+  // fourteen registers fewer: with the packed ring of horizontal sums 127 VGPRs, four waves per SIMD instead of three)
+  uint32_t vc[7], vl1[7], vl3[7], vr1[7], vr3[7];
+  uint32_t hsp[7];  // horizontal sums of the last seven rows, packed (<= 255 * 256 per half)
 #pragma unroll
   for (int k = 0; k < 7; ++k) {
-    vc[k] = vl1[k] = vl2[k] = vl3[k] = vr1[k] = vr2[k] = vr3[k] = 0u;
-    hsl[k] = hsh[k] = 0u;
+    vc[k] = vl1[k] = vl3[k] = vr1[k] = vr3[k] = 0u;
+    hsp[k] = 0u;
   }
   uint32_t hm_a = 0u, hm_b = 0u, s_b = 0u, lr_b = 0u;  // NMS state (packed), as the one-pixel form's
   uint32_t hx_prev[2] = {0u, 0u};
@@ -657,6 +660,7 @@ __global__ __launch_bounds__(kThreads) void orb_level_pass_kernel(const LevelPas
     if (t > t_last) return;  // uniform
     const uint32_t e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e_next.x);
     const uint32_t e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e_next.y);
+    uint32_t row_nx, row_pv;  // row t's pairs of the neighbour lanes: (x+2, x+3), (x-2, x-1)
     {
       const uint32_t c = __builtin_amdgcn_perm(0u, c_pre[P], unpack_sel);  // row t: (x, x + 1) as 16-bit halves
       e_next = s_tab[min(t + 1, t_last) + 3];
@@ -664,11 +668,11 @@ __global__ __launch_bounds__(kThreads) void orb_level_pass_kernel(const LevelPas
       const uint32_t pv = (uint32_t)fs_from_left((int)c), pv2 = (uint32_t)fs_from_left((int)pv);     // (x-2, x-1), (x-4, x-3)
       vc[P] = c;
       vr1[P] = __builtin_amdgcn_alignbit(nx, c, 16);    // (x+1, x+2)
-      vr2[P] = nx;
       vr3[P] = __builtin_amdgcn_alignbit(nx2, nx, 16);  // (x+3, x+4)
       vl1[P] = __builtin_amdgcn_alignbit(c, pv, 16);    // (x-1, x)
-      vl2[P] = pv;
       vl3[P] = __builtin_amdgcn_alignbit(pv, pv2, 16);  // (x-3, x-2)
+      row_nx = nx;
+      row_pv = pv;
     }
     // ---- next level ----
     if (A.next) {  // uniform
@@ -676,7 +680,7 @@ __global__ __launch_bounds__(kThreads) void orb_level_pass_kernel(const LevelPas
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const uint32_t q0 = (uint32_t)__builtin_amdgcn_ds_bpermute(la[q], (int)vc[P]);
-        const uint32_t q1 = (uint32_t)__builtin_amdgcn_ds_bpermute(la[q], (int)vr2[P]);
+        const uint32_t q1 = (uint32_t)__builtin_amdgcn_ds_bpermute(la[q], (int)row_nx);
         const uint32_t win = __builtin_amdgcn_alignbit(q1, q0, (uint32_t)sh[q]);  // (pixel x0, pixel x0 + 1)
         hx[q] = orb_mad24(wx1[q], win >> 16, orb_mul24(2048u - wx1[q], win & 0xFFFFu));
       }
@@ -696,15 +700,16 @@ __global__ __launch_bounds__(kThreads) void orb_level_pass_kernel(const LevelPas
     if (e1 & kRtHsum) {  // uniform
       // horizontal sums fit 16 bits (255 * 256): packed multiply-adds
       const orb_us2 hp = pk_u(vc[P]) * (unsigned short)54 + (pk_u(vl1[P]) + pk_u(vr1[P])) * (unsigned short)49 +
-                         (pk_u(vl2[P]) + pk_u(vr2[P])) * (unsigned short)34 + (pk_u(vl3[P]) + pk_u(vr3[P])) * (unsigned short)18;
-      const uint32_t hpw = pk_w(hp);
-      hsl[P] = hpw & 0xFFFFu;
-      hsh[P] = hpw >> 16;
+                         (pk_u(row_pv) + pk_u(row_nx)) * (unsigned short)34 + (pk_u(vl3[P]) + pk_u(vr3[P])) * (unsigned short)18;
+      hsp[P] = pk_w(hp);
       if (e1 & kRtBlurOut) {  // uniform; rows t-6 .. t live in slots P+1 .. P+7 (mod 7)
-        const uint32_t vl = orb_mad24(18u, hsl[(P + 1) % 7] + hsl[P], orb_mad24(34u, hsl[(P + 2) % 7] + hsl[(P + 6) % 7],
-                                      orb_mad24(49u, hsl[(P + 3) % 7] + hsl[(P + 5) % 7], orb_mul24(54u, hsl[(P + 4) % 7]))));
-        const uint32_t vh = orb_mad24(18u, hsh[(P + 1) % 7] + hsh[P], orb_mad24(34u, hsh[(P + 2) % 7] + hsh[(P + 6) % 7],
-                                      orb_mad24(49u, hsh[(P + 3) % 7] + hsh[(P + 5) % 7], orb_mul24(54u, hsh[(P + 4) % 7]))));
+        // (the ring stays packed -- seven registers, not fourteen --; the vertical sums need 32 bits per half)
+        auto lo = [](uint32_t x) { return x & 0xFFFFu; };
+        auto hi = [](uint32_t x) { return x >> 16; };
+        const uint32_t h1 = hsp[(P + 1) % 7], h2 = hsp[(P + 2) % 7], h3 = hsp[(P + 3) % 7], h4 = hsp[(P + 4) % 7], h5 = hsp[(P + 5) % 7],
+                       h6 = hsp[(P + 6) % 7], h7 = hsp[P];
+        const uint32_t vl = orb_mad24(18u, lo(h1) + lo(h7), orb_mad24(34u, lo(h2) + lo(h6), orb_mad24(49u, lo(h3) + lo(h5), orb_mul24(54u, lo(h4)))));
+        const uint32_t vh = orb_mad24(18u, hi(h1) + hi(h7), orb_mad24(34u, hi(h2) + hi(h6), orb_mad24(49u, hi(h3) + hi(h5), orb_mul24(54u, hi(h4)))));
         const uint32_t bl = (vl + 32768u) >> 16, bh = (vh + 32768u) >> 16;
         uint8_t* o = bo + (uint32_t)((t - 3) * cols) + (uint32_t)x_lo;
         if (out_hi) {
@@ -721,8 +726,10 @@ __global__ __launch_bounds__(kThreads) void orb_level_pass_kernel(const LevelPas
     if (e1 & kRtScore) {  // uniform
       constexpr int s3 = (P + 7) % 7, s2 = (P + 6) % 7, s1 = (P + 5) % 7, s0 = (P + 4) % 7, m1 = (P + 3) % 7, m2 = (P + 2) % 7,
                     m3 = (P + 1) % 7;
-      const uint32_t v[16] = {vc[s3],  vr1[s3], vr2[s2], vr3[s1], vr3[s0], vr3[m1], vr2[m2], vr1[m3],
-                              vc[m3],  vl1[m3], vl2[m2], vl3[m1], vl3[s0], vl3[s1], vl2[s2], vl1[s3]};
+      const uint32_t r2s = (uint32_t)fs_from_right((int)vc[s2]), r2m = (uint32_t)fs_from_right((int)vc[m2]);  // (x+2, x+3) of rows y+2, y-2
+      const uint32_t l2s = (uint32_t)fs_from_left((int)vc[s2]), l2m = (uint32_t)fs_from_left((int)vc[m2]);    // (x-2, x-1)
+      const uint32_t v[16] = {vc[s3],  vr1[s3], r2s, vr3[s1], vr3[s0], vr3[m1], r2m, vr1[m3],
+                              vc[m3],  vl1[m3], l2m, vl3[m1], vl3[s0], vl3[s1], l2s, vl1[s3]};
       s = fast_score_pk(v, vc[s0], thr_pk, thrm1_pk, valid_pk);
     }
     // packed scores of the left / right neighbours: (x-1, x) and (x+1, x+2)
