@@ -12,6 +12,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "build", "libsosvo_oracle.so")
+# SOSVO_ORACLE_LIB: another build of the same sources (the sanitizer build of `make -C oracle sanitize`,
+# scripts/oracle_sanitize.sh); never set by the package, the bench or the GPU tests.
+_LIB_OVERRIDE = os.environ.get("SOSVO_ORACLE_LIB")
 _lib = None
 
 KEY_SHIFT = 20
@@ -32,7 +35,7 @@ def lib():
     global _lib
     if _lib is None:
         build()
-        _lib = ctypes.CDLL(LIB_PATH)
+        _lib = ctypes.CDLL(_LIB_OVERRIDE or LIB_PATH)
     return _lib
 
 
