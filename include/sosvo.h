@@ -71,6 +71,11 @@ int32_t sosvo_set_stream(sosvo_ctx* ctx, void* stream);
  * workgroups per CU so that the others find wave slots (+1.3 % on the three-stream step, -2.5 % for that kernel alone).
  * sosvo_frame_pair_batch_streams sets it on its internal contexts itself. */
 #define SOSVO_HINT_SHARED_DEVICE 1
+/* SOSVO_HINT_SCORE_FP64_ONLY (value != 0): the RANSAC scoring kernel skips its single-precision first tier (which decides
+ * an inlier test only where a proven rounding bound allows and leaves the rest to double precision) and evaluates every
+ * test in double precision, as rounds 1 - 3 did.  Same counts, bit for bit (tests/test_gpu_ransac.py compares the two
+ * forms); ~1.6 x the kernel's time.  For A/B measurements (scripts/score_tiers.py). */
+#define SOSVO_HINT_SCORE_FP64_ONLY 2
 int32_t sosvo_set_hint(sosvo_ctx* ctx, int32_t hint, int32_t value);
 int32_t sosvo_synchronize(sosvo_ctx* ctx);
 const char* sosvo_last_error(const sosvo_ctx* ctx);

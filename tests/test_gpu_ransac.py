@@ -231,3 +231,64 @@ def test_twopt_hypotheses_bit_exact(ctx):
     for b, pr in enumerate(probs):
         assert np.array_equal(got["T"][b][:, :3], np.eye(3)) and got["n_inliers"][b] >= 0.9 * pr["is_inlier"].sum()
     _run_batch(ctx, probs, 1024, False, 2000, seed=4, adaptive=True, twopt=True)
+
+
+def _threshold_cone_problem(rng, n, scale=1.0, f_scale=1.0, noncentral=True):
+    """Inliers whose bearing error sits ON the 5-degree cone of the true pose, give or take 1e-9 .. 1e-3 rad (the band
+    in which single precision cannot decide), plus ordinary inliers and outliers; world points scaled by `scale`
+    (the tracker's threshold is an angle: units do not matter to the reference), bearings by `f_scale`."""
+    pr = synth.make_abs_pose_problem(rng, n, inlier_frac=0.8, noise_deg=0.05, noncentral=noncentral)
+    f = pr["f"]
+    k = n // 2
+    ang = np.deg2rad(5.0) + rng.choice([-1.0, 1.0], k) * 10.0 ** rng.uniform(-9, -3, k)
+    ang[: k // 8] = np.deg2rad(5.0)
+    ax = np.cross(f[:k], rng.normal(size=(k, 3)))
+    ax /= np.linalg.norm(ax, axis=1, keepdims=True)
+    f[:k] = f[:k] * np.cos(ang)[:, None] + np.cross(ax, f[:k]) * np.sin(ang)[:, None]
+    order = rng.permutation(n)
+    for key in ("f", "p") + (("cam",) if noncentral else ()):
+        pr[key] = np.ascontiguousarray(pr[key][order])
+    if noncentral:  # the hypothesis kernel samples per camera: keep the cameras in blocks as the front end delivers them
+        o2 = np.argsort(pr["cam"], kind="stable")
+        for key in ("f", "p", "cam"):
+            pr[key] = np.ascontiguousarray(pr[key][o2])
+        pr["cam_off"] = pr["cam_off"] * scale
+    pr["p"] = pr["p"] * scale
+    pr["f"] = pr["f"] * f_scale
+    return pr
+
+
+def test_score_single_precision_tier_on_the_threshold_cone_and_odd_inputs(ctx):
+    """ransac_score_kernel's single-precision first tier (csrc/ransac.hip, score_tier1_*) may only decide where its
+    rounding bound allows: counts bit-exact against the oracle where the decision is hardest (bearings on the cone),
+    in other units (metres, kilometres, magnitudes beyond the tier's range and far below it), with bearings that are
+    not of unit length, and with NaN / inf coordinates -- and identical to the double-precision-only form."""
+    rng = np.random.default_rng(41)
+    probs = [_threshold_cone_problem(rng, 700), _threshold_cone_problem(rng, 400, f_scale=1.0 + 3e-7),
+             _threshold_cone_problem(rng, 300, f_scale=1.001), _threshold_cone_problem(rng, 300, f_scale=2.0)]
+    bad = _threshold_cone_problem(rng, 500)
+    bad["p"][7] = np.nan
+    bad["p"][300, 1] = np.inf
+    bad["f"][9, 2] = np.nan
+    bad["p"][11] = 0.0
+    bad["p"][12] = 1e200
+    probs.append(bad)
+    args, out, got = _run_batch(ctx, probs, 768, True, 300, seed=3, ident=True)
+    for scale in (1e-3, 1e-6, 1e12, 1e-17):  # (a batch shares one rig: the camera offsets scale with the points)
+        _run_batch(ctx, [_threshold_cone_problem(rng, 333, scale=scale), _threshold_cone_problem(rng, 130, scale=scale)], 384,
+                   True, 300, seed=5, ident=True)
+    central = [_threshold_cone_problem(rng, 640, noncentral=False), _threshold_cone_problem(rng, 90, scale=1e-3, noncentral=False)]
+    _run_batch(ctx, central, 640, False, 300, seed=4)
+    # the same launch without the tier: every output identical
+    tf, tp, tcam, tn, kw = args
+    ctx.set_hint_score_fp64_only(True)
+    try:
+        ref = ctx.ransac_abs_pose(tf, tp, tn, synth.THR_5DEG, 300, seed=3, want_counts=True, **kw)
+        ctx.synchronize()
+    finally:
+        ctx.set_hint_score_fp64_only(False)
+    for k in ("counts", "mask", "idx", "n_inliers", "info"):
+        assert torch.equal(ref[k], out[k]), k
+    assert np.array_equal(ref["T"].cpu().numpy(), got["T"], equal_nan=True)
+    # (the cone really is populated: the exact pose leaves a good share of every problem within 1e-3 rad of it)
+    assert got["n_inliers"][0] > 200

@@ -111,6 +111,7 @@ SIGNATURES = {
 }
 
 HINT_SHARED_DEVICE = 1
+HINT_SCORE_FP64_ONLY = 2
 FLAG_CAM_ROT_IDENTITY = 1
 FLAG_EPNP = 2
 FLAG_GP3P = 4

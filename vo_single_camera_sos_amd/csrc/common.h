@@ -33,6 +33,7 @@ struct sosvo_ctx {
   sosvo_ctx* sub[kSosvoMaxSubStreams];
   hipEvent_t sub_done[kSosvoMaxSubStreams], sub_median[kSosvoMaxSubStreams], sub_begin;
   int32_t n_sub;
+  int32_t hint_score_fp64_only;  // sosvo_set_hint(SOSVO_HINT_SCORE_FP64_ONLY): no single-precision tier in ransac_score_kernel
   int32_t hint_shared_device;  // sosvo_set_hint(SOSVO_HINT_SHARED_DEVICE): other streams' kernels share the chip
   int32_t sub_last;  // parts of the most recent sosvo_frame_pair_batch_streams[_enqueue] call
   // un-joined work of an ..._enqueue call is pending on the part streams: only then does the next call chain its first

@@ -40,8 +40,15 @@ int32_t sosvo_create(sosvo_ctx** out, int32_t device, void* stream) {
 
 int32_t sosvo_set_hint(sosvo_ctx* ctx, int32_t hint, int32_t value) {
   if (!ctx) return SOSVO_ERR_ARG;
-  if (hint != SOSVO_HINT_SHARED_DEVICE) return sosvo_fail(ctx, SOSVO_ERR_ARG, __func__, "unknown hint");
-  ctx->hint_shared_device = value != 0;
+  if (hint == SOSVO_HINT_SHARED_DEVICE) {
+    ctx->hint_shared_device = value != 0;
+  } else if (hint == SOSVO_HINT_SCORE_FP64_ONLY) {
+    ctx->hint_score_fp64_only = value != 0;
+    for (int i = 0; i < ctx->n_sub; ++i)  // the internal contexts of sosvo_frame_pair_batch_streams follow
+      if (ctx->sub[i]) ctx->sub[i]->hint_score_fp64_only = value != 0;
+  } else {
+    return sosvo_fail(ctx, SOSVO_ERR_ARG, __func__, "unknown hint");
+  }
   return SOSVO_OK;
 }
 

@@ -540,6 +540,7 @@ static int32_t sosvo_frame_pair_batch_streams_impl(sosvo_ctx* ctx, const sosvo_r
       return sosvo_fail(ctx, rc, __func__, "cannot create an internal stream context");
     }
     ctx->sub[i]->hint_shared_device = 1;  // the parts run side by side
+    ctx->sub[i]->hint_score_fp64_only = ctx->hint_score_fp64_only;
     SOSVO_HIP(ctx, hipEventCreateWithFlags(&ctx->sub_done[i], hipEventDisableTiming));
     SOSVO_HIP(ctx, hipEventCreateWithFlags(&ctx->sub_median[i], hipEventDisableTiming));
     ctx->n_sub = i + 1;

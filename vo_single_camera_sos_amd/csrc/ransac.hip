@@ -19,6 +19,7 @@
 //                  replayed over the counts; exact inlier mask + ascending index list of the winner.
 //   5. refine      one workgroup per problem, Levenberg-Marquardt on (t, Cayley) with fixed-order
 //                  reductions (deterministic run to run).
+#include <type_traits>
 #include "common.h"
 #include "ransac_core.h"
 #include "epnp_core.h"
@@ -301,16 +302,78 @@ __device__ __forceinline__ bool inlier_exact(const double* __restrict__ h, const
   return (1.0 - (((fx * gx) + (fy * gy)) + (fz * gz))) < thr;
 }
 
-template <bool IDENT, int PPT>
-__global__ __launch_bounds__(kThreads) void ransac_score_kernel(
+// ---- tier 1 of the scoring decision: single precision with a proven error term ------------------------------
+// The reference decides  1 - f.u/|u| < thr  with u = R p + (i - o), i.e. (thr < 0.5)  s > 0 and s^2 > c2 q  with
+// s = f.u, q = u.u, c2 = (1 - thr)^2.  Tier 1 evaluates s~, q~ in single precision (inputs rounded to float, the same
+// fma chains as the double-precision fast tier) and decides only where the outcome cannot depend on the rounding:
+//   every component of u~ is off by at most  E = 5.1 eps (rho P1 + |i|_inf + |o|_inf)   (eps = 2^-24, rho = max |R_k|,
+//   P1 = |px| + |py| + |pz|: two input roundings + at most three fma roundings per term), so |u~ - u| <= sqrt(3) E,
+//   |s~ - s| <= sqrt(3) E + 4.1 eps n,  |q~ - n^2| <= 3 eps n^2,  | |u|^2 - n^2 | <= 2 sqrt(3) n E + 3 E^2  (n = |u~|),
+//   and with  n E <= (K E^2 + n^2 / K) / 2  for any K > 0:
+//     s~^2 > (c2 + 3.47 / K + 20 eps) q~ + (3.47 K + 6) E^2   =>  s^2 > c2 (1 + 1e-9) q  and s > 0   (inlier),
+//     s~ <= 0  or  s~^2 < (c2 - 3.47 / K - 20 eps) q~ - (3.47 K + 6) E^2   =>  s <= 0 or s^2 < c2 (1 - 1e-9) q   (not one)
+//   (the 1e-9 margins are the double-precision fast tier's: beyond them its evaluation and the reference's agree).
+// E^2 <= 78.03 eps^2 (rho^2 P1^2 + |i|_inf^2 + |o|_inf^2) <= 78.03 eps^2 (max(rho^2, 1) (P1^2 + |o|_inf^2) + |i|_inf^2): one
+// fma of a per-hypothesis pair (ea, eb) with a per-lane constant.  K = 2^20 balances the two terms for |u| ~ |p|: the
+// band is ~6e-6 of c2 wide, 3e-5 rad around the threshold angle at 5 degrees.  The bound assumes float arithmetic without
+// overflow: hypotheses and points with a magnitude above 1e9, NaNs, and bearing vectors that are not of unit length get a
+// NaN / +inf error coefficient, every comparison with it is false and the lane stays undecided.
+constexpr double kTier1K = 1048576.0;
+constexpr double kTier1Eps = 5.9604644775390625e-08;
+constexpr double kTier1QBand = 3.47 / kTier1K + 20.0 * kTier1Eps;
+constexpr double kTier1Max = 1e9;
+constexpr double kTier1E2 = (3.47 * kTier1K + 6.0) * 78.03 * kTier1Eps * kTier1Eps * (1.0 + 1e-4);
+
+__device__ __forceinline__ float score_tier1_lane(double fx, double fy, double fz, double px, double py, double pz, double ox,
+                                                  double oy, double oz) {
+  const double p1 = fabs(px) + fabs(py) + fabs(pz);
+  const double om = fmax(fabs(ox), fmax(fabs(oy), fabs(oz)));
+  const double fn = fx * fx + fy * fy + fz * fz;
+  const double l = (p1 * p1 + om * om) * (1.0 + 1e-6);
+  // magnitudes up to 1e9 on both sides (kTier1Max): |u_k| <= 1e18 + 2e9, q <= 3.1e36 -- nothing overflows in float
+  return (fabs(fn - 1.0) <= 1e-6 && p1 <= kTier1Max && om <= kTier1Max) ? (float)l : __builtin_inff();
+}
+
+// h: R[9], -R^T t [3] in double precision -> hs[0..11] the same as floats, hs[12] = ea, hs[13] = eb (rounded up)
+__device__ __forceinline__ void score_tier1_hyp(const double* __restrict__ h, float* __restrict__ hs) {
+  double rho = 0.0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    hs[k] = (float)h[k];
+    rho = fmax(rho, fabs(h[k]));
+  }
+  const double im = fmax(fabs(h[9]), fmax(fabs(h[10]), fabs(h[11])));
+  hs[9] = (float)h[9], hs[10] = (float)h[10], hs[11] = (float)h[11];
+  // (fmax drops a NaN operand: test the sums, which keep it)
+  const double chk = (((((((h[0] + h[1]) + h[2]) + h[3]) + h[4]) + h[5]) + h[6]) + h[7]) + h[8] + h[9] + h[10] + h[11];
+  const double ea = kTier1E2 * fmax(rho * rho, 1.0) * (1.0 + 1e-6);
+  // the floor of eb keeps every lane with q below ~1e-24 undecided (float underflow in the squares is then < 1e-14 of q)
+  const double eb = kTier1E2 * (im * im) * (1.0 + 1e-6) + 1e-24;
+  const bool fin = chk == chk && rho <= kTier1Max && im <= kTier1Max;
+  hs[12] = fin ? (float)ea : __builtin_nanf("");
+  hs[13] = fin ? (float)eb : __builtin_nanf("");
+  hs[14] = 0.0f, hs[15] = 0.0f;
+}
+
+// T1 = false: double-precision tiers only (thr >= 0.5, or camera rotations that are not the identity) and the lane's
+// constants in double precision in registers.  T1 = true: tier 1 in front; the lane keeps the float copies and its
+// row, and re-reads bearing, point and camera offset in the rare fallback (128 VGPRs, four waves per SIMD).
+template <bool IDENT, int PPT, bool T1>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(T1 ? 4 : 1))) void ransac_score_kernel(
     const double* __restrict__ f, const double* __restrict__ p, const int32_t* __restrict__ cam,
     const double* __restrict__ cam_off, const double* __restrict__ cam_rot, const int32_t* __restrict__ n_arr,
-    int stride, int H, int hchunk, double thr, int fast_ok, const double* __restrict__ hyp,
+    int stride, int H, int hchunk, int hspan, double thr, int fast_ok, const double* __restrict__ hyp,
     int32_t* __restrict__ counts) {
+  static_assert(!T1 || (IDENT && PPT <= 4), "tier 1 is written for the identity-rotation form");
   SOSVO_LATENCY_BOUND_PRIO();
-  __shared__ int lcnt[kScoreHypChunkMax];
+  constexpr bool KEEP = !T1;
+  __shared__ int lcnt[kScoreHypChunkMax];  // by position in the compacted list
   __shared__ double shyp[kScoreHypChunkMax][12];
   __shared__ unsigned long long sok[(kScoreHypChunkMax + 63) / 64];  // bit = hypothesis of the chunk is a solved one
+  __shared__ int sidx[kScoreHypChunkMax];   // compacted list of the solved hypotheses of the chunk
+  // tier 1: the solved hypotheses once more in single precision, R, -R^T t and the two coefficients of the error term
+  // (see score_tier1_hyp), in list order
+  __shared__ float shyp32[T1 ? kScoreHypChunkMax : 1][16];
   const int tid = threadIdx.x, b = blockIdx.z;
   const int n = min(n_arr[b], stride);
   // XCD-aware grid: workgroups are dealt round-robin over the 8 XCDs by linear id, so the dimension with
@@ -324,137 +387,231 @@ __global__ __launch_bounds__(kThreads) void ransac_score_kernel(
   const int spb = (nsets + nb - 1) / nb;
   const int set0 = blockIdx.y * spb, set1 = min(set0 + spb, nsets);
   const int p0 = set0 * 64;
-  const int h0 = blockIdx.x * hchunk;
-  const int h1 = min(H, h0 + hchunk);
-  for (int k = tid; k < hchunk; k += kThreads) lcnt[k] = 0;
 
-  double fx[PPT], fy[PPT], fz[PPT], px[PPT], py[PPT], pz[PPT], ox[PPT], oy[PPT], oz[PPT];
+  double fx[KEEP ? PPT : 1], fy[KEEP ? PPT : 1], fz[KEEP ? PPT : 1];
+  double px[KEEP ? PPT : 1], py[KEEP ? PPT : 1], pz[KEEP ? PPT : 1];
+  double ox[KEEP ? PPT : 1], oy[KEEP ? PPT : 1], oz[KEEP ? PPT : 1];
+  float fxs[T1 ? PPT : 1], fys[T1 ? PPT : 1], fzs[T1 ? PPT : 1], pxs[T1 ? PPT : 1], pys[T1 ? PPT : 1], pzs[T1 ? PPT : 1];
+  float oxs[T1 ? PPT : 1], oys[T1 ? PPT : 1], ozs[T1 ? PPT : 1], lerr[T1 ? PPT : 1];
+  int rowi[PPT];  // the lane's row of set r, relative to the problem's first row
   double Rc[IDENT ? 1 : 9];
   // point sets of 64 are dealt round-robin over the 4 waves (set = r * 4 + wave): the live sets of a ragged
   // problem spread evenly, and a wave skips its sets beyond n altogether.  Everything that steers the hot loop
   // is wave-uniform and kept in SGPRs (wave index by readfirstlane, ballots, popcounts): the loop has scalar
   // branches only, no exec-mask juggling.
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  // wave w of a workgroup sits on SIMD w: which wave takes the short column of a ragged block rotates with the
+  // workgroup, or SIMD 0 would always carry the most sets and SIMD 3 the fewest
+  const int wslot = (wave + blockIdx.x + blockIdx.y + blockIdx.z) & (kThreads / 64 - 1);
   const size_t base = (size_t)b * stride;
-  bool live[PPT];
   unsigned long long vmask[PPT];
+  int nlive_v = 0;
 #pragma unroll
   for (int r = 0; r < PPT; ++r) {
-    const int set = set0 + r * (kThreads / 64) + wave;
+    const int set = set0 + r * (kThreads / 64) + wslot;
     const int i0 = set * 64;
     const int i = i0 + lane;
-    live[r] = set < set1;
+    nlive_v += set < set1 ? 1 : 0;
     const bool valid = i < n;
     vmask[r] = __ballot(valid);
-    const size_t row = base + (valid ? i : p0);
-    fx[r] = f[3 * row + 0];
-    fy[r] = f[3 * row + 1];
-    fz[r] = f[3 * row + 2];
-    px[r] = p[3 * row + 0];
-    py[r] = p[3 * row + 1];
-    pz[r] = p[3 * row + 2];
+    rowi[r] = valid ? i : p0;
+    const size_t row = base + rowi[r];
+    const double lfx = f[3 * row + 0], lfy = f[3 * row + 1], lfz = f[3 * row + 2];
+    const double lpx = p[3 * row + 0], lpy = p[3 * row + 1], lpz = p[3 * row + 2];
     const int c = cam ? cam[row] : 0;
     const double* o = cam ? cam_off + 3 * c : kZero3;
-    ox[r] = o[0];
-    oy[r] = o[1];
-    oz[r] = o[2];
+    const double lox = o[0], loy = o[1], loz = o[2];
+    if (KEEP) {
+      fx[r] = lfx, fy[r] = lfy, fz[r] = lfz;
+      px[r] = lpx, py[r] = lpy, pz[r] = lpz;
+      ox[r] = lox, oy[r] = loy, oz[r] = loz;
+    }
     if (!IDENT) {
       const double* rc = cam ? cam_rot + 9 * c : kEye9;
 #pragma unroll
       for (int k = 0; k < 9; ++k) Rc[k] = rc[k];
     }
+    if (T1) {
+      fxs[r] = (float)lfx, fys[r] = (float)lfy, fzs[r] = (float)lfz;
+      pxs[r] = (float)lpx, pys[r] = (float)lpy, pzs[r] = (float)lpz;
+      oxs[r] = (float)lox, oys[r] = (float)loy, ozs[r] = (float)loz;
+      lerr[r] = score_tier1_lane(lfx, lfy, lfz, lpx, lpy, lpz, lox, loy, loz);
+    }
   }
+  // the live sets of a wave are its first nlive ones (set grows with r); scalar
+  const int nlive = __builtin_amdgcn_readfirstlane(nlive_v);
   const double c1 = 1.0 - thr;
   const double c2 = c1 * c1;
   const double c2hi = c2 * (1.0 + 1e-9), c2lo = c2 * (1.0 - 1e-9);
-  // stage this chunk's hypotheses (R and -R^T t, 12 doubles each) in LDS with coalesced loads; the scoring
-  // loop then reads them as wave-wide LDS broadcasts instead of dependent scalar loads from L2
+  const float c2hs = (float)((c2 + kTier1QBand) * (1.0 + 1e-6)), c2ls = (float)((c2 - kTier1QBand) * (1.0 - 1e-6));
+  // the workgroup's hypotheses [blockIdx.x * hspan, + hspan) go through LDS in chunks of hchunk: the lanes' points are
+  // loaded and converted once for all of them
+  const int hend = min(H, ((int)blockIdx.x + 1) * hspan);
+  for (int h0 = blockIdx.x * hspan; h0 < hend; h0 += hchunk) {
+  const int h1 = min(hend, h0 + hchunk);
+  for (int k = tid; k < kScoreHypChunkMax; k += kThreads) lcnt[k] = 0;
+  const int nh = h1 - h0;
   const double* hb = hyp + ((size_t)b * H + h0) * kHypDoubles;
-  for (int k = tid; k < (h1 - h0) * 12; k += kThreads) {
-    const int hh = k / 12, e = k - hh * 12;
-    shyp[hh][e] = hb[(size_t)hh * kHypDoubles + (e < 9 ? e : e + 3)];
-  }
-  if (wave * 64 < h1 - h0) {  // wave w flags hypotheses [64 w, 64 w + 64): a failed minimal solve left a NaN in R[0]
+  static_assert(kScoreHypChunkMax == 128, "two words of solved-hypothesis flags");
+  if (wave < 2) {  // wave w flags hypotheses [64 w, 64 w + 64): a failed minimal solve left a NaN in R[0]
     const int hh = wave * 64 + lane;
-    const double r00 = hh < h1 - h0 ? hb[(size_t)hh * kHypDoubles] : 0.0;
-    const unsigned long long okb = __ballot(hh < h1 - h0 && r00 == r00);
+    const double r00 = hh < nh ? hb[(size_t)hh * kHypDoubles] : 0.0;
+    const unsigned long long okb = __ballot(hh < nh && r00 == r00);
     if (lane == 0) sok[wave] = okb;
   }
   __syncthreads();
-
-  for (int w64 = 0; w64 * 64 < h1 - h0; ++w64) {
-    const unsigned long long okw = sok[w64];
-    unsigned long long todo = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(okw >> 32)) << 32) |
-                              (uint32_t)__builtin_amdgcn_readfirstlane((int)okw);
-    while (todo) {
-      const int hh = w64 * 64 + __builtin_ctzll(todo);
-      todo &= todo - 1;
-      const double* hp = shyp[hh];
-      const double r0 = hp[0], r1 = hp[1], r2 = hp[2], r3 = hp[3], r4 = hp[4], r5 = hp[5], r6 = hp[6], r7 = hp[7], r8 = hp[8];
-      const double ix = hp[9], iy = hp[10], iz = hp[11];
-      // Fast decision with fused multiply-adds (21 instead of 34 FP64 ops): squared-cosine test with a relative
-      // guard band of 1e-9, five orders of magnitude above the rounding difference between this evaluation and
-      // the exact one for |p| / |u| < 1e6.  Lanes inside the band are left to the oracle's formula, operation for
-      // operation (no contraction), so the counts are identical to the sequential reference.  The predicates are
-      // combined without branches; one wave-wide test per hypothesis tells whether any lane is undecided.
-      int total = 0;
-      unsigned long long und[PPT], any = 0ULL;
-#pragma unroll
-      for (int r = 0; r < PPT; ++r) {
-        und[r] = 0ULL;
-        if (!live[r]) continue;  // scalar
-        if (fast_ok) {
-          double ux = fma(r0, px[r], fma(r3, py[r], fma(r6, pz[r], ix - ox[r])));
-          double uy = fma(r1, px[r], fma(r4, py[r], fma(r7, pz[r], iy - oy[r])));
-          double uz = fma(r2, px[r], fma(r5, py[r], fma(r8, pz[r], iz - oz[r])));
-          if (!IDENT) {
-            const double wx = ux, wy = uy, wz = uz;
-            ux = fma(Rc[0], wx, fma(Rc[IDENT ? 0 : 3], wy, Rc[IDENT ? 0 : 6] * wz));
-            uy = fma(Rc[IDENT ? 0 : 1], wx, fma(Rc[IDENT ? 0 : 4], wy, Rc[IDENT ? 0 : 7] * wz));
-            uz = fma(Rc[IDENT ? 0 : 2], wx, fma(Rc[IDENT ? 0 : 5], wy, Rc[IDENT ? 0 : 8] * wz));
-          }
-          const double s = fma(fx[r], ux, fma(fy[r], uy, fz[r] * uz));
-          const double q = fma(ux, ux, fma(uy, uy, uz * uz));
-          const double lhs = s * s;
-          // thr < 0.5: an inlier has cosine > 0.5, far from any rounding of s (NaN: not an inlier)
-          const unsigned long long pos = __ballot(s > 0.0) & vmask[r];
-          const unsigned long long hi = __ballot(lhs > c2hi * q);
-          const unsigned long long lo = __ballot(lhs < c2lo * q);
-          total += __popcll(pos & hi);
-          und[r] = pos & ~hi & ~lo;
-        } else {
-          und[r] = vmask[r];
-        }
-        any |= und[r];
-      }
-      if (any) {  // scalar; rare when fast_ok
-#pragma unroll
-        for (int r = 0; r < PPT; ++r) {
-          if (!und[r]) continue;  // scalar
-          const double vx = (((r0 * px[r]) + (r3 * py[r])) + (r6 * pz[r])) + ix;
-          const double vy = (((r1 * px[r]) + (r4 * py[r])) + (r7 * pz[r])) + iy;
-          const double vz = (((r2 * px[r]) + (r5 * py[r])) + (r8 * pz[r])) + iz;
-          const double wx = vx - ox[r], wy = vy - oy[r], wz = vz - oz[r];
-          double ux = wx, uy = wy, uz = wz;
-          if (!IDENT) {
-            ux = ((Rc[0] * wx) + (Rc[IDENT ? 0 : 3] * wy)) + (Rc[IDENT ? 0 : 6] * wz);
-            uy = ((Rc[IDENT ? 0 : 1] * wx) + (Rc[IDENT ? 0 : 4] * wy)) + (Rc[IDENT ? 0 : 7] * wz);
-            uz = ((Rc[IDENT ? 0 : 2] * wx) + (Rc[IDENT ? 0 : 5] * wy)) + (Rc[IDENT ? 0 : 8] * wz);
-          }
-          const double q = ((ux * ux) + (uy * uy)) + (uz * uz);
-          const double nrm = sqrt(q);
-          const double gx = ux / nrm, gy = uy / nrm, gz = uz / nrm;
-          total += __popcll(__ballot((1.0 - (((fx[r] * gx) + (fy[r] * gy)) + (fz[r] * gz))) < thr) & und[r]);
-        }
-      }
-      if (total && lane == 0) atomicAdd(&lcnt[hh], total);
+  // the solved hypotheses go to LDS as a compact list (position = rank among the solved ones, coalesced loads): the
+  // loop below walks it without bit scans and reads an entry as wave-wide LDS broadcasts
+  const unsigned long long ok0 = sok[0], ok1 = sok[1];
+  const int nok = __builtin_amdgcn_readfirstlane(__popcll(ok0) + __popcll(ok1));
+  for (int k = tid; k < nh * 12; k += kThreads) {
+    const int hh = k / 12, e = k - hh * 12;
+    const unsigned long long w = hh < 64 ? ok0 : ok1;
+    if ((w >> (hh & 63)) & 1ULL) {
+      const int pos = __popcll(w & ((1ULL << (hh & 63)) - 1ULL)) + (hh < 64 ? 0 : __popcll(ok0));
+      shyp[pos][e] = hb[(size_t)hh * kHypDoubles + (e < 9 ? e : e + 3)];
+      if (e == 0) sidx[pos] = hh;
     }
   }
   __syncthreads();
-  for (int k = tid; k < h1 - h0; k += kThreads) {
-    const int v = lcnt[k];
-    if (v) atomicAdd(&counts[(size_t)b * H + h0 + k], v);
+  if (T1) {
+    for (int pos = tid; pos < nok; pos += kThreads) score_tier1_hyp(shyp[pos], shyp32[pos]);
+    __syncthreads();
   }
+
+  // the double-precision tiers for the lanes `und1[r]` of one hypothesis; returns what they add to its count
+  auto tier2 = [&](auto nl, const int j, const unsigned long long* und1) -> int {
+    constexpr int NL = decltype(nl)::value;
+    int total = 0;
+    const double* hp = shyp[j];
+    const double r0 = hp[0], r1 = hp[1], r2 = hp[2], r3 = hp[3], r4 = hp[4], r5 = hp[5], r6 = hp[6], r7 = hp[7], r8 = hp[8];
+    const double ix = hp[9], iy = hp[10], iz = hp[11];
+    // Fast decision with fused multiply-adds (21 instead of 34 FP64 ops): squared-cosine test with a relative
+    // guard band of 1e-9, five orders of magnitude above the rounding difference between this evaluation and
+    // the exact one for |p| / |u| < 1e6.  Lanes inside the band are left to the oracle's formula, operation for
+    // operation (no contraction), so the counts are identical to the sequential reference.  The predicates are
+    // combined without branches; one wave-wide test per set tells whether any lane is undecided.
+#pragma unroll
+    for (int r = 0; r < NL && r < PPT; ++r) {
+      if (!und1[r]) continue;  // scalar
+      double Fx, Fy, Fz, Px, Py, Pz, Ox, Oy, Oz;
+      if (KEEP) {
+        Fx = fx[r], Fy = fy[r], Fz = fz[r], Px = px[r], Py = py[r], Pz = pz[r];
+        Ox = ox[r], Oy = oy[r], Oz = oz[r];
+      } else {
+        const size_t row = base + rowi[r];
+        Fx = f[3 * row + 0], Fy = f[3 * row + 1], Fz = f[3 * row + 2];
+        Px = p[3 * row + 0], Py = p[3 * row + 1], Pz = p[3 * row + 2];
+        const double* o = cam ? cam_off + 3 * cam[row] : kZero3;
+        Ox = o[0], Oy = o[1], Oz = o[2];
+      }
+      unsigned long long und = und1[r];
+      if (fast_ok) {
+        double ux = fma(r0, Px, fma(r3, Py, fma(r6, Pz, ix - Ox)));
+        double uy = fma(r1, Px, fma(r4, Py, fma(r7, Pz, iy - Oy)));
+        double uz = fma(r2, Px, fma(r5, Py, fma(r8, Pz, iz - Oz)));
+        if (!IDENT) {
+          const double wx = ux, wy = uy, wz = uz;
+          ux = fma(Rc[0], wx, fma(Rc[IDENT ? 0 : 3], wy, Rc[IDENT ? 0 : 6] * wz));
+          uy = fma(Rc[IDENT ? 0 : 1], wx, fma(Rc[IDENT ? 0 : 4], wy, Rc[IDENT ? 0 : 7] * wz));
+          uz = fma(Rc[IDENT ? 0 : 2], wx, fma(Rc[IDENT ? 0 : 5], wy, Rc[IDENT ? 0 : 8] * wz));
+        }
+        const double s = fma(Fx, ux, fma(Fy, uy, Fz * uz));
+        const double q = fma(ux, ux, fma(uy, uy, uz * uz));
+        const double lhs = s * s;
+        // thr < 0.5: an inlier has cosine > 0.5, far from any rounding of s (NaN: not an inlier)
+        const unsigned long long pos = __ballot(s > 0.0) & und1[r];
+        const unsigned long long hi = __ballot(lhs > c2hi * q);
+        const unsigned long long lo = __ballot(lhs < c2lo * q);
+        total += __popcll(pos & hi);
+        und = pos & ~hi & ~lo;
+      }
+      if (und) {  // scalar; rare when fast_ok
+        const double vx = (((r0 * Px) + (r3 * Py)) + (r6 * Pz)) + ix;
+        const double vy = (((r1 * Px) + (r4 * Py)) + (r7 * Pz)) + iy;
+        const double vz = (((r2 * Px) + (r5 * Py)) + (r8 * Pz)) + iz;
+        const double wx = vx - Ox, wy = vy - Oy, wz = vz - Oz;
+        double ux = wx, uy = wy, uz = wz;
+        if (!IDENT) {
+          ux = ((Rc[0] * wx) + (Rc[IDENT ? 0 : 3] * wy)) + (Rc[IDENT ? 0 : 6] * wz);
+          uy = ((Rc[IDENT ? 0 : 1] * wx) + (Rc[IDENT ? 0 : 4] * wy)) + (Rc[IDENT ? 0 : 7] * wz);
+          uz = ((Rc[IDENT ? 0 : 2] * wx) + (Rc[IDENT ? 0 : 5] * wy)) + (Rc[IDENT ? 0 : 8] * wz);
+        }
+        const double q = ((ux * ux) + (uy * uy)) + (uz * uz);
+        const double nrm = sqrt(q);
+        const double gx = ux / nrm, gy = uy / nrm, gz = uz / nrm;
+        total += __popcll(__ballot((1.0 - (((Fx * gx) + (Fy * gy)) + (Fz * gz))) < thr) & und);
+      }
+    }
+    return total;
+  };
+
+  // Tier 1 for one hypothesis of the list: the decision in single precision with a per-lane, per-hypothesis error
+  // term (score_tier1_lane, score_tier1_hyp: a proven bound on what single precision can do to s^2 - c2 q); 23
+  // fast-rate operations and two compares per set instead of 21 double-precision operations and three.  Lanes it
+  // cannot decide (~1e-4 of them; one wave-step in ~30 has any) are returned in und1 and go through tier2, so the
+  // counts stay those of the sequential reference.  Straight-line code over the wave's NL live sets.
+  auto tier1 = [&](auto nl, const int j, unsigned long long* und1, unsigned long long& any1) -> int {
+    constexpr int NL = decltype(nl)::value;
+    int total = 0;
+    const float* hs = shyp32[T1 ? j : 0];
+    const float q0 = hs[0], q1 = hs[1], q2 = hs[2], q3 = hs[3], q4 = hs[4], q5 = hs[5], q6 = hs[6], q7 = hs[7], q8 = hs[8];
+    const float jx = hs[9], jy = hs[10], jz = hs[11], ea = hs[12], eb = hs[13];
+#pragma unroll
+    for (int r = 0; r < NL && r < PPT; ++r) {
+      const float ux = fmaf(q0, pxs[T1 ? r : 0], fmaf(q3, pys[T1 ? r : 0], fmaf(q6, pzs[T1 ? r : 0], jx - oxs[T1 ? r : 0])));
+      const float uy = fmaf(q1, pxs[T1 ? r : 0], fmaf(q4, pys[T1 ? r : 0], fmaf(q7, pzs[T1 ? r : 0], jy - oys[T1 ? r : 0])));
+      const float uz = fmaf(q2, pxs[T1 ? r : 0], fmaf(q5, pys[T1 ? r : 0], fmaf(q8, pzs[T1 ? r : 0], jz - ozs[T1 ? r : 0])));
+      const float sv = fmaf(fxs[T1 ? r : 0], ux, fmaf(fys[T1 ? r : 0], uy, fzs[T1 ? r : 0] * uz));
+      const float qv = fmaf(ux, ux, fmaf(uy, uy, uz * uz));
+      const float sp = fmaxf(sv, 0.0f);
+      const float lhs = sp * sp;
+      const float e2 = fmaf(ea, lerr[T1 ? r : 0], eb);
+      const unsigned long long hi = __ballot(lhs > fmaf(c2hs, qv, e2));
+      const unsigned long long lo = __ballot(lhs < fmaf(c2ls, qv, -e2));
+      total += __popcll(hi & vmask[r]);
+      und1[r] = ~hi & ~lo & vmask[r];
+      any1 |= und1[r];
+    }
+    return total;
+  };
+
+  // the wave's count of live sets is fixed: the hypothesis loop exists once per count (no switch inside it).  The
+  // count of list entry j stays in lane j & 63 of the wave until 64 entries are through.
+  auto hyp_loop = [&](auto nl) {
+    constexpr int NL = decltype(nl)::value;
+    int cntv = 0;
+    for (int j = 0; j < nok; ++j) {
+      unsigned long long und[PPT], any = 0ULL;
+      int tot = 0;
+      if (T1) {
+        tot = tier1(nl, j, und, any);
+      } else {
+#pragma unroll
+        for (int r = 0; r < NL && r < PPT; ++r) {
+          und[r] = vmask[r];
+          any |= vmask[r];
+        }
+      }
+      if (any) tot += tier2(nl, j, und);  // scalar; with tier 1 in front: rare
+      if (lane == (j & 63)) cntv += tot;
+      if ((j & 63) == 63) {
+        if (cntv) atomicAdd(&lcnt[(j & ~63) + lane], cntv);
+        cntv = 0;
+      }
+    }
+    if (cntv) atomicAdd(&lcnt[((nok - 1) & ~63) + lane], cntv);
+  };
+  if (nlive >= 4) hyp_loop(std::integral_constant<int, 4>{});
+  else if (nlive == 3) hyp_loop(std::integral_constant<int, 3>{});
+  else if (nlive == 2) hyp_loop(std::integral_constant<int, 2>{});
+  else if (nlive == 1) hyp_loop(std::integral_constant<int, 1>{});
+  __syncthreads();
+  for (int k = tid; k < nok; k += kThreads) {
+    const int v = lcnt[k];
+    if (v) atomicAdd(&counts[(size_t)b * H + h0 + sidx[k]], v);
+  }
+  }  // chunks of the workgroup
 }
 
 // ---- 4. select ------------------------------------------------------------------------------
@@ -826,19 +983,26 @@ int32_t sosvo_ransac_abs_pose(sosvo_ctx* ctx, const double* f, const double* p, 
   // (point blocks beyond n exit at once, so the live workgroups are ~hchunks * nprob * cdiv(n, points per block))
   const int ppt = ident ? 4 : 1;
   const int gx = cdiv(stride, kThreads * ppt);
-  int hchunks = cdiv(8192, nprob);
+  // tier 1 in front: identity camera rotations and a threshold below 0.5 (the squared-cosine form of the test)
+  const bool t1 = ident && fast_ok && !ctx->hint_score_fp64_only;
+  // workgroups per launch: enough to fill the chip several times over; the tier-1 form amortises its per-lane set-up
+  // (loads, conversions, error constants) over twice the hypotheses (measured: 0.50 -> 0.47 ms per 256 x 1285 x 2000)
+  const int wg_target = t1 ? 4096 : 8192;
+  int hchunks = cdiv(wg_target, nprob);
   if (hchunks < 1) hchunks = 1;
-  int hchunk = cdiv(H, hchunks);
-  if (hchunk > kScoreHypChunkMax) hchunk = kScoreHypChunkMax;
-  if (hchunk < 32) hchunk = H < 32 ? H : 32;
-  hchunks = cdiv(H, hchunk);
+  int hspan = cdiv(H, hchunks);  // hypotheses per workgroup, in LDS chunks of at most kScoreHypChunkMax
+  if (hspan < 32) hspan = H < 32 ? H : 32;
+  hchunks = cdiv(H, hspan);
+  const int hchunk = cdiv(hspan, cdiv(hspan, kScoreHypChunkMax));
   dim3 grid(hchunks, gx, nprob);
-  if (ident)
-    SOSVO_LAUNCH(ctx,(ransac_score_kernel<true, 4>), grid, dim3(kThreads), 0, ctx->stream, f, p, cam, cam_off,
-                       cam_rot, n, stride, H, hchunk, thr, fast_ok, hyp, counts);
+#define SOSVO_SCORE_ARGS grid, dim3(kThreads), 0, ctx->stream, f, p, cam, cam_off, cam_rot, n, stride, H, hchunk, hspan, thr, fast_ok, hyp, counts
+  if (t1)
+    SOSVO_LAUNCH(ctx,(ransac_score_kernel<true, 4, true>), SOSVO_SCORE_ARGS);
+  else if (ident)
+    SOSVO_LAUNCH(ctx,(ransac_score_kernel<true, 4, false>), SOSVO_SCORE_ARGS);
   else
-    SOSVO_LAUNCH(ctx,(ransac_score_kernel<false, 1>), grid, dim3(kThreads), 0, ctx->stream, f, p, cam, cam_off,
-                       cam_rot, n, stride, H, hchunk, thr, fast_ok, hyp, counts);
+    SOSVO_LAUNCH(ctx,(ransac_score_kernel<false, 1, false>), SOSVO_SCORE_ARGS);
+#undef SOSVO_SCORE_ARGS
   SOSVO_LAUNCH_CHECK(ctx);
   if (ident)
     SOSVO_LAUNCH(ctx,(ransac_select_kernel<true>), dim3(nprob), dim3(kThreads), 0, ctx->stream, f, p, cam,

@@ -89,6 +89,11 @@ class Context(object):
         """sosvo_set_hint(SOSVO_HINT_SHARED_DEVICE): other contexts' kernels run beside this one's (scheduling only)."""
         self._call(self._lib.sosvo_set_hint, _lib.HINT_SHARED_DEVICE, 1 if on else 0)
 
+    def set_hint_score_fp64_only(self, on=True):
+        """sosvo_set_hint(SOSVO_HINT_SCORE_FP64_ONLY): RANSAC scoring without its single-precision first tier (same counts;
+        for A/B measurements and the cross-check of the two forms)."""
+        self._call(self._lib.sosvo_set_hint, _lib.HINT_SCORE_FP64_ONLY, 1 if on else 0)
+
     def set_stream(self, stream):
         """Enqueue on `stream` (a torch.cuda.Stream) from now on, e.g. the capture stream of a HIP graph."""
         self._call(self._lib.sosvo_set_stream, c_p(stream.cuda_stream))
