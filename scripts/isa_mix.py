@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CYC_E32, CYC_OTHER = 2.7, 4.4   # class means; per-opcode values below where measured
 FAST = {"v_and_b32": 2.79, "v_xor_b32": 2.84, "v_or_b32": 2.63, "v_not_b32": 2.58, "v_add_u32": 2.79, "v_sub_u32": 2.76,
         "v_subrev_u32": 2.76, "v_lshrrev_b32": 2.51, "v_ashrrev_i32": 2.60, "v_mov_b32": 2.57, "v_bitop3_b32": 2.67,
-        "v_add_f32": 2.79, "v_mul_f32": 2.55, "v_fma_f32": 2.81, "v_min_u16": 2.51, "v_max_u16": 2.51, "v_sub_u16": 2.77,
+        "v_add_f32": 2.79, "v_mul_f32": 2.55, "v_fma_f32": 2.81, "v_fmac_f32": 2.64, "v_sub_f32": 2.63, "v_subrev_f32": 2.63, "v_min_u16": 2.51, "v_max_u16": 2.51, "v_sub_u16": 2.77,
         "v_max_f16": 2.69}
 
 

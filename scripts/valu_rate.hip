@@ -75,6 +75,10 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, int iters, uint32_t seed
   if (OP == 68) asm volatile("v_pk_sub_i16 %0, %0, %1" : "+v"(a[i]) : "v"(b));                               \
   if (OP == 69) asm volatile("v_pk_lshrrev_b16 %0, 15, %0" : "+v"(a[i]) : );                                 \
   if (OP == 70) asm volatile("v_max_f16 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                  \
+  if (OP == 71) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));                         \
+  if (OP == 72) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                  \
+  if (OP == 73) asm volatile("v_cmp_gt_f32 vcc, %0, %1" : : "v"(a[i]), "v"(b) : "vcc");                      \
+  if (OP == 74) asm volatile("v_cmp_lt_f32 %0, %1, %2" : "=s"(bal) : "v"(a[i]), "v"(b));                     \
   if (OP == 4) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                   \
   if (OP == 5) asm volatile("v_lshrrev_b64 %0, %1, %2" : "=v"(bal) : "v"(a[i] & 63), "s"(bal2));             \
   if (OP == 6) asm volatile("v_cmp_ne_u32 %0, %1, %2" : "=s"(bal) : "v"(a[i]), "v"(b));                      \
@@ -195,5 +199,9 @@ int main() {
   run<68>("v_pk_sub_i16", out);
   run<69>("v_pk_lshrrev_b16", out);
   run<70>("v_max_f16", out);
+  run<71>("v_fmac_f32", out);
+  run<72>("v_sub_f32", out);
+  run<73>("v_cmp_gt_f32 vcc", out);
+  run<74>("v_cmp_lt_f32 sgpr", out);
   return 0;
 }
