@@ -71,6 +71,29 @@ def test_sequence_engine_equals_the_pair_batch_for_every_window(ctx):
         assert np.array_equal(got, want), (window, np.argwhere(got != want)[:6])
         assert counts_ref is None or counts == counts_ref
         counts_ref = counts
+        # the same windows staged and copied AHEAD on the engine's copy stream (what run_VO's helper thread does), through
+        # alternating pinned / device input buffers, from another host thread: the same records
+        if window in (2, 3):
+            import threading
+            eng3 = SequenceEngine(ctx, model, RigConfig(**rig_kw), window=window, **kw)
+            got3, buf = [], 0
+            chunks = [list(frames[w0:w0 + window]) for w0 in range(0, n, window)]
+
+            def stage(c, b):
+                eng3.stage_host(c, b)
+                eng3.upload_staged(b, len(c))
+            stage(chunks[0], 0)
+            for k, c in enumerate(chunks):
+                th = None
+                if k + 1 < len(chunks):     # the next window goes up while this one is pushed
+                    th = threading.Thread(target=stage, args=(chunks[k + 1], 1 - buf))
+                    th.start()
+                infos = eng3.push_staged(buf, len(c))
+                got3 += [info["spec"] for info in infos if info["spec"] is not None]
+                if th is not None:
+                    th.join()
+                buf = 1 - buf
+            assert np.array_equal(np.stack(got3), want), window
         # a serial call against the keyframe slot: frame 1 promoted, frame 3 tracked against it (not its predecessor)
         if window >= 4:
             eng2 = SequenceEngine(ctx, model, RigConfig(**rig_kw), window=window, **kw)

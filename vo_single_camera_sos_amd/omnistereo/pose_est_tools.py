@@ -819,6 +819,8 @@ def run_VO(visualizer_3D_VO, camera_model, gt_poses_filename=None, est_poses_fil
                         t0 = time.perf_counter()
                         eng.stage_host(images_of(c), b)
                         eng.stage_s["stage_to_pinned"] += time.perf_counter() - t0
+                        if eng.early_upload:
+                            eng.upload_staged(b, len(c))   # the copy to the device starts now, beside the current window's kernels
                         ready.put((c, b))
                     ready.put((None, None))
                 except BaseException as e:   # handed to the consumer

@@ -399,6 +399,8 @@ class _SequenceBase(object):
     was the reference and asks for one serial track() call where it was not.  Either way the records are those of the
     serial loop, whatever the window size.  Subclasses provide _stage / _front_end / _track / _counts / _copy."""
 
+    early_upload = True   # run_VO's staging thread starts a window's host-to-device copy itself (upload_staged); False: A/B
+
     def _init_windows(self, window):
         self.W = max(1, int(window))
         self.slots, self.key_slot = 2 * self.W + 1, 2 * self.W
@@ -413,6 +415,11 @@ class _SequenceBase(object):
         self.frames_seen = 0     # frames pushed so far (frame t of the sequence is tracked with seed t - 1)
         self.serial_calls = 0    # tracking calls the speculation did not cover
         self._key_src = None     # slot of a promoted frame whose record has not been copied to the keyframe slot yet
+        self._up_pending = [0, 0]  # frames of pinned buffer b already on their way to device buffer b (upload_staged)
+        if not hasattr(self, "_copy_stream"):
+            self._copy_stream, self._up_event = None, None
+        elif self._copy_stream is not None:
+            self._copy_stream.synchronize()   # (a copy an aborted run left in flight)
         self.stage_s = dict(stage_to_pinned=0.0, enqueue=0.0, wait_and_readback=0.0, serial_track=0.0)   # host wall clock
 
     def push_window(self, images):
@@ -435,6 +442,25 @@ class _SequenceBase(object):
         window into the other buffer while this one is processed (numpy's copy releases the GIL) -- run_VO does."""
         self._stage_host(images, int(buf))
 
+    def upload_staged(self, buf, n):
+        """Starts the host-to-device copy of the n frames staged in pinned buffer `buf` on the engine's COPY stream, into
+        device input buffer `buf`; push_staged(buf, n) then only waits for its event.  Optional: without it push_staged
+        copies on the compute stream itself.  The helper thread that staged the window calls it (run_VO does), so the copy
+        of window k + 1 runs on the DMA engines while window k's kernels run -- ~0.6 ms of 2.6 ms per window of 32 frames
+        off the GPU-side critical path.  Buffer `buf` (host and device side) is free again when the push_staged that
+        consumed it has returned (it synchronises)."""
+        import torch
+        buf, n = int(buf), int(n)
+        if n <= 0:
+            return
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=self.ctx.device)
+            self._up_event = [torch.cuda.Event(), torch.cuda.Event()]
+        with torch.cuda.stream(self._copy_stream):
+            self._upload(buf, n)
+            self._up_event[buf].record(self._copy_stream)
+        self._up_pending[buf] = n
+
     def push_staged(self, buf, n):
         """push_window for n frames already staged in pinned buffer `buf`."""
         import time
@@ -443,12 +469,17 @@ class _SequenceBase(object):
         if n > self.W:
             raise ValueError("more frames than the window holds")
         t1 = time.perf_counter()
+        buf = int(buf)
         self.half = 1 - self.half
         first = self.half * self.W
         if self._key_src is not None and first <= self._key_src < first + self.W:
             self._flush_promotion()   # the promoted frame's record is about to be overwritten
-        self._upload(int(buf), n)
-        self._front_end(n, first)
+        if self._up_pending[buf] == n:            # copied ahead by upload_staged: order the compute stream behind it
+            self.ctx.stream.wait_event(self._up_event[buf])
+        else:
+            self._upload(buf, n)
+        self._up_pending[buf] = 0
+        self._front_end(n, first, buf)
         # speculative tracking: frame i of the window against its predecessor (the first one against the previous
         # window's last frame; the very first frame of the sequence has nothing to track against)
         slots = [first + i for i in range(n)]
@@ -549,7 +580,7 @@ class SequenceEngine(_SequenceBase):
             raise ValueError("bad sequence configuration")
         dev = ctx.device
         self.workspace = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
-        self.omni = torch.zeros((self.W, model.H, model.W, 3), dtype=torch.uint8, device=dev)
+        self._omni = [torch.zeros((self.W, model.H, model.W, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
         self._host = [torch.zeros((self.W, model.H, model.W, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
         self._host_np = [h.numpy() for h in self._host]
         self.spec = torch.zeros((self.W, 16), dtype=torch.float64, device=dev)
@@ -560,12 +591,12 @@ class SequenceEngine(_SequenceBase):
         _stage_rows(self._host_np[buf], images)
 
     def _upload(self, buf, n):
-        self.omni[:n].copy_(self._host[buf][:n], non_blocking=True)
+        self._omni[buf][:n].copy_(self._host[buf][:n], non_blocking=True)
 
-    def _front_end(self, n, first):
+    def _front_end(self, n, first, buf):
         m = self.model
-        self.ctx.sequence_front_end(self.rig, self.cfg, self.W, self.slots, self.omni[:n], first, m.unwrap_table, m.mask_bits,
-                                    m.pattern, self.workspace)
+        self.ctx.sequence_front_end(self.rig, self.cfg, self.W, self.slots, self._omni[buf][:n], first, m.unwrap_table,
+                                    m.mask_bits, m.pattern, self.workspace)
 
     def _track(self, ref_slots, cur_slots, seed, out):
         self.ctx.sequence_track(self.rig, self.cfg, self.W, self.slots, ref_slots, cur_slots, seed, self.workspace, out)
@@ -817,8 +848,8 @@ class RGBDSequenceEngine(_SequenceBase):
         if nbytes <= 0:
             raise ValueError("bad sequence configuration")
         self.workspace = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
-        self.bgr = torch.zeros((self.W, rows, cols, 3), dtype=torch.uint8, device=dev)
-        self.depth = torch.zeros((self.W, rows, cols), dtype=torch.float32, device=dev)
+        self._bgr = [torch.zeros((self.W, rows, cols, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+        self._depth = [torch.zeros((self.W, rows, cols), dtype=torch.float32, device=dev) for _ in range(2)]
         self._host_bgr = [torch.zeros((self.W, rows, cols, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
         self._host_depth = [torch.zeros((self.W, rows, cols), dtype=torch.float32).pin_memory() for _ in range(2)]
         self._np_bgr, self._np_depth = [h.numpy() for h in self._host_bgr], [h.numpy() for h in self._host_depth]
@@ -831,11 +862,11 @@ class RGBDSequenceEngine(_SequenceBase):
         _stage_rows(self._np_depth[buf], [np.asarray(im[1], dtype=np.float32) for im in images])
 
     def _upload(self, buf, n):
-        self.bgr[:n].copy_(self._host_bgr[buf][:n], non_blocking=True)
-        self.depth[:n].copy_(self._host_depth[buf][:n], non_blocking=True)
+        self._bgr[buf][:n].copy_(self._host_bgr[buf][:n], non_blocking=True)
+        self._depth[buf][:n].copy_(self._host_depth[buf][:n], non_blocking=True)
 
-    def _front_end(self, n, first):
-        self.ctx.rgbd_sequence_front_end(self.cam, self.cfg, self.W, self.slots, self.bgr[:n], self.depth[:n], first,
+    def _front_end(self, n, first, buf):
+        self.ctx.rgbd_sequence_front_end(self.cam, self.cfg, self.W, self.slots, self._bgr[buf][:n], self._depth[buf][:n], first,
                                          self.mask_bits, self.pattern, self.workspace)
 
     def _track(self, ref_slots, cur_slots, seed, out):
