@@ -19,7 +19,8 @@ def main():
     ap.add_argument("--frames", type=int, default=256)
     ap.add_argument("--top", type=int, default=35)
     ap.add_argument("--window", type=int, default=32)
-    ap.add_argument("--ab", type=int, default=0, help="A/B of the early upload (copy stream): this many alternating run pairs, medians")
+    ap.add_argument("--ab", type=int, default=0, help="A/B of the early upload (copy stream) and of enqueueing the next window ahead: "
+                                                     "this many runs of each mode, interleaved; medians")
     args = ap.parse_args()
     from vo_single_camera_sos_amd import synthetic
     from vo_single_camera_sos_amd.omnistereo.gum import synthetic_gums
@@ -37,21 +38,22 @@ def main():
             yield k, seq[k], None
     if args.ab > 0:
         from vo_single_camera_sos_amd import pipeline
-        times = {True: [], False: []}
+        times = {0: [], 1: [], 2: []}
         with tempfile.TemporaryDirectory() as d:
             with contextlib.redirect_stdout(io.StringIO()):
                 run_VO(None, gs, results_path=d, _live_frames=lambda: frames(min(args.frames, 34)), frame_window=args.window)
-                for k in range(2 * args.ab):
-                    on = k % 2 == 0
-                    pipeline._SequenceBase.early_upload = on
+                for k in range(3 * args.ab):
+                    on = k % 3          # 0: neither, 1: early upload, 2: early upload + the next window enqueued ahead
+                    pipeline._SequenceBase.early_upload = on >= 1
+                    pipeline._SequenceBase.enqueue_ahead = on >= 2
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
                     run_VO(None, gs, results_path=d, _live_frames=frames, frame_window=args.window)
                     torch.cuda.synchronize()
                     times[on].append(time.perf_counter() - t0)
-        for on in (False, True):
+        for on in (0, 1, 2):
             ts = sorted(times[on])
-            print("early upload %-5s: median %.2f ms per %d frames = %.0f frames/s (min %.2f, max %.2f ms)" % (
+            print("mode %d (0 neither, 1 early upload, 2 + enqueue ahead): median %.2f ms per %d frames = %.0f frames/s (min %.2f, max %.2f ms)" % (
                 on, 1e3 * ts[len(ts) // 2], args.frames, args.frames / ts[len(ts) // 2], 1e3 * ts[0], 1e3 * ts[-1]))
         return
     with tempfile.TemporaryDirectory() as d:

@@ -94,6 +94,30 @@ def test_sequence_engine_equals_the_pair_batch_for_every_window(ctx):
                     th.join()
                 buf = 1 - buf
             assert np.array_equal(np.stack(got3), want), window
+        # windows enqueued AHEAD (run_VO's loop: window k + 1 is on the GPU while the host works through window k), with a
+        # keyframe whose half is refilled under it and a serial call behind the next window's work
+        if window == 2:
+            eng4 = SequenceEngine(ctx, model, RigConfig(**rig_kw), window=2, **kw)
+            with pytest.raises(RuntimeError):
+                eng4.collect()                                    # nothing pending
+            eng4.stage_host(list(frames[0:2]), 0)
+            eng4.enqueue_staged(0, 2)
+            with pytest.raises(RuntimeError):
+                eng4.enqueue_staged(1, 2)                         # one window may be pending
+            i0 = eng4.collect()
+            eng4.stage_host(list(frames[2:4]), 1)
+            eng4.enqueue_staged(1, 2)                             # window 1 goes ahead ...
+            eng4.promote(i0[1]["slot"])                           # ... while the host makes frame 1 the keyframe
+            i1 = eng4.collect()
+            eng4.stage_host(list(frames[4:6]), 0)
+            eng4.enqueue_staged(0, 2)                             # refills the half frame 1 lives in: its record moves first
+            rec = eng4.track(eng4.key_slot, i1[1]["slot"], seed=2)   # frame 3 against keyframe 1, behind window 2's work
+            pb = FramePairBatch(ctx, model, RigConfig(**rig_kw), 1, seed=2, **kw)
+            pb.load_frames(frames[[1, 3]])
+            assert np.array_equal(rec, pb.step().cpu().numpy()[0])
+            i2 = eng4.collect()
+            got4 = [i["spec"] for i in i0 + i1 + i2 if i["spec"] is not None]
+            assert np.array_equal(np.stack(got4), want[:5])
         # a serial call against the keyframe slot: frame 1 promoted, frame 3 tracked against it (not its predecessor)
         if window >= 4:
             eng2 = SequenceEngine(ctx, model, RigConfig(**rig_kw), window=window, **kw)

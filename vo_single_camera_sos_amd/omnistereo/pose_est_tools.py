@@ -832,17 +832,37 @@ def run_VO(visualizer_3D_VO, camera_model, gt_poses_filename=None, est_poses_fil
             worker.start()
             seq_index, buf = 0, 0
             try:
+                t0 = time.perf_counter()
+                eng.enqueue_staged(buf, len(chunk))
+                engine_state["window_s"] += time.perf_counter() - t0
                 while chunk:
                     t0 = time.perf_counter()
-                    infos = eng.push_staged(buf, len(chunk))     # (synchronises: the upload from `buf` is complete)
-                    engine_state["window_s"] += time.perf_counter() - t0
+                    infos = eng.collect()                        # (synchronises: the upload from `buf` is complete)
                     engine_state["windows"] += 1
                     free.put(buf)
+                    # the next window goes onto the GPU BEFORE this one's records are worked through, when the helper thread
+                    # has it staged already (an image sequence: nearly always; a live source: never -- its frames are not
+                    # held back for it)
+                    nxt = None
+                    if eng.enqueue_ahead:
+                        try:
+                            nxt = ready.get_nowait()
+                        except queue.Empty:
+                            nxt = None
+                        if nxt is not None and nxt[0] is not None and not isinstance(nxt[0], BaseException):
+                            eng.enqueue_staged(nxt[1], len(nxt[0]))
+                    engine_state["window_s"] += time.perf_counter() - t0
                     flush_output()                               # the previous window's lines, off the per-frame path
                     for item, info in zip(chunk, infos):
                         yield item[0], item[1], None, info, seq_index
                         seq_index += 1
-                    chunk, buf = ready.get()
+                    if nxt is None:
+                        nxt = ready.get()
+                        if nxt[0] is not None and not isinstance(nxt[0], BaseException):
+                            t0 = time.perf_counter()
+                            eng.enqueue_staged(nxt[1], len(nxt[0]))
+                            engine_state["window_s"] += time.perf_counter() - t0
+                    chunk, buf = nxt
                     if isinstance(chunk, BaseException):
                         raise chunk
             finally:

@@ -400,6 +400,7 @@ class _SequenceBase(object):
     serial loop, whatever the window size.  Subclasses provide _stage / _front_end / _track / _counts / _copy."""
 
     early_upload = True   # run_VO's staging thread starts a window's host-to-device copy itself (upload_staged); False: A/B
+    enqueue_ahead = True  # run_VO enqueues window k + 1 before it works through window k's records (enqueue_staged); False: A/B
 
     def _init_windows(self, window):
         self.W = max(1, int(window))
@@ -415,6 +416,7 @@ class _SequenceBase(object):
         self.frames_seen = 0     # frames pushed so far (frame t of the sequence is tracked with seed t - 1)
         self.serial_calls = 0    # tracking calls the speculation did not cover
         self._key_src = None     # slot of a promoted frame whose record has not been copied to the keyframe slot yet
+        self._pending = None     # the window enqueue_staged() put on the stream and collect() has not fetched yet
         self._up_pending = [0, 0]  # frames of pinned buffer b already on their way to device buffer b (upload_staged)
         if not hasattr(self, "_copy_stream"):
             self._copy_stream, self._up_event = None, None
@@ -462,12 +464,25 @@ class _SequenceBase(object):
         self._up_pending[buf] = n
 
     def push_staged(self, buf, n):
-        """push_window for n frames already staged in pinned buffer `buf`."""
-        import time
+        """push_window for n frames already staged in pinned buffer `buf`: enqueue_staged + collect."""
         if n == 0:
             return []
-        if n > self.W:
-            raise ValueError("more frames than the window holds")
+        self.enqueue_staged(buf, n)
+        return self.collect()
+
+    def enqueue_staged(self, buf, n):
+        """The device work of push_staged(buf, n) WITHOUT waiting for it: copy (or the wait for upload_staged's copy), front end,
+        the two speculative tracking batches.  collect() synchronises and returns the window's records.  A caller that has
+        the next window ready enqueues it BEFORE it works through the records of the current one (run_VO does): the GPU
+        then runs window k + 1 while the host's keyframe policy runs on window k.  What keeps that safe: the window halves
+        alternate (window k + 1 refills the half of window k - 1), a promoted frame's record is copied to the keyframe slot
+        before its half is refilled (here, as ever), serial track() calls read the keyframe slot and a slot of window k
+        only, and everything is ordered on one stream.  One window may be pending."""
+        import time
+        if n <= 0 or n > self.W:
+            raise ValueError("1 .. window frames per push")
+        if self._pending is not None:
+            raise RuntimeError("collect() the pending window first")
         t1 = time.perf_counter()
         buf = int(buf)
         self.half = 1 - self.half
@@ -500,24 +515,34 @@ class _SequenceBase(object):
         prev2 = [older[k0 + i - 2] for i in range(n) if k0 + i - 2 >= 0]
         if cur2:
             self._track(prev2, cur2, self.frames_seen + (n - len(cur2)) - 1, self.spec2)
-        t2 = time.perf_counter()
-        counts = self._counts(first, n)   # synchronises
-        spec = self.spec[:len(cur)].cpu().numpy() if cur else np.zeros((0, 16))
-        spec2 = self.spec2[:len(cur2)].cpu().numpy() if cur2 else np.zeros((0, 16))
-        t3 = time.perf_counter()
-        self.stage_s["enqueue"] += t2 - t1
-        self.stage_s["wait_and_readback"] += t3 - t2
-        out = []
-        for i in range(n):
-            t = self.frames_seen + i            # index of the frame in the sequence
-            j = i if self.last_slot is not None else i - 1
-            has = j >= 0 and len(cur) > 0
-            j2 = i - (n - len(cur2))
-            out.append(dict(slot=slots[i], count=counts[i], seed=max(t - 1, 0), spec_ref=prev[j] if has else None,
-                            spec=spec[j].copy() if has else None, spec2=spec2[j2].copy() if j2 >= 0 else None))
+        self._pending = dict(first=first, n=n, slots=slots, prev=prev, n_cur=len(cur), n_cur2=len(cur2),
+                             frames_seen=self.frames_seen, had_last=self.last_slot is not None)
         self.frames_seen += n
         self.last2_slot = slots[-2] if n >= 2 else self.last_slot
         self.last_slot = slots[-1]
+        self.stage_s["enqueue"] += time.perf_counter() - t1
+
+    def collect(self):
+        """Waits for the window enqueue_staged() put on the stream and returns its n dicts (see push_window)."""
+        import time
+        p = self._pending
+        if p is None:
+            raise RuntimeError("no window pending")
+        t2 = time.perf_counter()
+        n, slots, prev = p["n"], p["slots"], p["prev"]
+        counts = self._counts(p["first"], n)   # synchronises
+        spec = self.spec[:p["n_cur"]].cpu().numpy() if p["n_cur"] else np.zeros((0, 16))
+        spec2 = self.spec2[:p["n_cur2"]].cpu().numpy() if p["n_cur2"] else np.zeros((0, 16))
+        self._pending = None
+        self.stage_s["wait_and_readback"] += time.perf_counter() - t2
+        out = []
+        for i in range(n):
+            t = p["frames_seen"] + i            # index of the frame in the sequence
+            j = i if p["had_last"] else i - 1
+            has = j >= 0 and p["n_cur"] > 0
+            j2 = i - (n - p["n_cur2"])
+            out.append(dict(slot=slots[i], count=counts[i], seed=max(t - 1, 0), spec_ref=prev[j] if has else None,
+                            spec=spec[j].copy() if has else None, spec2=spec2[j2].copy() if j2 >= 0 else None))
         return out
 
     def track(self, ref_slot, cur_slot, seed):
