@@ -266,8 +266,10 @@ def sequence_subrecord(seq_omni, seq_poses, pano_width, mirror_frames=32):
     out["mirror_max_abs_pose_difference"] = float(np.abs(a - b).max())
     out["value"], out["unit"] = out["frame_window_32"]["frames_per_s"], "frames/s"
     hw = out["frame_window_32"].get("host_wall_s")
-    if hw:   # what the host spent WAITING for the GPU (front ends + speculative tracking of a window, serial tracking calls)
-        out["gpu_ms_per_frame"] = 1e3 * (hw["wait_and_readback"] + hw["serial_track"]) / out["frame_window_32"]["frames"]
+    if hw:   # the windows' time on the stream (events around a window's front end + speculative tracking; the loop enqueues
+        # window k + 1 under the host's work on window k, so the host's WAIT is shorter than this) + the serial tracking calls
+        gpu_s = hw.get("gpu_windows") or hw["wait_and_readback"]
+        out["gpu_ms_per_frame"] = 1e3 * (gpu_s + hw["serial_track"]) / out["frame_window_32"]["frames"]
     return out
 
 

@@ -419,10 +419,11 @@ class _SequenceBase(object):
         self._pending = None     # the window enqueue_staged() put on the stream and collect() has not fetched yet
         self._up_pending = [0, 0]  # frames of pinned buffer b already on their way to device buffer b (upload_staged)
         if not hasattr(self, "_copy_stream"):
-            self._copy_stream, self._up_event = None, None
+            self._copy_stream, self._up_event, self._win_events = None, None, None
         elif self._copy_stream is not None:
             self._copy_stream.synchronize()   # (a copy an aborted run left in flight)
-        self.stage_s = dict(stage_to_pinned=0.0, enqueue=0.0, wait_and_readback=0.0, serial_track=0.0)   # host wall clock
+        # host wall clock per stage; gpu_windows: the windows' own time on the stream (events around enqueue_staged's work)
+        self.stage_s = dict(stage_to_pinned=0.0, enqueue=0.0, wait_and_readback=0.0, serial_track=0.0, gpu_windows=0.0)
 
     def push_window(self, images):
         """images: list of n <= window frames that continue the sequence (omnistereo: omni images [H,W,3] u8; RGB-D:
@@ -485,10 +486,14 @@ class _SequenceBase(object):
             raise RuntimeError("collect() the pending window first")
         t1 = time.perf_counter()
         buf = int(buf)
+        if self._win_events is None:
+            import torch
+            self._win_events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         self.half = 1 - self.half
         first = self.half * self.W
         if self._key_src is not None and first <= self._key_src < first + self.W:
             self._flush_promotion()   # the promoted frame's record is about to be overwritten
+        self._win_events[0].record(self.ctx.stream)
         if self._up_pending[buf] == n:            # copied ahead by upload_staged: order the compute stream behind it
             self.ctx.stream.wait_event(self._up_event[buf])
         else:
@@ -515,6 +520,7 @@ class _SequenceBase(object):
         prev2 = [older[k0 + i - 2] for i in range(n) if k0 + i - 2 >= 0]
         if cur2:
             self._track(prev2, cur2, self.frames_seen + (n - len(cur2)) - 1, self.spec2)
+        self._win_events[1].record(self.ctx.stream)
         self._pending = dict(first=first, n=n, slots=slots, prev=prev, n_cur=len(cur), n_cur2=len(cur2),
                              frames_seen=self.frames_seen, had_last=self.last_slot is not None)
         self.frames_seen += n
@@ -535,6 +541,7 @@ class _SequenceBase(object):
         spec2 = self.spec2[:p["n_cur2"]].cpu().numpy() if p["n_cur2"] else np.zeros((0, 16))
         self._pending = None
         self.stage_s["wait_and_readback"] += time.perf_counter() - t2
+        self.stage_s["gpu_windows"] += 1e-3 * self._win_events[0].elapsed_time(self._win_events[1])
         out = []
         for i in range(n):
             t = p["frames_seen"] + i            # index of the frame in the sequence
