@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--frames", type=int, default=256)
     ap.add_argument("--top", type=int, default=35)
     ap.add_argument("--window", type=int, default=32)
+    ap.add_argument("--stage-threads", type=int, default=0, help="threads of the staging copies (0 = the package's default)")
     ap.add_argument("--ab", type=int, default=0, help="A/B of the early upload (copy stream) and of enqueueing the next window ahead: "
                                                      "this many runs of each mode, interleaved; medians")
     args = ap.parse_args()
@@ -32,6 +33,9 @@ def main():
     seq, _ = synthetic.make_sequence(gs, args.frames, seed=1241, workers=min(16, len(os.sched_getaffinity(0))))
     import torch
     from vo_single_camera_sos_amd.omnistereo.pose_est_tools import run_VO
+    if args.stage_threads > 0:
+        from vo_single_camera_sos_amd import pipeline as _p
+        _p._STAGE_THREADS = args.stage_threads
 
     def frames(n=args.frames):
         for k in range(n):

@@ -374,6 +374,7 @@ class FramePairBatch(object):
 
 
 _STAGE_POOL = None
+_STAGE_THREADS = 4
 
 
 def _stage_rows(dst_np, images):
@@ -387,7 +388,7 @@ def _stage_rows(dst_np, images):
         return
     if _STAGE_POOL is None:
         from concurrent.futures import ThreadPoolExecutor
-        _STAGE_POOL = ThreadPoolExecutor(4, thread_name_prefix="sosvo-stage")
+        _STAGE_POOL = ThreadPoolExecutor(_STAGE_THREADS, thread_name_prefix="sosvo-stage")
     list(_STAGE_POOL.map(lambda i: np.copyto(dst_np[i], images[i]), range(len(images))))
 
 
