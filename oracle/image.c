@@ -29,7 +29,9 @@
  * differ in rounding details by version).  (3) The annulus masks are x^2 + y^2 <= r^2 discs built on the
  * host, not OpenCV's circle rasteriser.
  * Parity status: UNPINNED against OpenCV binaries (no golden vectors exist in the reference); pinned by
- * hand-checkable known-answer tests in tests/test_oracle_image.py.
+ * hand-checkable known-answer tests in tests/test_oracle_image.py and by third-party implementations on photographs
+ * (tests/test_oracle_thirdparty.py: median, FAST-9 corner set, remap, ORB orientation / Harris response, the Gaussian, and --
+ * every descriptor byte -- the rotated-BRIEF sampling rule against scikit-image's ORB descriptor loop).
  */
 #include <math.h>
 #include <stdint.h>

@@ -5,6 +5,8 @@ tests/golden/make_thirdparty_fixtures.py.  Bit-exact 
   sosvo_detect_fast      keypoints lie in skimage.feature.corner_fast's FAST-9 corner set and cover its components
   sosvo_match_hamming    1-NN / 2-NN keys == skimage.feature.match_descriptors / scipy cdist on skimage ORB descriptors
   sosvo_unwrap           == round-half-up of scipy's exact bilinear value on the 1/32-pixel grid, border taps 0
+  sosvo_describe_orb / sosvo_describe_orb_levels  == skimage.feature.orb_cy._orb_loop (the rotated-BRIEF sampling of its ORB) on the
+                         7 x 7-Gaussian-blurred photograph, one angle per call and one angle per keypoint: every descriptor byte
 These are not OpenCV binaries (K1-K7 stay "parity unpinned" against those)."""
 import numpy as np
 import pytest
@@ -105,3 +107,30 @@ def test_orb_orientation_agrees_with_skimage_corner_orientations(ctx, tag, gray,
     tp.check_orientations(kp4[0, :k].cpu().numpy(), xy, angle)
     harris = dict((t, h) for t, _, _, h in tp.harris_cases())[tag]   # the same run's Harris responses against scipy's
     tp.check_harris(kp4[0, :k].cpu().numpy(), resp[0, :k].cpu().numpy(), xy, harris)
+
+
+@pytest.mark.parametrize("tag,gray,xy,angles,descs,angle_each,desc_each", tp.brief_cases(), ids=lambda v: v if isinstance(v, str) else "")
+def test_rotated_brief_descriptors_equal_skimage_orb_loop(ctx, tag, gray, xy, angles, descs, angle_each, desc_each):
+    """sosvo_describe_orb (one angle per call: the GFT path; blur + orb_describe_kernel) and sosvo_describe_orb_levels (an angle
+    per keypoint: the ORB path; pyramid + blur + orb_describe_levels_kernel) on photographs: every descriptor byte equal to
+    scikit-image's ORB descriptor loop at the same positions and angles."""
+    from vo_single_camera_sos_amd import orb_pattern as op
+    n = len(xy)
+    cap = -(-n // 64) * 64
+    t_img, t_pat = _to(ctx.device, gray[None], op.orb_pattern())
+    kp = np.zeros((1, cap, 2), np.float32)
+    kp[0, :n] = xy
+    for deg, want in zip(angles, descs):
+        ca, sa = op.angle_cos_sin(deg)
+        t_kp, t_n = _to(ctx.device, kp.copy(), np.array([n], np.int32))
+        desc = ctx.describe_orb(t_img, t_kp, t_n, 1, t_pat, float(ca), float(sa))
+        ctx.synchronize()
+        assert int(t_n.cpu().numpy()[0]) == n and np.array_equal(t_kp.cpu().numpy()[0, :n], kp[0, :n])   # nothing dropped
+        assert np.array_equal(desc.cpu().numpy()[0, :n], want), (tag, deg)
+    kp4 = np.zeros((1, cap, 4), np.float32)
+    kp4[0, :n, :2], kp4[0, :n, 2] = xy, angle_each
+    t_kp4, t_n = _to(ctx.device, kp4, np.array([n], np.int32))
+    desc, kp_xy = ctx.describe_orb_levels(t_img, t_kp4, t_n, 1, t_pat)
+    ctx.synchronize()
+    assert int(t_n.cpu().numpy()[0]) == n and np.array_equal(kp_xy.cpu().numpy()[0, :n], xy.astype(np.float32))
+    assert np.array_equal(desc.cpu().numpy()[0, :n], desc_each), tag

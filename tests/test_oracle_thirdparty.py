@@ -63,3 +63,19 @@ def test_orb_harris_response_agrees_with_scipy(tag, gray, xy, harris):
 @pytest.mark.parametrize("tag,gray,want", tp.gauss7_cases(), ids=lambda v: v if isinstance(v, str) else "")
 def test_gauss7_equals_scipy_integer_correlation(tag, gray, want):
     assert np.array_equal(oracle.gauss7(gray), want)
+
+
+@pytest.mark.parametrize("tag,gray,xy,angles,descs,angle_each,desc_each", tp.brief_cases(), ids=lambda v: v if isinstance(v, str) else "")
+def test_rotated_brief_descriptors_equal_skimage_orb_loop(tag, gray, xy, angles, descs, angle_each, desc_each):
+    """K6's sampling rule (OpenCV's table, x / y columns, rotation + rounding, comparison, bit order) against scikit-image's
+    ORB descriptor loop on photographs: every bit of every descriptor, for one angle per call (the GFT path) and one angle per
+    keypoint (the ORB path, level 0)."""
+    import vo_single_camera_sos_amd.orb_pattern as op
+    blurred = oracle.gauss7(gray)
+    for deg, want in zip(angles, descs):
+        ca, sa = op.angle_cos_sin(deg)
+        d, kept = oracle.orb_describe(blurred, xy.astype(np.float32), ca, sa, op.orb_pattern(), 31)
+        assert len(kept) == len(xy) and np.array_equal(d, want), (tag, deg)
+    kp4 = np.concatenate([xy.astype(np.float32), angle_each[:, None].astype(np.float32), np.zeros((len(xy), 1), np.float32)], axis=1)
+    d, kept = oracle.orb_describe_levels(gray, kp4, op.orb_pattern())
+    assert len(kept) == len(xy) and np.array_equal(d, desc_each), tag

@@ -135,3 +135,13 @@ def check_orientations(kp4, xy, angle_deg, tol_deg=0.02):
     d = np.minimum(d, 360.0 - d)
     assert d.max() <= tol_deg, (float(d.max()), int(d.argmax()))
     return float(d.max())
+
+
+def brief_cases():
+    """-> list of (tag, gray [rows, cols] u8, xy [n, 2] i32, angles_deg list, desc per angle [n, 32] u8, angle_each_deg [n] f32,
+    desc_each [n, 32] u8): rotated-BRIEF descriptors by scikit-image's descriptor loop on the grey crops of the orientation
+    fixture after the 7 x 7 fixed-point Gaussian (tests/golden/make_thirdparty_brief.py)."""
+    B, G = load("brief"), load("orientation")
+    angles = [float(a) for a in B["angles_deg"]]
+    return [(tag, G[tag + "_gray"], B[tag + "_xy"], angles, [B[tag + "_desc_%d" % k] for k in range(len(angles))],
+             B[tag + "_angle_each_deg"], B[tag + "_desc_each"]) for tag in ("camera", "astronaut", "coffee")]
