@@ -18,6 +18,10 @@ class _Stream(object):
 class _Ctx(object):
     stream = _Stream()
     device = "cpu"
+    synced = 0
+
+    def synchronize(self):
+        self.synced += 1
 
 
 class Recorder(_SequenceBase):
@@ -162,6 +166,13 @@ def test_one_window_pending_and_argument_checks():
     with pytest.raises(ValueError):
         eng.enqueue_staged(0, 4)
     assert eng.push_staged(0, 0) == []
+    # a run that ends with a window still on the stream: reset() lets it finish before the buffers are reused
+    eng.stage_host([7], 1)
+    eng.enqueue_staged(1, 1)
+    eng.reset()
+    assert eng.ctx.synced == 1 and eng._pending is None
+    eng.stage_host([0, 1, 2], 0)
+    assert len(eng.push_staged(0, 3)) == 3
     # an upload issued ahead is consumed exactly once, and only when the frame count matches
     eng._up_pending[1] = 2
     eng._up_event = [_Ev(), _Ev()]

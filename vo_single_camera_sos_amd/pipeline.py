@@ -417,6 +417,8 @@ class _SequenceBase(object):
         self.frames_seen = 0     # frames pushed so far (frame t of the sequence is tracked with seed t - 1)
         self.serial_calls = 0    # tracking calls the speculation did not cover
         self._key_src = None     # slot of a promoted frame whose record has not been copied to the keyframe slot yet
+        if getattr(self, "_pending", None) is not None:
+            self.ctx.synchronize()   # (a window an aborted run left on the stream: let it finish before its buffers are reused)
         self._pending = None     # the window enqueue_staged() put on the stream and collect() has not fetched yet
         self._up_pending = [0, 0]  # frames of pinned buffer b already on their way to device buffer b (upload_staged)
         if not hasattr(self, "_copy_stream"):
