@@ -62,8 +62,7 @@ def tier1(f, p, o, h, thr):
             u.append(fma32(H[:, k, None], P[None, :, 0], t))
         s = fma32(Fv[None, :, 0], u[0], fma32(Fv[None, :, 1], u[1], (Fv[None, :, 2] * u[2]).astype(F32)))
         q = fma32(u[0], u[0], fma32(u[1], u[1], (u[2] * u[2]).astype(F32)))
-        sp = np.where(s > 0, s, F32(0))      # v_max_f32(s, 0): a NaN gives 0
-        lhs = (sp * sp).astype(F32)
+        lhs = (s * np.abs(s)).astype(F32)    # the signed square
         e2 = fma32(ea, L[None, :], eb)
         hi = lhs > fma32(np.broadcast_to(c2h, q.shape), q, e2)
         lo = lhs < fma32(np.broadcast_to(c2l, q.shape), q, -e2)

@@ -311,8 +311,12 @@ __device__ __forceinline__ bool inlier_exact(const double* __restrict__ h, const
 //   |s~ - s| <= sqrt(3) E + 4.1 eps n,  |q~ - n^2| <= 3 eps n^2,  | |u|^2 - n^2 | <= 2 sqrt(3) n E + 3 E^2  (n = |u~|),
 //   and with  n E <= (K E^2 + n^2 / K) / 2  for any K > 0:
 //     s~^2 > (c2 + 3.47 / K + 20 eps) q~ + (3.47 K + 6) E^2   =>  s^2 > c2 (1 + 1e-9) q  and s > 0   (inlier),
-//     s~ <= 0  or  s~^2 < (c2 - 3.47 / K - 20 eps) q~ - (3.47 K + 6) E^2   =>  s <= 0 or s^2 < c2 (1 - 1e-9) q   (not one)
-//   (the 1e-9 margins are the double-precision fast tier's: beyond them its evaluation and the reference's agree).
+//     s~ |s~| < (c2 - 3.47 / K - 20 eps) q~ - (3.47 K + 6) E^2   =>  s <= 0 or s^2 < c2 (1 - 1e-9) q   (not one)
+//   (the 1e-9 margins are the double-precision fast tier's: beyond them its evaluation and the reference's agree; the
+//   kernel compares the SIGNED square s~ |s~| on both lines.  For s~ < 0 the second line reads s~^2 + (c2 - ..) q~ > (..) E^2:
+//   either s~ <= -(sqrt(3) E + 4.1 eps n), then s <= 0; or s~^2 is below that bound's square, which leaves
+//   (c2 - ..) q~ > 3.47 K E^2 - 34 eps^2 n^2, i.e. E < n / 1900, and s < 2 (sqrt(3) E + 4.1 eps n) < 2e-3 n gives
+//   s^2 < 4e-6 n^2 < c2 (1 - 1e-9) |u|^2 with c2 > 1/4.)
 // E^2 <= 78.03 eps^2 (rho^2 P1^2 + |i|_inf^2 + |o|_inf^2) <= 78.03 eps^2 (max(rho^2, 1) (P1^2 + |o|_inf^2) + |i|_inf^2): one
 // fma of a per-hypothesis pair (ea, eb) with a per-lane constant.  K = 2^20 balances the two terms for |u| ~ |p|: the
 // band is ~6e-6 of c2 wide, 3e-5 rad around the threshold angle at 5 degrees.  The bound assumes float arithmetic without
@@ -564,8 +568,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(T1 ? 4
       const float uz = fmaf(q2, pxs[T1 ? r : 0], fmaf(q5, pys[T1 ? r : 0], fmaf(q8, pzs[T1 ? r : 0], jz - ozs[T1 ? r : 0])));
       const float sv = fmaf(fxs[T1 ? r : 0], ux, fmaf(fys[T1 ? r : 0], uy, fzs[T1 ? r : 0] * uz));
       const float qv = fmaf(ux, ux, fmaf(uy, uy, uz * uz));
-      const float sp = fmaxf(sv, 0.0f);
-      const float lhs = sp * sp;
+      const float lhs = sv * fabsf(sv);  // the signed square (one fast-rate multiply with |.| on an operand; v_max_f32 is slow-rate)
       const float e2 = fmaf(ea, lerr[T1 ? r : 0], eb);
       const unsigned long long hi = __ballot(lhs > fmaf(c2hs, qv, e2));
       const unsigned long long lo = __ballot(lhs < fmaf(c2ls, qv, -e2));
