@@ -79,3 +79,14 @@ def test_rotated_brief_descriptors_equal_skimage_orb_loop(tag, gray, xy, angles,
     kp4 = np.concatenate([xy.astype(np.float32), angle_each[:, None].astype(np.float32), np.zeros((len(xy), 1), np.float32)], axis=1)
     d, kept = oracle.orb_describe_levels(gray, kp4, op.orb_pattern())
     assert len(kept) == len(xy) and np.array_equal(d, desc_each), tag
+
+
+@pytest.mark.parametrize("tag,gray,yx,eig,emax", tp.mineigen_cases(), ids=lambda v: v if isinstance(v, str) else "")
+def test_min_eigenvalue_response_agrees_with_scipy(tag, gray, yx, eig, emax):
+    """K4a's corner response (Sobel 3 scaled by 1 / (4 * 3 * 255), 3 x 3 block sums, reflect-101 border, closed-form smaller
+    eigenvalue) in float32 with a pinned operation order against float64 by scipy.ndimage: 2.1e-7 of the map's maximum measured,
+    at every border pixel and 3000 interior ones per photograph; the maximum itself (what the quality level multiplies) to 1e-6."""
+    got = oracle.min_eigen(gray).astype(np.float64)
+    d = np.abs(got[yx[:, 0].astype(np.int64), yx[:, 1].astype(np.int64)] - eig)
+    assert d.max() <= 1e-6 * emax, (tag, d.max() / emax)
+    assert abs(got.max() - emax) <= 1e-6 * emax

@@ -145,3 +145,10 @@ def brief_cases():
     angles = [float(a) for a in B["angles_deg"]]
     return [(tag, G[tag + "_gray"], B[tag + "_xy"], angles, [B[tag + "_desc_%d" % k] for k in range(len(angles))],
              B[tag + "_angle_each_deg"], B[tag + "_desc_each"]) for tag in ("camera", "astronaut", "coffee")]
+
+
+def mineigen_cases():
+    """-> list of (tag, gray [rows, cols] u8, yx [n, 2] i16, eig [n] f64, max f64): the minimum-eigenvalue corner response by
+    scipy.ndimage in double precision at the border ring and 3000 interior pixels (tests/golden/make_thirdparty_mineigen.py)."""
+    M, G = load("mineigen"), load("orientation")
+    return [(tag, G[tag + "_gray"], M[tag + "_yx"], M[tag + "_eig"], float(M[tag + "_max"])) for tag in ("camera", "astronaut", "coffee")]
